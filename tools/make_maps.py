@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Generate the synthetic 200x200 8-bit maps committed under tests/golden/maps/.
+
+Every .pgm/.png under the reference's data/ is a Git-LFS pointer, so
+the benchmark rasters are unavailable; these stand-ins keep the reference's
+conventions (map_shelves_io.rs:150-156: 255 free, 127..254 low obstacle = shelf,
+0..126 high obstacle = wall; zone rasters: 255 = no zone, k = zone k;
+map_io.rs:165-174: 0 obstacle, 255 free, anything else = door whose zone id comes
+from the zone raster) and the start/goal coordinates used by the reference's
+drivers (src/main.rs:486-848, src/pto.rs:466-540).  They are labelled synthetic
+everywhere they are used.
+
+The one real raster recoverable offline is the 200x200 door map embedded (base64
+PNG) in data/maps_paper/map_4/map.svg; `--paper-map` re-extracts it when
+/root/reference is present (it is data, not source).  Its zone raster is an LFS
+pointer, so door zones are labelled here by connected components.
+
+Run from the repo root:  python tools/make_maps.py
+"""
+import argparse
+import base64
+import io
+import os
+import re
+
+import numpy as np
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "maps")
+W = H = 200
+LOW, UP = -1.0, 1.0
+PPM = W / (UP - LOW)
+
+
+def to_pixel(x, y):
+    """map_shelves_io.rs:165-170 (for in-range points)."""
+    i = int((H - 1) - (y - LOW) * PPM)
+    j = int((x - LOW) * PPM)
+    return max(i, 0), max(j, 0)
+
+
+def rect(a, x0, y0, x1, y1, v):
+    i0, j0 = to_pixel(x0, y1)
+    i1, j1 = to_pixel(x1, y0)
+    a[max(i0, 0):min(i1, H - 1) + 1, max(j0, 0):min(j1, W - 1) + 1] = v
+
+
+def write_pgm(path, a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"P5\n# synthetic map, tools/make_maps.py\n%d %d\n255\n" % (a.shape[1], a.shape[0]))
+        f.write(a.tobytes())
+
+
+def read_pgm(path):
+    with open(path, "rb") as f:
+        data = f.read()
+    # P5 with optional comments
+    toks, pos = [], 2
+    assert data[:2] == b"P5"
+    while len(toks) < 3:
+        while data[pos:pos + 1].isspace():
+            pos += 1
+        if data[pos:pos + 1] == b"#":
+            pos = data.index(b"\n", pos) + 1
+            continue
+        end = pos
+        while not data[end:end + 1].isspace():
+            end += 1
+        toks.append(int(data[pos:end]))
+        pos = end
+    pos += 1
+    w, h, _ = toks
+    return np.frombuffer(data[pos:pos + w * h], dtype=np.uint8).reshape(h, w).copy()
+
+
+def clear_disk(a, x, y, r):
+    for i in range(H):
+        for j in range(W):
+            cx = j / PPM + LOW + 0.5 / PPM
+            cy = (H - 1 - i) / PPM + LOW + 0.5 / PPM
+            if abs(cx - x) + abs(cy - y) <= r:
+                a[i, j] = 255
+
+
+def map0_like():
+    """One room with two interior walls (cfg1 plumbing; start (0,0), goal (0,0.9))."""
+    a = np.full((H, W), 255, np.uint8)
+    rect(a, -0.6, 0.35, 0.45, 0.40, 0)
+    rect(a, -0.45, -0.45, -0.40, 0.2, 0)
+    rect(a, 0.3, -0.7, 0.35, -0.1, 0)
+    clear_disk(a, 0.0, 0.0, 0.08)
+    clear_disk(a, 0.0, 0.9, 0.08)
+    return a
+
+
+def benchmark_like(seed):
+    """Perimeter shelves + interior racks and pillars; start (0,-1); goals on the
+    perimeter lattice used by main.rs:491-497, 767-774 (+-0.9 / +-0.5 / 0)."""
+    rng = np.random.default_rng(1000 + seed)
+    a = np.full((H, W), 255, np.uint8)
+    shelf = 200
+    # perimeter shelves (low obstacles), broken by gaps
+    for (x0, x1) in [(-1.0, -0.93), (0.93, 1.0)]:
+        for y0 in np.arange(-0.8, 0.8, 0.4):
+            rect(a, x0, y0 + 0.06, x1, y0 + 0.34, shelf)
+    for x0 in np.arange(-0.8, 0.8, 0.4):
+        rect(a, x0 + 0.06, 0.93, x0 + 0.34, 1.0, shelf)
+    # interior racks: random axis-aligned low obstacles and a few high pillars
+    n_racks = 10 + seed % 3
+    for _ in range(n_racks):
+        cx, cy = rng.uniform(-0.75, 0.75), rng.uniform(-0.7, 0.75)
+        if rng.random() < 0.5:
+            w, h = rng.uniform(0.15, 0.35), 0.05
+        else:
+            w, h = 0.05, rng.uniform(0.15, 0.35)
+        rect(a, cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2, shelf if rng.random() < 0.6 else 0)
+    for _ in range(6):
+        cx, cy = rng.uniform(-0.8, 0.8), rng.uniform(-0.6, 0.8)
+        rect(a, cx - 0.03, cy - 0.03, cx + 0.03, cy + 0.03, 0)
+    # keep start and goal surroundings free
+    clear_disk(a, 0.0, -1.0, 0.12)
+    for gx, gy in [(-0.9, -0.5), (-0.9, 0.0), (-0.9, 0.5), (-0.5, 0.9), (0.5, 0.9), (0.9, 0.5), (0.9, 0.0), (0.9, -0.5)]:
+        clear_disk(a, gx * 0.92, gy * 0.92, 0.09)
+    return a
+
+
+def benchmark_zone_ids(n):
+    """zone k = the shelf cell behind goal k (main.rs:491-497, 767-774 order)."""
+    goals = {2: [(-0.9, 0.0), (0.9, 0.0)],
+             4: [(-0.9, 0.0), (-0.5, 0.9), (0.5, 0.9), (0.9, 0.0)],
+             6: [(-0.9, -0.5), (-0.9, 0.5), (-0.5, 0.9), (0.5, 0.9), (0.9, 0.5), (0.9, -0.5)],
+             8: [(-0.9, -0.5), (-0.9, 0.0), (-0.9, 0.5), (-0.5, 0.9), (0.5, 0.9), (0.9, 0.5), (0.9, 0.0), (0.9, -0.5)]}[n]
+    z = np.full((H, W), 255, np.uint8)
+    for k, (gx, gy) in enumerate(goals):
+        sx = np.sign(gx) if abs(gx) > abs(gy) else 0
+        sy = np.sign(gy) if abs(gy) >= abs(gx) else 0
+        cx, cy = gx + 0.06 * sx, gy + 0.06 * sy
+        rect(z, cx - 0.03, cy - 0.03, cx + 0.03, cy + 0.03, k)
+    return z, goals
+
+
+def map1_2_goals_like():
+    """Two shelf goals on the right, a dividing wall (pto.rs:466-479)."""
+    a = np.full((H, W), 255, np.uint8)
+    rect(a, -0.2, -0.15, 0.9, -0.10, 0)     # wall between the two goal corridors
+    rect(a, -0.25, -0.6, -0.2, 0.5, 0)
+    rect(a, 0.74, -0.55, 0.80, -0.35, 200)  # shelf 0
+    rect(a, 0.74, 0.28, 0.80, 0.48, 200)    # shelf 1
+    z = np.full((H, W), 255, np.uint8)
+    rect(z, 0.75, -0.48, 0.79, -0.42, 0)
+    rect(z, 0.75, 0.35, 0.79, 0.41, 1)
+    return a, z
+
+
+def map5_12_goals_like():
+    """4x3 lattice of shelves (main.rs:386-408): x in {-0.75,-0.25,0.25,0.75},
+    y in {0.75,0.25,-0.25}; goal k sits just below shelf k."""
+    a = np.full((H, W), 255, np.uint8)
+    z = np.full((H, W), 255, np.uint8)
+    goals = []
+    k = 0
+    for y in (0.75, 0.25, -0.25):
+        for x in (-0.75, -0.25, 0.25, 0.75):
+            rect(a, x - 0.12, y + 0.07, x + 0.12, y + 0.13, 200)
+            rect(z, x - 0.03, y + 0.08, x + 0.03, y + 0.12, k)
+            goals.append((x, y))
+            k += 1
+    rect(a, -0.5, -0.55, 0.5, -0.5, 0)
+    return a, z, goals
+
+
+def door_zone_ids(occ):
+    """Label door pixels (not 0 / 255) by 4-connected components in scan order."""
+    z = np.full(occ.shape, 255, np.uint8)
+    door = (occ != 0) & (occ != 255)
+    seen = np.zeros(occ.shape, bool)
+    k = 0
+    for i in range(occ.shape[0]):
+        for j in range(occ.shape[1]):
+            if door[i, j] and not seen[i, j]:
+                stack = [(i, j)]
+                seen[i, j] = True
+                while stack:
+                    ci, cj = stack.pop()
+                    z[ci, cj] = k
+                    for di, dj in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                        ni, nj = ci + di, cj + dj
+                        if 0 <= ni < occ.shape[0] and 0 <= nj < occ.shape[1] and door[ni, nj] and not seen[ni, nj]:
+                            seen[ni, nj] = True
+                            stack.append((ni, nj))
+                k += 1
+    return z, k
+
+
+def door_map_like():
+    """Two rooms split by a wall with two doors (value 128), map_io.rs conventions."""
+    a = np.full((H, W), 255, np.uint8)
+    rect(a, -1.0, 0.0, 1.0, 0.04, 0)
+    rect(a, -0.6, 0.0, -0.45, 0.04, 128)
+    rect(a, 0.4, 0.0, 0.55, 0.04, 128)
+    rect(a, 0.0, 0.04, 0.04, 0.6, 0)
+    return a
+
+
+def extract_paper_map():
+    from PIL import Image
+    svg = "/root/reference/data/maps_paper/map_4/map.svg"
+    s = open(svg).read()
+    m = re.findall(r'base64,([A-Za-z0-9+/=\s]+)"', s)[0]
+    return np.array(Image.open(io.BytesIO(base64.b64decode(m))).convert("L"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--paper-map", action="store_true", help="re-extract the raster embedded in the reference's map_4 svg")
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    write_pgm(os.path.join(OUT, "map0_like.pgm"), map0_like())
+    write_pgm(os.path.join(OUT, "map_benchmark_like.pgm"), benchmark_like(0))
+    for idx, letter in enumerate("abcdefghi"):
+        write_pgm(os.path.join(OUT, "map_benchmark_like_%s.pgm" % letter), benchmark_like(idx + 1))
+    for n in (2, 4, 6, 8):
+        z, _ = benchmark_zone_ids(n)
+        write_pgm(os.path.join(OUT, "map_benchmark_like_%d_goals_zone_ids.pgm" % n), z)
+    a, z = map1_2_goals_like()
+    write_pgm(os.path.join(OUT, "map1_2_goals_like.pgm"), a)
+    write_pgm(os.path.join(OUT, "map1_2_goals_like_zone_ids.pgm"), z)
+    a, z, _ = map5_12_goals_like()
+    write_pgm(os.path.join(OUT, "map5_like.pgm"), a)
+    write_pgm(os.path.join(OUT, "map5_like_12_goals_zone_ids.pgm"), z)
+    d = door_map_like()
+    write_pgm(os.path.join(OUT, "door_map_like.pgm"), d)
+    write_pgm(os.path.join(OUT, "door_map_like_zone_ids.pgm"), door_zone_ids(d)[0])
+    paper = os.path.join(OUT, "paper_map_4.pgm")
+    if args.paper_map:
+        write_pgm(paper, extract_paper_map())
+    if os.path.exists(paper):
+        occ = read_pgm(paper)
+        z, k = door_zone_ids(occ)
+        write_pgm(os.path.join(OUT, "paper_map_4_zone_ids.pgm"), z)
+        print("paper_map_4: %d door zones" % k)
+    for f in sorted(os.listdir(OUT)):
+        a = read_pgm(os.path.join(OUT, f))
+        print("%-46s free %.1f%%  low %.1f%%  high %.1f%%" % (f, 100 * (a == 255).mean(),
+              100 * ((a >= 127) & (a < 255)).mean(), 100 * (a < 127).mean()))
+
+
+if __name__ == "__main__":
+    main()
