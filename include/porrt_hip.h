@@ -1,0 +1,150 @@
+/*
+ * porrt_hip.h -- C ABI of the MI355X-native batched belief-space RRT expansion
+ * engine (libporrt_hip.so).  Plain pointers and sizes only; no torch / HIP types.
+ *
+ * It is the drop-in for ONE path of cambyse/po-rrt: the grow/extend loop
+ *     RRT::grow_tree   src/rrt.rs:102-174  (RRT* with best-parent + rewire)
+ *     PTO::grow_graph  src/pto.rs:55-139   (belief-space RRG + Reachability)
+ * instantiated for the reference's grid-backed domains
+ *     MapShelfDomain   src/map_shelves_io.rs:65-203,459-488 (RTTFuncs adapter
+ *                      src/map_shelves_tamp_rrt.rs:35-47)
+ *     Map (doors)      src/map_io.rs:67-241,482-513
+ * and its declarative goals (SquareGoal src/common.rs:304-350, ObservationGoal
+ * src/rrt.rs:325-341).  The reference's trait callbacks (RTTFuncs rrt.rs:64-76,
+ * PTOFuncs pto_graph.rs:121-168, GoalFuncs common.rs:294-302) are opaque host
+ * closures, so the engine takes their DATA (grid, zones, goal table, sampler box
+ * and seed) instead of their code.  The style follows the reference's own C
+ * boundary (src/pto_c.rs:63-270: opaque handle, setters, plan, getters) without
+ * callbacks and without taking ownership of caller memory.
+ *
+ * Conventions: every call returns 0 on success or a negative PORRT_ERR_* code
+ * (porrt_last_error() gives the text); nothing panics across the boundary; the
+ * caller owns all host buffers; one context drives one GPU and is not
+ * thread-safe (it mirrors `&mut self` of RRT::plan, rrt.rs:88); sampler state
+ * persists across porrt_grow calls on one context (the reference reuses one RRT
+ * object for many plans, src/map_shelves_tamp_rrt.rs:196-232).
+ */
+#ifndef PORRT_HIP_H
+#define PORRT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct porrt_ctx porrt_ctx;
+
+enum {
+    PORRT_OK = 0,
+    PORRT_INCOMPLETE = 1,           /* PTO: "final nodes are not reached for each world" (pto.rs:137) */
+    PORRT_ERR_INVALID = -1,         /* bad argument / call order */
+    PORRT_ERR_INVALID_START = -2,   /* pto.rs:61 expect("Start from a valid state!") */
+    PORRT_ERR_RASTER = -3,          /* pixel access outside the map, door pixel without zone id, or a
+                                       segment crossing two zones: the reference panics there
+                                       (image get_pixel; map_io.rs:233) */
+    PORRT_ERR_DEVICE = -4,          /* HIP runtime error */
+    PORRT_ERR_CAPACITY = -5,        /* a neighbour list outgrew its capacity even after regrowth */
+    PORRT_ERR_NO_DEVICE = -6
+};
+
+enum { PORRT_DOMAIN_SHELF = 0, PORRT_DOMAIN_DOOR = 1 };   /* MapShelfDomain / Map */
+enum { PORRT_MODE_RRT = 0, PORRT_MODE_PTO = 1 };          /* RRT::grow_tree / PTO::grow_graph */
+
+/* ---- lifetime.  Replaces: RRT::new (rrt.rs:84-86) / PTO::new (pto.rs:37-53) --------- */
+porrt_ctx  *porrt_create(int device);      /* NULL when no HIP device is usable */
+void        porrt_destroy(porrt_ctx *ctx);
+const char *porrt_last_error(const porrt_ctx *ctx);
+
+/* ---- domain data.  Replaces: MapShelfDomain::open/build (map_shelves_io.rs:80-94),
+ * Map::open/build (map_io.rs:82-96): ppm = W / (up[0] - low[0]); raster row-major,
+ * occ[i*W + j] = img.get_pixel(j, i). */
+int porrt_set_grid(porrt_ctx *ctx, const uint8_t *occ, uint32_t W, uint32_t H,
+                   const double low[2], const double up[2], int domain);
+/* Replaces: add_zones (map_shelves_io.rs:106-148, map_io.rs:113-161): zone raster
+ * (255 = none), zone centroids, worlds and world validities are derived inside. */
+int porrt_set_zones(porrt_ctx *ctx, const uint8_t *zone_ids, double visibility);
+
+/* ---- samplers.  Replaces: ContinuousSampler::new + DiscreteSampler::new
+ * (sample_space.rs:13-21,45-49; the reference hard-codes seed 0).  The stream is
+ * rand_pcg Pcg64::seed_from_u64(seed) with rand 0.8 gen_range, generated on the GPU. */
+int porrt_set_sampler(porrt_ctx *ctx, const double low[2], const double up[2], uint64_t seed);
+int porrt_set_discrete_seed(porrt_ctx *ctx, uint64_t seed);
+/* Inject the stream instead: xy[2*i..] is the i-th value ContinuousSampler::sample()
+ * would return (goal-biased iterations consume none, rrt.rs:176-181); worlds[i] is
+ * the i-th DiscreteSampler::sample() value (one per iteration, pto.rs:142). */
+int porrt_set_samples(porrt_ctx *ctx, const double *xy, size_t n);
+int porrt_set_worlds(porrt_ctx *ctx, const uint32_t *worlds, size_t n);
+
+/* ---- goals.  Replaces: SquareGoal::new (common.rs:310-333); bit w of masks[g] is
+ * world w of the goal's validity.  ObservationGoal (rrt.rs:325-341). */
+int porrt_set_square_goal(porrt_ctx *ctx, const double *centers /* G*2 */, const uint64_t *masks,
+                          uint32_t G, double l1_radius);
+int porrt_set_observation_goal(porrt_ctx *ctx, uint32_t zone_id);
+
+/* ---- the hot path.  Replaces: RRT::grow_tree (rrt.rs:102-174) when mode is
+ * PORRT_MODE_RRT and PTO::grow_graph (pto.rs:55-139) when PORRT_MODE_PTO.
+ * batch_K samples are expanded per step against the tree as it stands at the start
+ * of the step; batch_K = 1 is the reference's loop.  Returns PORRT_OK,
+ * PORRT_INCOMPLETE (PTO only) or an error. */
+int porrt_grow(porrt_ctx *ctx, const double start[2], double max_step, double search_radius,
+               uint64_t n_iter_min, uint64_t n_iter_max, uint32_t batch_K, int mode);
+
+/* ---- results, copied into caller-owned buffers (query the sizes first).
+ * Replaces: RRTTree{nodes: Vec<RRTNode{state,parent_id,dist_from_root}>} (rrt.rs:14-22)
+ * and the final ids returned by grow_tree (rrt.rs:103,165-167). */
+uint64_t porrt_num_nodes(const porrt_ctx *ctx);
+uint64_t porrt_num_iterations(const porrt_ctx *ctx);
+int      porrt_get_tree(const porrt_ctx *ctx, double *xy /* N*2 */, int64_t *parent /* -1 = root */,
+                        double *dist_root);
+uint64_t porrt_num_final(const porrt_ctx *ctx);
+int      porrt_get_final_ids(const porrt_ctx *ctx, uint64_t *ids);
+int      porrt_get_final_masks(const porrt_ctx *ctx, uint64_t *masks);
+/* PTO mode.  Replaces: Reachability::reachability (pto_reachability.rs:54-56),
+ * PTONode.validity_id and the PTOGraph edges (pto_graph.rs:171-207): forward edges
+ * (neighbour -> new node) sorted by (to, from); the reference also stores each
+ * reverse edge with the same validity id (pto.rs:117-120). */
+int      porrt_get_reach(const porrt_ctx *ctx, uint64_t *masks /* N */);
+int      porrt_get_node_validity(const porrt_ctx *ctx, uint32_t *validity_ids /* N */);
+uint64_t porrt_num_edges(const porrt_ctx *ctx);
+int      porrt_get_edges(const porrt_ctx *ctx, uint32_t *from, uint32_t *to, uint32_t *validity_id);
+int      porrt_is_final_set_complete(const porrt_ctx *ctx);   /* pto_reachability.rs:81-90 */
+/* derived domain data (map_shelves_io.rs:113,132-148; map_io.rs:121-126) */
+int      porrt_n_worlds(const porrt_ctx *ctx);
+int      porrt_get_validities(const porrt_ctx *ctx, uint64_t *masks /* <= 65 */);
+int      porrt_get_zone_positions(const porrt_ctx *ctx, double *xy /* <= 64*2 */);
+
+/* Host side of RRT::plan (get_best_solution rrt.rs:183-193, get_path_to 48-61,
+ * get_path_cost 223-227): length of the best path (0 = "No solution found");
+ * path_xy may be NULL to query the length. */
+uint64_t porrt_best_solution(const porrt_ctx *ctx, double *path_xy, uint64_t cap, double *cost);
+
+/* ---- measurement */
+typedef struct {
+    uint64_t n_iter;          /* iterations run */
+    uint64_t n_nodes;         /* tree size incl. root */
+    uint64_t n_steps;         /* batched steps launched */
+    uint64_t n_tie_fallbacks; /* equal-cost parent ties not covered by the goal-path rule (expected 0) */
+    double   total_s;         /* wall time of porrt_grow */
+    double   setup_s;         /* part of total_s: host tables + uploads (radius table, worlds) */
+    double   device_s;        /* HIP-event time from first to last kernel of the growth loop */
+    double   scan_s;          /* HIP-event time summed over the nn_scan + radius_scan kernels
+                                 (only filled when profiling is enabled) */
+    uint64_t scan_launches;
+    double   scan_pairs;      /* sample x node pairs evaluated by those kernels */
+    double   scan_bytes;      /* algorithmic bytes of those kernels */
+} porrt_metrics;
+int porrt_get_metrics(const porrt_ctx *ctx, porrt_metrics *out);
+/* options: "profile" (0/1 per-kernel HIP events), "cand_cap" (initial neighbour-list
+ * capacity per sample), "graph" (0/1 replay the growth loop as a hipGraph) */
+int porrt_set_option(porrt_ctx *ctx, const char *name, int64_t value);
+
+/* Device arithmetic self-test: sqrt and divide of n doubles on the GPU versus the host's correctly
+ * rounded results; both mismatch counts must be 0 for bit-exact parity (rrt.rs costs, common.rs:218). */
+int porrt_selftest(porrt_ctx *ctx, uint64_t n, uint64_t *sqrt_mismatch, uint64_t *div_mismatch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

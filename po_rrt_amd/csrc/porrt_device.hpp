@@ -1,0 +1,860 @@
+// porrt_device.hpp -- gfx950 kernels of the batched RRT*/PTO expansion engine.
+//
+// One grow step ("batch") of K samples runs five kernels on one stream:
+//   k_nn_scan        K x N_b brute-force nearest-neighbour scan   (replaces KdTree::nearest_neighbor[_filtered],
+//                                                                  src/nearest_neighbor.rs:48-92)
+//   k_nn_reduce_steer  argmin over node chunks (wave shfl), steer, point validity
+//                                                                 (src/common.rs:215-225, map_shelves_io.rs:158-170,
+//                                                                  map_io.rs:165-181)
+//   k_radius_scan    K x N_b radius scan, neighbour lists          (replaces KdTree::nearest_neighbors,
+//                                                                  src/nearest_neighbor.rs:94-126)
+//   k_connect_rrt / k_connect_pto   Bresenham raycasts on the LDS-resident grid, best parent (wave argmin),
+//                    new node, rewire phase 1 / reachability        (src/rrt.rs:123-161, src/pto.rs:95-124,
+//                                                                  map_shelves_io.rs:187-203, map_io.rs:216-241,
+//                                                                  pto_reachability.rs:42-52)
+//   k_commit_rrt / k_commit_pto     rewire phase 2 (deterministic winner) / reach sync, step counter
+// plus k_gen_samples (Pcg64 + gen_range on the device, sample_space.rs:30-36, rrt.rs:176-181) once per grow
+// and k_goal_path (kd pre-order bookkeeping for equal-cost parents) once per RRT* step.
+//
+// Scan layout: one LANE per sample, the node stream is wave-uniform (scalar loads broadcast x,y to all 64
+// lanes), so the hot loop is pure FP64 VALU: 2 sub, 2 mul, 1 add, 1 compare per (sample, node) pair -- no
+// cross-lane traffic, no LDS.  Arithmetic is IEEE f64 without contraction (-ffp-contract=off): it has to
+// reproduce the reference's rounding exactly (integer parents bit-exact, coordinates bit-exact).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace porrt {
+
+constexpr int kScanBlock = 256;      // lanes = samples per scan workgroup
+constexpr int kMaxChunks = 256;      // node chunks per scan (grid.y)
+constexpr int kConnectWaves = 8;     // samples per connect workgroup (one wave each)
+constexpr uint32_t kLdsGridMax = 96 * 1024;
+
+enum : uint32_t {
+    ERR_RASTER = 1u,        // pixel outside the raster / door pixel without zone / two zones on one segment
+    ERR_CAND_OVERFLOW = 2u, // neighbour list capacity
+    ERR_RNG_RETRY = 4u,     // gen_range would have redrawn (host regenerates the stream exactly)
+    ERR_EDGE_OVERFLOW = 8u,
+    ERR_GPATH_OVERFLOW = 16u
+};
+
+// pixel classes of the pre-classified raster (host builds it in set_grid/set_zones)
+enum : uint8_t { CLS_FREE = 0, CLS_LOW = 1, CLS_HIGH = 2, CLS_HIGH0 = 3 /* raw pixel 0 */, CLS_ZONE = 16, CLS_BAD = 255 };
+
+struct Counters {
+    uint32_t n_final;
+    uint32_t n_edges;
+    uint32_t err;
+    uint32_t tie_fallbacks;
+    unsigned long long finality;
+    uint32_t g_len;
+    uint32_t pad;
+};
+
+struct RunConst {
+    // node SoA
+    double *nx, *ny;
+    double *distA, *distB;      // dist_root: A = snapshot read by the step, B = rewire accumulator
+    int *parent;
+    unsigned long long *reachA, *reachB;
+    uint8_t *vid;               // PTO validity id per node
+    uint8_t *final_flag;
+    unsigned long long *final_mask;
+    uint32_t *n_at;             // n_at[b] = tree size at the start of step b
+    unsigned long long *valid_mask; // per step: bit k = sample k produced a node
+    Counters *cnt;
+    // sample stream for the run (one entry per iteration)
+    double *sx, *sy;
+    uint32_t *sworld;
+    const double *inj_xy;       // injected ContinuousSampler values or null
+    unsigned long long inj_base, inj_n;
+    // per-sample step scratch
+    double *q_x, *q_y;          // steered state
+    int *q_nn;
+    int *q_vid;
+    double *part_D;
+    int *part_id;
+    uint32_t *cand_cnt;
+    int *cand_id;
+    double *cand_val;
+    uint32_t cand_cap;
+    // radius tables: T2[n] = largest d^2 whose sqrt rounds to <= heuristic_radius(n)
+    const double *rad_T2;
+    // edges (PTO)
+    uint32_t *e_from, *e_to, *e_tv;
+    uint32_t e_cap;
+    // goal path (RRT* tie order)
+    int *g_id;
+    uint32_t g_cap;
+    double gp_x, gp_y;
+    // grid
+    const uint8_t *cls;
+    uint32_t W, H;
+    double low0, low1, ppm;
+    int domain, has_grid;
+    int n_validities;
+    unsigned long long validities[65];
+    unsigned long long all_worlds;
+    // goal
+    int goal_kind;              // 0 none, 1 square, 2 observation
+    uint32_t G;
+    double gcx[64], gcy[64];
+    unsigned long long gmask[64];
+    double g_l1;
+    double w2g_x[64], w2g_y[64];
+    double zone_x, zone_y, visibility;
+    // sampler box + params
+    double s_low0, s_low1, s_up0, s_up1;
+    double max_step;
+    int mode;
+};
+
+// ------------------------------------------------------------------ small helpers
+__device__ __forceinline__ unsigned long long f64_bits(double d) { return (unsigned long long)__double_as_longlong(d); }
+
+// Rust `f64 as u32`: truncate toward zero, saturate, NaN -> 0
+__device__ __forceinline__ uint32_t f64_as_u32(double v) {
+    if (!(v == v)) return 0u;
+    if (v <= 0.0) return 0u;
+    if (v >= 4294967295.0) return 4294967295u;
+    return (uint32_t)v;
+}
+
+// map_shelves_io.rs:165-170 == map_io.rs:176-181
+__device__ __forceinline__ void to_pixel(const RunConst &rc, double x, double y, uint32_t &i, uint32_t &j) {
+    double t = (y - rc.low1) * rc.ppm;
+    i = f64_as_u32((double)(rc.H - 1) - t);
+    j = f64_as_u32((x - rc.low0) * rc.ppm);
+}
+
+// common.rs:203-213 with a = node, b = query
+__device__ __forceinline__ double dist2(double ax, double ay, double bx, double by) {
+    double dx = bx - ax, dy = by - ay;
+    double xx = dx * dx, yy = dy * dy;
+    return xx + yy;
+}
+
+// line_drawing 0.8 octant transforms (Bresenham<i32>, used at map_shelves_io.rs:196 / map_io.rs:225)
+__device__ __forceinline__ void oct_to(int o, int x, int y, int &ox, int &oy) {
+    switch (o) {
+    case 0: ox = x; oy = y; break;
+    case 1: ox = y; oy = x; break;
+    case 2: ox = y; oy = -x; break;
+    case 3: ox = -x; oy = y; break;
+    case 4: ox = -x; oy = -y; break;
+    case 5: ox = -y; oy = -x; break;
+    case 6: ox = -y; oy = x; break;
+    default: ox = x; oy = -y; break;
+    }
+}
+__device__ __forceinline__ void oct_from(int o, int x, int y, int &ox, int &oy) {
+    switch (o) {
+    case 0: ox = x; oy = y; break;
+    case 1: ox = y; oy = x; break;
+    case 2: ox = -y; oy = x; break;
+    case 3: ox = -x; oy = y; break;
+    case 4: ox = -x; oy = -y; break;
+    case 5: ox = -y; oy = -x; break;
+    case 6: ox = y; oy = -x; break;
+    default: ox = x; oy = -y; break;
+    }
+}
+
+// Traversed-space class of the segment a -> b (map_shelves_io.rs:187-203, map_io.rs:216-241).
+// Returns CLS_FREE / CLS_LOW / CLS_HIGH / CLS_ZONE+z.  Raster faults set *err and read as CLS_HIGH.
+template <class GridPtr>
+__device__ int traversed_class(const RunConst &rc, GridPtr grid, double ax, double ay, double bx, double by, uint32_t *err) {
+    uint32_t ai, aj, bi, bj;
+    to_pixel(rc, ax, ay, ai, aj);
+    to_pixel(rc, bx, by, bi, bj);
+    if (ai >= rc.H || bi >= rc.H || aj >= rc.W || bj >= rc.W) {
+        *err |= ERR_RASTER;
+        return CLS_HIGH;
+    }
+    int x0 = (int)ai, y0 = (int)aj, x1 = (int)bi, y1 = (int)bj;
+    int o = 0;
+    {
+        int dx = x1 - x0, dy = y1 - y0;
+        if (dy < 0) { dx = -dx; dy = -dy; o += 4; }
+        if (dx < 0) { int t = dx; dx = dy; dy = -t; o += 2; }
+        if (dx < dy) o += 1;
+    }
+    int sx, sy, ex, ey;
+    oct_to(o, x0, y0, sx, sy);
+    oct_to(o, x1, y1, ex, ey);
+    const int ddx = ex - sx, ddy = ey - sy;
+    int e = ddy - ddx;
+    int worst = CLS_FREE;
+    for (int x = sx, y = sy; x <= ex; ++x) {
+        int pi, pj;
+        oct_from(o, x, y, pi, pj);
+        int c = grid[(uint32_t)pi * rc.W + (uint32_t)pj];
+        if (rc.domain == 0) {
+            if (c == CLS_HIGH0) return CLS_HIGH;       // lowest_pixel == 0: early return
+            worst = c > worst ? c : worst;
+        } else {
+            if (c != CLS_FREE) {
+                if (c == CLS_HIGH || c == CLS_HIGH0) return CLS_HIGH;   // Obstacle: immediate return
+                if (c == CLS_BAD) { *err |= ERR_RASTER; return CLS_HIGH; }
+                if (worst >= CLS_ZONE && worst != c) { *err |= ERR_RASTER; return CLS_HIGH; } // two zones: reference asserts
+                worst = c;
+            }
+        }
+        if (e >= 0) { y += 1; e -= ddx; }
+        e += ddy;
+    }
+    return worst;
+}
+
+// class of one state (map_shelves_io.rs:158-163, map_io.rs:165-174); global raster
+__device__ __forceinline__ int state_class(const RunConst &rc, double x, double y, uint32_t *err) {
+    uint32_t i, j;
+    to_pixel(rc, x, y, i, j);
+    if (i >= rc.H || j >= rc.W) { *err |= ERR_RASTER; return CLS_HIGH; }
+    int c = rc.cls[i * rc.W + j];
+    if (c == CLS_BAD) { *err |= ERR_RASTER; return CLS_HIGH; }
+    return c == CLS_HIGH0 ? CLS_HIGH : c;
+}
+
+// PTOFuncs validity ids (map_shelves_io.rs:464-488, map_io.rs:487-513); -1 = None
+__device__ __forceinline__ int class_to_validity(const RunConst &rc, int cls) {
+    if (cls == CLS_FREE) return rc.n_validities - 1;
+    if (cls >= CLS_ZONE) return cls - CLS_ZONE;
+    return -1;
+}
+
+// GoalFuncs::goal (common.rs:336-345; rrt.rs:330-336 + map_shelves_io.rs:259-265)
+template <class GridPtr>
+__device__ bool goal_hit(const RunConst &rc, GridPtr grid, double x, double y, unsigned long long &mask, uint32_t *err) {
+    if (rc.goal_kind == 1) {
+        for (uint32_t g = 0; g < rc.G; ++g) {
+            double d = fabs(rc.gcx[g] - x);
+            d += fabs(rc.gcy[g] - y);
+            if (d < rc.g_l1) { mask = rc.gmask[g]; return true; }
+        }
+        return false;
+    }
+    if (rc.goal_kind == 2) {
+        double D = sqrt(dist2(x, y, rc.zone_x, rc.zone_y));
+        if (D < rc.visibility) {
+            int c = traversed_class(rc, grid, x, y, rc.zone_x, rc.zone_y, err);
+            if (c != CLS_HIGH) { mask = 1ull; return true; }
+        }
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------ Pcg64 on the device
+typedef unsigned __int128 u128;
+__device__ __forceinline__ u128 mk128(unsigned long long lo, unsigned long long hi) { return ((u128)hi << 64) | lo; }
+
+struct PcgJump { // LCG jump tables: entry i advances 2^i steps
+    unsigned long long mult_lo[64], mult_hi[64], plus_lo[64], plus_hi[64];
+};
+
+__device__ __forceinline__ unsigned long long pcg_output(u128 s) {
+    uint32_t rot = (uint32_t)(s >> 122);
+    unsigned long long xsl = (unsigned long long)(s >> 64) ^ (unsigned long long)s;
+    return (xsl >> rot) | (xsl << ((64 - rot) & 63));
+}
+
+// rand 0.8 UniformFloat<f64>::sample_single, one draw; *retry is set when the reference would redraw
+__device__ __forceinline__ double gen_range_once(unsigned long long r, double low, double high, bool *retry) {
+    double v12 = __longlong_as_double((long long)((r >> 12) | 0x3FF0000000000000ull));
+    double v01 = v12 - 1.0;
+    double scale = high - low;
+    double prod = v01 * scale;
+    double res = prod + low;
+    if (!(res < high)) *retry = true;
+    return res;
+}
+
+// One thread per iteration of the run: goal-biased sample (rrt.rs:176-181, pto.rs:141-149).
+__global__ void k_gen_samples(const RunConst *__restrict__ rcp, const PcgJump *__restrict__ jt, unsigned long long it0,
+                              unsigned long long n, unsigned long long st_lo, unsigned long long st_hi,
+                              unsigned long long inc_lo, unsigned long long inc_hi, unsigned long long draws_before) {
+    const RunConst &rc = *rcp;
+    unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    unsigned long long idx = it0 + t;     // 0-based iteration of this grow call
+    unsigned long long it = idx + 1;
+    if (it % 100 == 0) {
+        uint32_t w = rc.mode == 1 ? rc.sworld[idx] : 0u;
+        double gx = 0.0, gy = 0.0;
+        if (rc.goal_kind == 1) { gx = rc.w2g_x[w & 63]; gy = rc.w2g_y[w & 63]; }
+        else if (rc.goal_kind == 2) { gx = rc.zone_x; gy = rc.zone_y; }
+        rc.sx[idx] = gx;
+        rc.sy[idx] = gy;
+        return;
+    }
+    unsigned long long di = idx - idx / 100;   // sampler calls made before this iteration in this grow
+    if (rc.inj_xy) {
+        unsigned long long e = rc.inj_base + di;
+        if (e >= rc.inj_n) { atomicOr(&rc.cnt->err, ERR_RNG_RETRY); rc.sx[idx] = 0.0; rc.sy[idx] = 0.0; return; }
+        rc.sx[idx] = rc.inj_xy[2 * e];
+        rc.sy[idx] = rc.inj_xy[2 * e + 1];
+        return;
+    }
+    // jump the LCG ahead by 2*di steps from the state at the start of this grow
+    (void)draws_before;
+    unsigned long long delta = 2ull * di;
+    u128 acc_mult = 1, acc_plus = 0;
+    for (int b = 0; b < 64 && (delta >> b); ++b) {
+        if ((delta >> b) & 1ull) {
+            u128 m = mk128(jt->mult_lo[b], jt->mult_hi[b]), p = mk128(jt->plus_lo[b], jt->plus_hi[b]);
+            acc_mult = acc_mult * m;
+            acc_plus = acc_plus * m + p;
+        }
+    }
+    const u128 MULT = mk128(0x4385DF649FCCF645ull, 0x2360ED051FC65DA4ull);
+    u128 inc = mk128(inc_lo, inc_hi);
+    u128 s = acc_mult * mk128(st_lo, st_hi) + acc_plus;
+    bool retry = false;
+    s = s * MULT + inc;
+    double x = gen_range_once(pcg_output(s), rc.s_low0, rc.s_up0, &retry);
+    s = s * MULT + inc;
+    double y = gen_range_once(pcg_output(s), rc.s_low1, rc.s_up1, &retry);
+    if (retry) atomicOr(&rc.cnt->err, ERR_RNG_RETRY);
+    rc.sx[idx] = x;
+    rc.sy[idx] = y;
+}
+
+// ------------------------------------------------------------------ scans
+// The node arrays are read-only inside a scan kernel and indexed wave-uniformly.  Viewing them through the
+// constant address space makes hipcc emit scalar loads (s_load_dwordx2/x4 into SGPRs) that feed the VALU
+// directly as broadcast operands; the scalar cache is invalidated at every kernel start, so nodes written
+// by the previous step's kernels are seen.
+typedef const __attribute__((address_space(4))) double *cdouble_p;
+__device__ __forceinline__ cdouble_p as_const(const double *p) { return (cdouble_p)(uintptr_t)p; }
+
+__device__ __forceinline__ void chunk_range(uint32_t N, uint32_t NC, uint32_t c, uint32_t &j0, uint32_t &j1) {
+    uint32_t C = (N + NC - 1) / NC;
+    C = (C + 7u) & ~7u;                 // chunks start on 64-byte boundaries of the x / y arrays
+    j0 = c * C;
+    uint32_t e = j0 + C;
+    j1 = e < N ? e : N;
+    if (j0 > N) j0 = N;
+}
+
+constexpr int kUnroll = 8;
+
+// Stream the nodes [j0, j1) of one chunk past the lanes' samples.  `visit(j, d2)` is called for every node
+// whose squared distance passes `hit(d2)`; both see wave-uniform j.  Eight nodes are fetched per iteration
+// with two 64-byte scalar loads; the eight distance evaluations are independent FP64 VALU chains.
+template <class Hit, class Visit>
+__device__ __forceinline__ void scan_chunk(cdouble_p nx, cdouble_p ny, uint32_t j0, uint32_t j1, double qx, double qy,
+                                           Hit hit, Visit visit) {
+    uint32_t j = j0;
+    cdouble_p px = nx + j0, py = ny + j0;     // 64-bit bases: constant offsets merge into wide scalar loads
+    for (; j + kUnroll <= j1; j += kUnroll, px += kUnroll, py += kUnroll) {
+        double ax[kUnroll], ay[kUnroll], d2[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) { ax[u] = px[u]; ay[u] = py[u]; }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) d2[u] = dist2(ax[u], ay[u], qx, qy);
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) any |= hit(d2[u]);
+        if (any) {                       // rare: one branch per eight nodes
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (hit(d2[u])) visit(j + u, d2[u]);
+        }
+    }
+    for (; j < j1; ++j, ++px, ++py) {
+        const double d2 = dist2(px[0], py[0], qx, qy);
+        if (hit(d2)) visit(j, d2);
+    }
+}
+
+// K x N nearest-neighbour scan.  grid = (ceil(nb/256), NC); lane <-> sample, nodes broadcast.
+// Output per (sample, chunk): lexicographic min of (norm2, id) over the chunk's nodes that pass the world
+// filter (nearest_neighbor.rs:61-62: `d < dmin && validator(id)`, ascending id so the first wins ties).
+template <bool PTO>
+__global__ __launch_bounds__(kScanBlock) void k_nn_scan(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb,
+                                                          uint32_t NC) {
+    const RunConst &rc = *rcp;
+    const uint32_t k = blockIdx.x * kScanBlock + threadIdx.x;
+    const uint32_t c = blockIdx.y;
+    const uint32_t N = __builtin_amdgcn_readfirstlane(rc.n_at[b]);
+    uint32_t j0, j1;
+    chunk_range(N, NC, c, j0, j1);
+    const bool live = k < nb;
+    const double qx = live ? rc.sx[i0 + k] : 0.0, qy = live ? rc.sy[i0 + k] : 0.0;
+    uint32_t world = 0;
+    if (PTO) world = live ? rc.sworld[i0 + k] : 0u;
+    double m2 = __longlong_as_double(0x7FF0000000000000ll);   // +inf
+    double bestD = m2;
+    int best = -1;
+    const unsigned long long *reach = rc.reachA;
+    scan_chunk(as_const(rc.nx), as_const(rc.ny), j0, j1, qx, qy,
+               [&](double d2) { return d2 < m2; },
+               [&](uint32_t j, double d2) {
+                   bool pass = true;
+                   if (PTO) pass = (reach[j] >> world) & 1ull;
+                   if (pass) {
+                       const double D = sqrt(d2);      // the reference compares rounded distances
+                       if (D < bestD) { bestD = D; best = (int)j; m2 = d2; }
+                   }
+               });
+    if (live) {
+        rc.part_D[(size_t)k * kMaxChunks + c] = bestD;
+        rc.part_id[(size_t)k * kMaxChunks + c] = best;
+    }
+}
+
+// wave per sample: argmin over chunks (shfl), steer (L1 step length), point validity
+__global__ __launch_bounds__(256) void k_nn_reduce_steer(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb,
+                                                          uint32_t NC, uint32_t vwords) {
+    const RunConst &rc = *rcp;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t k = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    if (k >= nb) return;
+    double D = __longlong_as_double(0x7FF0000000000000ll);
+    int id = 0x7FFFFFFF;
+    for (uint32_t c = lane; c < NC; c += 64) {
+        double d = rc.part_D[(size_t)k * kMaxChunks + c];
+        int i = rc.part_id[(size_t)k * kMaxChunks + c];
+        if (i >= 0 && (d < D || (d == D && i < id))) { D = d; id = i; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        double d = __shfl_xor(D, off);
+        int i = __shfl_xor(id, off);
+        if (d < D || (d == D && i < id)) { D = d; id = i; }
+    }
+    if (lane != 0) return;
+    const int nn = id == 0x7FFFFFFF ? 0 : id;   // nothing passed the filter: the root (nearest_neighbor.rs:90)
+    const double fx = rc.nx[nn], fy = rc.ny[nn];
+    double tx = rc.sx[i0 + k], ty = rc.sy[i0 + k];
+    // common.rs:215-225
+    double step = fabs(tx - fx);
+    step += fabs(ty - fy);
+    if (step > rc.max_step) {
+        const double lambda = rc.max_step / step;
+        double ux = (tx - fx) * lambda, uy = (ty - fy) * lambda;
+        tx = fx + ux;
+        ty = fy + uy;
+    }
+    uint32_t err = 0;
+    int vid = 0;
+    bool valid = true;
+    if (rc.has_grid) {
+        int cls = state_class(rc, tx, ty, &err);
+        if (rc.mode == 0) valid = cls == CLS_FREE;            // RTTFuncs adapter (tamp_rrt.rs:40-42)
+        else { vid = class_to_validity(rc, cls); valid = vid >= 0; }
+        if (err) valid = false;
+    }
+    rc.q_x[k] = tx;
+    rc.q_y[k] = ty;
+    rc.q_nn[k] = nn;
+    rc.q_vid[k] = valid ? vid : -1;
+    rc.cand_cnt[k] = 0;
+    if (valid) atomicOr(&rc.valid_mask[(size_t)b * vwords + (k >> 6)], 1ull << (k & 63u));
+    if (err) atomicOr(&rc.cnt->err, err);
+}
+
+// K x N radius scan: neighbour ids with norm2 <= radius  <=>  d2 <= T2 (T2 from the host table)
+__global__ __launch_bounds__(kScanBlock) void k_radius_scan(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t NC) {
+    const RunConst &rc = *rcp;
+    const uint32_t k = blockIdx.x * kScanBlock + threadIdx.x;
+    const uint32_t c = blockIdx.y;
+    const uint32_t N = __builtin_amdgcn_readfirstlane(rc.n_at[b]);
+    uint32_t j0, j1;
+    chunk_range(N, NC, c, j0, j1);
+    const bool live = k < nb && rc.q_vid[k < nb ? k : 0] >= 0;
+    const double qx = live ? rc.q_x[k] : 0.0, qy = live ? rc.q_y[k] : 0.0;
+    // rrt.rs:121 uses the size before insertion, pto.rs:88 after it
+    const double T2s = rc.rad_T2[N + (rc.mode == 1 ? 1u : 0u)];
+    const double T2 = live ? T2s : -1.0;
+    uint32_t *cand_cnt = rc.cand_cnt;
+    int *cand_id = rc.cand_id;
+    const uint32_t cap = rc.cand_cap;
+    Counters *cnt = rc.cnt;
+    scan_chunk(as_const(rc.nx), as_const(rc.ny), j0, j1, qx, qy,
+               [&](double d2) { return d2 <= T2; },
+               [&](uint32_t j, double) {
+                   uint32_t slot = atomicAdd(&cand_cnt[k], 1u);
+                   if (slot < cap) cand_id[(size_t)k * cap + slot] = (int)j;
+                   else atomicOr(&cnt->err, ERR_CAND_OVERFLOW);
+               });
+}
+
+// ------------------------------------------------------------------ connect
+__device__ __forceinline__ uint32_t rank_before(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k) {
+    uint32_t r = 0;
+    const unsigned long long *vm = rc.valid_mask + (size_t)b * vwords;
+    for (uint32_t w = 0; w < (k >> 6); ++w) r += __popcll(vm[w]);
+    r += __popcll(vm[k >> 6] & ((1ull << (k & 63u)) - 1ull));
+    return r;
+}
+
+__device__ __forceinline__ void load_grid_lds(const RunConst &rc, uint8_t *lds, bool use_lds) {
+    if (!use_lds) return;
+    const uint32_t n = rc.W * rc.H;
+    const uint32_t n16 = n >> 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(rc.cls);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    for (uint32_t t = threadIdx.x; t < n16; t += blockDim.x) dst[t] = src[t];
+    for (uint32_t t = (n16 << 4) + threadIdx.x; t < n; t += blockDim.x) lds[t] = rc.cls[t];
+}
+
+template <class T>
+__device__ __forceinline__ T wave_min_u(T v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        T o = __shfl_xor(v, off);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off);
+    return v;
+}
+
+// left of node w at tree depth `depth` (nearest_neighbor.rs:32: state[axis] < current.state[axis])
+__device__ __forceinline__ bool kd_left(double x, double y, double wx, double wy, uint32_t depth) {
+    return (depth & 1u) ? (y < wy) : (x < wx);
+}
+
+// RRT*: validated neighbours, best parent, new node, rewire phase 1.  One wave per sample.
+template <bool LDSGRID>
+__global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
+                                                                     uint32_t vwords) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_grid[];
+    const RunConst &rc = *rcp;
+    load_grid_lds(rc, lds_grid, LDSGRID && rc.has_grid);
+    __syncthreads();
+    const uint8_t *grid = (LDSGRID && rc.has_grid) ? (const uint8_t *)lds_grid : rc.cls;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t k = blockIdx.x * kConnectWaves + (threadIdx.x >> 6);
+    if (k >= nb || rc.q_vid[k] < 0) return;
+    const uint32_t N = rc.n_at[b];
+    const uint32_t id = N + rank_before(rc, b, vwords, k);
+    const double px = rc.q_x[k], py = rc.q_y[k];
+    const uint32_t cnt = rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap;
+    int *cid = rc.cand_id + (size_t)k * rc.cand_cap;
+    double *cval = rc.cand_val + (size_t)k * rc.cand_cap;
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    uint32_t err = 0;
+
+    // pass 1: raycast every neighbour, total cost through it (rrt.rs:124, 137-140)
+    double bt = INF;
+    int bj = 0x7FFFFFFF;
+    uint32_t nvalid = 0;
+    for (uint32_t a = lane; a < cnt; a += 64) {
+        const int j = cid[a];
+        const double ax = rc.nx[j], ay = rc.ny[j];
+        const double cost = sqrt(dist2(ax, ay, px, py));
+        bool ok = true;
+        if (rc.has_grid) ok = traversed_class(rc, grid, ax, ay, px, py, &err) == CLS_FREE;
+        cval[a] = ok ? cost : -1.0;
+        if (ok) {
+            ++nvalid;
+            const double total = rc.distA[j] + cost;
+            if (total < bt || (total == bt && j < bj)) { bt = total; bj = j; }
+        }
+    }
+    nvalid = wave_sum(nvalid);
+    for (int off = 32; off > 0; off >>= 1) {
+        double t = __shfl_xor(bt, off);
+        int j = __shfl_xor(bj, off);
+        if (t < bt || (t == bt && j < bj)) { bt = t; bj = j; }
+    }
+    int best;
+    double best_cost, dnew;
+    if (nvalid == 0) {
+        // rrt.rs:132-134: fall back to the nearest node, not collision-checked
+        best = rc.q_nn[k];
+        best_cost = sqrt(dist2(rc.nx[best], rc.ny[best], px, py));
+        dnew = rc.distA[best] + best_cost;
+    } else {
+        // equal totals: the reference keeps the first in kd-tree pre-order (rrt.rs:143-145)
+        uint32_t n_tie = 0, n_other = 0;
+        int a_min = 0x7FFFFFFF, p_min = 0x7FFFFFFF;
+        for (uint32_t a = lane; a < cnt; a += 64) {
+            const double cost = cval[a];
+            if (cost >= 0.0) {
+                const int j = cid[a];
+                if (rc.distA[j] + cost == bt) {
+                    ++n_tie;
+                    if (rc.nx[j] == px && rc.ny[j] == py) a_min = j < a_min ? j : a_min;
+                    else { ++n_other; p_min = j < p_min ? j : p_min; }
+                }
+            }
+        }
+        n_tie = wave_sum(n_tie);
+        best = bj;
+        if (n_tie > 1) {
+            n_other = wave_sum(n_other);
+            a_min = wave_min_u(a_min);
+            p_min = wave_min_u(p_min);
+            if (n_other == 0) {
+                best = a_min;   // same position: the earlier node is a kd ancestor of the later ones
+            } else if (n_other == 1 && a_min != 0x7FFFFFFF && px == rc.gp_x && py == rc.gp_y) {
+                // one node P elsewhere + duplicates of the goal point: place P against the goal path G
+                const uint32_t glen = rc.cnt->g_len;
+                const double qx = rc.nx[p_min], qy = rc.ny[p_min];
+                uint32_t idxW = 0xFFFFFFFFu, idxA = 0xFFFFFFFFu;
+                for (uint32_t i = lane; i < glen; i += 64) {
+                    const int w = rc.g_id[i];
+                    const double wx = rc.nx[w], wy = rc.ny[w];
+                    const bool sep = (w == p_min) || (kd_left(qx, qy, wx, wy, i) != kd_left(px, py, wx, wy, i));
+                    if (sep && i < idxW) idxW = i;
+                    if (w == a_min) idxA = i;
+                }
+                idxW = wave_min_u(idxW);
+                idxA = wave_min_u(idxA);
+                if (idxW == 0xFFFFFFFFu || idxA == 0xFFFFFFFFu) {
+                    if (lane == 0) atomicAdd(&rc.cnt->tie_fallbacks, 1u);
+                } else if (idxA <= idxW) {
+                    best = a_min;                       // a_min is an ancestor-or-self of the split node
+                } else {
+                    const int w = rc.g_id[idxW];
+                    const bool p_first = (w == p_min) || kd_left(qx, qy, rc.nx[w], rc.ny[w], idxW);
+                    best = p_first ? p_min : a_min;
+                }
+            } else {
+                if (lane == 0) atomicAdd(&rc.cnt->tie_fallbacks, 1u);
+            }
+        }
+        best_cost = sqrt(dist2(rc.nx[best], rc.ny[best], px, py));
+        dnew = rc.distA[best] + best_cost;
+    }
+
+    // new node (rrt.rs:148, 30-37) and goal test (rrt.rs:165-167)
+    if (lane == 0) {
+        rc.nx[id] = px;
+        rc.ny[id] = py;
+        rc.parent[id] = best;
+        rc.distA[id] = dnew;
+        rc.distB[id] = dnew;
+        unsigned long long mask = 0;
+        const bool fin = goal_hit(rc, grid, px, py, mask, &err);
+        rc.final_flag[id] = fin ? 1 : 0;
+        rc.final_mask[id] = fin ? mask : 0ull;
+        if (fin) atomicAdd(&rc.cnt->n_final, 1u);
+    }
+    // rewire phase 1 (rrt.rs:152-161): dist_root candidates, min wins
+    for (uint32_t a = lane; a < cnt; a += 64) {
+        const double cost = cval[a];
+        const int j = cid[a];
+        int keep = -1;
+        if (nvalid != 0 && cost >= 0.0 && j != best) {
+            const double via = dnew + cost;
+            if (via < rc.distA[j]) {
+                atomicMin(reinterpret_cast<unsigned long long *>(&rc.distB[j]), f64_bits(via));
+                cval[a] = via;
+                keep = j;
+            }
+        }
+        cid[a] = keep;
+    }
+    if (err) atomicOr(&rc.cnt->err, err);
+}
+
+// RRT*: rewire phase 2.  A pair wins iff its candidate equals the accumulated minimum; among equal
+// candidates the lowest new id wins (sequential order of the reference, strict `<`, rrt.rs:157).
+__global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
+    const RunConst &rc = *rcp;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t k = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t N = rc.n_at[b];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t add = 0;
+        for (uint32_t w = 0; w < vwords; ++w) add += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
+        rc.n_at[b + 1] = N + add;
+    }
+    if (k >= nb || rc.q_vid[k] < 0) return;
+    const int id = (int)(N + rank_before(rc, b, vwords, k));
+    const uint32_t cnt = rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap;
+    const int *cid = rc.cand_id + (size_t)k * rc.cand_cap;
+    const double *cval = rc.cand_val + (size_t)k * rc.cand_cap;
+    for (uint32_t a = lane; a < cnt; a += 64) {
+        const int j = cid[a];
+        if (j < 0) continue;
+        const double via = cval[a];
+        if (f64_bits(via) != f64_bits(rc.distB[j])) continue;
+        int old = rc.parent[j];
+        while (old < (int)N || id < old) {      // parents from before this step are always < N
+            const int seen = atomicCAS(&rc.parent[j], old, id);
+            if (seen == old) break;
+            old = seen;
+        }
+        rc.distA[j] = via;
+    }
+}
+
+// Extend the kd descent path of the goal point with this step's nodes (sequential insertion order).
+__global__ __launch_bounds__(1024) void k_goal_path(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
+    const RunConst &rc = *rcp;
+    __shared__ int s_min;
+    __shared__ uint32_t s_len;
+    const uint32_t N = rc.n_at[b];
+    if (threadIdx.x == 0) s_len = rc.cnt->g_len;
+    __syncthreads();
+    const uint32_t glen0 = s_len;
+    const double px = rc.gp_x, py = rc.gp_y;
+    // a node joins the path only if it falls on the goal point's side at every node of the path
+    constexpr int kPer = 4;   // supports batch_K up to 4096
+    bool agree[kPer];
+    double vx[kPer], vy[kPer];
+    int vidn[kPer];
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+        const uint32_t k = threadIdx.x + r * 1024u;
+        agree[r] = k < nb && rc.q_vid[k < nb ? k : 0] >= 0;
+        vx[r] = agree[r] ? rc.q_x[k] : 0.0;
+        vy[r] = agree[r] ? rc.q_y[k] : 0.0;
+        vidn[r] = agree[r] ? (int)(N + rank_before(rc, b, vwords, k)) : 0x7FFFFFFF;
+    }
+    for (uint32_t i = 0; i < glen0; ++i) {
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < kPer; ++r) any |= agree[r];
+        if (!__syncthreads_or(any)) break;
+        const int w = rc.g_id[i];
+        const double wx = rc.nx[w], wy = rc.ny[w];
+        const bool gl = kd_left(px, py, wx, wy, i);
+#pragma unroll
+        for (int r = 0; r < kPer; ++r) agree[r] = agree[r] && (kd_left(vx[r], vy[r], wx, wy, i) == gl);
+    }
+    uint32_t glen = glen0;
+    for (;;) {
+        if (threadIdx.x == 0) s_min = 0x7FFFFFFF;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kPer; ++r)
+            if (agree[r]) atomicMin(&s_min, vidn[r]);
+        __syncthreads();
+        const int w = s_min;
+        __syncthreads();
+        if (w == 0x7FFFFFFF) break;
+        if (glen >= rc.g_cap) {
+            if (threadIdx.x == 0) atomicOr(&rc.cnt->err, ERR_GPATH_OVERFLOW);
+            break;
+        }
+        if (threadIdx.x == 0) rc.g_id[glen] = w;
+        // w's coordinates were written by k_connect_rrt of this step
+        const double wx = rc.nx[w], wy = rc.ny[w];
+        const bool gl = kd_left(px, py, wx, wy, glen);
+#pragma unroll
+        for (int r = 0; r < kPer; ++r)
+            agree[r] = agree[r] && vidn[r] != w && (kd_left(vx[r], vy[r], wx, wy, glen) == gl);
+        ++glen;
+    }
+    if (threadIdx.x == 0) rc.cnt->g_len = glen;
+}
+
+// PTO: edges to every neighbour with a valid transition, reachability phase 1 and 2 (pto.rs:95-124)
+template <bool LDSGRID>
+__global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
+                                                                     uint32_t vwords) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_grid[];
+    const RunConst &rc = *rcp;
+    load_grid_lds(rc, lds_grid, LDSGRID);
+    __syncthreads();
+    const uint8_t *grid = LDSGRID ? (const uint8_t *)lds_grid : rc.cls;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t k = blockIdx.x * kConnectWaves + (threadIdx.x >> 6);
+    if (k >= nb || rc.q_vid[k] < 0) return;
+    const uint32_t N = rc.n_at[b];
+    const uint32_t id = N + rank_before(rc, b, vwords, k);
+    const double px = rc.q_x[k], py = rc.q_y[k];
+    uint32_t cnt = rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap;
+    int *cid = rc.cand_id + (size_t)k * rc.cand_cap;
+    double *cval = rc.cand_val + (size_t)k * rc.cand_cap;
+    if (cnt == 0) {                       // pto.rs:99: nobody in range -> the nearest node
+        if (lane == 0) { cid[0] = rc.q_nn[k]; rc.cand_cnt[k] = 1; }   // lane 0 is also the only reader of slot 0
+        cnt = 1;
+    }
+    uint32_t err = 0;
+    unsigned long long r_new = 0;
+    uint32_t n_edges = 0;
+    for (uint32_t a = lane; a < cnt; a += 64) {
+        const int j = cid[a];
+        const int cls = traversed_class(rc, grid, rc.nx[j], rc.ny[j], px, py, &err);
+        const int tv = class_to_validity(rc, cls);
+        cval[a] = (double)tv;
+        if (tv >= 0) {
+            r_new |= rc.reachA[j] & rc.validities[tv];      // pto.rs:111-114, pto_reachability.rs:42-52
+            ++n_edges;
+        }
+    }
+    r_new = wave_or(r_new);
+    // edge slots: one atomic per wave, lanes take consecutive slots
+    uint32_t lane_off = n_edges;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t v = __shfl_up(lane_off, off);
+        if ((int)lane >= off) lane_off += v;
+    }
+    const uint32_t total = __shfl(lane_off, 63);
+    uint32_t base = 0;
+    if (lane == 0 && total) base = atomicAdd(&rc.cnt->n_edges, total);
+    base = __shfl(base, 0);
+    uint32_t slot = base + lane_off - n_edges;
+    for (uint32_t a = lane; a < cnt; a += 64) {
+        const int tv = (int)cval[a];
+        const int j = cid[a];
+        if (tv >= 0) {
+            if (slot < rc.e_cap) {
+                rc.e_from[slot] = (uint32_t)j;
+                rc.e_to[slot] = id;
+                rc.e_tv[slot] = (uint32_t)tv;
+            } else {
+                err |= ERR_EDGE_OVERFLOW;
+            }
+            ++slot;
+            atomicOr(&rc.reachB[j], r_new & rc.validities[tv]);   // pto.rs:117-120
+        }
+    }
+    if (lane == 0) {
+        rc.nx[id] = px;
+        rc.ny[id] = py;
+        rc.parent[id] = -1;
+        rc.distA[id] = 0.0;
+        rc.distB[id] = 0.0;
+        rc.vid[id] = (uint8_t)rc.q_vid[k];
+        rc.reachA[id] = r_new;
+        rc.reachB[id] = r_new;
+        unsigned long long mask = 0;
+        const bool fin = goal_hit(rc, grid, px, py, mask, &err);
+        rc.final_flag[id] = fin ? 1 : 0;
+        rc.final_mask[id] = fin ? mask : 0ull;
+        if (fin) {
+            atomicAdd(&rc.cnt->n_final, 1u);
+            atomicOr(&rc.cnt->finality, r_new & mask);
+        }
+    }
+    if (err) atomicOr(&rc.cnt->err, err);
+}
+
+// PTO: publish the reach masks touched in this step and refresh the finality (pto_reachability.rs:92-101)
+__global__ __launch_bounds__(256) void k_commit_pto(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
+    const RunConst &rc = *rcp;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t k = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t N = rc.n_at[b];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t add = 0;
+        for (uint32_t w = 0; w < vwords; ++w) add += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
+        rc.n_at[b + 1] = N + add;
+    }
+    if (k >= nb || rc.q_vid[k] < 0) return;
+    const uint32_t cnt = rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap;
+    const int *cid = rc.cand_id + (size_t)k * rc.cand_cap;
+    const double *cval = rc.cand_val + (size_t)k * rc.cand_cap;
+    for (uint32_t a = lane; a < cnt; a += 64) {
+        if ((int)cval[a] < 0) continue;
+        const int j = cid[a];
+        const unsigned long long r = rc.reachB[j];
+        rc.reachA[j] = r;
+        if (rc.final_flag[j]) atomicOr(&rc.cnt->finality, r & rc.final_mask[j]);
+    }
+}
+
+} // namespace porrt

@@ -1,0 +1,1031 @@
+// porrt_engine.hip -- host side of libporrt_hip.so: context, domain preprocessing, the batched growth
+// loop (launch schedule of the kernels in porrt_device.hpp) and the C ABI of include/porrt_hip.h.
+//
+// The host mirrors what the reference does OUTSIDE its per-iteration work:
+//   - MapShelfDomain::build/add_zones (src/map_shelves_io.rs:88-148), Map::build/add_zones
+//     (src/map_io.rs:90-161): ppm, zone centroids, worlds, world validities;
+//   - the loop condition and batching of RRT::grow_tree (src/rrt.rs:109) / PTO::grow_graph (src/pto.rs:67);
+//   - heuristic_radius (src/common.rs:357-369) with the platform libm, tabulated per tree size;
+//   - the sampler state that persists across plans (src/sample_space.rs, tamp_rrt.rs:196-232);
+//   - get_best_solution / get_path_to / get_path_cost (src/rrt.rs:183-193, 48-61, 223-227).
+// No CPU fallback exists: without a HIP device porrt_create() fails.
+#include "../../include/porrt_hip.h"
+#include "porrt_device.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace porrt;
+typedef unsigned __int128 u128;
+
+namespace {
+
+#define HIPCHK(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            set_err(std::string(#expr) + ": " + hipGetErrorString(e_));                            \
+            return PORRT_ERR_DEVICE;                                                               \
+        }                                                                                          \
+    } while (0)
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- rand_pcg 0.3 Pcg64 (Lcg128Xsl64) + rand_core 0.6 seed_from_u64 + rand 0.8 gen_range on the host.
+// The device generates the continuous stream (k_gen_samples); the host keeps the authoritative state,
+// draws the rejection-sampled world indices and is the exact fallback when a float draw would retry.
+const u128 PCG_MULT = (((u128)0x2360ED051FC65DA4ULL) << 64) | (u128)0x4385DF649FCCF645ULL;
+struct Pcg64 {
+    u128 state, inc;
+    void from_state_incr(u128 s, u128 i) {
+        state = s; inc = i;
+        state += inc;
+        step();
+    }
+    void step() { state = state * PCG_MULT + inc; }
+    void seed_from_u64(uint64_t s) {
+        const uint64_t MUL = 6364136223846793005ULL, INC = 11634580027462260723ULL;
+        uint32_t w[8];
+        for (int c = 0; c < 8; ++c) {
+            s = s * MUL + INC;
+            uint32_t xs = (uint32_t)(((s >> 18) ^ s) >> 27), rot = (uint32_t)(s >> 59);
+            w[c] = (xs >> rot) | (xs << ((32 - rot) & 31));
+        }
+        uint64_t q[4];
+        for (int i = 0; i < 4; ++i) q[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+        from_state_incr((u128)q[0] | ((u128)q[1] << 64), ((u128)q[2] | ((u128)q[3] << 64)) | 1);
+    }
+    uint64_t next_u64() {
+        step();
+        uint32_t rot = (uint32_t)(state >> 122);
+        uint64_t xsl = (uint64_t)(state >> 64) ^ (uint64_t)state;
+        return (xsl >> rot) | (xsl << ((64 - rot) & 63));
+    }
+    void advance(u128 delta) {
+        u128 am = 1, ap = 0, cm = PCG_MULT, cp = inc;
+        while (delta > 0) {
+            if (delta & 1) { am *= cm; ap = ap * cm + cp; }
+            cp = (cm + 1) * cp;
+            cm *= cm;
+            delta >>= 1;
+        }
+        state = am * state + ap;
+    }
+    double gen_range_f64(double low, double high) {
+        double scale = high - low;
+        for (;;) {
+            uint64_t bits = (next_u64() >> 12) | 0x3FF0000000000000ULL;
+            double v12;
+            memcpy(&v12, &bits, 8);
+            volatile double prod = (v12 - 1.0) * scale;
+            double res = prod + low;
+            if (res < high) return res;
+        }
+    }
+    uint64_t gen_range_usize(uint64_t n) {
+        if (n == 0) return next_u64();
+        uint64_t zone = (n << __builtin_clzll(n)) - 1;
+        for (;;) {
+            u128 m = (u128)next_u64() * (u128)n;
+            if ((uint64_t)m <= zone) return (uint64_t)(m >> 64);
+        }
+    }
+};
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t reserve(size_t want) {
+        if (want <= n) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+uint64_t ones(int n) { return n >= 64 ? ~0ULL : ((1ULL << n) - 1); }
+
+} // namespace
+
+struct porrt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    void set_err(const std::string &s) { err = s; }
+
+    // ---- domain (host copies)
+    std::vector<uint8_t> occ, zones, cls;
+    uint32_t W = 0, H = 0;
+    double low[2] = {0, 0}, ppm = 0;
+    int domain = 0;
+    bool has_grid = false, cls_dirty = true;
+    double visibility = 0;
+    int n_zones = 0, n_worlds = 1, n_validities = 1;
+    double zone_pos[64][2];
+    uint64_t validities[65];
+    // ---- samplers
+    double s_low[2] = {-1, -1}, s_up[2] = {1, 1};
+    Pcg64 crng, drng;
+    std::vector<double> inj_xy;
+    size_t inj_pos = 0;
+    bool has_inj = false, inj_dirty = false;
+    std::vector<uint32_t> inj_worlds;
+    size_t inj_wpos = 0;
+    bool has_inj_worlds = false;
+    // ---- goal
+    int goal_kind = 0;
+    uint32_t G = 0;
+    double gcx[64], gcy[64];
+    uint64_t gmask[64];
+    double g_l1 = 0;
+    double w2g[64][2];
+    uint32_t obs_zone = 0;
+    // ---- options
+    bool opt_profile = false;
+    bool opt_graph = false;
+    uint32_t opt_cand_cap = 2048;
+    // ---- device buffers
+    DevBuf<double> d_nx, d_ny, d_distA, d_distB, d_sx, d_sy, d_qx, d_qy, d_partD, d_candval, d_radT2, d_inj;
+    DevBuf<int> d_parent, d_qnn, d_qvid, d_partid, d_candid, d_gid;
+    DevBuf<unsigned long long> d_reachA, d_reachB, d_finalmask, d_validmask;
+    DevBuf<uint8_t> d_vid, d_finalflag, d_cls;
+    DevBuf<uint32_t> d_nat, d_sworld, d_candcnt, d_efrom, d_eto, d_etv;
+    DevBuf<Counters> d_cnt;
+    DevBuf<RunConst> d_rc;
+    DevBuf<PcgJump> d_jump;
+    // radius table cache
+    std::vector<double> radT2;
+    double rad_max_step = -1, rad_search_radius = -1;
+    int rad_mode = -1;
+    size_t rad_uploaded = 0;
+    // ---- run state / results
+    RunConst rc;
+    int mode = 0;
+    uint64_t n_iter = 0, n_nodes = 0, n_steps = 0;
+    Counters counters;
+    bool complete = false;
+    bool have_results = false, downloaded = false;
+    std::vector<double> h_nx, h_ny, h_dist;
+    std::vector<int> h_parent;
+    std::vector<unsigned long long> h_reach, h_finalmask;
+    std::vector<uint8_t> h_vid, h_finalflag;
+    std::vector<uint64_t> h_final_ids;
+    std::vector<uint32_t> h_efrom, h_eto, h_etv;
+    porrt_metrics metrics;
+    std::vector<hipEvent_t> ev_pool;
+
+    int build_cls();
+    int ensure_radius_table(double max_step, double search_radius, size_t n_needed);
+    int grow(const double start[2], double max_step, double search_radius, uint64_t n_iter_min, uint64_t n_iter_max,
+             uint32_t K, int mode);
+    int grow_once(const double start[2], double max_step, double search_radius, uint64_t n_iter_min, uint64_t n_iter_max,
+                  uint32_t K, int mode, bool host_samples);
+    int download();
+    void launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, size_t lds_bytes, bool prof, size_t &ev_used);
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Pre-classified raster: one byte per pixel holding what the raycast needs (map_shelves_io.rs:150-156;
+// map_io.rs:165-174,190-196).
+int porrt_ctx::build_cls() {
+    if (!has_grid) return PORRT_OK;
+    if (!cls_dirty) return PORRT_OK;
+    size_t n = (size_t)W * H;
+    cls.resize(n);
+    for (size_t p = 0; p < n; ++p) {
+        uint8_t v = occ[p];
+        uint8_t c;
+        if (domain == PORRT_DOMAIN_SHELF) {
+            c = v == 255 ? CLS_FREE : (v >= 127 ? CLS_LOW : (v == 0 ? CLS_HIGH0 : CLS_HIGH));
+        } else {
+            if (v == 255) c = CLS_FREE;
+            else if (v == 0) c = CLS_HIGH0;
+            else if (zones.empty() || zones[p] == 255 || zones[p] >= 64) c = CLS_BAD;
+            else c = (uint8_t)(CLS_ZONE + zones[p]);
+        }
+        cls[p] = c;
+    }
+    HIPCHK(d_cls.reserve(n + 16));
+    HIPCHK(hipMemcpyAsync(d_cls.p, cls.data(), n, hipMemcpyHostToDevice, stream));
+    cls_dirty = false;
+    return PORRT_OK;
+}
+
+// heuristic_radius(n) (src/common.rs:357-369, platform libm as Rust's f64::ln/powf) turned into the exact
+// threshold on the squared distance: norm2 <= radius  <=>  d2 <= T2 with T2 = max{t : sqrt(t) <= radius}.
+int porrt_ctx::ensure_radius_table(double max_step, double search_radius, size_t n_needed) {
+    if (max_step != rad_max_step || search_radius != rad_search_radius) {
+        radT2.clear();
+        rad_uploaded = 0;
+        rad_max_step = max_step;
+        rad_search_radius = search_radius;
+    }
+    size_t have = radT2.size();
+    if (have < n_needed) {
+        radT2.resize(n_needed);
+        for (size_t n = have; n < n_needed; ++n) {
+            double nn = (double)n;
+            double s = search_radius * pow(log(nn) / nn, 1.0 / 2.0);
+            double r = s < max_step ? s : max_step;
+            double t;
+            if (!(r >= 0.0)) {
+                t = -1.0;   // n = 0 is never used
+            } else {
+                t = r * r;
+                while (sqrt(nextafter(t, INFINITY)) <= r) t = nextafter(t, INFINITY);
+                while (t > 0.0 && sqrt(t) > r) t = nextafter(t, -INFINITY);
+            }
+            radT2[n] = t;
+        }
+    }
+    if (d_radT2.n < n_needed) { set_err("radius table capacity"); return PORRT_ERR_INVALID; }
+    if (rad_uploaded < n_needed) {
+        HIPCHK(hipMemcpyAsync(d_radT2.p + rad_uploaded, radT2.data() + rad_uploaded, (n_needed - rad_uploaded) * sizeof(double),
+                              hipMemcpyHostToDevice, stream));
+        rad_uploaded = n_needed;
+    }
+    return PORRT_OK;
+}
+
+// IEEE check of the two non-trivial f64 operations the path relies on (sqrt, divide) against the host
+__global__ void k_selftest(const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out_sqrt,
+                           double *__restrict__ out_div, unsigned long long n) {
+    unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    out_sqrt[t] = sqrt(a[t]);
+    out_div[t] = a[t] / b[t];
+}
+
+__global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y, unsigned long long reach, int vid) {
+    const RunConst &rc = *rcp;
+    rc.nx[0] = x;
+    rc.ny[0] = y;
+    rc.parent[0] = -1;
+    rc.distA[0] = 0.0;
+    rc.distB[0] = 0.0;
+    rc.reachA[0] = reach;
+    rc.reachB[0] = reach;
+    rc.vid[0] = (uint8_t)vid;
+    rc.final_flag[0] = 0;
+    rc.final_mask[0] = 0;
+    rc.n_at[0] = 1;
+    rc.g_id[0] = 0;          // the root is on every kd descent path
+    rc.cnt->g_len = 1;
+}
+
+void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, size_t lds_bytes, bool prof, size_t &ev_used) {
+    // at most one node per iteration so far (+ root): bound on the tree size at the start of this step
+    const uint32_t n_ub = i0 + 1;
+    uint32_t NC = (n_ub + 127) / 128;
+    NC = std::max(1u, std::min<uint32_t>(NC, kMaxChunks));
+    const dim3 scan_grid((nb + kScanBlock - 1) / kScanBlock, NC);
+    const uint32_t wave_blocks = (nb * 64 + 255) / 256;
+    const RunConst *rcp = d_rc.p;
+    auto ev = [&](void) {
+        if (prof && ev_used < ev_pool.size()) (void)hipEventRecord(ev_pool[ev_used++], stream);
+    };
+    ev();
+    if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_nn_scan<true>, scan_grid, dim3(kScanBlock), 0, stream, rcp, b, i0, nb, NC);
+    else hipLaunchKernelGGL(k_nn_scan<false>, scan_grid, dim3(kScanBlock), 0, stream, rcp, b, i0, nb, NC);
+    ev();
+    hipLaunchKernelGGL(k_nn_reduce_steer, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, i0, nb, NC, vwords);
+    ev();
+    hipLaunchKernelGGL(k_radius_scan, scan_grid, dim3(kScanBlock), 0, stream, rcp, b, nb, NC);
+    ev();
+    const dim3 cgrid((nb + kConnectWaves - 1) / kConnectWaves), cblock(kConnectWaves * 64);
+    if (mode == PORRT_MODE_PTO) {
+        if (lds_bytes) hipLaunchKernelGGL(k_connect_pto<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
+        else hipLaunchKernelGGL(k_connect_pto<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
+        hipLaunchKernelGGL(k_commit_pto, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, nb, vwords);
+    } else {
+        if (lds_bytes) hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
+        else hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
+        hipLaunchKernelGGL(k_commit_rrt, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, nb, vwords);
+        hipLaunchKernelGGL(k_goal_path, dim3(1), dim3(1024), 0, stream, rcp, b, nb, vwords);
+    }
+}
+
+int porrt_ctx::grow(const double start[2], double max_step, double search_radius, uint64_t n_iter_min, uint64_t n_iter_max,
+                    uint32_t K, int mode_) {
+    if (K == 0 || K > 4096) { set_err("batch_K must be in 1..4096"); return PORRT_ERR_INVALID; }
+    if (mode_ != PORRT_MODE_RRT && mode_ != PORRT_MODE_PTO) { set_err("bad mode"); return PORRT_ERR_INVALID; }
+    if (mode_ == PORRT_MODE_PTO && !has_grid) { set_err("PTO mode needs a grid"); return PORRT_ERR_INVALID; }
+    if (n_iter_max < n_iter_min) n_iter_max = n_iter_min;
+    if (n_iter_max + 2 >= 0x7FFFFFF0ull) { set_err("n_iter_max too large"); return PORRT_ERR_INVALID; }
+    if (!(max_step > 0.0) || !(search_radius >= 0.0)) { set_err("max_step / search_radius"); return PORRT_ERR_INVALID; }
+    have_results = false;
+    downloaded = false;
+    // the sampler state must survive a capacity retry
+    const Pcg64 c0 = crng, d0 = drng;
+    const size_t ip0 = inj_pos, iw0 = inj_wpos;
+    bool host_samples = false;
+    for (int attempt = 0; attempt < 12; ++attempt) {
+        int rc_ = grow_once(start, max_step, search_radius, n_iter_min, n_iter_max, K, mode_, host_samples);
+        if (rc_ == -100) {          // neighbour list overflow: regrow the lists and replay
+            opt_cand_cap = (uint32_t)std::min<uint64_t>((uint64_t)opt_cand_cap * 4, n_iter_max + 2);
+        } else if (rc_ == -101) {   // a float draw would have retried: replay with the exact host stream
+            host_samples = true;
+        } else {
+            return rc_;
+        }
+        crng = c0; drng = d0; inj_pos = ip0; inj_wpos = iw0;
+    }
+    set_err("neighbour list capacity");
+    return PORRT_ERR_CAPACITY;
+}
+
+int porrt_ctx::grow_once(const double start[2], double max_step, double search_radius, uint64_t n_iter_min, uint64_t n_iter_max,
+                         uint32_t K, int mode_, bool host_samples) {
+    const double t_begin = now_s();
+    double t_setup = 0.0;
+    HIPCHK(hipSetDevice(device));
+    mode = mode_;
+    memset(&metrics, 0, sizeof metrics);
+
+    // ---- capacities
+    const uint64_t Nmax = n_iter_max + 2;
+    const uint64_t steps_max = n_iter_max / K + 4;
+    const uint32_t vwords = (K + 63) / 64;
+    const uint32_t cand_cap = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(opt_cand_cap, 64), Nmax);
+    {
+        double t0 = now_s();
+        HIPCHK(d_nx.reserve(Nmax)); HIPCHK(d_ny.reserve(Nmax)); HIPCHK(d_distA.reserve(Nmax)); HIPCHK(d_distB.reserve(Nmax));
+        HIPCHK(d_parent.reserve(Nmax)); HIPCHK(d_reachA.reserve(Nmax)); HIPCHK(d_reachB.reserve(Nmax));
+        HIPCHK(d_vid.reserve(Nmax)); HIPCHK(d_finalflag.reserve(Nmax)); HIPCHK(d_finalmask.reserve(Nmax));
+        HIPCHK(d_nat.reserve(steps_max + 2)); HIPCHK(d_validmask.reserve((steps_max + 2) * vwords));
+        HIPCHK(d_sx.reserve(n_iter_max + 1)); HIPCHK(d_sy.reserve(n_iter_max + 1)); HIPCHK(d_sworld.reserve(n_iter_max + 1));
+        HIPCHK(d_qx.reserve(K)); HIPCHK(d_qy.reserve(K)); HIPCHK(d_qnn.reserve(K)); HIPCHK(d_qvid.reserve(K));
+        HIPCHK(d_partD.reserve((size_t)K * kMaxChunks)); HIPCHK(d_partid.reserve((size_t)K * kMaxChunks));
+        HIPCHK(d_candcnt.reserve(K)); HIPCHK(d_candid.reserve((size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
+        HIPCHK(d_gid.reserve(Nmax));
+        if (d_radT2.n < Nmax + 8) { HIPCHK(d_radT2.reserve(Nmax + 8)); rad_uploaded = 0; }
+        HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_jump.reserve(1));
+        if (mode == PORRT_MODE_PTO) {
+            const uint64_t ecap = std::min<uint64_t>(Nmax * 256 + 4096, 1ull << 28);
+            HIPCHK(d_efrom.reserve(ecap)); HIPCHK(d_eto.reserve(ecap)); HIPCHK(d_etv.reserve(ecap));
+        }
+        int r = build_cls();
+        if (r) return r;
+        if (has_inj && inj_dirty) {
+            HIPCHK(d_inj.reserve(inj_xy.size() + 2));
+            HIPCHK(hipMemcpyAsync(d_inj.p, inj_xy.data(), inj_xy.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+            inj_dirty = false;
+        }
+        t_setup += now_s() - t0;
+    }
+
+    // ---- run constants
+    RunConst &c = rc;
+    memset(&c, 0, sizeof c);
+    c.nx = d_nx.p; c.ny = d_ny.p; c.distA = d_distA.p; c.distB = d_distB.p; c.parent = d_parent.p;
+    c.reachA = d_reachA.p; c.reachB = d_reachB.p; c.vid = d_vid.p; c.final_flag = d_finalflag.p; c.final_mask = d_finalmask.p;
+    c.n_at = d_nat.p; c.valid_mask = d_validmask.p; c.cnt = d_cnt.p;
+    c.sx = d_sx.p; c.sy = d_sy.p; c.sworld = d_sworld.p;
+    c.inj_xy = (has_inj && !host_samples) ? d_inj.p : nullptr;
+    c.inj_base = inj_pos; c.inj_n = inj_xy.size() / 2;
+    c.q_x = d_qx.p; c.q_y = d_qy.p; c.q_nn = d_qnn.p; c.q_vid = d_qvid.p;
+    c.part_D = d_partD.p; c.part_id = d_partid.p;
+    c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
+    c.rad_T2 = d_radT2.p;
+    c.e_from = d_efrom.p; c.e_to = d_eto.p; c.e_tv = d_etv.p; c.e_cap = (uint32_t)d_efrom.n;
+    c.g_id = d_gid.p; c.g_cap = (uint32_t)std::min<uint64_t>(d_gid.n, 0xFFFFFFFFull);
+    c.cls = d_cls.p; c.W = W; c.H = H; c.low0 = low[0]; c.low1 = low[1]; c.ppm = ppm; c.domain = domain; c.has_grid = has_grid;
+    c.n_validities = n_validities;
+    for (int i = 0; i < n_validities; ++i) c.validities[i] = validities[i];
+    c.all_worlds = ones(n_worlds);
+    c.goal_kind = goal_kind; c.G = G; c.g_l1 = g_l1;
+    for (uint32_t g = 0; g < G; ++g) { c.gcx[g] = gcx[g]; c.gcy[g] = gcy[g]; c.gmask[g] = gmask[g]; }
+    for (int w = 0; w < 64; ++w) { c.w2g_x[w] = w2g[w][0]; c.w2g_y[w] = w2g[w][1]; }
+    if (goal_kind == 2) { c.zone_x = zone_pos[obs_zone][0]; c.zone_y = zone_pos[obs_zone][1]; }
+    c.visibility = visibility;
+    // the point every 100th RRT* iteration re-adds (rrt.rs:176-181: goal_example(0))
+    if (goal_kind == 1) { c.gp_x = w2g[0][0]; c.gp_y = w2g[0][1]; }
+    else if (goal_kind == 2) { c.gp_x = c.zone_x; c.gp_y = c.zone_y; }
+    c.s_low0 = s_low[0]; c.s_low1 = s_low[1]; c.s_up0 = s_up[0]; c.s_up1 = s_up[1];
+    c.max_step = max_step; c.mode = mode;
+
+    // ---- root (rrt.rs:105-106 / pto.rs:61-64)
+    uint64_t root_reach = 0;
+    int root_vid = 0;
+    if (mode == PORRT_MODE_PTO) {
+        // state_validity(start) on the host raster (same arithmetic as the device)
+        volatile double ty = (start[1] - low[1]) * ppm;
+        double fi = (double)(H - 1) - ty;
+        volatile double fj = (start[0] - low[0]) * ppm;
+        auto as_u32 = [](double v) -> uint64_t { if (!(v == v) || v <= 0.0) return 0; if (v >= 4294967295.0) return 4294967295ull; return (uint64_t)v; };
+        uint64_t i = as_u32(fi), j = as_u32(fj);
+        if (i >= H || j >= W) { set_err("start outside the map"); return PORRT_ERR_RASTER; }
+        uint8_t cc = cls[i * W + j];
+        if (cc == CLS_BAD) { set_err("door pixel without zone id at the start"); return PORRT_ERR_RASTER; }
+        if (cc == CLS_FREE) root_vid = n_validities - 1;
+        else if (cc >= CLS_ZONE) root_vid = cc - CLS_ZONE;
+        else { set_err("Start from a valid state!"); return PORRT_ERR_INVALID_START; }
+        root_reach = validities[root_vid];
+    }
+
+    // ---- sampler jump tables for this grow
+    PcgJump jt;
+    {
+        u128 cm = PCG_MULT, cp = crng.inc;
+        for (int b = 0; b < 64; ++b) {
+            jt.mult_lo[b] = (uint64_t)cm; jt.mult_hi[b] = (uint64_t)(cm >> 64);
+            jt.plus_lo[b] = (uint64_t)cp; jt.plus_hi[b] = (uint64_t)(cp >> 64);
+            cp = (cm + 1) * cp;
+            cm *= cm;
+        }
+    }
+    const Pcg64 crng0 = crng;
+    {
+        double t0 = now_s();
+        HIPCHK(hipMemcpyAsync(d_rc.p, &c, sizeof c, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(d_jump.p, &jt, sizeof jt, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemsetAsync(d_cnt.p, 0, sizeof(Counters), stream));
+        HIPCHK(hipMemsetAsync(d_validmask.p, 0, (steps_max + 2) * vwords * sizeof(unsigned long long), stream));
+        t_setup += now_s() - t0;
+    }
+    hipLaunchKernelGGL(k_init_root, dim3(1), dim3(1), 0, stream, d_rc.p, start[0], start[1], (unsigned long long)root_reach, root_vid);
+
+    size_t lds_bytes = 0;
+    if (has_grid && (size_t)W * H <= kLdsGridMax) {
+        lds_bytes = ((size_t)W * H + 15) & ~(size_t)15;
+        if (lds_bytes > 48 * 1024) {
+            if (mode == PORRT_MODE_PTO) HIPCHK(hipFuncSetAttribute((const void *)k_connect_pto<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            else HIPCHK(hipFuncSetAttribute((const void *)k_connect_rrt<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        }
+    }
+
+    // profiling events
+    const bool prof = opt_profile;
+    size_t ev_used = 0;
+    if (prof) {
+        size_t want = (size_t)(steps_max + 2) * 4 + 4;
+        while (ev_pool.size() < want) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            ev_pool.push_back(e);
+        }
+    }
+    hipEvent_t ev_first, ev_last;
+    HIPCHK(hipEventCreate(&ev_first));
+    HIPCHK(hipEventCreate(&ev_last));
+
+    std::vector<uint32_t> worlds;
+    std::vector<double> hs_x, hs_y;
+    Pcg64 hs_rng = crng0;   // exact host stream (fallback)
+    // produce the samples of iterations [it0, it0+n) on the device buffers
+    auto make_samples = [&](uint64_t it0, uint64_t n) -> int {
+        double t0 = now_s();
+        if (mode == PORRT_MODE_PTO) {
+            worlds.resize(n);
+            for (uint64_t t = 0; t < n; ++t) {
+                if (has_inj_worlds) {
+                    if (inj_wpos >= inj_worlds.size()) { set_err("injected world stream exhausted"); return PORRT_ERR_INVALID; }
+                    worlds[t] = inj_worlds[inj_wpos++];
+                } else {
+                    worlds[t] = (uint32_t)drng.gen_range_usize((uint64_t)n_worlds);   // pto.rs:142
+                }
+                if (worlds[t] >= (uint32_t)n_worlds) { set_err("world index out of range"); return PORRT_ERR_INVALID; }
+            }
+            HIPCHK(hipMemcpyAsync(d_sworld.p + it0, worlds.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            if (!opt_graph) HIPCHK(hipStreamSynchronize(stream));   // `worlds` is reused by the next call
+        }
+        if (host_samples) {
+            hs_x.resize(n); hs_y.resize(n);
+            for (uint64_t t = 0; t < n; ++t) {
+                uint64_t it = it0 + t + 1;
+                if (it % 100 == 0) {
+                    uint32_t w = mode == PORRT_MODE_PTO ? worlds[t] : 0;
+                    if (goal_kind == 1) { hs_x[t] = w2g[w & 63][0]; hs_y[t] = w2g[w & 63][1]; }
+                    else if (goal_kind == 2) { hs_x[t] = zone_pos[obs_zone][0]; hs_y[t] = zone_pos[obs_zone][1]; }
+                    else { hs_x[t] = 0; hs_y[t] = 0; }
+                } else if (has_inj) {
+                    if (inj_pos >= inj_xy.size() / 2) { set_err("injected sample stream exhausted"); return PORRT_ERR_INVALID; }
+                    hs_x[t] = inj_xy[2 * inj_pos]; hs_y[t] = inj_xy[2 * inj_pos + 1];
+                    ++inj_pos;
+                } else {
+                    hs_x[t] = hs_rng.gen_range_f64(s_low[0], s_up[0]);
+                    hs_y[t] = hs_rng.gen_range_f64(s_low[1], s_up[1]);
+                }
+            }
+            HIPCHK(hipMemcpyAsync(d_sx.p + it0, hs_x.data(), n * sizeof(double), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(d_sy.p + it0, hs_y.data(), n * sizeof(double), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        } else {
+            hipLaunchKernelGGL(k_gen_samples, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const RunConst *)d_rc.p,
+                               (const PcgJump *)d_jump.p, (unsigned long long)it0, (unsigned long long)n,
+                               (unsigned long long)(uint64_t)crng0.state, (unsigned long long)(uint64_t)(crng0.state >> 64),
+                               (unsigned long long)(uint64_t)crng0.inc, (unsigned long long)(uint64_t)(crng0.inc >> 64), 0ull);
+        }
+        t_setup += now_s() - t0;
+        return PORRT_OK;
+    };
+
+    // ---- growth loop (rrt.rs:109 / pto.rs:67)
+    uint64_t i = 0;
+    uint32_t b = 0;
+    int rcode = PORRT_OK;
+    if (n_iter_min > 0) {
+        double t0 = now_s();
+        int r = ensure_radius_table(max_step, search_radius, n_iter_min + 4);
+        if (r) return r;
+        t_setup += now_s() - t0;
+        r = make_samples(0, n_iter_min);
+        if (r) return r;
+    }
+    HIPCHK(hipEventRecord(ev_first, stream));
+    while (i < n_iter_min) {
+        uint32_t nb = (uint32_t)std::min<uint64_t>(K, n_iter_min - i);
+        launch_step(b, (uint32_t)i, nb, vwords, lds_bytes, prof, ev_used);
+        i += nb;
+        ++b;
+    }
+    Counters hc;
+    auto read_counters = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(&hc, d_cnt.p, sizeof hc, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return PORRT_OK;
+    };
+    auto is_done = [&]() {
+        if (mode == PORRT_MODE_RRT) return hc.n_final > 0;                                       // rrt.rs:109
+        return hc.n_final > 0 && (hc.finality & c.all_worlds) == c.all_worlds;                    // pto_reachability.rs:81-90
+    };
+    {
+        int r = read_counters();
+        if (r) return r;
+    }
+    while (!is_done() && i < n_iter_max && !(hc.err & (ERR_CAND_OVERFLOW | ERR_RNG_RETRY))) {
+        uint32_t nb = (uint32_t)std::min<uint64_t>(K, n_iter_max - i);
+        double t0 = now_s();
+        int r = ensure_radius_table(max_step, search_radius, i + nb + 4);
+        if (r) return r;
+        t_setup += now_s() - t0;
+        r = make_samples(i, nb);
+        if (r) return r;
+        launch_step(b, (uint32_t)i, nb, vwords, lds_bytes, prof, ev_used);
+        i += nb;
+        ++b;
+        r = read_counters();
+        if (r) return r;
+    }
+    HIPCHK(hipEventRecord(ev_last, stream));
+    uint32_t n_final_nodes = 0;
+    HIPCHK(hipMemcpyAsync(&n_final_nodes, d_nat.p + b, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_err(std::string("kernel launch: ") + hipGetErrorString(e)); return PORRT_ERR_DEVICE; }
+    }
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev_first, ev_last));
+    (void)hipEventDestroy(ev_first);
+    (void)hipEventDestroy(ev_last);
+
+    if (hc.err & ERR_CAND_OVERFLOW) return -100;
+    if (hc.err & ERR_RNG_RETRY) {
+        if (has_inj) { set_err("injected sample stream exhausted"); return PORRT_ERR_INVALID; }
+        return -101;
+    }
+    counters = hc;
+    n_iter = i;
+    n_steps = b;
+    n_nodes = n_final_nodes;
+    complete = mode == PORRT_MODE_PTO ? is_done() : hc.n_final > 0;
+    have_results = true;
+    downloaded = false;
+
+    // advance the persistent sampler state by what this grow consumed
+    const uint64_t calls = i - i / 100;
+    if (host_samples) { if (!has_inj) crng = hs_rng; }
+    else if (has_inj) inj_pos += calls;
+    else crng.advance((u128)2 * calls);
+
+    metrics.n_iter = n_iter;
+    metrics.n_nodes = n_nodes;
+    metrics.n_steps = n_steps;
+    metrics.n_tie_fallbacks = hc.tie_fallbacks + ((hc.err & ERR_GPATH_OVERFLOW) ? 1 : 0);
+    metrics.device_s = ms * 1e-3;
+    if (prof) {
+        // events were recorded around nn_scan [0,1], reduce [1,2], radius_scan [2,3] of every step
+        std::vector<uint32_t> nat(b + 1);
+        HIPCHK(hipMemcpy(nat.data(), d_nat.p, (b + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        double scan = 0, pairs = 0, bytes = 0;
+        uint64_t launches = 0;
+        uint64_t it = 0;
+        for (uint32_t s = 0; s < b && (size_t)(4 * s + 3) < ev_used; ++s) {
+            float a = 0, r2 = 0;
+            (void)hipEventElapsedTime(&a, ev_pool[4 * s + 0], ev_pool[4 * s + 1]);
+            (void)hipEventElapsedTime(&r2, ev_pool[4 * s + 2], ev_pool[4 * s + 3]);
+            scan += (a + r2) * 1e-3;
+            launches += 2;
+            uint64_t nbq = std::min<uint64_t>(K, (it < n_iter_min ? n_iter_min : n_iter_max) - it);
+            it += nbq;
+            pairs += 2.0 * (double)nbq * (double)nat[s];
+            bytes += 2.0 * (16.0 * (double)nat[s] + 28.0 * (double)nbq);
+        }
+        metrics.scan_s = scan;
+        metrics.scan_launches = launches;
+        metrics.scan_pairs = pairs;
+        metrics.scan_bytes = bytes;
+    }
+    metrics.setup_s = t_setup;
+    metrics.total_s = now_s() - t_begin;
+
+    if (hc.err & ERR_RASTER) { set_err("raster access outside the map, door pixel without zone id, or two zones on one segment (the reference panics here)"); return PORRT_ERR_RASTER; }
+    if (hc.err & ERR_EDGE_OVERFLOW) { set_err("edge pool overflow"); return PORRT_ERR_CAPACITY; }
+    if (mode == PORRT_MODE_PTO && !complete) { set_err("final nodes are not reached for each world"); rcode = PORRT_INCOMPLETE; }
+    return rcode;
+}
+
+int porrt_ctx::download() {
+    if (!have_results) { set_err("no results: call porrt_grow first"); return PORRT_ERR_INVALID; }
+    if (downloaded) return PORRT_OK;
+    HIPCHK(hipSetDevice(device));
+    const size_t N = n_nodes;
+    h_nx.resize(N); h_ny.resize(N); h_dist.resize(N); h_parent.resize(N); h_reach.resize(N); h_finalmask.resize(N);
+    h_vid.resize(N); h_finalflag.resize(N);
+    HIPCHK(hipMemcpy(h_nx.data(), d_nx.p, N * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h_ny.data(), d_ny.p, N * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h_dist.data(), d_distA.p, N * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h_parent.data(), d_parent.p, N * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h_reach.data(), d_reachA.p, N * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h_finalmask.data(), d_finalmask.p, N * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h_vid.data(), d_vid.p, N, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h_finalflag.data(), d_finalflag.p, N, hipMemcpyDeviceToHost));
+    h_final_ids.clear();
+    for (size_t j = 0; j < N; ++j)
+        if (h_finalflag[j]) h_final_ids.push_back(j);   // ascending id == push order of the reference
+    if (mode == PORRT_MODE_PTO) {
+        const size_t E = counters.n_edges;
+        std::vector<uint32_t> f(E), t(E), v(E);
+        if (E) {
+            HIPCHK(hipMemcpy(f.data(), d_efrom.p, E * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(t.data(), d_eto.p, E * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(v.data(), d_etv.p, E * 4, hipMemcpyDeviceToHost));
+        }
+        std::vector<uint32_t> order(E);
+        for (size_t e = 0; e < E; ++e) order[e] = (uint32_t)e;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b2) {
+            return t[a] != t[b2] ? t[a] < t[b2] : f[a] < f[b2];
+        });
+        h_efrom.resize(E); h_eto.resize(E); h_etv.resize(E);
+        for (size_t e = 0; e < E; ++e) { h_efrom[e] = f[order[e]]; h_eto[e] = t[order[e]]; h_etv[e] = v[order[e]]; }
+    } else {
+        h_efrom.clear(); h_eto.clear(); h_etv.clear();
+    }
+    downloaded = true;
+    return PORRT_OK;
+}
+
+// ========================================================================================== C ABI
+extern "C" {
+
+porrt_ctx *porrt_create(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    porrt_ctx *c = new porrt_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    c->crng.seed_from_u64(0);   // sample_space.rs:18
+    c->drng.seed_from_u64(0);   // sample_space.rs:47
+    c->validities[0] = 1;       // map_io.rs:108-111 init_without_zones
+    memset(&c->metrics, 0, sizeof c->metrics);
+    memset(&c->counters, 0, sizeof c->counters);
+    for (int w = 0; w < 64; ++w) c->w2g[w][0] = c->w2g[w][1] = 0.0;
+    return c;
+}
+
+void porrt_destroy(porrt_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->d_nx.release(); c->d_ny.release(); c->d_distA.release(); c->d_distB.release(); c->d_sx.release(); c->d_sy.release();
+    c->d_qx.release(); c->d_qy.release(); c->d_partD.release(); c->d_candval.release(); c->d_radT2.release(); c->d_inj.release();
+    c->d_parent.release(); c->d_qnn.release(); c->d_qvid.release(); c->d_partid.release(); c->d_candid.release(); c->d_gid.release();
+    c->d_reachA.release(); c->d_reachB.release(); c->d_finalmask.release(); c->d_validmask.release();
+    c->d_vid.release(); c->d_finalflag.release(); c->d_cls.release();
+    c->d_nat.release(); c->d_sworld.release(); c->d_candcnt.release(); c->d_efrom.release(); c->d_eto.release(); c->d_etv.release();
+    c->d_cnt.release(); c->d_rc.release(); c->d_jump.release();
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *porrt_last_error(const porrt_ctx *c) { return c ? c->err.c_str() : "null context (no HIP device?)"; }
+
+int porrt_set_grid(porrt_ctx *c, const uint8_t *occ, uint32_t W, uint32_t H, const double low[2], const double up[2], int domain) {
+    if (!c) return PORRT_ERR_INVALID;
+    if (!occ || W == 0 || H == 0 || !(up[0] > low[0])) { c->set_err("set_grid: empty grid or bad bounds"); return PORRT_ERR_INVALID; }
+    if (domain != PORRT_DOMAIN_SHELF && domain != PORRT_DOMAIN_DOOR) { c->set_err("set_grid: bad domain"); return PORRT_ERR_INVALID; }
+    c->occ.assign(occ, occ + (size_t)W * H);
+    c->zones.clear();
+    c->W = W; c->H = H;
+    c->low[0] = low[0]; c->low[1] = low[1];
+    c->ppm = (double)W / (up[0] - low[0]);      // map_shelves_io.rs:89
+    c->domain = domain;
+    c->has_grid = true;
+    c->cls_dirty = true;
+    c->n_zones = 0; c->n_worlds = 1; c->n_validities = 1; c->validities[0] = 1; c->visibility = 0.0;
+    if (c->goal_kind == 2) c->goal_kind = 0;
+    return PORRT_OK;
+}
+
+int porrt_set_zones(porrt_ctx *c, const uint8_t *zone_ids, double visibility) {
+    if (!c) return PORRT_ERR_INVALID;
+    if (!c->has_grid || !zone_ids) { c->set_err("set_zones: call set_grid first"); return PORRT_ERR_INVALID; }
+    const size_t n = (size_t)c->W * c->H;
+    int max_id = 0;
+    for (size_t p = 0; p < n; ++p)
+        if (zone_ids[p] != 255 && zone_ids[p] > max_id) max_id = zone_ids[p];
+    const int nz = max_id + 1;                   // map_shelves_io.rs:116-130
+    if (nz > 64 || (c->domain == PORRT_DOMAIN_DOOR && nz > 6)) { c->set_err("set_zones: too many zones (64 shelves / 6 doors)"); return PORRT_ERR_INVALID; }
+    // integer centroids in u32 arithmetic, then to_coordinates with its swapped offsets (map_shelves_io.rs:132-148,172-177)
+    std::vector<uint32_t> si(nz, 0), sj(nz, 0), cnt(nz, 0);
+    for (uint32_t i = 0; i < c->H; ++i)
+        for (uint32_t j = 0; j < c->W; ++j) {
+            uint8_t z = zone_ids[(size_t)i * c->W + j];
+            if (z != 255) { si[z] += i; sj[z] += j; cnt[z]++; }
+        }
+    for (int z = 0; z < nz; ++z) {
+        if (cnt[z] == 0) { c->set_err("set_zones: zone id without pixels (the reference divides by zero)"); return PORRT_ERR_INVALID; }
+        uint32_t ci = si[z] / cnt[z], cj = sj[z] / cnt[z];
+        c->zone_pos[z][0] = (double)cj / c->ppm + c->low[1];
+        c->zone_pos[z][1] = (double)(c->H - 1 - ci) / c->ppm + c->low[0];
+    }
+    c->zones.assign(zone_ids, zone_ids + n);
+    c->n_zones = nz;
+    c->visibility = visibility;
+    if (c->domain == PORRT_DOMAIN_SHELF) {       // map_shelves_io.rs:106-114
+        c->n_worlds = nz;
+        c->n_validities = 1;
+        c->validities[0] = ones(nz);
+    } else {                                     // map_io.rs:113-128,198-214
+        c->n_worlds = 1 << nz;
+        for (int z = 0; z < nz; ++z) {
+            uint64_t m = 0;
+            for (int w = 0; w < c->n_worlds; ++w)
+                if (w & (1 << z)) m |= 1ULL << w;
+            c->validities[z] = m;
+        }
+        c->validities[nz] = ones(c->n_worlds);
+        c->n_validities = nz + 1;
+    }
+    c->cls_dirty = true;
+    return PORRT_OK;
+}
+
+int porrt_set_sampler(porrt_ctx *c, const double low[2], const double up[2], uint64_t seed) {
+    if (!c) return PORRT_ERR_INVALID;
+    for (int i = 0; i < 2; ++i)
+        if (!(low[i] < up[i]) || !std::isfinite(low[i]) || !std::isfinite(up[i])) { c->set_err("set_sampler: low >= up"); return PORRT_ERR_INVALID; }
+    for (int i = 0; i < 2; ++i) { c->s_low[i] = low[i]; c->s_up[i] = up[i]; }
+    c->crng.seed_from_u64(seed);
+    c->drng.seed_from_u64(seed);
+    c->has_inj = false; c->inj_xy.clear(); c->inj_pos = 0;
+    c->has_inj_worlds = false; c->inj_worlds.clear(); c->inj_wpos = 0;
+    return PORRT_OK;
+}
+
+int porrt_set_discrete_seed(porrt_ctx *c, uint64_t seed) {
+    if (!c) return PORRT_ERR_INVALID;
+    c->drng.seed_from_u64(seed);
+    return PORRT_OK;
+}
+
+int porrt_set_samples(porrt_ctx *c, const double *xy, size_t n) {
+    if (!c || (!xy && n)) return PORRT_ERR_INVALID;
+    c->inj_xy.assign(xy, xy + 2 * n);
+    c->inj_pos = 0;
+    c->has_inj = true;
+    c->inj_dirty = true;
+    return PORRT_OK;
+}
+
+int porrt_set_worlds(porrt_ctx *c, const uint32_t *worlds, size_t n) {
+    if (!c || (!worlds && n)) return PORRT_ERR_INVALID;
+    c->inj_worlds.assign(worlds, worlds + n);
+    c->inj_wpos = 0;
+    c->has_inj_worlds = true;
+    return PORRT_OK;
+}
+
+int porrt_set_square_goal(porrt_ctx *c, const double *centers, const uint64_t *masks, uint32_t G, double l1_radius) {
+    if (!c) return PORRT_ERR_INVALID;
+    if (!centers || !masks || G == 0 || G > 64) { c->set_err("set_square_goal: need 1..64 goals"); return PORRT_ERR_INVALID; }
+    double w2g[64][2];
+    for (int w = 0; w < 64; ++w) {              // common.rs:310-333
+        w2g[w][0] = w2g[w][1] = 0.0;
+        bool has = false;
+        for (uint32_t g = 0; g < G; ++g)
+            if ((masks[g] >> w) & 1) {
+                if (has) { c->set_err("set_square_goal: validities overlap"); return PORRT_ERR_INVALID; }
+                w2g[w][0] = centers[2 * g]; w2g[w][1] = centers[2 * g + 1];
+                has = true;
+            }
+    }
+    memcpy(c->w2g, w2g, sizeof w2g);
+    c->goal_kind = 1; c->G = G; c->g_l1 = l1_radius;
+    for (uint32_t g = 0; g < G; ++g) { c->gcx[g] = centers[2 * g]; c->gcy[g] = centers[2 * g + 1]; c->gmask[g] = masks[g]; }
+    return PORRT_OK;
+}
+
+int porrt_set_observation_goal(porrt_ctx *c, uint32_t zone_id) {
+    if (!c) return PORRT_ERR_INVALID;
+    if (c->zones.empty() || (int)zone_id >= c->n_zones) { c->set_err("set_observation_goal: unknown zone"); return PORRT_ERR_INVALID; }
+    c->goal_kind = 2; c->obs_zone = zone_id;
+    return PORRT_OK;
+}
+
+int porrt_grow(porrt_ctx *c, const double start[2], double max_step, double search_radius, uint64_t n_iter_min, uint64_t n_iter_max,
+               uint32_t batch_K, int mode) {
+    if (!c || !start) return PORRT_ERR_INVALID;
+    return c->grow(start, max_step, search_radius, n_iter_min, n_iter_max, batch_K, mode);
+}
+
+uint64_t porrt_num_nodes(const porrt_ctx *c) { return c && c->have_results ? c->n_nodes : 0; }
+uint64_t porrt_num_iterations(const porrt_ctx *c) { return c && c->have_results ? c->n_iter : 0; }
+
+int porrt_get_tree(const porrt_ctx *cc, double *xy, int64_t *parent, double *dist_root) {
+    porrt_ctx *c = const_cast<porrt_ctx *>(cc);
+    if (!c) return PORRT_ERR_INVALID;
+    int r = c->download();
+    if (r) return r;
+    for (size_t j = 0; j < c->n_nodes; ++j) {
+        if (xy) { xy[2 * j] = c->h_nx[j]; xy[2 * j + 1] = c->h_ny[j]; }
+        if (parent) parent[j] = c->h_parent[j];
+        if (dist_root) dist_root[j] = c->h_dist[j];
+    }
+    return PORRT_OK;
+}
+
+uint64_t porrt_num_final(const porrt_ctx *c) { return c && c->have_results ? c->counters.n_final : 0; }
+
+int porrt_get_final_ids(const porrt_ctx *cc, uint64_t *ids) {
+    porrt_ctx *c = const_cast<porrt_ctx *>(cc);
+    if (!c) return PORRT_ERR_INVALID;
+    int r = c->download();
+    if (r) return r;
+    for (size_t k = 0; k < c->h_final_ids.size(); ++k) ids[k] = c->h_final_ids[k];
+    return PORRT_OK;
+}
+
+int porrt_get_final_masks(const porrt_ctx *cc, uint64_t *masks) {
+    porrt_ctx *c = const_cast<porrt_ctx *>(cc);
+    if (!c) return PORRT_ERR_INVALID;
+    int r = c->download();
+    if (r) return r;
+    for (size_t k = 0; k < c->h_final_ids.size(); ++k) masks[k] = c->h_finalmask[c->h_final_ids[k]];
+    return PORRT_OK;
+}
+
+int porrt_get_reach(const porrt_ctx *cc, uint64_t *masks) {
+    porrt_ctx *c = const_cast<porrt_ctx *>(cc);
+    if (!c) return PORRT_ERR_INVALID;
+    int r = c->download();
+    if (r) return r;
+    for (size_t j = 0; j < c->n_nodes; ++j) masks[j] = c->h_reach[j];
+    return PORRT_OK;
+}
+
+int porrt_get_node_validity(const porrt_ctx *cc, uint32_t *v) {
+    porrt_ctx *c = const_cast<porrt_ctx *>(cc);
+    if (!c) return PORRT_ERR_INVALID;
+    int r = c->download();
+    if (r) return r;
+    for (size_t j = 0; j < c->n_nodes; ++j) v[j] = c->h_vid[j];
+    return PORRT_OK;
+}
+
+uint64_t porrt_num_edges(const porrt_ctx *c) { return c && c->have_results && c->mode == PORRT_MODE_PTO ? c->counters.n_edges : 0; }
+
+int porrt_get_edges(const porrt_ctx *cc, uint32_t *from, uint32_t *to, uint32_t *validity_id) {
+    porrt_ctx *c = const_cast<porrt_ctx *>(cc);
+    if (!c) return PORRT_ERR_INVALID;
+    int r = c->download();
+    if (r) return r;
+    for (size_t e = 0; e < c->h_efrom.size(); ++e) { from[e] = c->h_efrom[e]; to[e] = c->h_eto[e]; validity_id[e] = c->h_etv[e]; }
+    return PORRT_OK;
+}
+
+int porrt_is_final_set_complete(const porrt_ctx *c) { return c && c->have_results && c->complete; }
+int porrt_n_worlds(const porrt_ctx *c) { return c ? c->n_worlds : 0; }
+int porrt_get_validities(const porrt_ctx *c, uint64_t *masks) {
+    if (!c) return PORRT_ERR_INVALID;
+    for (int i = 0; i < c->n_validities; ++i) masks[i] = c->validities[i];
+    return c->n_validities;
+}
+int porrt_get_zone_positions(const porrt_ctx *c, double *xy) {
+    if (!c) return PORRT_ERR_INVALID;
+    for (int z = 0; z < c->n_zones; ++z) { xy[2 * z] = c->zone_pos[z][0]; xy[2 * z + 1] = c->zone_pos[z][1]; }
+    return c->n_zones;
+}
+
+// rrt.rs:183-193 (first final node of minimal path cost), 48-61, 223-227
+uint64_t porrt_best_solution(const porrt_ctx *cc, double *path_xy, uint64_t cap, double *cost) {
+    porrt_ctx *c = const_cast<porrt_ctx *>(cc);
+    if (!c || c->download()) return 0;
+    if (c->h_final_ids.empty()) return 0;
+    uint64_t best_len = 0, best_id = 0;
+    double best_cost = 0;
+    bool have = false;
+    std::vector<uint64_t> ids;
+    for (uint64_t fid : c->h_final_ids) {
+        ids.clear();
+        for (int64_t p = (int64_t)fid; p >= 0; p = c->h_parent[p]) {
+            ids.push_back((uint64_t)p);
+            if (ids.size() > c->n_nodes) return 0;   // defensive: a parent cycle cannot be walked
+        }
+        std::reverse(ids.begin(), ids.end());
+        double sum = 0.0;
+        for (size_t a = 0; a + 1 < ids.size(); ++a) {
+            double dx = c->h_nx[ids[a + 1]] - c->h_nx[ids[a]], dy = c->h_ny[ids[a + 1]] - c->h_ny[ids[a]];
+            volatile double xx = dx * dx, yy = dy * dy;
+            sum += sqrt(xx + yy);
+        }
+        if (!have || sum < best_cost) { have = true; best_cost = sum; best_id = fid; best_len = ids.size(); }
+    }
+    if (cost) *cost = best_cost;
+    if (path_xy && cap >= best_len) {
+        uint64_t pos = best_len;
+        for (int64_t p = (int64_t)best_id; p >= 0; p = c->h_parent[p]) {
+            --pos;
+            path_xy[2 * pos] = c->h_nx[p];
+            path_xy[2 * pos + 1] = c->h_ny[p];
+        }
+    }
+    return best_len;
+}
+
+int porrt_get_metrics(const porrt_ctx *c, porrt_metrics *out) {
+    if (!c || !out) return PORRT_ERR_INVALID;
+    *out = c->metrics;
+    return PORRT_OK;
+}
+
+// Runs sqrt and divide on n pseudo-random doubles on the device and counts results that differ from the
+// host's correctly rounded ones.  Bit-exact parity with the reference needs both counts to be zero.
+int porrt_selftest(porrt_ctx *c, uint64_t n, uint64_t *sqrt_mismatch, uint64_t *div_mismatch) {
+    if (!c || !n) return PORRT_ERR_INVALID;
+    std::vector<double> a(n), b(n), rs(n), rd(n);
+    Pcg64 r;
+    r.seed_from_u64(12345);
+    for (uint64_t i = 0; i < n; ++i) {
+        // mix of magnitudes: squared distances (1e-12..8), pixel-scale values, general doubles
+        double u = r.gen_range_f64(0.0, 1.0), v = r.gen_range_f64(0.0, 1.0);
+        int e = (int)(r.next_u64() % 80) - 40;
+        a[i] = ldexp(u, (i % 3 == 0) ? e : ((i % 3 == 1) ? -10 : 2));
+        b[i] = ldexp(v + 1e-3, (i % 5 == 0) ? -e : 0);
+    }
+    double *da = nullptr, *db = nullptr, *ds = nullptr, *dd = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return PORRT_ERR_DEVICE;
+    if (hipMalloc((void **)&da, n * 8) != hipSuccess || hipMalloc((void **)&db, n * 8) != hipSuccess ||
+        hipMalloc((void **)&ds, n * 8) != hipSuccess || hipMalloc((void **)&dd, n * 8) != hipSuccess) {
+        c->set_err("selftest: hipMalloc");
+        return PORRT_ERR_DEVICE;
+    }
+    (void)hipMemcpy(da, a.data(), n * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, da, db, ds, dd, (unsigned long long)n);
+    (void)hipStreamSynchronize(c->stream);
+    hipError_t e1 = hipMemcpy(rs.data(), ds, n * 8, hipMemcpyDeviceToHost);
+    hipError_t e2 = hipMemcpy(rd.data(), dd, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(ds); (void)hipFree(dd);
+    if (e1 != hipSuccess || e2 != hipSuccess) { c->set_err("selftest: copy back"); return PORRT_ERR_DEVICE; }
+    uint64_t ms = 0, md = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        volatile double hs = sqrt(a[i]), hd = a[i] / b[i];
+        double xs = hs, xd = hd;
+        if (memcmp(&xs, &rs[i], 8)) ++ms;
+        if (memcmp(&xd, &rd[i], 8)) ++md;
+    }
+    if (sqrt_mismatch) *sqrt_mismatch = ms;
+    if (div_mismatch) *div_mismatch = md;
+    return PORRT_OK;
+}
+
+int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
+    if (!c || !name) return PORRT_ERR_INVALID;
+    if (!strcmp(name, "profile")) c->opt_profile = value != 0;
+    else if (!strcmp(name, "cand_cap")) c->opt_cand_cap = (uint32_t)std::max<int64_t>(64, std::min<int64_t>(value, 1 << 26));
+    else if (!strcmp(name, "graph")) c->opt_graph = value != 0;
+    else { c->set_err(std::string("unknown option ") + name); return PORRT_ERR_INVALID; }
+    return PORRT_OK;
+}
+
+} // extern "C"

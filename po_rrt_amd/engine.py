@@ -1,0 +1,248 @@
+"""ctypes binding of libporrt_hip.so -- the C ABI declared in include/porrt_hip.h.
+
+This is plumbing only: every method forwards to one exported symbol.  There is no CPU
+fallback; constructing an Engine without the HIP library or without a GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libporrt_hip.so")
+
+MODE_RRT, MODE_PTO = 0, 1
+DOMAIN_SHELF, DOMAIN_DOOR = 0, 1
+OK, INCOMPLETE = 0, 1
+
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+# every symbol include/porrt_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "porrt_create", "porrt_destroy", "porrt_last_error", "porrt_set_grid", "porrt_set_zones", "porrt_set_sampler",
+    "porrt_set_discrete_seed", "porrt_set_samples", "porrt_set_worlds", "porrt_set_square_goal",
+    "porrt_set_observation_goal", "porrt_grow", "porrt_num_nodes", "porrt_num_iterations", "porrt_get_tree",
+    "porrt_num_final", "porrt_get_final_ids", "porrt_get_final_masks", "porrt_get_reach", "porrt_get_node_validity",
+    "porrt_num_edges", "porrt_get_edges", "porrt_is_final_set_complete", "porrt_n_worlds", "porrt_get_validities",
+    "porrt_get_zone_positions", "porrt_best_solution", "porrt_get_metrics", "porrt_set_option", "porrt_selftest",
+]
+
+
+class Metrics(C.Structure):
+    _fields_ = [("n_iter", C.c_uint64), ("n_nodes", C.c_uint64), ("n_steps", C.c_uint64),
+                ("n_tie_fallbacks", C.c_uint64), ("total_s", C.c_double), ("setup_s", C.c_double),
+                ("device_s", C.c_double), ("scan_s", C.c_double), ("scan_launches", C.c_uint64),
+                ("scan_pairs", C.c_double), ("scan_bytes", C.c_double)]
+
+
+class PorrtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("porrt error %d: %s" % (code, msg))
+        self.code = code
+
+
+_LIB = None
+
+
+def load_library():
+    """dlopen the in-tree HIP library; fails loudly when it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("porrt_create", vp, C.c_int)
+    sig("porrt_destroy", None, vp)
+    sig("porrt_last_error", C.c_char_p, vp)
+    sig("porrt_set_grid", C.c_int, vp, _u8p, C.c_uint32, C.c_uint32, _f64p, _f64p, C.c_int)
+    sig("porrt_set_zones", C.c_int, vp, _u8p, C.c_double)
+    sig("porrt_set_sampler", C.c_int, vp, _f64p, _f64p, C.c_uint64)
+    sig("porrt_set_discrete_seed", C.c_int, vp, C.c_uint64)
+    sig("porrt_set_samples", C.c_int, vp, _f64p, C.c_size_t)
+    sig("porrt_set_worlds", C.c_int, vp, _u32p, C.c_size_t)
+    sig("porrt_set_square_goal", C.c_int, vp, _f64p, _u64p, C.c_uint32, C.c_double)
+    sig("porrt_set_observation_goal", C.c_int, vp, C.c_uint32)
+    sig("porrt_grow", C.c_int, vp, _f64p, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int)
+    sig("porrt_num_nodes", C.c_uint64, vp)
+    sig("porrt_num_iterations", C.c_uint64, vp)
+    sig("porrt_get_tree", C.c_int, vp, _f64p, _i64p, _f64p)
+    sig("porrt_num_final", C.c_uint64, vp)
+    sig("porrt_get_final_ids", C.c_int, vp, _u64p)
+    sig("porrt_get_final_masks", C.c_int, vp, _u64p)
+    sig("porrt_get_reach", C.c_int, vp, _u64p)
+    sig("porrt_get_node_validity", C.c_int, vp, _u32p)
+    sig("porrt_num_edges", C.c_uint64, vp)
+    sig("porrt_get_edges", C.c_int, vp, _u32p, _u32p, _u32p)
+    sig("porrt_is_final_set_complete", C.c_int, vp)
+    sig("porrt_n_worlds", C.c_int, vp)
+    sig("porrt_get_validities", C.c_int, vp, _u64p)
+    sig("porrt_get_zone_positions", C.c_int, vp, _f64p)
+    sig("porrt_best_solution", C.c_uint64, vp, vp, C.c_uint64, C.POINTER(C.c_double))
+    sig("porrt_get_metrics", C.c_int, vp, C.POINTER(Metrics))
+    sig("porrt_set_option", C.c_int, vp, C.c_char_p, C.c_int64)
+    sig("porrt_selftest", C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+    _LIB = L
+    return L
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+class Engine:
+    """One porrt_ctx on one GPU (mirrors the `&mut self` RRT / PTO object of the reference)."""
+
+    def __init__(self, device=0):
+        self._l = load_library()
+        self._c = self._l.porrt_create(device)
+        if not self._c:
+            raise PorrtError(-6, "porrt_create failed: no usable HIP device %d" % device)
+
+    def close(self):
+        if getattr(self, "_c", None):
+            self._l.porrt_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise PorrtError(rc, self._l.porrt_last_error(self._c).decode())
+        return rc
+
+    def set_option(self, name, value):
+        self._chk(self._l.porrt_set_option(self._c, name.encode(), int(value)))
+
+    def set_grid(self, occ, low=(-1.0, -1.0), up=(1.0, 1.0), domain=DOMAIN_SHELF):
+        occ = np.ascontiguousarray(occ, dtype=np.uint8)
+        H, W = occ.shape
+        self._chk(self._l.porrt_set_grid(self._c, occ, W, H, _f64(low), _f64(up), domain))
+
+    def set_zones(self, zone_ids, visibility):
+        self._chk(self._l.porrt_set_zones(self._c, np.ascontiguousarray(zone_ids, dtype=np.uint8), visibility))
+
+    def set_sampler(self, low=(-1.0, -1.0), up=(1.0, 1.0), seed=0):
+        self._chk(self._l.porrt_set_sampler(self._c, _f64(low), _f64(up), seed))
+
+    def set_discrete_seed(self, seed):
+        self._chk(self._l.porrt_set_discrete_seed(self._c, seed))
+
+    def set_samples(self, xy):
+        xy = _f64(xy).reshape(-1, 2)
+        self._chk(self._l.porrt_set_samples(self._c, xy, xy.shape[0]))
+
+    def set_worlds(self, worlds):
+        w = np.ascontiguousarray(worlds, dtype=np.uint32)
+        self._chk(self._l.porrt_set_worlds(self._c, w, w.size))
+
+    def set_square_goal(self, centers, masks, l1_radius):
+        centers = _f64(centers).reshape(-1, 2)
+        masks = np.ascontiguousarray(masks, dtype=np.uint64)
+        self._chk(self._l.porrt_set_square_goal(self._c, centers, masks, centers.shape[0], l1_radius))
+
+    def set_observation_goal(self, zone_id):
+        self._chk(self._l.porrt_set_observation_goal(self._c, zone_id))
+
+    def n_worlds(self):
+        return self._l.porrt_n_worlds(self._c)
+
+    def validities(self):
+        out = np.zeros(65, dtype=np.uint64)
+        n = self._chk(self._l.porrt_get_validities(self._c, out))
+        return out[:n].copy()
+
+    def zone_positions(self):
+        out = np.zeros((64, 2), dtype=np.float64)
+        n = self._chk(self._l.porrt_get_zone_positions(self._c, out))
+        return out[:n].copy()
+
+    def grow(self, start, max_step, search_radius, n_iter_min, n_iter_max, batch_K=1024, mode=MODE_RRT):
+        """RRT::grow_tree (rrt.rs:102-174) / PTO::grow_graph (pto.rs:55-139) on the GPU."""
+        return self._chk(self._l.porrt_grow(self._c, _f64(start), max_step, search_radius, n_iter_min, n_iter_max,
+                                            batch_K, mode))
+
+    def num_nodes(self):
+        return self._l.porrt_num_nodes(self._c)
+
+    def num_iterations(self):
+        return self._l.porrt_num_iterations(self._c)
+
+    def tree(self):
+        n = self.num_nodes()
+        xy = np.zeros((n, 2))
+        parent = np.zeros(n, dtype=np.int64)
+        dist = np.zeros(n)
+        self._chk(self._l.porrt_get_tree(self._c, xy, parent, dist))
+        return xy, parent, dist
+
+    def final_ids(self):
+        n = self._l.porrt_num_final(self._c)
+        ids = np.zeros(n, dtype=np.uint64)
+        if n:
+            self._chk(self._l.porrt_get_final_ids(self._c, ids))
+        return ids
+
+    def final_masks(self):
+        n = self._l.porrt_num_final(self._c)
+        m = np.zeros(n, dtype=np.uint64)
+        if n:
+            self._chk(self._l.porrt_get_final_masks(self._c, m))
+        return m
+
+    def reach(self):
+        m = np.zeros(self.num_nodes(), dtype=np.uint64)
+        self._chk(self._l.porrt_get_reach(self._c, m))
+        return m
+
+    def node_validity(self):
+        v = np.zeros(self.num_nodes(), dtype=np.uint32)
+        self._chk(self._l.porrt_get_node_validity(self._c, v))
+        return v
+
+    def edges(self):
+        n = self._l.porrt_num_edges(self._c)
+        f = np.zeros(n, dtype=np.uint32)
+        t = np.zeros(n, dtype=np.uint32)
+        v = np.zeros(n, dtype=np.uint32)
+        if n:
+            self._chk(self._l.porrt_get_edges(self._c, f, t, v))
+        return f, t, v
+
+    def is_final_set_complete(self):
+        return bool(self._l.porrt_is_final_set_complete(self._c))
+
+    def best_solution(self):
+        cost = C.c_double(0.0)
+        n = self._l.porrt_best_solution(self._c, None, 0, C.byref(cost))
+        if n == 0:
+            return None
+        path = np.zeros((n, 2))
+        self._l.porrt_best_solution(self._c, path.ctypes.data_as(C.c_void_p), n, C.byref(cost))
+        return path, cost.value
+
+    def selftest(self, n=1 << 20):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._l.porrt_selftest(self._c, n, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def metrics(self):
+        m = Metrics()
+        self._chk(self._l.porrt_get_metrics(self._c, C.byref(m)))
+        return {k: getattr(m, k) for k, _ in Metrics._fields_}

@@ -1,0 +1,195 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar: integer data (parents, final ids, reach masks, validity ids, edges, iteration counts) bit-exact;
+f64 node coordinates and dist_root bit-exact as well (the contract only asks for 1e-9).
+"""
+import numpy as np
+import pytest
+
+import cases
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    from po_rrt_amd import build
+    build.build()
+    import po_rrt_amd
+    return po_rrt_amd
+
+
+def run_gpu(eng_mod, case, K, **opts):
+    e = eng_mod.Engine()
+    for k, v in opts.items():
+        e.set_option(k, v)
+    cases.configure(e, case)
+    rc = cases.grow(e, case, K=K)
+    return e, rc
+
+
+def run_orc(case, K, algo=orc.ALGO_BATCHED_KD):
+    o = cases.configure(orc.Oracle(), case)
+    rc = cases.grow(o, case, K=K, algo=algo)
+    return o, rc
+
+
+def assert_same(e, o, pto=False):
+    assert e.num_iterations() == o.num_iterations()
+    assert e.num_nodes() == o.num_nodes()
+    xe, pe, de = e.tree()
+    xo, po, do = o.tree()
+    assert np.array_equal(xe.view(np.uint64), xo.view(np.uint64)), "node coordinates differ"
+    bad = np.nonzero(pe != po)[0]
+    assert bad.size == 0, "parents differ at %s" % bad[:8]
+    assert np.array_equal(de.view(np.uint64), do.view(np.uint64)), "dist_root differs"
+    assert np.array_equal(e.final_ids(), o.final_ids())
+    assert np.array_equal(e.final_masks(), o.final_masks())
+    assert e.metrics()["n_tie_fallbacks"] == 0
+    if pto:
+        assert np.array_equal(e.reach(), o.reach())
+        assert np.array_equal(e.node_validity(), o.node_validity())
+        fe, te, ve = e.edges()
+        fo, to, vo = o.edges()
+        order = np.lexsort((fo, to))
+        assert np.array_equal(fe, fo[order]) and np.array_equal(te, to[order]) and np.array_equal(ve, vo[order])
+        assert e.is_final_set_complete() == o.is_final_set_complete()
+
+
+def test_device_sqrt_and_divide_are_ieee(eng_mod):
+    e = eng_mod.Engine()
+    assert e.selftest(1 << 21) == (0, 0)
+
+
+RRT_SMALL = [cases.empty_space(1000, 10000), cases.cfg1(3000), cases.cfg2(4000), cases.cfg2(3000, seed=3, grid="map_benchmark_like_c"),
+             cases.cfg2_obs(1500)]
+
+
+@pytest.mark.parametrize("K", [1, 64, 1024])
+@pytest.mark.parametrize("case", RRT_SMALL, ids=lambda c: c.name)
+def test_rrt_matches_oracle(eng_mod, case, K):
+    if K == 1:
+        case = cases.Case(case)
+        case.update(n_iter_min=min(case.n_iter_min, 600), n_iter_max=min(case.n_iter_max, 1200))
+    e, _ = run_gpu(eng_mod, case, K)
+    o, _ = run_orc(case, K)
+    assert e.num_nodes() > 50
+    assert_same(e, o)
+    be, bo = e.best_solution(), o.best_solution()
+    assert (be is None) == (bo is None)
+    if be is not None:
+        assert np.array_equal(be[0], bo[0]) and be[1] == bo[1]
+
+
+def test_rrt_k1_is_the_reference_loop(eng_mod):
+    """K = 1 against the literal sequential restatement (kd-tree and all)."""
+    case = cases.cfg2(1500)
+    e, _ = run_gpu(eng_mod, case, 1)
+    o, _ = run_orc(case, 1, algo=orc.ALGO_SEQ)
+    assert_same(e, o)
+
+
+PTO_SMALL = [cases.cfg3(1500, 20000), cases.cfg4(1500, 4000), cases.cfg_door(1200, 20000), cases.cfg_door(1500, 6000, paper=True)]
+
+
+@pytest.mark.parametrize("K", [1, 16, 256])
+@pytest.mark.parametrize("case", PTO_SMALL, ids=lambda c: c.name)
+def test_pto_matches_oracle(eng_mod, case, K):
+    if K == 1:
+        case = cases.Case(case)
+        case.update(n_iter_min=min(case.n_iter_min, 500), n_iter_max=min(case.n_iter_max, 1500))
+    e, rce = run_gpu(eng_mod, case, K)
+    o, rco = run_orc(case, K)
+    assert rce == rco
+    assert_same(e, o, pto=True)
+
+
+def test_pto_k1_is_the_reference_loop(eng_mod):
+    case = cases.cfg3(800, 3000)
+    e, rce = run_gpu(eng_mod, case, 1)
+    o, rco = run_orc(case, 1, algo=orc.ALGO_SEQ)
+    assert rce == rco
+    # ref_seq lists neighbours in kd pre-order; both sides are compared sorted by (to, from)
+    assert_same(e, o, pto=True)
+
+
+def test_headline_config_full_size(eng_mod):
+    """BASELINE.json configs[1]: map_benchmark-like, K=1024, ~100k-node tree, against the oracle."""
+    case = cases.cfg2(125000)
+    e, _ = run_gpu(eng_mod, case, 1024)
+    o, _ = run_orc(case, 1024)
+    assert e.num_nodes() > 90000
+    assert_same(e, o)
+
+
+def test_injected_samples_equal_seeded_stream(eng_mod):
+    case = cases.cfg1(2000)
+    e1, _ = run_gpu(eng_mod, case, 256)
+    s = cases.configure(orc.Oracle(), case)
+    xy = np.array([s.sample() for _ in range(2000 - 20)])
+    e2 = eng_mod.Engine()
+    cases.configure(e2, case)
+    e2.set_samples(xy)
+    cases.grow(e2, case, K=256)
+    for a, b in zip(e1.tree(), e2.tree()):
+        assert np.array_equal(a, b)
+
+
+def test_sampler_state_persists_across_grows(eng_mod):
+    """tamp_rrt.rs:196-232: one RRT object (one RNG stream) serves many plans."""
+    case = cases.cfg1(700)
+    e = cases.configure(eng_mod.Engine(), case)
+    o = cases.configure(orc.Oracle(), case)
+    for _ in range(3):
+        cases.grow(e, case, K=128)
+        cases.grow(o, case, K=128, algo=orc.ALGO_BATCHED_KD)
+        assert_same(e, o)
+
+
+def test_errors(eng_mod):
+    from po_rrt_amd import PorrtError
+    case = cases.cfg3(100, 100)
+    case.update(start=(-0.22, 0.0))            # inside a wall: pto.rs:61
+    e = cases.configure(eng_mod.Engine(), case)
+    with pytest.raises(PorrtError) as ei:
+        cases.grow(e, case, K=16)
+    assert ei.value.code == -2
+    e = eng_mod.Engine()
+    with pytest.raises(PorrtError):
+        e.grow((0.0, 0.0), 0.1, 1.0, 10, 10, batch_K=0)
+    with pytest.raises(PorrtError):
+        e.set_square_goal([[0, 0], [1, 1]], [1, 1], 0.1)     # overlapping validities (common.rs:321)
+    with pytest.raises(PorrtError):
+        e.tree()                                             # nothing grown yet
+
+
+def test_neighbour_list_regrowth(eng_mod):
+    """A tiny initial capacity forces the overflow -> regrow -> replay path; results are unchanged."""
+    case = cases.cfg1(2500)
+    e1, _ = run_gpu(eng_mod, case, 256)
+    e2, _ = run_gpu(eng_mod, case, 256, cand_cap=64)
+    for a, b in zip(e1.tree(), e2.tree()):
+        assert np.array_equal(a, b)
+
+
+def test_size_independent_properties(eng_mod):
+    """Properties that hold at any size: every parent exists, no cycles, dist_root of a node is at least
+    the straight-line distance to the root, every edge of the tree is collision-free on the grid except
+    the reference's unchecked fallback edge."""
+    case = cases.cfg2(30000)
+    e, _ = run_gpu(eng_mod, case, 1024)
+    xy, parent, dist = e.tree()
+    n = len(parent)
+    assert parent[0] == -1 and (parent[1:] >= 0).all() and (parent[1:] < n).all()
+    hops = np.zeros(n, dtype=np.int64)
+    cur = parent.copy()
+    for _ in range(n):
+        live = cur >= 0
+        if not live.any():
+            break
+        hops[live] += 1
+        cur[live] = parent[cur[live]]
+    assert not (cur >= 0).any(), "cycle in parents"
+    straight = np.sqrt(((xy - xy[0]) ** 2).sum(axis=1))
+    assert (dist + 1e-9 >= straight).all()
