@@ -30,6 +30,8 @@ constexpr int kScanBlock = 256;      // lanes = samples per scan workgroup
 constexpr int kMaxChunks = 256;      // node chunks per scan (grid.y)
 constexpr int kConnectWaves = 8;     // samples per connect workgroup (one wave each)
 constexpr uint32_t kLdsGridMax = 96 * 1024;
+constexpr int kEmpty = 0x7FFFFFFF;       // empty kd child slot (atomicMin claims it)
+constexpr uint32_t kOnG = 0x80000000u;
 
 enum : uint32_t {
     ERR_RASTER = 1u,        // pixel outside the raster / door pixel without zone / two zones on one segment
@@ -84,8 +86,13 @@ struct RunConst {
     // edges (PTO)
     uint32_t *e_from, *e_to, *e_tv;
     uint32_t e_cap;
-    // goal path (RRT* tie order)
-    int *g_id;
+    // kd-tree structure of the reference (RRT* tie order, see k_kd_insert): child ids (kEmpty = none),
+    // parent id, depth, and where the node's root path leaves the goal path G (bit 31: the node is ON G)
+    int *kd_child;
+    int *kd_up;
+    uint32_t *kd_depth;
+    uint32_t *kd_gexit;
+    int *g_id;                  // G[i] = node at depth i on the kd descent path of the goal point
     uint32_t g_cap;
     double gp_x, gp_y;
     // grid
@@ -521,6 +528,49 @@ __device__ __forceinline__ bool kd_left(double x, double y, double wx, double wy
     return (depth & 1u) ? (y < wy) : (x < wx);
 }
 
+// True iff node u is visited before node v (u != v) by a pre-order walk of the reference's kd-tree -- the
+// order in which KdTree::nearest_neighbors lists its results (nearest_neighbor.rs:101-117).  Every root path
+// starts along the goal path G and leaves it at depth kd_gexit (or stays on it), which settles most pairs
+// in O(1); two nodes that leave G at the same node are compared by walking up to their common ancestor.
+__device__ bool kd_preorder_less(const RunConst &rc, int u, int v) {
+    const uint32_t gu = rc.kd_gexit[u], gv = rc.kd_gexit[v];
+    const bool ou = gu & kOnG, ov = gv & kOnG;
+    const uint32_t iu = gu & ~kOnG, iv = gv & ~kOnG;
+    if (ou && ov) return iu < iv;                       // both on G: the ancestor comes first
+    if (ou) {                                           // u = G[iu]; v leaves G after G[iv]
+        if (iu <= iv) return true;                      // u is an ancestor of v
+        const int w = rc.g_id[iv];                      // u lies below G[iv] on the goal side, v on the other side
+        return !kd_left(rc.nx[v], rc.ny[v], rc.nx[w], rc.ny[w], iv);
+    }
+    if (ov) {
+        if (iv <= iu) return false;                     // v is an ancestor of u
+        const int w = rc.g_id[iu];
+        return kd_left(rc.nx[u], rc.ny[u], rc.nx[w], rc.ny[w], iu);
+    }
+    if (iu != iv) {                                     // both off G: the one leaving first splits them
+        if (iu < iv) {
+            const int w = rc.g_id[iu];
+            return kd_left(rc.nx[u], rc.ny[u], rc.nx[w], rc.ny[w], iu);
+        }
+        const int w = rc.g_id[iv];
+        return !kd_left(rc.nx[v], rc.ny[v], rc.nx[w], rc.ny[w], iv);
+    }
+    // same exit node, same (non-goal) side: plain LCA walk, bounded by the depth below the exit node
+    int a = u, b = v;
+    uint32_t da = rc.kd_depth[a], db = rc.kd_depth[b];
+    int a_from = -1, b_from = -1;       // 0 = came up from a left child, 1 = right
+    while (da > db) { const int p = rc.kd_up[a]; a_from = rc.kd_child[2 * p + 1] == a; a = p; --da; }
+    while (db > da) { const int p = rc.kd_up[b]; b_from = rc.kd_child[2 * p + 1] == b; b = p; --db; }
+    if (a == b) return a_from >= 0 ? false : true;                 // the one that did not move is the ancestor
+    while (a != b) {
+        const int pa = rc.kd_up[a], pb = rc.kd_up[b];
+        a_from = rc.kd_child[2 * pa + 1] == a;
+        b_from = rc.kd_child[2 * pb + 1] == b;
+        a = pa; b = pb;
+    }
+    return a_from < b_from;
+}
+
 // RRT*: validated neighbours, best parent, new node, rewire phase 1.  One wave per sample.
 template <bool LDSGRID>
 __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
@@ -574,53 +624,31 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunCon
         dnew = rc.distA[best] + best_cost;
     } else {
         // equal totals: the reference keeps the first in kd-tree pre-order (rrt.rs:143-145)
-        uint32_t n_tie = 0, n_other = 0;
-        int a_min = 0x7FFFFFFF, p_min = 0x7FFFFFFF;
+        uint32_t n_tie = 0;
+        int on_min = kEmpty;        // tied nodes ON the goal path: an ancestor chain, the lowest id is first
+        int off_best = kEmpty;      // pre-order-first tied node off the goal path (per lane, then per wave)
         for (uint32_t a = lane; a < cnt; a += 64) {
             const double cost = cval[a];
             if (cost >= 0.0) {
                 const int j = cid[a];
                 if (rc.distA[j] + cost == bt) {
                     ++n_tie;
-                    if (rc.nx[j] == px && rc.ny[j] == py) a_min = j < a_min ? j : a_min;
-                    else { ++n_other; p_min = j < p_min ? j : p_min; }
+                    if (rc.kd_gexit[j] & kOnG) on_min = j < on_min ? j : on_min;
+                    else if (off_best == kEmpty || kd_preorder_less(rc, j, off_best)) off_best = j;
                 }
             }
         }
         n_tie = wave_sum(n_tie);
         best = bj;
         if (n_tie > 1) {
-            n_other = wave_sum(n_other);
-            a_min = wave_min_u(a_min);
-            p_min = wave_min_u(p_min);
-            if (n_other == 0) {
-                best = a_min;   // same position: the earlier node is a kd ancestor of the later ones
-            } else if (n_other == 1 && a_min != 0x7FFFFFFF && px == rc.gp_x && py == rc.gp_y) {
-                // one node P elsewhere + duplicates of the goal point: place P against the goal path G
-                const uint32_t glen = rc.cnt->g_len;
-                const double qx = rc.nx[p_min], qy = rc.ny[p_min];
-                uint32_t idxW = 0xFFFFFFFFu, idxA = 0xFFFFFFFFu;
-                for (uint32_t i = lane; i < glen; i += 64) {
-                    const int w = rc.g_id[i];
-                    const double wx = rc.nx[w], wy = rc.ny[w];
-                    const bool sep = (w == p_min) || (kd_left(qx, qy, wx, wy, i) != kd_left(px, py, wx, wy, i));
-                    if (sep && i < idxW) idxW = i;
-                    if (w == a_min) idxA = i;
-                }
-                idxW = wave_min_u(idxW);
-                idxA = wave_min_u(idxA);
-                if (idxW == 0xFFFFFFFFu || idxA == 0xFFFFFFFFu) {
-                    if (lane == 0) atomicAdd(&rc.cnt->tie_fallbacks, 1u);
-                } else if (idxA <= idxW) {
-                    best = a_min;                       // a_min is an ancestor-or-self of the split node
-                } else {
-                    const int w = rc.g_id[idxW];
-                    const bool p_first = (w == p_min) || kd_left(qx, qy, rc.nx[w], rc.ny[w], idxW);
-                    best = p_first ? p_min : a_min;
-                }
-            } else {
-                if (lane == 0) atomicAdd(&rc.cnt->tie_fallbacks, 1u);
+            on_min = wave_min_u(on_min);
+            for (int off = 32; off > 0; off >>= 1) {
+                const int o = __shfl_xor(off_best, off);
+                if (o != kEmpty && (off_best == kEmpty || (o != off_best && kd_preorder_less(rc, o, off_best)))) off_best = o;
             }
+            if (off_best == kEmpty) best = on_min;
+            else if (on_min == kEmpty) best = off_best;
+            else best = kd_preorder_less(rc, on_min, off_best) ? on_min : off_best;
         }
         best_cost = sqrt(dist2(rc.nx[best], rc.ny[best], px, py));
         dnew = rc.distA[best] + best_cost;
@@ -689,65 +717,107 @@ __global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__
     }
 }
 
-// Extend the kd descent path of the goal point with this step's nodes (sequential insertion order).
-__global__ __launch_bounds__(1024) void k_goal_path(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
+// Insert this step's nodes into the reference's kd-tree in id order (KdTree::add, nearest_neighbor.rs:29-46;
+// rrt.rs:163) -- only the STRUCTURE is kept (child / parent / depth), searches stay brute force.  It exists to
+// reproduce the order in which the reference resolves equal-cost parents (kd pre-order).
+//   phase 1  every new node descends the tree as it stood before the step.  The part of the descent that runs
+//            along the goal path G (the path of the point every 100th iteration re-adds, which grows by one
+//            exact duplicate each time and is thousands of levels deep late in a run) is a scan of the G array.
+//   phase 2  nodes that reached the same empty slot are ordered by rounds: the lowest id takes the slot
+//            (atomicMin), the others step below it.  Contenders of one slot always arrive in the same round
+//            because they share the whole path above it, so this equals sequential insertion.
+// One workgroup; a thread owns up to kPer nodes (batch_K <= 4096).
+__global__ __launch_bounds__(1024) void k_kd_insert(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
     const RunConst &rc = *rcp;
-    __shared__ int s_min;
     __shared__ uint32_t s_len;
     const uint32_t N = rc.n_at[b];
     if (threadIdx.x == 0) s_len = rc.cnt->g_len;
     __syncthreads();
     const uint32_t glen0 = s_len;
     const double px = rc.gp_x, py = rc.gp_y;
-    // a node joins the path only if it falls on the goal point's side at every node of the path
-    constexpr int kPer = 4;   // supports batch_K up to 4096
-    bool agree[kPer];
+    constexpr int kPer = 4;
+    bool todo[kPer], onpath[kPer];
     double vx[kPer], vy[kPer];
-    int vidn[kPer];
+    int vidn[kPer], cur[kPer];
+    uint32_t side[kPer], dcur[kPer], gex[kPer];
 #pragma unroll
     for (int r = 0; r < kPer; ++r) {
         const uint32_t k = threadIdx.x + r * 1024u;
-        agree[r] = k < nb && rc.q_vid[k < nb ? k : 0] >= 0;
-        vx[r] = agree[r] ? rc.q_x[k] : 0.0;
-        vy[r] = agree[r] ? rc.q_y[k] : 0.0;
-        vidn[r] = agree[r] ? (int)(N + rank_before(rc, b, vwords, k)) : 0x7FFFFFFF;
+        todo[r] = k < nb && rc.q_vid[k < nb ? k : 0] >= 0;
+        onpath[r] = todo[r];
+        vx[r] = todo[r] ? rc.q_x[k] : 0.0;
+        vy[r] = todo[r] ? rc.q_y[k] : 0.0;
+        vidn[r] = todo[r] ? (int)(N + rank_before(rc, b, vwords, k)) : kEmpty;
+        cur[r] = 0; side[r] = 0; dcur[r] = 0; gex[r] = 0;
     }
+    // phase 1a: follow G while the node falls on the goal point's side
     for (uint32_t i = 0; i < glen0; ++i) {
         bool any = false;
 #pragma unroll
-        for (int r = 0; r < kPer; ++r) any |= agree[r];
-        if (!__syncthreads_or(any)) break;
+        for (int r = 0; r < kPer; ++r) any |= onpath[r];
+        if (!__any(any)) break;                 // wave-level: most waves leave G within a few levels
         const int w = rc.g_id[i];
         const double wx = rc.nx[w], wy = rc.ny[w];
         const bool gl = kd_left(px, py, wx, wy, i);
 #pragma unroll
-        for (int r = 0; r < kPer; ++r) agree[r] = agree[r] && (kd_left(vx[r], vy[r], wx, wy, i) == gl);
-    }
-    uint32_t glen = glen0;
-    for (;;) {
-        if (threadIdx.x == 0) s_min = 0x7FFFFFFF;
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < kPer; ++r)
-            if (agree[r]) atomicMin(&s_min, vidn[r]);
-        __syncthreads();
-        const int w = s_min;
-        __syncthreads();
-        if (w == 0x7FFFFFFF) break;
-        if (glen >= rc.g_cap) {
-            if (threadIdx.x == 0) atomicOr(&rc.cnt->err, ERR_GPATH_OVERFLOW);
-            break;
+        for (int r = 0; r < kPer; ++r) {
+            if (onpath[r]) {
+                const bool vl = kd_left(vx[r], vy[r], wx, wy, i);
+                cur[r] = w; dcur[r] = i; side[r] = vl ? 0u : 1u;
+                if (vl != gl) { onpath[r] = false; gex[r] = i; }
+            }
         }
-        if (threadIdx.x == 0) rc.g_id[glen] = w;
-        // w's coordinates were written by k_connect_rrt of this step
-        const double wx = rc.nx[w], wy = rc.ny[w];
-        const bool gl = kd_left(px, py, wx, wy, glen);
-#pragma unroll
-        for (int r = 0; r < kPer; ++r)
-            agree[r] = agree[r] && vidn[r] != w && (kd_left(vx[r], vy[r], wx, wy, glen) == gl);
-        ++glen;
     }
-    if (threadIdx.x == 0) rc.cnt->g_len = glen;
+    // phase 1b: nodes that left G descend the old tree to an empty slot
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+        if (todo[r] && !onpath[r]) {
+            for (;;) {
+                const int c = rc.kd_child[2 * cur[r] + (int)side[r]];
+                if (c == kEmpty) break;
+                cur[r] = c;
+                dcur[r] += 1;
+                side[r] = kd_left(vx[r], vy[r], rc.nx[c], rc.ny[c], dcur[r]) ? 0u : 1u;
+            }
+        }
+    }
+    __syncthreads();
+    // phase 2: claim rounds
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < kPer; ++r) {
+            if (todo[r]) { atomicMin(&rc.kd_child[2 * cur[r] + (int)side[r]], vidn[r]); any = true; }
+        }
+        if (!__syncthreads_or(any)) break;
+#pragma unroll
+        for (int r = 0; r < kPer; ++r) {
+            if (!todo[r]) continue;
+            const int w = atomicMin(&rc.kd_child[2 * cur[r] + (int)side[r]], kEmpty);   // read the winner at L2
+            const uint32_t dw = dcur[r] + 1;
+            if (w == vidn[r]) {
+                rc.kd_up[w] = cur[r];
+                rc.kd_depth[w] = dw;
+                rc.kd_child[2 * w] = kEmpty;
+                rc.kd_child[2 * w + 1] = kEmpty;
+                if (onpath[r]) {
+                    if (dw < rc.g_cap) rc.g_id[dw] = w; else atomicOr(&rc.cnt->err, ERR_GPATH_OVERFLOW);
+                    rc.kd_gexit[w] = dw | kOnG;
+                    atomicMax(&rc.cnt->g_len, dw + 1);
+                } else {
+                    rc.kd_gexit[w] = gex[r];
+                }
+                todo[r] = false;
+            } else {
+                // step below the winner (its coordinates were written by k_connect_rrt of this step)
+                const double wx = rc.nx[w], wy = rc.ny[w];
+                const bool vl = kd_left(vx[r], vy[r], wx, wy, dw);
+                if (onpath[r] && vl != kd_left(px, py, wx, wy, dw)) { onpath[r] = false; gex[r] = dw; }
+                cur[r] = w; dcur[r] = dw; side[r] = vl ? 0u : 1u;
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // PTO: edges to every neighbour with a valid transition, reachability phase 1 and 2 (pto.rs:95-124)

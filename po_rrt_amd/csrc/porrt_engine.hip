@@ -162,7 +162,8 @@ struct porrt_ctx {
     uint32_t opt_cand_cap = 2048;
     // ---- device buffers
     DevBuf<double> d_nx, d_ny, d_distA, d_distB, d_sx, d_sy, d_qx, d_qy, d_partD, d_candval, d_radT2, d_inj;
-    DevBuf<int> d_parent, d_qnn, d_qvid, d_partid, d_candid, d_gid;
+    DevBuf<int> d_parent, d_qnn, d_qvid, d_partid, d_candid, d_gid, d_kdchild, d_kdup;
+    DevBuf<uint32_t> d_kddepth, d_kdgexit;
     DevBuf<unsigned long long> d_reachA, d_reachB, d_finalmask, d_validmask;
     DevBuf<uint8_t> d_vid, d_finalflag, d_cls;
     DevBuf<uint32_t> d_nat, d_sworld, d_candcnt, d_efrom, d_eto, d_etv;
@@ -287,6 +288,11 @@ __global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y
     rc.n_at[0] = 1;
     rc.g_id[0] = 0;          // the root is on every kd descent path
     rc.cnt->g_len = 1;
+    rc.kd_child[0] = kEmpty;
+    rc.kd_child[1] = kEmpty;
+    rc.kd_up[0] = -1;
+    rc.kd_depth[0] = 0;
+    rc.kd_gexit[0] = kOnG;
 }
 
 void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, size_t lds_bytes, bool prof, size_t &ev_used) {
@@ -317,7 +323,7 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
         if (lds_bytes) hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
         else hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
         hipLaunchKernelGGL(k_commit_rrt, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, nb, vwords);
-        hipLaunchKernelGGL(k_goal_path, dim3(1), dim3(1024), 0, stream, rcp, b, nb, vwords);
+        hipLaunchKernelGGL(k_kd_insert, dim3(1), dim3(1024), 0, stream, rcp, b, nb, vwords);
     }
 }
 
@@ -374,6 +380,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(d_partD.reserve((size_t)K * kMaxChunks)); HIPCHK(d_partid.reserve((size_t)K * kMaxChunks));
         HIPCHK(d_candcnt.reserve(K)); HIPCHK(d_candid.reserve((size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
         HIPCHK(d_gid.reserve(Nmax));
+        HIPCHK(d_kdchild.reserve(2 * Nmax)); HIPCHK(d_kdup.reserve(Nmax)); HIPCHK(d_kddepth.reserve(Nmax)); HIPCHK(d_kdgexit.reserve(Nmax));
         if (d_radT2.n < Nmax + 8) { HIPCHK(d_radT2.reserve(Nmax + 8)); rad_uploaded = 0; }
         HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_jump.reserve(1));
         if (mode == PORRT_MODE_PTO) {
@@ -404,6 +411,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
     c.rad_T2 = d_radT2.p;
     c.e_from = d_efrom.p; c.e_to = d_eto.p; c.e_tv = d_etv.p; c.e_cap = (uint32_t)d_efrom.n;
+    c.kd_child = d_kdchild.p; c.kd_up = d_kdup.p; c.kd_depth = d_kddepth.p; c.kd_gexit = d_kdgexit.p;
     c.g_id = d_gid.p; c.g_cap = (uint32_t)std::min<uint64_t>(d_gid.n, 0xFFFFFFFFull);
     c.cls = d_cls.p; c.W = W; c.H = H; c.low0 = low[0]; c.low1 = low[1]; c.ppm = ppm; c.domain = domain; c.has_grid = has_grid;
     c.n_validities = n_validities;
@@ -602,6 +610,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         return -101;
     }
     counters = hc;
+    if (getenv("PORRT_DEBUG")) fprintf(stderr, "[porrt] tie fallbacks %u g_len %u\n", hc.tie_fallbacks, hc.g_len);
     n_iter = i;
     n_steps = b;
     n_nodes = n_final_nodes;
@@ -717,7 +726,7 @@ void porrt_destroy(porrt_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     c->d_nx.release(); c->d_ny.release(); c->d_distA.release(); c->d_distB.release(); c->d_sx.release(); c->d_sy.release();
     c->d_qx.release(); c->d_qy.release(); c->d_partD.release(); c->d_candval.release(); c->d_radT2.release(); c->d_inj.release();
-    c->d_parent.release(); c->d_qnn.release(); c->d_qvid.release(); c->d_partid.release(); c->d_candid.release(); c->d_gid.release();
+    c->d_parent.release(); c->d_qnn.release(); c->d_qvid.release(); c->d_partid.release(); c->d_candid.release(); c->d_gid.release(); c->d_kdchild.release(); c->d_kdup.release(); c->d_kddepth.release(); c->d_kdgexit.release();
     c->d_reachA.release(); c->d_reachB.release(); c->d_finalmask.release(); c->d_validmask.release();
     c->d_vid.release(); c->d_finalflag.release(); c->d_cls.release();
     c->d_nat.release(); c->d_sworld.release(); c->d_candcnt.release(); c->d_efrom.release(); c->d_eto.release(); c->d_etv.release();
