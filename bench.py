@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: RRT node-expansions/sec on the map_benchmark-like map (BASELINE.json configs[1]).
+
+A "step" is one whole planning query: porrt_grow() of an RRT* tree with batch K=1024 samples per GPU step
+until n_iter iterations are spent (~100k-node tree), on the synthetic 200x200 map_benchmark stand-in
+(the reference's raster is a Git-LFS pointer).  Inputs (grid, tables) are resident in HBM before the timed
+region; the tree stays on the device (results are downloaded lazily, outside the timed region).
+
+  python bench.py --gpus N --steps K --warmup W
+For N > 1 it is launched by torch.distributed.run, one rank per GPU: every rank plans its own independent
+queries (different RNG seeds, no data-path collective: weak scaling) and the job ends with ONE RCCL exchange:
+all_gather of the best path costs + broadcast of the winning tree.
+Rank 0 prints one JSON line.  `roofline` is measured live with HIP events around the scan kernels;
+`cpu_baseline` times the single-thread C restatement of the reference loop (oracle/) on the host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64 (half the 157.3 TF FP32 vector rate)
+FLOP_PER_PAIR = 6.0            # 2 sub, 2 mul, 1 add, 1 compare
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n-iter", type=int, default=111500, help="iterations per query (~100k-node tree)")
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed steps")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import cases
+    import po_rrt_amd
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    case = cases.cfg2(args.n_iter)
+    eng = po_rrt_amd.Engine(local_rank)
+    cases.configure(eng, case)
+    eng.set_option("profile", 0 if args.no_profile else 1)
+
+    def run_query(q):
+        eng.set_sampler((-1.0, -1.0), (1.0, 1.0), q)          # query q = RNG seed q
+        cases.grow(eng, case, K=args.batch)
+        return eng.num_nodes() - 1
+
+    for w in range(args.warmup):
+        run_query(10_000 + w * world + rank)
+
+    agg = dict(nodes=0, scan_s=0.0, scan_pairs=0.0, scan_bytes=0.0, scan_launches=0, device_s=0.0, setup_s=0.0)
+    best_cost, best_tree = float("inf"), None
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        agg["nodes"] += run_query(s * world + rank)
+        m = eng.metrics()
+        for k in ("scan_s", "scan_pairs", "scan_bytes", "device_s", "setup_s"):
+            agg[k] += m[k]
+        agg["scan_launches"] += m["scan_launches"]
+    t_loop = time.perf_counter() - t0
+    # the one exchange of the job: who holds the best tree?  (download happens here, once per rank)
+    sol = eng.best_solution()
+    my_cost = sol[1] if sol is not None else float("inf")
+    xy, parent, dist_root = eng.tree()
+    winner, win_cost, win_nodes = rank, my_cost, len(parent)
+    if world > 1:
+        costs = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(costs, torch.tensor([my_cost], dtype=torch.float64, device="cuda"))
+        costs = [float(c.item()) for c in costs]
+        winner = int(np.argmin(costs))
+        win_cost = costs[winner]
+        n_t = torch.tensor([len(parent)], dtype=torch.int64, device="cuda")
+        dist.broadcast(n_t, src=winner)
+        win_nodes = int(n_t.item())
+        if rank == winner:
+            t_xy = torch.from_numpy(xy).cuda()
+            t_par = torch.from_numpy(parent).cuda()
+            t_dist = torch.from_numpy(dist_root).cuda()
+        else:
+            t_xy = torch.empty((win_nodes, 2), dtype=torch.float64, device="cuda")
+            t_par = torch.empty(win_nodes, dtype=torch.int64, device="cuda")
+            t_dist = torch.empty(win_nodes, dtype=torch.float64, device="cuda")
+        for t in (t_xy, t_par, t_dist):
+            dist.broadcast(t, src=winner)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # max over ranks of the timed region, sum over ranks of the work
+    if world > 1:
+        t_el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        elapsed = float(t_el.item())
+        t_nodes = torch.tensor([float(agg["nodes"])], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t_nodes, op=dist.ReduceOp.SUM)
+        total_nodes = float(t_nodes.item())
+    else:
+        total_nodes = float(agg["nodes"])
+
+    if rank == 0:
+        out = {
+            "metric": "RRT node-expansions/sec on map_benchmark.pgm",
+            "value": total_nodes / elapsed,
+            "unit": "node-expansions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "map_benchmark-like 200x200 synthetic map (reference raster is a Git-LFS pointer), 2D RRT* "
+                            "(rrt.rs grow_tree), batch K=%d samples/step, %d iterations -> ~%d-node tree per query, "
+                            "max_step 0.1, search_radius 2.0, start (0,-1), SquareGoal (0.9,0) r=0.05; "
+                            "one query per step per GPU, seeds differ" % (args.batch, args.n_iter, agg["nodes"] // max(args.steps, 1) + 1),
+                "batch_K": args.batch,
+                "n_iter": args.n_iter,
+                "nodes_per_query": agg["nodes"] / max(args.steps, 1),
+                "parallelism": "independent queries per GPU (x%d), one RCCL all_gather+broadcast at the end" % world,
+                "best_path_cost": win_cost,
+                "winner_rank": winner,
+                "loop_s_rank0": t_loop,
+            },
+        }
+        if agg["scan_s"] > 0:
+            achieved = agg["scan_bytes"] / agg["scan_s"] / 1e9
+            tflops = FLOP_PER_PAIR * agg["scan_pairs"] / agg["scan_s"] / 1e12
+            out["roofline"] = {
+                "bound": "hbm",
+                "kernel": "k_nn_scan + k_radius_scan (same loop body; K x N_b sample-node pairs per launch)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_launch_us": 1e6 * agg["scan_s"] / max(agg["scan_launches"], 1),
+                "launches": agg["scan_launches"],
+                "algorithmic_bytes_per_launch": agg["scan_bytes"] / max(agg["scan_launches"], 1),
+                "note": "the scan is FP64-VALU bound by design (K=1024 samples reuse every node byte); see valu_f64",
+                "valu_f64": {"achieved_tflops": tflops, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                             "frac": tflops / FP64_VALU_PEAK_TFLOPS, "flop_per_pair": FLOP_PER_PAIR},
+                "scan_share_of_device_time": agg["scan_s"] / max(agg["device_s"], 1e-12),
+            }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(case, args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(case, args):
+    """Single-thread C restatement of RRT::grow_tree (kd-tree and all) on the same workload -- the Rust
+    reference cannot be built here (no rustc/cargo; crates not vendored)."""
+    import cases
+    from oracle import orc
+    orc.build()
+    reps, times, nodes = 3, [], 0
+    for r in range(reps):
+        o = cases.configure(orc.Oracle(), cases.Case(case, seed=r))
+        t0 = time.perf_counter()
+        cases.grow(o, case, K=1, algo=orc.ALGO_SEQ)
+        times.append(time.perf_counter() - t0)
+        nodes = o.num_nodes() - 1
+    times.sort()
+    return {
+        "value": nodes / times[len(times) // 2],
+        "unit": "node-expansions/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "the full workload (%d iterations, %d nodes), median of %d runs, seeds 0..%d; "
+                  "C restatement of rrt.rs:102-174 with the reference's kd-tree, gcc -O2 -ffp-contract=off"
+                  % (args.n_iter, nodes, reps, reps - 1),
+        "host_cpus": os.cpu_count(),
+        "seconds_median": times[len(times) // 2],
+    }
+
+
+if __name__ == "__main__":
+    main()

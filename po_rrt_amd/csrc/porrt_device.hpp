@@ -28,8 +28,8 @@ namespace porrt {
 
 constexpr int kScanBlock = 256;      // lanes = samples per scan workgroup
 constexpr int kMaxChunks = 256;      // node chunks per scan (grid.y)
-constexpr int kConnectWaves = 8;     // samples per connect workgroup (one wave each)
-constexpr uint32_t kLdsGridMax = 96 * 1024;
+constexpr int kConnectWaves = 4;     // samples per connect workgroup (one wave each)
+constexpr uint32_t kTileRMax = 31;             // LDS tile half-width limit (pixels); above it rays read global
 constexpr int kEmpty = 0x7FFFFFFF;       // empty kd child slot (atomicMin claims it)
 constexpr uint32_t kOnG = 0x80000000u;
 
@@ -44,6 +44,11 @@ enum : uint32_t {
 // pixel classes of the pre-classified raster (host builds it in set_grid/set_zones)
 enum : uint8_t { CLS_FREE = 0, CLS_LOW = 1, CLS_HIGH = 2, CLS_HIGH0 = 3 /* raw pixel 0 */, CLS_ZONE = 16, CLS_BAD = 255 };
 
+struct __attribute__((aligned(8))) KdRec {
+    double x, y;
+    int child[2];
+};
+
 struct Counters {
     uint32_t n_final;
     uint32_t n_edges;
@@ -51,12 +56,17 @@ struct Counters {
     uint32_t tie_fallbacks;
     unsigned long long finality;
     uint32_t g_len;
-    uint32_t pad;
+    uint32_t n_heavy;
 };
 
 struct RunConst {
     // node SoA
     double *nx, *ny;
+    float *fx, *fy, *f2;        // f32 filter view of the nodes: fl(x), fl(y), fl(x^2+y^2) (see scan_chunk)
+    int *rep;                   // cell -> some node in that cell (3-level pyramid), only ever used for bounds
+    double bx0, by0, binv_w, binv_h;   // box the pyramid covers
+    double filt_E;              // absolute error bound of the f32 key
+    float *q_ax, *q_ay, *q_thr; // per-sample filter operands: -2qx, -2qy, threshold on the key
     double *distA, *distB;      // dist_root: A = snapshot read by the step, B = rewire accumulator
     int *parent;
     unsigned long long *reachA, *reachB;
@@ -77,6 +87,8 @@ struct RunConst {
     int *q_vid;
     double *part_D;
     int *part_id;
+    unsigned long long *dbg;    // optional per-step phase stamps (diagnostic builds of the host only)
+    uint32_t *heavy_list;       // samples routed to the team connect kernel this step
     uint32_t *cand_cnt;
     int *cand_id;
     double *cand_val;
@@ -88,11 +100,12 @@ struct RunConst {
     uint32_t e_cap;
     // kd-tree structure of the reference (RRT* tie order, see k_kd_insert): child ids (kEmpty = none),
     // parent id, depth, and where the node's root path leaves the goal path G (bit 31: the node is ON G)
-    int *kd_child;
+    KdRec *kd_rec;              // packed {x, y, child[2]}: one load per level of a descent
     int *kd_up;
     uint32_t *kd_depth;
     uint32_t *kd_gexit;
     int *g_id;                  // G[i] = node at depth i on the kd descent path of the goal point
+    double *g_x, *g_y;          // its coordinates, contiguous (the path is scanned, not chased)
     uint32_t g_cap;
     double gp_x, gp_y;
     // grid
@@ -115,6 +128,8 @@ struct RunConst {
     double s_low0, s_low1, s_up0, s_up1;
     double max_step;
     int mode;
+    uint32_t tile_R;            // LDS tile half-width in pixels (0 = no tile: read the raster from global)
+    uint32_t part_stride;       // stride of the per-chunk NN partials ([chunk][sample] layout)
 };
 
 // ------------------------------------------------------------------ small helpers
@@ -168,10 +183,31 @@ __device__ __forceinline__ void oct_from(int o, int x, int y, int &ox, int &oy) 
     }
 }
 
+// Raster accessors for the raycasts.  GlobalGrid reads the pre-classified raster in HBM/L2; TileGrid reads
+// the wave's private LDS tile (a (2R+1)^2 window around the new node: every neighbour lies within
+// radius <= max_step of it, so all of a sample's rays stay inside) and falls back to global outside it.
+struct GlobalGrid {
+    const uint8_t *p;
+    uint32_t W;
+    __device__ __forceinline__ int at(uint32_t i, uint32_t j) const { return p[i * W + j]; }
+};
+struct TileGrid {
+    const uint8_t *lds;     // TW x TW bytes
+    const uint8_t *glob;
+    uint32_t W;
+    int oi, oj;             // raster coordinates of tile[0][0]
+    uint32_t TW;
+    __device__ __forceinline__ int at(uint32_t i, uint32_t j) const {
+        const uint32_t ri = (uint32_t)((int)i - oi), rj = (uint32_t)((int)j - oj);
+        if (ri < TW && rj < TW) return lds[ri * TW + rj];
+        return glob[i * W + j];
+    }
+};
+
 // Traversed-space class of the segment a -> b (map_shelves_io.rs:187-203, map_io.rs:216-241).
 // Returns CLS_FREE / CLS_LOW / CLS_HIGH / CLS_ZONE+z.  Raster faults set *err and read as CLS_HIGH.
-template <class GridPtr>
-__device__ int traversed_class(const RunConst &rc, GridPtr grid, double ax, double ay, double bx, double by, uint32_t *err) {
+template <class Grid>
+__device__ int traversed_class(const RunConst &rc, const Grid &grid, double ax, double ay, double bx, double by, uint32_t *err) {
     uint32_t ai, aj, bi, bj;
     to_pixel(rc, ax, ay, ai, aj);
     to_pixel(rc, bx, by, bi, bj);
@@ -196,7 +232,7 @@ __device__ int traversed_class(const RunConst &rc, GridPtr grid, double ax, doub
     for (int x = sx, y = sy; x <= ex; ++x) {
         int pi, pj;
         oct_from(o, x, y, pi, pj);
-        int c = grid[(uint32_t)pi * rc.W + (uint32_t)pj];
+        int c = grid.at((uint32_t)pi, (uint32_t)pj);
         if (rc.domain == 0) {
             if (c == CLS_HIGH0) return CLS_HIGH;       // lowest_pixel == 0: early return
             worst = c > worst ? c : worst;
@@ -232,8 +268,8 @@ __device__ __forceinline__ int class_to_validity(const RunConst &rc, int cls) {
 }
 
 // GoalFuncs::goal (common.rs:336-345; rrt.rs:330-336 + map_shelves_io.rs:259-265)
-template <class GridPtr>
-__device__ bool goal_hit(const RunConst &rc, GridPtr grid, double x, double y, unsigned long long &mask, uint32_t *err) {
+template <class Grid>
+__device__ bool goal_hit(const RunConst &rc, const Grid &grid, double x, double y, unsigned long long &mask, uint32_t *err) {
     if (rc.goal_kind == 1) {
         for (uint32_t g = 0; g < rc.G; ++g) {
             double d = fabs(rc.gcx[g] - x);
@@ -327,6 +363,106 @@ __global__ void k_gen_samples(const RunConst *__restrict__ rcp, const PcgJump *_
     rc.sy[idx] = y;
 }
 
+// ------------------------------------------------------------------ bound pyramid
+// rep[] holds, for every cell of a 256^2 / 32^2 / 4^2 pyramid over the sampling box, the id of SOME node
+// inside that cell (last writer wins; races are harmless).  It is never used to answer a query: it only
+// yields an upper bound on the nearest-neighbour distance so that the brute-force scan can reject almost
+// every node with the cheap f32 key.  Results do not depend on its content.
+constexpr int kRepLevels = 3;
+__device__ __forceinline__ int rep_dim(int l) { return l == 0 ? 256 : (l == 1 ? 32 : 4); }
+__device__ __forceinline__ int rep_off(int l) { return l == 0 ? 0 : (l == 1 ? 65536 : 65536 + 1024); }
+constexpr int kRepTotal = 65536 + 1024 + 16;
+
+__device__ __forceinline__ void rep_cell(const RunConst &rc, double x, double y, int G, int &cx, int &cy) {
+    double fx = (x - rc.bx0) * rc.binv_w * (double)G, fy = (y - rc.by0) * rc.binv_h * (double)G;
+    cx = fx < 0.0 ? 0 : (fx >= (double)G ? G - 1 : (int)fx);
+    cy = fy < 0.0 ? 0 : (fy >= (double)G ? G - 1 : (int)fy);
+}
+
+__device__ __forceinline__ void rep_insert(const RunConst &rc, double x, double y, int id) {
+#pragma unroll
+    for (int l = 0; l < kRepLevels; ++l) {
+        int cx, cy;
+        const int G = rep_dim(l);
+        rep_cell(rc, x, y, G, cx, cy);
+        rc.rep[rep_off(l) + cy * G + cx] = id;
+    }
+}
+
+// f32 filter view of one node
+__device__ __forceinline__ void write_filter_view(const RunConst &rc, int id, double x, double y) {
+    rc.fx[id] = (float)x;
+    rc.fy[id] = (float)y;
+    const double xx = x * x, yy = y * y;
+    rc.f2[id] = (float)(xx + yy);
+}
+
+// threshold on the f32 key  key(n) = fl32(|n|^2 - 2 q.n)  that no node with exact d2 <= bound can exceed
+__device__ __forceinline__ float key_threshold(const RunConst &rc, double bound_d2, double qx, double qy) {
+    const double q2 = qx * qx + qy * qy;
+    const double t = bound_d2 * (1.0 + 1e-15) - q2 + rc.filt_E;
+    float f = (float)t;
+    if ((double)f < t) f = __int_as_float(__float_as_int(f) + (f >= 0.0f ? 1 : -1));   // round up
+    return __int_as_float(__float_as_int(f) + (f >= 0.0f ? 1 : -1)) ;                    // one more ulp of slack
+}
+
+// threshold below which a node's exact d2 is certainly <= bound (so no exact re-evaluation is needed)
+__device__ __forceinline__ float key_threshold_inner(const RunConst &rc, double bound_d2, double qx, double qy) {
+    const double q2 = qx * qx + qy * qy;
+    const double t = bound_d2 * (1.0 - 1e-15) - q2 - rc.filt_E;
+    float f = (float)t;
+    if ((double)f > t) f = __int_as_float(__float_as_int(f) + (f > 0.0f ? -1 : 1));     // round down
+    return __int_as_float(__float_as_int(f) + (f > 0.0f ? -1 : 1));                      // one more ulp of slack
+}
+
+// One thread per sample: upper bound of its nearest-neighbour distance from the pyramid (finest level whose
+// 3x3 neighbourhood holds a node that passes the world filter), turned into the scan's key threshold.
+template <bool PTO>
+__global__ __launch_bounds__(256) void k_nn_bound(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb) {
+    const RunConst &rc = *rcp;
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nb) return;
+    const uint32_t N = rc.n_at[b];
+    const double qx = rc.sx[i0 + k], qy = rc.sy[i0 + k];
+    uint32_t world = 0;
+    if (PTO) world = rc.sworld[i0 + k];
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    double m = INF;
+    for (int l = 0; l < kRepLevels && m == INF; ++l) {
+        const int G = rep_dim(l);
+        int cx, cy;
+        rep_cell(rc, qx, qy, G, cx, cy);
+        int r9[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {                    // nine independent loads
+            const int x = cx + (t % 3) - 1, y = cy + (t / 3) - 1;
+            const bool ok = x >= 0 && y >= 0 && x < G && y < G;
+            r9[t] = ok ? rc.rep[rep_off(l) + y * G + x] : -1;
+        }
+        double x9[9], y9[9];
+        unsigned long long m9[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const bool ok = r9[t] >= 0 && (uint32_t)r9[t] < N;
+            const int r = ok ? r9[t] : 0;
+            x9[t] = rc.nx[r]; y9[t] = rc.ny[r];
+            m9[t] = PTO ? rc.reachA[r] : ~0ull;
+            if (!ok) m9[t] = 0;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if ((m9[t] >> world) & 1ull) {
+                const double d2 = dist2(x9[t], y9[t], qx, qy);
+                m = d2 < m ? d2 : m;
+            }
+        }
+    }
+    if (m == INF && !PTO) m = dist2(rc.nx[0], rc.ny[0], qx, qy);      // the root always exists
+    rc.q_ax[k] = (float)(-2.0 * qx);
+    rc.q_ay[k] = (float)(-2.0 * qy);
+    rc.q_thr[k] = m == INF ? __int_as_float(0x7F800000) : key_threshold(rc, m, qx, qy);
+}
+
 // ------------------------------------------------------------------ scans
 // The node arrays are read-only inside a scan kernel and indexed wave-uniformly.  Viewing them through the
 // constant address space makes hipcc emit scalar loads (s_load_dwordx2/x4 into SGPRs) that feed the VALU
@@ -345,33 +481,52 @@ __device__ __forceinline__ void chunk_range(uint32_t N, uint32_t NC, uint32_t c,
 }
 
 constexpr int kUnroll = 8;
+typedef const __attribute__((address_space(4))) float *cfloat_p;
+__device__ __forceinline__ cfloat_p as_constf(const float *p) { return (cfloat_p)(uintptr_t)p; }
 
-// Stream the nodes [j0, j1) of one chunk past the lanes' samples.  `visit(j, d2)` is called for every node
-// whose squared distance passes `hit(d2)`; both see wave-uniform j.  Eight nodes are fetched per iteration
-// with two 64-byte scalar loads; the eight distance evaluations are independent FP64 VALU chains.
-template <class Hit, class Visit>
-__device__ __forceinline__ void scan_chunk(cdouble_p nx, cdouble_p ny, uint32_t j0, uint32_t j1, double qx, double qy,
-                                           Hit hit, Visit visit) {
+// Stream the nodes [j0, j1) of one chunk past the lanes' samples.  Hot loop (all lanes, wave-uniform node):
+//     key = fma(fx, -2qx, fma(fy, -2qy, f2))        f32, 2 FMA
+//     hit = key <= thr                              1 compare
+// key approximates d2 - |q|^2 with absolute error < filt_E, and thr was rounded up past bound - |q|^2 +
+// filt_E, so a node whose exact squared distance is <= bound can never be rejected (DESIGN.md gives the
+// error budget).  `visit(j)` runs only for hits and redoes the arithmetic exactly in f64.  Eight nodes are
+// fetched per iteration with three 32-byte scalar loads, double-buffered.
+template <class Visit>
+__device__ __forceinline__ void scan_chunk(cfloat_p fx, cfloat_p fy, cfloat_p f2, uint32_t j0, uint32_t j1, float ax, float ay,
+                                           const float &thr, Visit visit) {
     uint32_t j = j0;
-    cdouble_p px = nx + j0, py = ny + j0;     // 64-bit bases: constant offsets merge into wide scalar loads
-    for (; j + kUnroll <= j1; j += kUnroll, px += kUnroll, py += kUnroll) {
-        double ax[kUnroll], ay[kUnroll], d2[kUnroll];
+    cfloat_p px = fx + j0, py = fy + j0, p2 = f2 + j0;
+    if (j + kUnroll <= j1) {
+        float cx[kUnroll], cy[kUnroll], c2[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) { ax[u] = px[u]; ay[u] = py[u]; }
+        for (int u = 0; u < kUnroll; ++u) { cx[u] = px[u]; cy[u] = py[u]; c2[u] = p2[u]; }
+        for (;;) {
+            const bool more = j + 2 * kUnroll <= j1;
+            float nx_[kUnroll], ny_[kUnroll], n2_[kUnroll];
+            if (more) {
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) d2[u] = dist2(ax[u], ay[u], qx, qy);
-        bool any = false;
+                for (int u = 0; u < kUnroll; ++u) { nx_[u] = px[kUnroll + u]; ny_[u] = py[kUnroll + u]; n2_[u] = p2[kUnroll + u]; }
+            }
+            float key[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) any |= hit(d2[u]);
-        if (any) {                       // rare: one branch per eight nodes
+            for (int u = 0; u < kUnroll; ++u) key[u] = __builtin_fmaf(cx[u], ax, __builtin_fmaf(cy[u], ay, c2[u]));
+            bool any = false;
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
-                if (hit(d2[u])) visit(j + u, d2[u]);
+            for (int u = 0; u < kUnroll; ++u) any |= key[u] <= thr;
+            if (any) {                       // rare: one branch per eight nodes
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u)
+                    if (key[u] <= thr) visit(j + u);
+            }
+            j += kUnroll; px += kUnroll; py += kUnroll; p2 += kUnroll;
+            if (!more) break;
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) { cx[u] = nx_[u]; cy[u] = ny_[u]; c2[u] = n2_[u]; }
         }
     }
-    for (; j < j1; ++j, ++px, ++py) {
-        const double d2 = dist2(px[0], py[0], qx, qy);
-        if (hit(d2)) visit(j, d2);
+    for (; j < j1; ++j, ++px, ++py, ++p2) {
+        const float key = __builtin_fmaf(px[0], ax, __builtin_fmaf(py[0], ay, p2[0]));
+        if (key <= thr) visit(j);
     }
 }
 
@@ -389,48 +544,76 @@ __global__ __launch_bounds__(kScanBlock) void k_nn_scan(const RunConst *__restri
     chunk_range(N, NC, c, j0, j1);
     const bool live = k < nb;
     const double qx = live ? rc.sx[i0 + k] : 0.0, qy = live ? rc.sy[i0 + k] : 0.0;
+    const float ax = live ? rc.q_ax[k] : 0.0f, ay = live ? rc.q_ay[k] : 0.0f;
+    float thr = live ? rc.q_thr[k] : __int_as_float(0xFF800000);   // -inf: dead lanes never hit
     uint32_t world = 0;
     if (PTO) world = live ? rc.sworld[i0 + k] : 0u;
     double m2 = __longlong_as_double(0x7FF0000000000000ll);   // +inf
     double bestD = m2;
     int best = -1;
     const unsigned long long *reach = rc.reachA;
-    scan_chunk(as_const(rc.nx), as_const(rc.ny), j0, j1, qx, qy,
-               [&](double d2) { return d2 < m2; },
-               [&](uint32_t j, double d2) {
-                   bool pass = true;
-                   if (PTO) pass = (reach[j] >> world) & 1ull;
-                   if (pass) {
-                       const double D = sqrt(d2);      // the reference compares rounded distances
-                       if (D < bestD) { bestD = D; best = (int)j; m2 = d2; }
+    const double *nx = rc.nx, *ny = rc.ny;
+    scan_chunk(as_constf(rc.fx), as_constf(rc.fy), as_constf(rc.f2), j0, j1, ax, ay, thr,
+               [&](uint32_t j) {
+                   const double d2 = dist2(nx[j], ny[j], qx, qy);          // exact, as the reference computes it
+                   if (d2 < m2) {
+                       bool pass = true;
+                       if (PTO) pass = (reach[j] >> world) & 1ull;
+                       if (pass) {
+                           const double D = sqrt(d2);                       // the reference compares rounded distances
+                           if (D < bestD) {
+                               bestD = D; best = (int)j; m2 = d2;
+                               const float t = key_threshold(rc, d2, qx, qy);  // tighten the filter
+                               thr = t < thr ? t : thr;
+                           }
+                       }
                    }
                });
     if (live) {
-        rc.part_D[(size_t)k * kMaxChunks + c] = bestD;
-        rc.part_id[(size_t)k * kMaxChunks + c] = best;
+        rc.part_D[(size_t)c * rc.part_stride + k] = bestD;      // [chunk][sample]: coalesced
+        rc.part_id[(size_t)c * rc.part_stride + k] = best;
     }
 }
 
-// wave per sample: argmin over chunks (shfl), steer (L1 step length), point validity
+// argmin over node chunks, steer (L1 step length), point validity.  A workgroup of 4 waves serves 64
+// samples: wave r reduces chunks r, r+4, ... for all 64 (coalesced reads of the [chunk][sample] partials),
+// the four candidates meet in LDS and a quad of lanes finishes with a shuffle argmin.
 __global__ __launch_bounds__(256) void k_nn_reduce_steer(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb,
                                                           uint32_t NC, uint32_t vwords) {
     const RunConst &rc = *rcp;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t k = (blockIdx.x * 256u + threadIdx.x) >> 6;
-    if (k >= nb) return;
+    __shared__ double s_D[4][64];
+    __shared__ int s_id[4][64];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t k = blockIdx.x * 64u + lane;
     double D = __longlong_as_double(0x7FF0000000000000ll);
     int id = 0x7FFFFFFF;
-    for (uint32_t c = lane; c < NC; c += 64) {
-        double d = rc.part_D[(size_t)k * kMaxChunks + c];
-        int i = rc.part_id[(size_t)k * kMaxChunks + c];
-        if (i >= 0 && (d < D || (d == D && i < id))) { D = d; id = i; }
+    if (k < nb) {
+        for (uint32_t c0 = wv; c0 < NC; c0 += 32) {      // 8 independent loads in flight per lane
+            double d[8];
+            int i[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t c = c0 + 4u * u;
+                const bool ok = c < NC;
+                i[u] = ok ? rc.part_id[(size_t)c * rc.part_stride + k] : -1;
+                d[u] = ok ? rc.part_D[(size_t)c * rc.part_stride + k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i[u] >= 0 && (d[u] < D || (d[u] == D && i[u] < id))) { D = d[u]; id = i[u]; }
+        }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        double d = __shfl_xor(D, off);
-        int i = __shfl_xor(id, off);
+    s_D[wv][lane] = D;
+    s_id[wv][lane] = id;
+    __syncthreads();
+    if (wv != 0 || k >= nb) return;
+    // wavefront shuffle argmin over the four slices (lanes q*16.. hold slice q of 16 samples each pass)
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+        const double d = s_D[r][lane];
+        const int i = s_id[r][lane];
         if (d < D || (d == D && i < id)) { D = d; id = i; }
     }
-    if (lane != 0) return;
     const int nn = id == 0x7FFFFFFF ? 0 : id;   // nothing passed the filter: the root (nearest_neighbor.rs:90)
     const double fx = rc.nx[nn], fy = rc.ny[nn];
     double tx = rc.sx[i0 + k], ty = rc.sy[i0 + k];
@@ -457,11 +640,16 @@ __global__ __launch_bounds__(256) void k_nn_reduce_steer(const RunConst *__restr
     rc.q_nn[k] = nn;
     rc.q_vid[k] = valid ? vid : -1;
     rc.cand_cnt[k] = 0;
+    if (k == 0) rc.cnt->n_heavy = 0;
     if (valid) atomicOr(&rc.valid_mask[(size_t)b * vwords + (k >> 6)], 1ull << (k & 63u));
     if (err) atomicOr(&rc.cnt->err, err);
 }
 
-// K x N radius scan: neighbour ids with norm2 <= radius  <=>  d2 <= T2 (T2 from the host table)
+// K x N radius scan: neighbour ids with norm2 <= radius  <=>  d2 <= T2 (T2 from the host table).
+// The f32 key settles almost every node: key > thr_out rejects, key <= thr_in accepts (both margins are the
+// key's error bound), and only the thin shell in between is re-evaluated exactly in f64.  An accepted id is
+// appended with one atomic slot claim; the store of the id is deferred to the lane's next hit so that the
+// wave never waits for the atomic's round trip.
 __global__ __launch_bounds__(kScanBlock) void k_radius_scan(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t NC) {
     const RunConst &rc = *rcp;
     const uint32_t k = blockIdx.x * kScanBlock + threadIdx.x;
@@ -472,19 +660,38 @@ __global__ __launch_bounds__(kScanBlock) void k_radius_scan(const RunConst *__re
     const bool live = k < nb && rc.q_vid[k < nb ? k : 0] >= 0;
     const double qx = live ? rc.q_x[k] : 0.0, qy = live ? rc.q_y[k] : 0.0;
     // rrt.rs:121 uses the size before insertion, pto.rs:88 after it
-    const double T2s = rc.rad_T2[N + (rc.mode == 1 ? 1u : 0u)];
-    const double T2 = live ? T2s : -1.0;
+    const double T2 = rc.rad_T2[N + (rc.mode == 1 ? 1u : 0u)];
+    const float ax = (float)(-2.0 * qx), ay = (float)(-2.0 * qy);
+    const float NEG_INF = __int_as_float(0xFF800000);
+    const float thr = live ? key_threshold(rc, T2, qx, qy) : NEG_INF;
+    const float thr_in = live ? key_threshold_inner(rc, T2, qx, qy) : NEG_INF;
     uint32_t *cand_cnt = rc.cand_cnt;
-    int *cand_id = rc.cand_id;
+    int *cand_id = rc.cand_id + (size_t)(k < nb ? k : 0) * rc.cand_cap;
     const uint32_t cap = rc.cand_cap;
     Counters *cnt = rc.cnt;
-    scan_chunk(as_const(rc.nx), as_const(rc.ny), j0, j1, qx, qy,
-               [&](double d2) { return d2 <= T2; },
-               [&](uint32_t j, double) {
-                   uint32_t slot = atomicAdd(&cand_cnt[k], 1u);
-                   if (slot < cap) cand_id[(size_t)k * cap + slot] = (int)j;
-                   else atomicOr(&cnt->err, ERR_CAND_OVERFLOW);
+    const double *nx = rc.nx, *ny = rc.ny;
+    const cfloat_p fx = as_constf(rc.fx), fy = as_constf(rc.fy), f2 = as_constf(rc.f2);
+    uint32_t pend_slot = 0;
+    int pend_j = -1;
+    scan_chunk(fx, fy, f2, j0, j1, ax, ay, thr,
+               [&](uint32_t j) {
+                   // recompute the key of this node (cheaper than keeping eight of them live for the rare path)
+                   const float key = __builtin_fmaf(fx[j], ax, __builtin_fmaf(fy[j], ay, f2[j]));
+                   bool in = key <= thr_in;
+                   if (!in) in = dist2(nx[j], ny[j], qx, qy) <= T2;          // shell: exact test
+                   if (in) {
+                       if (pend_j >= 0) {
+                           if (pend_slot < cap) cand_id[pend_slot] = pend_j;
+                           else atomicOr(&cnt->err, ERR_CAND_OVERFLOW);
+                       }
+                       pend_slot = atomicAdd(&cand_cnt[k], 1u);
+                       pend_j = (int)j;
+                   }
                });
+    if (pend_j >= 0) {
+        if (pend_slot < cap) cand_id[pend_slot] = pend_j;
+        else atomicOr(&cnt->err, ERR_CAND_OVERFLOW);
+    }
 }
 
 // ------------------------------------------------------------------ connect
@@ -496,14 +703,23 @@ __device__ __forceinline__ uint32_t rank_before(const RunConst &rc, uint32_t b, 
     return r;
 }
 
-__device__ __forceinline__ void load_grid_lds(const RunConst &rc, uint8_t *lds, bool use_lds) {
-    if (!use_lds) return;
-    const uint32_t n = rc.W * rc.H;
-    const uint32_t n16 = n >> 4;
-    const uint4 *src = reinterpret_cast<const uint4 *>(rc.cls);
-    uint4 *dst = reinterpret_cast<uint4 *>(lds);
-    for (uint32_t t = threadIdx.x; t < n16; t += blockDim.x) dst[t] = src[t];
-    for (uint32_t t = (n16 << 4) + threadIdx.x; t < n; t += blockDim.x) lds[t] = rc.cls[t];
+// Fill the calling wave's LDS tile with the (2R+1)^2 raster window centred on the pixel of (px,py).
+__device__ __forceinline__ TileGrid load_tile(const RunConst &rc, uint8_t *tile, double px, double py, uint32_t lane, uint32_t stride) {
+    TileGrid g;
+    g.lds = tile; g.glob = rc.cls; g.W = rc.W; g.TW = 2u * rc.tile_R + 1u;
+    uint32_t ci, cj;
+    to_pixel(rc, px, py, ci, cj);
+    g.oi = (int)ci - (int)rc.tile_R;
+    g.oj = (int)cj - (int)rc.tile_R;
+    const uint32_t n = g.TW * g.TW;
+    for (uint32_t t = lane; t < n; t += stride) {
+        const uint32_t ri = t / g.TW, rj = t - ri * g.TW;
+        const int i = g.oi + (int)ri, j = g.oj + (int)rj;
+        uint8_t c = CLS_BAD;
+        if (i >= 0 && j >= 0 && (uint32_t)i < rc.H && (uint32_t)j < rc.W) c = rc.cls[(uint32_t)i * rc.W + (uint32_t)j];
+        tile[t] = c;
+    }
+    return g;
 }
 
 template <class T>
@@ -539,64 +755,117 @@ __device__ bool kd_preorder_less(const RunConst &rc, int u, int v) {
     if (ou && ov) return iu < iv;                       // both on G: the ancestor comes first
     if (ou) {                                           // u = G[iu]; v leaves G after G[iv]
         if (iu <= iv) return true;                      // u is an ancestor of v
-        const int w = rc.g_id[iv];                      // u lies below G[iv] on the goal side, v on the other side
-        return !kd_left(rc.nx[v], rc.ny[v], rc.nx[w], rc.ny[w], iv);
+        // u lies below G[iv] on the goal side, v on the other side
+        return !kd_left(rc.nx[v], rc.ny[v], rc.g_x[iv], rc.g_y[iv], iv);
     }
     if (ov) {
         if (iv <= iu) return false;                     // v is an ancestor of u
-        const int w = rc.g_id[iu];
-        return kd_left(rc.nx[u], rc.ny[u], rc.nx[w], rc.ny[w], iu);
+        return kd_left(rc.nx[u], rc.ny[u], rc.g_x[iu], rc.g_y[iu], iu);
     }
     if (iu != iv) {                                     // both off G: the one leaving first splits them
-        if (iu < iv) {
-            const int w = rc.g_id[iu];
-            return kd_left(rc.nx[u], rc.ny[u], rc.nx[w], rc.ny[w], iu);
-        }
-        const int w = rc.g_id[iv];
-        return !kd_left(rc.nx[v], rc.ny[v], rc.nx[w], rc.ny[w], iv);
+        if (iu < iv) return kd_left(rc.nx[u], rc.ny[u], rc.g_x[iu], rc.g_y[iu], iu);
+        return !kd_left(rc.nx[v], rc.ny[v], rc.g_x[iv], rc.g_y[iv], iv);
     }
     // same exit node, same (non-goal) side: plain LCA walk, bounded by the depth below the exit node
     int a = u, b = v;
     uint32_t da = rc.kd_depth[a], db = rc.kd_depth[b];
     int a_from = -1, b_from = -1;       // 0 = came up from a left child, 1 = right
-    while (da > db) { const int p = rc.kd_up[a]; a_from = rc.kd_child[2 * p + 1] == a; a = p; --da; }
-    while (db > da) { const int p = rc.kd_up[b]; b_from = rc.kd_child[2 * p + 1] == b; b = p; --db; }
+    while (da > db) { const int p = rc.kd_up[a]; a_from = rc.kd_rec[p].child[1] == a; a = p; --da; }
+    while (db > da) { const int p = rc.kd_up[b]; b_from = rc.kd_rec[p].child[1] == b; b = p; --db; }
     if (a == b) return a_from >= 0 ? false : true;                 // the one that did not move is the ancestor
     while (a != b) {
         const int pa = rc.kd_up[a], pb = rc.kd_up[b];
-        a_from = rc.kd_child[2 * pa + 1] == a;
-        b_from = rc.kd_child[2 * pb + 1] == b;
+        a_from = rc.kd_rec[pa].child[1] == a;
+        b_from = rc.kd_rec[pb].child[1] == b;
         a = pa; b = pb;
     }
     return a_from < b_from;
 }
 
-// RRT*: validated neighbours, best parent, new node, rewire phase 1.  One wave per sample.
-template <bool LDSGRID>
-__global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
-                                                                     uint32_t vwords) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_grid[];
-    const RunConst &rc = *rcp;
-    load_grid_lds(rc, lds_grid, LDSGRID && rc.has_grid);
-    __syncthreads();
-    const uint8_t *grid = (LDSGRID && rc.has_grid) ? (const uint8_t *)lds_grid : rc.cls;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t k = blockIdx.x * kConnectWaves + (threadIdx.x >> 6);
-    if (k >= nb || rc.q_vid[k] < 0) return;
+// ---- team reductions: a team is one wave (W = 1) or the W waves of a workgroup sharing `scr`
+template <int W>
+struct Team {
+    double *scr_d;      // W doubles
+    int *scr_i;         // W ints
+    uint32_t wave, lane;
+    __device__ __forceinline__ void sync() const { if (W > 1) __syncthreads(); }
+    __device__ __forceinline__ uint32_t sum(uint32_t v) const {
+        v = wave_sum(v);
+        if (W == 1) return v;
+        sync();
+        if (lane == 0) scr_i[wave] = (int)v;
+        sync();
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) t += (uint32_t)scr_i[w];
+        return t;
+    }
+    __device__ __forceinline__ int min_i(int v) const {
+        v = wave_min_u(v);
+        if (W == 1) return v;
+        sync();
+        if (lane == 0) scr_i[wave] = v;
+        sync();
+        int t = scr_i[0];
+#pragma unroll
+        for (int w = 1; w < W; ++w) t = scr_i[w] < t ? scr_i[w] : t;
+        return t;
+    }
+    // lexicographic min of (t, j)
+    __device__ __forceinline__ void argmin(double &t, int &j) const {
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ot = __shfl_xor(t, off);
+            const int oj = __shfl_xor(j, off);
+            if (ot < t || (ot == t && oj < j)) { t = ot; j = oj; }
+        }
+        if (W == 1) return;
+        sync();
+        if (lane == 0) { scr_d[wave] = t; scr_i[wave] = j; }
+        sync();
+        t = scr_d[0]; j = scr_i[0];
+#pragma unroll
+        for (int w = 1; w < W; ++w)
+            if (scr_d[w] < t || (scr_d[w] == t && scr_i[w] < j)) { t = scr_d[w]; j = scr_i[w]; }
+    }
+    // kd pre-order first of the team's candidates (kEmpty = none)
+    __device__ __forceinline__ int first_preorder(const RunConst &rc, int v) const {
+        for (int off = 32; off > 0; off >>= 1) {
+            const int o = __shfl_xor(v, off);
+            if (o != kEmpty && (v == kEmpty || (o != v && kd_preorder_less(rc, o, v)))) v = o;
+        }
+        if (W == 1) return v;
+        sync();
+        if (lane == 0) scr_i[wave] = v;
+        sync();
+        int t = scr_i[0];
+#pragma unroll
+        for (int w = 1; w < W; ++w) {
+            const int o = scr_i[w];
+            if (o != kEmpty && (t == kEmpty || (o != t && kd_preorder_less(rc, o, t)))) t = o;
+        }
+        return t;
+    }
+};
+
+// RRT*: validated neighbours, best parent, new node, rewire phase 1 for sample k by a team of W waves.
+template <int W, class Grid>
+__device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const Grid &grid, uint32_t b, uint32_t vwords, uint32_t k,
+                                   uint32_t cnt, uint32_t &err) {
+    const uint32_t tl = tm.wave * 64u + tm.lane, TS = W * 64u;
     const uint32_t N = rc.n_at[b];
     const uint32_t id = N + rank_before(rc, b, vwords, k);
     const double px = rc.q_x[k], py = rc.q_y[k];
-    const uint32_t cnt = rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap;
     int *cid = rc.cand_id + (size_t)k * rc.cand_cap;
     double *cval = rc.cand_val + (size_t)k * rc.cand_cap;
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
-    uint32_t err = 0;
+    GlobalGrid ggrid;
+    ggrid.p = rc.cls; ggrid.W = rc.W;
 
     // pass 1: raycast every neighbour, total cost through it (rrt.rs:124, 137-140)
     double bt = INF;
     int bj = 0x7FFFFFFF;
     uint32_t nvalid = 0;
-    for (uint32_t a = lane; a < cnt; a += 64) {
+    for (uint32_t a = tl; a < cnt; a += TS) {
         const int j = cid[a];
         const double ax = rc.nx[j], ay = rc.ny[j];
         const double cost = sqrt(dist2(ax, ay, px, py));
@@ -609,12 +878,8 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunCon
             if (total < bt || (total == bt && j < bj)) { bt = total; bj = j; }
         }
     }
-    nvalid = wave_sum(nvalid);
-    for (int off = 32; off > 0; off >>= 1) {
-        double t = __shfl_xor(bt, off);
-        int j = __shfl_xor(bj, off);
-        if (t < bt || (t == bt && j < bj)) { bt = t; bj = j; }
-    }
+    nvalid = tm.sum(nvalid);
+    tm.argmin(bt, bj);
     int best;
     double best_cost, dnew;
     if (nvalid == 0) {
@@ -626,8 +891,8 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunCon
         // equal totals: the reference keeps the first in kd-tree pre-order (rrt.rs:143-145)
         uint32_t n_tie = 0;
         int on_min = kEmpty;        // tied nodes ON the goal path: an ancestor chain, the lowest id is first
-        int off_best = kEmpty;      // pre-order-first tied node off the goal path (per lane, then per wave)
-        for (uint32_t a = lane; a < cnt; a += 64) {
+        int off_best = kEmpty;      // pre-order-first tied node off the goal path
+        for (uint32_t a = tl; a < cnt; a += TS) {
             const double cost = cval[a];
             if (cost >= 0.0) {
                 const int j = cid[a];
@@ -638,14 +903,11 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunCon
                 }
             }
         }
-        n_tie = wave_sum(n_tie);
+        n_tie = tm.sum(n_tie);
         best = bj;
         if (n_tie > 1) {
-            on_min = wave_min_u(on_min);
-            for (int off = 32; off > 0; off >>= 1) {
-                const int o = __shfl_xor(off_best, off);
-                if (o != kEmpty && (off_best == kEmpty || (o != off_best && kd_preorder_less(rc, o, off_best)))) off_best = o;
-            }
+            on_min = tm.min_i(on_min);
+            off_best = tm.first_preorder(rc, off_best);
             if (off_best == kEmpty) best = on_min;
             else if (on_min == kEmpty) best = off_best;
             else best = kd_preorder_less(rc, on_min, off_best) ? on_min : off_best;
@@ -655,20 +917,22 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunCon
     }
 
     // new node (rrt.rs:148, 30-37) and goal test (rrt.rs:165-167)
-    if (lane == 0) {
+    if (tl == 0) {
         rc.nx[id] = px;
         rc.ny[id] = py;
+        write_filter_view(rc, (int)id, px, py);
+        rep_insert(rc, px, py, (int)id);
         rc.parent[id] = best;
         rc.distA[id] = dnew;
         rc.distB[id] = dnew;
         unsigned long long mask = 0;
-        const bool fin = goal_hit(rc, grid, px, py, mask, &err);
+        const bool fin = goal_hit(rc, ggrid, px, py, mask, &err);
         rc.final_flag[id] = fin ? 1 : 0;
         rc.final_mask[id] = fin ? mask : 0ull;
         if (fin) atomicAdd(&rc.cnt->n_final, 1u);
     }
     // rewire phase 1 (rrt.rs:152-161): dist_root candidates, min wins
-    for (uint32_t a = lane; a < cnt; a += 64) {
+    for (uint32_t a = tl; a < cnt; a += TS) {
         const double cost = cval[a];
         const int j = cid[a];
         int keep = -1;
@@ -681,6 +945,61 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunCon
             }
         }
         cid[a] = keep;
+    }
+}
+
+constexpr uint32_t kHeavyCand = 128;     // samples with more neighbours than this go to the 4-wave team kernel
+
+// light samples: one wave each; heavy ones are queued for k_connect_rrt_heavy
+template <bool LDSGRID>
+__global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
+                                                                     uint32_t vwords) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_tiles[];
+    const RunConst &rc = *rcp;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t k = blockIdx.x * kConnectWaves + (threadIdx.x >> 6);
+    if (k >= nb || rc.q_vid[k] < 0) return;
+    const uint32_t cnt = rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap;
+    if (cnt > kHeavyCand) {
+        if (lane == 0) rc.heavy_list[atomicAdd(&rc.cnt->n_heavy, 1u)] = k;
+        return;
+    }
+    TileGrid grid;
+    if (LDSGRID) {
+        const uint32_t TW = 2u * rc.tile_R + 1u;
+        grid = load_tile(rc, lds_tiles + (threadIdx.x >> 6) * ((TW * TW + 15u) & ~15u), rc.q_x[k], rc.q_y[k], lane, 64u);
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0;
+    }
+    Team<1> tm;
+    tm.scr_d = nullptr; tm.scr_i = nullptr; tm.wave = 0; tm.lane = lane;
+    uint32_t err = 0;
+    connect_rrt_sample<1>(rc, tm, grid, b, vwords, k, cnt, err);
+    if (err) atomicOr(&rc.cnt->err, err);
+}
+
+// heavy samples (hundreds of neighbours: the dense start of a tree, duplicates of the goal point): a
+// workgroup of four waves per sample
+template <bool LDSGRID>
+__global__ __launch_bounds__(256) void k_connect_rrt_heavy(const RunConst *__restrict__ rcp, uint32_t b, uint32_t vwords) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_tiles[];
+    __shared__ double s_d[4];
+    __shared__ int s_i[4];
+    const RunConst &rc = *rcp;
+    const uint32_t n_heavy = rc.cnt->n_heavy;
+    Team<4> tm;
+    tm.scr_d = s_d; tm.scr_i = s_i; tm.wave = threadIdx.x >> 6; tm.lane = threadIdx.x & 63u;
+    uint32_t err = 0;
+    for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+        const uint32_t k = rc.heavy_list[h];
+        const uint32_t cnt = rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap;
+        TileGrid grid;
+        __syncthreads();
+        if (LDSGRID) grid = load_tile(rc, lds_tiles, rc.q_x[k], rc.q_y[k], threadIdx.x, 256u);
+        else { grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0; }
+        __syncthreads();
+        connect_rrt_sample<4>(rc, tm, grid, b, vwords, k, cnt, err);
     }
     if (err) atomicOr(&rc.cnt->err, err);
 }
@@ -727,13 +1046,11 @@ __global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__
 //            (atomicMin), the others step below it.  Contenders of one slot always arrive in the same round
 //            because they share the whole path above it, so this equals sequential insertion.
 // One workgroup; a thread owns up to kPer nodes (batch_K <= 4096).
-__global__ __launch_bounds__(1024) void k_kd_insert(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
+__global__ __launch_bounds__(1024) void k_kd_insert(const RunConst *__restrict__ rcp, uint32_t b) {
     const RunConst &rc = *rcp;
-    __shared__ uint32_t s_len;
     const uint32_t N = rc.n_at[b];
-    if (threadIdx.x == 0) s_len = rc.cnt->g_len;
-    __syncthreads();
-    const uint32_t glen0 = s_len;
+    const uint32_t n_new = rc.n_at[b + 1] - N;       // written by the commit kernel of step b
+    const uint32_t glen0 = __builtin_amdgcn_readfirstlane(rc.cnt->g_len);
     const double px = rc.gp_x, py = rc.gp_y;
     constexpr int kPer = 4;
     bool todo[kPer], onpath[kPer];
@@ -742,66 +1059,111 @@ __global__ __launch_bounds__(1024) void k_kd_insert(const RunConst *__restrict__
     uint32_t side[kPer], dcur[kPer], gex[kPer];
 #pragma unroll
     for (int r = 0; r < kPer; ++r) {
-        const uint32_t k = threadIdx.x + r * 1024u;
-        todo[r] = k < nb && rc.q_vid[k < nb ? k : 0] >= 0;
+        const uint32_t t = threadIdx.x + r * 1024u;
+        todo[r] = t < n_new;
         onpath[r] = todo[r];
-        vx[r] = todo[r] ? rc.q_x[k] : 0.0;
-        vy[r] = todo[r] ? rc.q_y[k] : 0.0;
-        vidn[r] = todo[r] ? (int)(N + rank_before(rc, b, vwords, k)) : kEmpty;
+        vidn[r] = todo[r] ? (int)(N + t) : kEmpty;
+        vx[r] = todo[r] ? rc.nx[N + t] : 0.0;
+        vy[r] = todo[r] ? rc.ny[N + t] : 0.0;
         cur[r] = 0; side[r] = 0; dcur[r] = 0; gex[r] = 0;
     }
-    // phase 1a: follow G while the node falls on the goal point's side
-    for (uint32_t i = 0; i < glen0; ++i) {
-        bool any = false;
-#pragma unroll
-        for (int r = 0; r < kPer; ++r) any |= onpath[r];
-        if (!__any(any)) break;                 // wave-level: most waves leave G within a few levels
-        const int w = rc.g_id[i];
-        const double wx = rc.nx[w], wy = rc.ny[w];
-        const bool gl = kd_left(px, py, wx, wy, i);
+    if (rc.dbg && threadIdx.x == 0) { rc.dbg[b * 8 + 0] = wall_clock64(); rc.dbg[b * 8 + 6] = clock64(); }
+    {
+        // phase 1a: follow G while the node falls on the goal point's side.  The path is staged in LDS as
+        // (split coordinate, goal side) per level with one coalesced pass; each lane then walks it on its own
+        // (no cross-lane traffic per level), eight levels per trip.
+        constexpr uint32_t kStage = 4096;
+        __shared__ double s_w[kStage];
+        __shared__ uint8_t s_gl[kStage];
+        for (uint32_t t = threadIdx.x; t < glen0 && t < kStage; t += 1024) {
+            const double gx = rc.g_x[t], gy = rc.g_y[t];
+            s_w[t] = (t & 1u) ? gy : gx;
+            s_gl[t] = kd_left(px, py, gx, gy, t) ? 1 : 0;
+        }
+        __syncthreads();
 #pragma unroll
         for (int r = 0; r < kPer; ++r) {
-            if (onpath[r]) {
-                const bool vl = kd_left(vx[r], vy[r], wx, wy, i);
-                cur[r] = w; dcur[r] = i; side[r] = vl ? 0u : 1u;
-                if (vl != gl) { onpath[r] = false; gex[r] = i; }
+            if (r * 1024u >= n_new) break;
+            uint32_t my_exit = 0xFFFFFFFFu;
+            bool my_left = false;
+            bool walking = todo[r];
+            for (uint32_t i0 = 0; i0 < glen0; i0 += 8) {
+                if (!__any(walking)) break;
+                double w[8];
+                bool gl[8];
+                if (i0 + 8 <= kStage) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { w[u] = s_w[i0 + u]; gl[u] = s_gl[i0 + u]; }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {                  // very long paths: the tail comes from global
+                        const uint32_t i = i0 + u;
+                        const double gx = rc.g_x[i], gy = rc.g_y[i];
+                        w[u] = (u & 1) ? gy : gx;
+                        gl[u] = kd_left(px, py, gx, gy, i);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t i = i0 + u;
+                    const bool vl = ((u & 1) ? vy[r] : vx[r]) < w[u];   // depth parity = parity of u
+                    if (walking && i < glen0 && vl != gl[u]) { walking = false; my_exit = i; my_left = vl; }
+                }
+            }
+            if (todo[r]) {
+                if (my_exit != 0xFFFFFFFFu) { onpath[r] = false; gex[r] = my_exit; dcur[r] = my_exit; side[r] = my_left ? 0u : 1u; }
+                else {
+                    // stayed on G to its end: below the last node, on the goal point's side
+                    const uint32_t last = glen0 - 1;
+                    dcur[r] = last;
+                    side[r] = kd_left(px, py, rc.g_x[last], rc.g_y[last], last) ? 0u : 1u;
+                }
             }
         }
     }
-    // phase 1b: nodes that left G descend the old tree to an empty slot
+    if (rc.dbg && threadIdx.x == 0) rc.dbg[b * 8 + 1] = wall_clock64();
+    // phase 1b: nodes that left G descend the old tree to an empty slot (one 24-byte record per level)
 #pragma unroll
     for (int r = 0; r < kPer; ++r) {
-        if (todo[r] && !onpath[r]) {
-            for (;;) {
-                const int c = rc.kd_child[2 * cur[r] + (int)side[r]];
-                if (c == kEmpty) break;
-                cur[r] = c;
-                dcur[r] += 1;
-                side[r] = kd_left(vx[r], vy[r], rc.nx[c], rc.ny[c], dcur[r]) ? 0u : 1u;
-            }
+        if (!todo[r]) continue;
+        cur[r] = rc.g_id[dcur[r]];
+        if (onpath[r]) continue;
+        KdRec rec = rc.kd_rec[cur[r]];
+        for (;;) {                          // one dependent 24-byte load per level
+            const int c = side[r] ? rec.child[1] : rec.child[0];   // no dynamic register indexing
+            if (c == kEmpty) break;
+            rec = rc.kd_rec[c];
+            cur[r] = c;
+            dcur[r] += 1;
+            side[r] = kd_left(vx[r], vy[r], rec.x, rec.y, dcur[r]) ? 0u : 1u;
         }
     }
     __syncthreads();
+    if (rc.dbg && threadIdx.x == 0) rc.dbg[b * 8 + 2] = wall_clock64();
+    uint32_t rounds = 0;
     // phase 2: claim rounds
     for (;;) {
+        ++rounds;
         bool any = false;
 #pragma unroll
         for (int r = 0; r < kPer; ++r) {
-            if (todo[r]) { atomicMin(&rc.kd_child[2 * cur[r] + (int)side[r]], vidn[r]); any = true; }
+            if (todo[r]) { atomicMin(&rc.kd_rec[cur[r]].child[side[r]], vidn[r]); any = true; }
         }
         if (!__syncthreads_or(any)) break;
 #pragma unroll
         for (int r = 0; r < kPer; ++r) {
             if (!todo[r]) continue;
-            const int w = atomicMin(&rc.kd_child[2 * cur[r] + (int)side[r]], kEmpty);   // read the winner at L2
+            const int w = atomicMin(&rc.kd_rec[cur[r]].child[side[r]], kEmpty);   // read the winner at L2
             const uint32_t dw = dcur[r] + 1;
             if (w == vidn[r]) {
+                KdRec rec;
+                rec.x = vx[r]; rec.y = vy[r]; rec.child[0] = kEmpty; rec.child[1] = kEmpty;
+                rc.kd_rec[w] = rec;
                 rc.kd_up[w] = cur[r];
                 rc.kd_depth[w] = dw;
-                rc.kd_child[2 * w] = kEmpty;
-                rc.kd_child[2 * w + 1] = kEmpty;
                 if (onpath[r]) {
-                    if (dw < rc.g_cap) rc.g_id[dw] = w; else atomicOr(&rc.cnt->err, ERR_GPATH_OVERFLOW);
+                    if (dw + 8 < rc.g_cap) { rc.g_id[dw] = w; rc.g_x[dw] = vx[r]; rc.g_y[dw] = vy[r]; }
+                    else atomicOr(&rc.cnt->err, ERR_GPATH_OVERFLOW);
                     rc.kd_gexit[w] = dw | kOnG;
                     atomicMax(&rc.cnt->g_len, dw + 1);
                 } else {
@@ -818,23 +1180,31 @@ __global__ __launch_bounds__(1024) void k_kd_insert(const RunConst *__restrict__
         }
         __syncthreads();
     }
+    if (rc.dbg && threadIdx.x == 0) { rc.dbg[b * 8 + 3] = wall_clock64(); rc.dbg[b * 8 + 4] = rounds; rc.dbg[b * 8 + 5] = glen0; rc.dbg[b * 8 + 6] = clock64() - rc.dbg[b * 8 + 6]; }
 }
 
 // PTO: edges to every neighbour with a valid transition, reachability phase 1 and 2 (pto.rs:95-124)
 template <bool LDSGRID>
 __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
                                                                      uint32_t vwords) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_grid[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_tiles[];
     const RunConst &rc = *rcp;
-    load_grid_lds(rc, lds_grid, LDSGRID);
-    __syncthreads();
-    const uint8_t *grid = LDSGRID ? (const uint8_t *)lds_grid : rc.cls;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = blockIdx.x * kConnectWaves + (threadIdx.x >> 6);
     if (k >= nb || rc.q_vid[k] < 0) return;
+    const double px = rc.q_x[k], py = rc.q_y[k];
+    GlobalGrid ggrid;
+    ggrid.p = rc.cls; ggrid.W = rc.W;
+    TileGrid grid;
+    if (LDSGRID) {
+        const uint32_t TW = 2u * rc.tile_R + 1u;
+        grid = load_tile(rc, lds_tiles + (threadIdx.x >> 6) * ((TW * TW + 15u) & ~15u), px, py, lane, 64u);
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0;
+    }
     const uint32_t N = rc.n_at[b];
     const uint32_t id = N + rank_before(rc, b, vwords, k);
-    const double px = rc.q_x[k], py = rc.q_y[k];
     uint32_t cnt = rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap;
     int *cid = rc.cand_id + (size_t)k * rc.cand_cap;
     double *cval = rc.cand_val + (size_t)k * rc.cand_cap;
@@ -885,6 +1255,8 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
     if (lane == 0) {
         rc.nx[id] = px;
         rc.ny[id] = py;
+        write_filter_view(rc, (int)id, px, py);
+        rep_insert(rc, px, py, (int)id);
         rc.parent[id] = -1;
         rc.distA[id] = 0.0;
         rc.distB[id] = 0.0;
@@ -892,7 +1264,7 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
         rc.reachA[id] = r_new;
         rc.reachB[id] = r_new;
         unsigned long long mask = 0;
-        const bool fin = goal_hit(rc, grid, px, py, mask, &err);
+        const bool fin = goal_hit(rc, ggrid, px, py, mask, &err);
         rc.final_flag[id] = fin ? 1 : 0;
         rc.final_mask[id] = fin ? mask : 0ull;
         if (fin) {

@@ -158,15 +158,20 @@ struct porrt_ctx {
     uint32_t obs_zone = 0;
     // ---- options
     bool opt_profile = false;
-    bool opt_graph = false;
+    bool opt_graph = true;
     uint32_t opt_cand_cap = 2048;
     // ---- device buffers
     DevBuf<double> d_nx, d_ny, d_distA, d_distB, d_sx, d_sy, d_qx, d_qy, d_partD, d_candval, d_radT2, d_inj;
-    DevBuf<int> d_parent, d_qnn, d_qvid, d_partid, d_candid, d_gid, d_kdchild, d_kdup;
+    DevBuf<int> d_parent, d_qnn, d_qvid, d_partid, d_candid, d_gid, d_kdup;
+    DevBuf<KdRec> d_kdrec;
+    DevBuf<double> d_gx, d_gy;
+    DevBuf<float> d_fx, d_fy, d_f2, d_qax, d_qay, d_qthr;
+    DevBuf<int> d_rep;
+    DevBuf<unsigned long long> d_dbg;
     DevBuf<uint32_t> d_kddepth, d_kdgexit;
     DevBuf<unsigned long long> d_reachA, d_reachB, d_finalmask, d_validmask;
     DevBuf<uint8_t> d_vid, d_finalflag, d_cls;
-    DevBuf<uint32_t> d_nat, d_sworld, d_candcnt, d_efrom, d_eto, d_etv;
+    DevBuf<uint32_t> d_nat, d_sworld, d_candcnt, d_efrom, d_eto, d_etv, d_heavy;
     DevBuf<Counters> d_cnt;
     DevBuf<RunConst> d_rc;
     DevBuf<PcgJump> d_jump;
@@ -199,6 +204,13 @@ struct porrt_ctx {
                   uint32_t K, int mode, bool host_samples);
     int download();
     void launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, size_t lds_bytes, bool prof, size_t &ev_used);
+    void join_side();
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_step_done = nullptr, ev_kd_done = nullptr;
+    bool kd_pending = false;
+    // cached hipGraph of the steps up to n_iter_min
+    hipGraphExec_t graph_exec = nullptr;
+    uint64_t graph_key[6] = {0, 0, 0, 0, 0, 0};
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -286,10 +298,15 @@ __global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y
     rc.final_flag[0] = 0;
     rc.final_mask[0] = 0;
     rc.n_at[0] = 1;
+    write_filter_view(rc, 0, x, y);
+    rep_insert(rc, x, y, 0);
     rc.g_id[0] = 0;          // the root is on every kd descent path
     rc.cnt->g_len = 1;
-    rc.kd_child[0] = kEmpty;
-    rc.kd_child[1] = kEmpty;
+    KdRec rec;
+    rec.x = x; rec.y = y; rec.child[0] = kEmpty; rec.child[1] = kEmpty;
+    rc.kd_rec[0] = rec;
+    rc.g_x[0] = x;
+    rc.g_y[0] = y;
     rc.kd_up[0] = -1;
     rc.kd_depth[0] = 0;
     rc.kd_gexit[0] = kOnG;
@@ -298,33 +315,55 @@ __global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y
 void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, size_t lds_bytes, bool prof, size_t &ev_used) {
     // at most one node per iteration so far (+ root): bound on the tree size at the start of this step
     const uint32_t n_ub = i0 + 1;
-    uint32_t NC = (n_ub + 127) / 128;
+    uint32_t NC = (n_ub + 63) / 64;
     NC = std::max(1u, std::min<uint32_t>(NC, kMaxChunks));
     const dim3 scan_grid((nb + kScanBlock - 1) / kScanBlock, NC);
     const uint32_t wave_blocks = (nb * 64 + 255) / 256;
+    const uint32_t red_blocks = (nb + 63) / 64;
     const RunConst *rcp = d_rc.p;
     auto ev = [&](void) {
         if (prof && ev_used < ev_pool.size()) (void)hipEventRecord(ev_pool[ev_used++], stream);
     };
+    const dim3 kgrid((nb + 255) / 256);
+    if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_nn_bound<true>, kgrid, dim3(256), 0, stream, rcp, b, i0, nb);
+    else hipLaunchKernelGGL(k_nn_bound<false>, kgrid, dim3(256), 0, stream, rcp, b, i0, nb);
     ev();
     if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_nn_scan<true>, scan_grid, dim3(kScanBlock), 0, stream, rcp, b, i0, nb, NC);
     else hipLaunchKernelGGL(k_nn_scan<false>, scan_grid, dim3(kScanBlock), 0, stream, rcp, b, i0, nb, NC);
     ev();
-    hipLaunchKernelGGL(k_nn_reduce_steer, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, i0, nb, NC, vwords);
+    hipLaunchKernelGGL(k_nn_reduce_steer, dim3(red_blocks), dim3(256), 0, stream, rcp, b, i0, nb, NC, vwords);
     ev();
     hipLaunchKernelGGL(k_radius_scan, scan_grid, dim3(kScanBlock), 0, stream, rcp, b, nb, NC);
     ev();
     const dim3 cgrid((nb + kConnectWaves - 1) / kConnectWaves), cblock(kConnectWaves * 64);
+    // the kd structure of the previous step's nodes (side stream) is needed from here on
+    if (mode == PORRT_MODE_RRT && kd_pending) { (void)hipStreamWaitEvent(stream, ev_kd_done, 0); kd_pending = false; }
     if (mode == PORRT_MODE_PTO) {
         if (lds_bytes) hipLaunchKernelGGL(k_connect_pto<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
         else hipLaunchKernelGGL(k_connect_pto<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
         hipLaunchKernelGGL(k_commit_pto, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, nb, vwords);
     } else {
-        if (lds_bytes) hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
-        else hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
+        const dim3 hgrid(std::min<uint32_t>(nb, 1024u));
+        if (lds_bytes) {
+            hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
+            hipLaunchKernelGGL(k_connect_rrt_heavy<true>, hgrid, dim3(256), lds_bytes / kConnectWaves, stream, rcp, b, vwords);
+        } else {
+            hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
+            hipLaunchKernelGGL(k_connect_rrt_heavy<false>, hgrid, dim3(256), 0, stream, rcp, b, vwords);
+        }
         hipLaunchKernelGGL(k_commit_rrt, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, nb, vwords);
-        hipLaunchKernelGGL(k_kd_insert, dim3(1), dim3(1024), 0, stream, rcp, b, nb, vwords);
+        // order-exact kd insertion of this step's nodes runs beside the next step's bound / scans
+        (void)hipEventRecord(ev_step_done, stream);
+        (void)hipStreamWaitEvent(stream2, ev_step_done, 0);
+        hipLaunchKernelGGL(k_kd_insert, dim3(1), dim3(1024), 0, stream2, rcp, b);
+        (void)hipEventRecord(ev_kd_done, stream2);
+        kd_pending = true;
     }
+}
+
+// join the side stream back into the main stream (end of a launch sequence / of a capture)
+void porrt_ctx::join_side() {
+    if (kd_pending) { (void)hipStreamWaitEvent(stream, ev_kd_done, 0); kd_pending = false; }
 }
 
 int porrt_ctx::grow(const double start[2], double max_step, double search_radius, uint64_t n_iter_min, uint64_t n_iter_max,
@@ -378,9 +417,11 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(d_sx.reserve(n_iter_max + 1)); HIPCHK(d_sy.reserve(n_iter_max + 1)); HIPCHK(d_sworld.reserve(n_iter_max + 1));
         HIPCHK(d_qx.reserve(K)); HIPCHK(d_qy.reserve(K)); HIPCHK(d_qnn.reserve(K)); HIPCHK(d_qvid.reserve(K));
         HIPCHK(d_partD.reserve((size_t)K * kMaxChunks)); HIPCHK(d_partid.reserve((size_t)K * kMaxChunks));
-        HIPCHK(d_candcnt.reserve(K)); HIPCHK(d_candid.reserve((size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
+        HIPCHK(d_candcnt.reserve(K)); HIPCHK(d_heavy.reserve(K)); HIPCHK(d_candid.reserve((size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
         HIPCHK(d_gid.reserve(Nmax));
-        HIPCHK(d_kdchild.reserve(2 * Nmax)); HIPCHK(d_kdup.reserve(Nmax)); HIPCHK(d_kddepth.reserve(Nmax)); HIPCHK(d_kdgexit.reserve(Nmax));
+        HIPCHK(d_fx.reserve(Nmax + 64)); HIPCHK(d_fy.reserve(Nmax + 64)); HIPCHK(d_f2.reserve(Nmax + 64));
+        HIPCHK(d_qax.reserve(K)); HIPCHK(d_qay.reserve(K)); HIPCHK(d_qthr.reserve(K)); HIPCHK(d_rep.reserve(kRepTotal));
+        HIPCHK(d_kdrec.reserve(Nmax)); HIPCHK(d_gx.reserve(Nmax + 16)); HIPCHK(d_gy.reserve(Nmax + 16)); HIPCHK(d_kdup.reserve(Nmax)); HIPCHK(d_kddepth.reserve(Nmax)); HIPCHK(d_kdgexit.reserve(Nmax));
         if (d_radT2.n < Nmax + 8) { HIPCHK(d_radT2.reserve(Nmax + 8)); rad_uploaded = 0; }
         HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_jump.reserve(1));
         if (mode == PORRT_MODE_PTO) {
@@ -408,10 +449,23 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.inj_base = inj_pos; c.inj_n = inj_xy.size() / 2;
     c.q_x = d_qx.p; c.q_y = d_qy.p; c.q_nn = d_qnn.p; c.q_vid = d_qvid.p;
     c.part_D = d_partD.p; c.part_id = d_partid.p;
-    c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
+    c.heavy_list = d_heavy.p; c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
     c.rad_T2 = d_radT2.p;
     c.e_from = d_efrom.p; c.e_to = d_eto.p; c.e_tv = d_etv.p; c.e_cap = (uint32_t)d_efrom.n;
-    c.kd_child = d_kdchild.p; c.kd_up = d_kdup.p; c.kd_depth = d_kddepth.p; c.kd_gexit = d_kdgexit.p;
+    c.fx = d_fx.p; c.fy = d_fy.p; c.f2 = d_f2.p; c.rep = d_rep.p; c.q_ax = d_qax.p; c.q_ay = d_qay.p; c.q_thr = d_qthr.p;
+    {
+        // box of the bound pyramid and the error budget of the f32 key: every node and every sample lies in it
+        double x0 = std::min(s_low[0], start[0]), x1 = std::max(s_up[0], start[0]);
+        double y0 = std::min(s_low[1], start[1]), y1 = std::max(s_up[1], start[1]);
+        if (has_inj) for (size_t t = 0; t + 1 < inj_xy.size(); t += 2) { x0 = std::min(x0, inj_xy[t]); x1 = std::max(x1, inj_xy[t]); y0 = std::min(y0, inj_xy[t + 1]); y1 = std::max(y1, inj_xy[t + 1]); }
+        for (uint32_t g = 0; g < G; ++g) { x0 = std::min(x0, gcx[g]); x1 = std::max(x1, gcx[g]); y0 = std::min(y0, gcy[g]); y1 = std::max(y1, gcy[g]); }
+        for (int z = 0; z < n_zones; ++z) { x0 = std::min(x0, zone_pos[z][0]); x1 = std::max(x1, zone_pos[z][0]); y0 = std::min(y0, zone_pos[z][1]); y1 = std::max(y1, zone_pos[z][1]); }
+        c.bx0 = x0; c.by0 = y0; c.binv_w = 1.0 / (x1 - x0); c.binv_h = 1.0 / (y1 - y0);
+        const double Rm = std::max(std::max(fabs(x0), fabs(x1)), std::max(fabs(y0), fabs(y1)));
+        c.filt_E = 32.0 * ldexp(1.0, -24) * Rm * Rm + 1e-300;
+    }
+    if (getenv("PORRT_DEBUG")) { if (d_dbg.reserve((steps_max + 2) * 8) == hipSuccess) { (void)hipMemsetAsync(d_dbg.p, 0, (steps_max + 2) * 64, stream); c.dbg = d_dbg.p; } }
+    c.kd_rec = d_kdrec.p; c.g_x = d_gx.p; c.g_y = d_gy.p; c.kd_up = d_kdup.p; c.kd_depth = d_kddepth.p; c.kd_gexit = d_kdgexit.p;
     c.g_id = d_gid.p; c.g_cap = (uint32_t)std::min<uint64_t>(d_gid.n, 0xFFFFFFFFull);
     c.cls = d_cls.p; c.W = W; c.H = H; c.low0 = low[0]; c.low1 = low[1]; c.ppm = ppm; c.domain = domain; c.has_grid = has_grid;
     c.n_validities = n_validities;
@@ -427,6 +481,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     else if (goal_kind == 2) { c.gp_x = c.zone_x; c.gp_y = c.zone_y; }
     c.s_low0 = s_low[0]; c.s_low1 = s_low[1]; c.s_up0 = s_up[0]; c.s_up1 = s_up[1];
     c.max_step = max_step; c.mode = mode;
+    c.part_stride = K;
 
     // ---- root (rrt.rs:105-106 / pto.rs:61-64)
     uint64_t root_reach = 0;
@@ -464,19 +519,23 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(hipMemcpyAsync(d_rc.p, &c, sizeof c, hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(d_jump.p, &jt, sizeof jt, hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemsetAsync(d_cnt.p, 0, sizeof(Counters), stream));
+        HIPCHK(hipMemsetAsync(d_rep.p, 0xFF, kRepTotal * sizeof(int), stream));
         HIPCHK(hipMemsetAsync(d_validmask.p, 0, (steps_max + 2) * vwords * sizeof(unsigned long long), stream));
         t_setup += now_s() - t0;
     }
     hipLaunchKernelGGL(k_init_root, dim3(1), dim3(1), 0, stream, d_rc.p, start[0], start[1], (unsigned long long)root_reach, root_vid);
 
+    // LDS tile per wave for the raycasts: every neighbour lies within radius <= max_step of the new node
     size_t lds_bytes = 0;
-    if (has_grid && (size_t)W * H <= kLdsGridMax) {
-        lds_bytes = ((size_t)W * H + 15) & ~(size_t)15;
-        if (lds_bytes > 48 * 1024) {
-            if (mode == PORRT_MODE_PTO) HIPCHK(hipFuncSetAttribute((const void *)k_connect_pto<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            else HIPCHK(hipFuncSetAttribute((const void *)k_connect_rrt<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    {
+        double rpx = max_step * ppm;
+        if (has_grid && rpx < (double)(kTileRMax - 2)) {
+            c.tile_R = (uint32_t)ceil(rpx) + 2;
+            const uint32_t TW = 2 * c.tile_R + 1;
+            lds_bytes = (size_t)kConnectWaves * ((TW * TW + 15u) & ~15u);
         }
     }
+    HIPCHK(hipMemcpyAsync(d_rc.p, &c, sizeof c, hipMemcpyHostToDevice, stream));
 
     // profiling events
     const bool prof = opt_profile;
@@ -557,11 +616,41 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         if (r) return r;
     }
     HIPCHK(hipEventRecord(ev_first, stream));
-    while (i < n_iter_min) {
-        uint32_t nb = (uint32_t)std::min<uint64_t>(K, n_iter_min - i);
-        launch_step(b, (uint32_t)i, nb, vwords, lds_bytes, prof, ev_used);
-        i += nb;
-        ++b;
+    kd_pending = false;
+    if (opt_graph && !prof && n_iter_min > 0) {
+        // all steps up to n_iter_min as one hipGraph (two branches: main pipeline + kd insertion); the graph
+        // only depends on the launch geometry, so it is instantiated once and replayed by later grows
+        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)d_rc.p, 1};
+        if (!graph_exec || memcmp(key, graph_key, sizeof key)) {
+            double t0 = now_s();
+            if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            uint64_t ci = 0;
+            uint32_t cb = 0;
+            while (ci < n_iter_min) {
+                uint32_t nb = (uint32_t)std::min<uint64_t>(K, n_iter_min - ci);
+                launch_step(cb, (uint32_t)ci, nb, vwords, lds_bytes, false, ev_used);
+                ci += nb;
+                ++cb;
+            }
+            join_side();
+            HIPCHK(hipStreamEndCapture(stream, &g));
+            HIPCHK(hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+            memcpy(graph_key, key, sizeof key);
+            t_setup += now_s() - t0;
+        }
+        HIPCHK(hipGraphLaunch(graph_exec, stream));
+        while (i < n_iter_min) { i += std::min<uint64_t>(K, n_iter_min - i); ++b; }
+    } else {
+        while (i < n_iter_min) {
+            uint32_t nb = (uint32_t)std::min<uint64_t>(K, n_iter_min - i);
+            launch_step(b, (uint32_t)i, nb, vwords, lds_bytes, prof, ev_used);
+            i += nb;
+            ++b;
+        }
+        join_side();
     }
     Counters hc;
     auto read_counters = [&]() -> int {
@@ -586,6 +675,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         r = make_samples(i, nb);
         if (r) return r;
         launch_step(b, (uint32_t)i, nb, vwords, lds_bytes, prof, ev_used);
+        join_side();
         i += nb;
         ++b;
         r = read_counters();
@@ -610,7 +700,17 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         return -101;
     }
     counters = hc;
-    if (getenv("PORRT_DEBUG")) fprintf(stderr, "[porrt] tie fallbacks %u g_len %u\n", hc.tie_fallbacks, hc.g_len);
+    if (getenv("PORRT_DEBUG")) {
+        fprintf(stderr, "[porrt] tie fallbacks %u g_len %u\n", hc.tie_fallbacks, hc.g_len);
+        if (c.dbg) {
+            std::vector<unsigned long long> d((size_t)b * 8);
+            (void)hipMemcpy(d.data(), d_dbg.p, d.size() * 8, hipMemcpyDeviceToHost);
+            for (uint32_t s2 = 0; s2 < b; s2 += std::max(1u, b / 12))
+                fprintf(stderr, "[porrt] kd_insert step %3u: 1a %6.1f us  1b %6.1f us  rounds(%2llu) %6.1f us  glen %llu  clock %.0f MHz\n", s2,
+                        (d[s2 * 8 + 1] - d[s2 * 8 + 0]) * 0.01, (d[s2 * 8 + 2] - d[s2 * 8 + 1]) * 0.01, d[s2 * 8 + 4],
+                        (d[s2 * 8 + 3] - d[s2 * 8 + 2]) * 0.01, d[s2 * 8 + 5], (double)d[s2 * 8 + 6] / ((d[s2 * 8 + 3] - d[s2 * 8 + 0]) * 0.01));
+        }
+    }
     n_iter = i;
     n_steps = b;
     n_nodes = n_final_nodes;
@@ -711,6 +811,9 @@ porrt_ctx *porrt_create(int device) {
     porrt_ctx *c = new porrt_ctx();
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_step_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_kd_done, hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
     c->crng.seed_from_u64(0);   // sample_space.rs:18
     c->drng.seed_from_u64(0);   // sample_space.rs:47
     c->validities[0] = 1;       // map_io.rs:108-111 init_without_zones
@@ -726,12 +829,16 @@ void porrt_destroy(porrt_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     c->d_nx.release(); c->d_ny.release(); c->d_distA.release(); c->d_distB.release(); c->d_sx.release(); c->d_sy.release();
     c->d_qx.release(); c->d_qy.release(); c->d_partD.release(); c->d_candval.release(); c->d_radT2.release(); c->d_inj.release();
-    c->d_parent.release(); c->d_qnn.release(); c->d_qvid.release(); c->d_partid.release(); c->d_candid.release(); c->d_gid.release(); c->d_kdchild.release(); c->d_kdup.release(); c->d_kddepth.release(); c->d_kdgexit.release();
+    c->d_parent.release(); c->d_qnn.release(); c->d_qvid.release(); c->d_partid.release(); c->d_candid.release(); c->d_gid.release(); c->d_fx.release(); c->d_fy.release(); c->d_f2.release(); c->d_qax.release(); c->d_qay.release(); c->d_qthr.release(); c->d_rep.release(); c->d_kdrec.release(); c->d_gx.release(); c->d_gy.release(); c->d_kdup.release(); c->d_kddepth.release(); c->d_kdgexit.release();
     c->d_reachA.release(); c->d_reachB.release(); c->d_finalmask.release(); c->d_validmask.release();
     c->d_vid.release(); c->d_finalflag.release(); c->d_cls.release();
-    c->d_nat.release(); c->d_sworld.release(); c->d_candcnt.release(); c->d_efrom.release(); c->d_eto.release(); c->d_etv.release();
+    c->d_nat.release(); c->d_sworld.release(); c->d_candcnt.release(); c->d_heavy.release(); c->d_efrom.release(); c->d_eto.release(); c->d_etv.release();
     c->d_cnt.release(); c->d_rc.release(); c->d_jump.release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->ev_step_done) (void)hipEventDestroy(c->ev_step_done);
+    if (c->ev_kd_done) (void)hipEventDestroy(c->ev_kd_done);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
