@@ -57,6 +57,9 @@ struct Counters {
     unsigned long long finality;
     uint32_t g_len;
     uint32_t n_heavy;
+    uint32_t g_nd_len;          // non-duplicate levels of G
+    uint32_t g_first_dup[2];    // first level of even / odd depth held by a duplicate of the goal point
+    uint32_t pad;
 };
 
 struct RunConst {
@@ -104,6 +107,8 @@ struct RunConst {
     int *kd_up;
     uint32_t *kd_depth;
     uint32_t *kd_gexit;
+    int *loc_cur;               // per new node of the step: where k_kd_locate stopped (node, depth, G exit, flags)
+    uint32_t *loc_dcur, *loc_gex, *loc_flags, *g_nd;
     int *g_id;                  // G[i] = node at depth i on the kd descent path of the goal point
     double *g_x, *g_y;          // its coordinates, contiguous (the path is scanned, not chased)
     uint32_t g_cap;
@@ -1038,20 +1043,84 @@ __global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__
 
 // Insert this step's nodes into the reference's kd-tree in id order (KdTree::add, nearest_neighbor.rs:29-46;
 // rrt.rs:163) -- only the STRUCTURE is kept (child / parent / depth), searches stay brute force.  It exists to
-// reproduce the order in which the reference resolves equal-cost parents (kd pre-order).
-//   phase 1  every new node descends the tree as it stood before the step.  The part of the descent that runs
-//            along the goal path G (the path of the point every 100th iteration re-adds, which grows by one
-//            exact duplicate each time and is thousands of levels deep late in a run) is a scan of the G array.
-//   phase 2  nodes that reached the same empty slot are ordered by rounds: the lowest id takes the slot
-//            (atomicMin), the others step below it.  Contenders of one slot always arrive in the same round
-//            because they share the whole path above it, so this equals sequential insertion.
-// One workgroup; a thread owns up to kPer nodes (batch_K <= 4096).
-__global__ __launch_bounds__(1024) void k_kd_insert(const RunConst *__restrict__ rcp, uint32_t b) {
+// reproduce the order in which the reference resolves equal-cost parents (kd pre-order).  Two kernels:
+//   k_kd_locate  one thread per new node, spread over many CUs: descend the tree as it stood before the step
+//                down to an empty slot.  The part of the descent that runs along the goal path G (the path of
+//                the point every 100th iteration re-adds: one exact duplicate deeper each time, thousands of
+//                levels late in a run) is not walked: duplicate levels collapse to two comparisons and only the
+//                few non-duplicate levels are tested (see the kernel).
+//   k_kd_claim   one workgroup: nodes that reached the same empty slot are ordered by rounds -- the lowest id
+//                takes the slot (atomicMin), the others step below it.  Contenders of one slot always arrive in
+//                the same round because they share the whole path above it, so this equals sequential insertion.
+enum : uint32_t { LOC_SIDE = 1u, LOC_ONPATH = 2u };
+
+// descend from node `cur` (depth dcur, taking `side`) to an empty slot of the old tree
+__device__ __forceinline__ void kd_descend(const RunConst &rc, double vx, double vy, int &cur, uint32_t &dcur, uint32_t &side) {
+    KdRec rec = rc.kd_rec[cur];
+    for (;;) {                          // one dependent 24-byte load per level
+        const int c = side ? rec.child[1] : rec.child[0];
+        if (c == kEmpty) break;
+        rec = rc.kd_rec[c];
+        cur = c;
+        dcur += 1;
+        side = kd_left(vx, vy, rec.x, rec.y, dcur) ? 0u : 1u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ rcp, uint32_t b) {
     const RunConst &rc = *rcp;
     const uint32_t N = rc.n_at[b];
     const uint32_t n_new = rc.n_at[b + 1] - N;       // written by the commit kernel of step b
     const uint32_t glen0 = __builtin_amdgcn_readfirstlane(rc.cnt->g_len);
+    const uint32_t n_nd = __builtin_amdgcn_readfirstlane(rc.cnt->g_nd_len);
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_new) return;
     const double px = rc.gp_x, py = rc.gp_y;
+    const double vx = rc.nx[N + t], vy = rc.ny[N + t];
+    // Where does this node's descent leave the goal path G?  At the first level whose test it fails.  A level
+    // held by an exact duplicate of the goal point tests `x < p.x` (even depth) or `y < p.y` (odd depth), and
+    // the goal point itself always goes right there, so all duplicate levels reduce to two comparisons against
+    // the first duplicate of each parity; only the few non-duplicate levels (g_nd) are real tests.
+    uint32_t E = 0xFFFFFFFFu;
+    bool leftE = false;
+    for (uint32_t s = 0; s < n_nd; ++s) {             // wave-uniform: scalar loads
+        const uint32_t i = rc.g_nd[s];
+        const double wx = rc.g_x[i], wy = rc.g_y[i];
+        const bool gl = kd_left(px, py, wx, wy, i), vl = kd_left(vx, vy, wx, wy, i);
+        if (vl != gl && i < E) { E = i; leftE = vl; }
+    }
+    const uint32_t d0 = rc.cnt->g_first_dup[0], d1 = rc.cnt->g_first_dup[1];
+    if (vx < px && d0 < E) { E = d0; leftE = true; }
+    if (vy < py && d1 < E) { E = d1; leftE = true; }
+    int cur;
+    uint32_t dcur, side, gex = 0, flags = 0;
+    if (E == 0xFFFFFFFFu) {             // on G to its end: below the last node, on the goal point's side
+        dcur = glen0 - 1;
+        cur = rc.g_id[dcur];
+        side = kd_left(px, py, rc.g_x[dcur], rc.g_y[dcur], dcur) ? 0u : 1u;
+        flags = LOC_ONPATH;
+    } else {
+        dcur = E;
+        gex = E;
+        cur = rc.g_id[E];
+        side = leftE ? 0u : 1u;
+        kd_descend(rc, vx, vy, cur, dcur, side);
+    }
+    rc.loc_cur[t] = cur;
+    rc.loc_dcur[t] = dcur;
+    rc.loc_gex[t] = gex;
+    rc.loc_flags[t] = flags | (side ? LOC_SIDE : 0u);
+}
+
+// One workgroup; a thread owns up to kPer nodes (batch_K <= 4096).
+__global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ rcp, uint32_t b) {
+    const RunConst &rc = *rcp;
+    const uint32_t N = rc.n_at[b];
+    const uint32_t n_new = rc.n_at[b + 1] - N;
+    const uint32_t glen0 = __builtin_amdgcn_readfirstlane(rc.cnt->g_len);
+    const double px = rc.gp_x, py = rc.gp_y;
+    if (rc.dbg && threadIdx.x == 0) { rc.dbg[b * 8 + 0] = wall_clock64(); rc.dbg[b * 8 + 6] = clock64(); }
+    if (rc.dbg && threadIdx.x == 0) rc.dbg[b * 8 + 2] = wall_clock64();
     constexpr int kPer = 4;
     bool todo[kPer], onpath[kPer];
     double vx[kPer], vy[kPer];
@@ -1061,87 +1130,19 @@ __global__ __launch_bounds__(1024) void k_kd_insert(const RunConst *__restrict__
     for (int r = 0; r < kPer; ++r) {
         const uint32_t t = threadIdx.x + r * 1024u;
         todo[r] = t < n_new;
-        onpath[r] = todo[r];
+        const uint32_t tt = todo[r] ? t : 0u;
+        const uint32_t fl = rc.loc_flags[tt];
+        onpath[r] = todo[r] && (fl & LOC_ONPATH);
+        side[r] = (fl & LOC_SIDE) ? 1u : 0u;
+        cur[r] = rc.loc_cur[tt];
+        dcur[r] = rc.loc_dcur[tt];
+        gex[r] = rc.loc_gex[tt];
         vidn[r] = todo[r] ? (int)(N + t) : kEmpty;
         vx[r] = todo[r] ? rc.nx[N + t] : 0.0;
         vy[r] = todo[r] ? rc.ny[N + t] : 0.0;
-        cur[r] = 0; side[r] = 0; dcur[r] = 0; gex[r] = 0;
     }
-    if (rc.dbg && threadIdx.x == 0) { rc.dbg[b * 8 + 0] = wall_clock64(); rc.dbg[b * 8 + 6] = clock64(); }
-    {
-        // phase 1a: follow G while the node falls on the goal point's side.  The path is staged in LDS as
-        // (split coordinate, goal side) per level with one coalesced pass; each lane then walks it on its own
-        // (no cross-lane traffic per level), eight levels per trip.
-        constexpr uint32_t kStage = 4096;
-        __shared__ double s_w[kStage];
-        __shared__ uint8_t s_gl[kStage];
-        for (uint32_t t = threadIdx.x; t < glen0 && t < kStage; t += 1024) {
-            const double gx = rc.g_x[t], gy = rc.g_y[t];
-            s_w[t] = (t & 1u) ? gy : gx;
-            s_gl[t] = kd_left(px, py, gx, gy, t) ? 1 : 0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < kPer; ++r) {
-            if (r * 1024u >= n_new) break;
-            uint32_t my_exit = 0xFFFFFFFFu;
-            bool my_left = false;
-            bool walking = todo[r];
-            for (uint32_t i0 = 0; i0 < glen0; i0 += 8) {
-                if (!__any(walking)) break;
-                double w[8];
-                bool gl[8];
-                if (i0 + 8 <= kStage) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { w[u] = s_w[i0 + u]; gl[u] = s_gl[i0 + u]; }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {                  // very long paths: the tail comes from global
-                        const uint32_t i = i0 + u;
-                        const double gx = rc.g_x[i], gy = rc.g_y[i];
-                        w[u] = (u & 1) ? gy : gx;
-                        gl[u] = kd_left(px, py, gx, gy, i);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const uint32_t i = i0 + u;
-                    const bool vl = ((u & 1) ? vy[r] : vx[r]) < w[u];   // depth parity = parity of u
-                    if (walking && i < glen0 && vl != gl[u]) { walking = false; my_exit = i; my_left = vl; }
-                }
-            }
-            if (todo[r]) {
-                if (my_exit != 0xFFFFFFFFu) { onpath[r] = false; gex[r] = my_exit; dcur[r] = my_exit; side[r] = my_left ? 0u : 1u; }
-                else {
-                    // stayed on G to its end: below the last node, on the goal point's side
-                    const uint32_t last = glen0 - 1;
-                    dcur[r] = last;
-                    side[r] = kd_left(px, py, rc.g_x[last], rc.g_y[last], last) ? 0u : 1u;
-                }
-            }
-        }
-    }
-    if (rc.dbg && threadIdx.x == 0) rc.dbg[b * 8 + 1] = wall_clock64();
-    // phase 1b: nodes that left G descend the old tree to an empty slot (one 24-byte record per level)
-#pragma unroll
-    for (int r = 0; r < kPer; ++r) {
-        if (!todo[r]) continue;
-        cur[r] = rc.g_id[dcur[r]];
-        if (onpath[r]) continue;
-        KdRec rec = rc.kd_rec[cur[r]];
-        for (;;) {                          // one dependent 24-byte load per level
-            const int c = side[r] ? rec.child[1] : rec.child[0];   // no dynamic register indexing
-            if (c == kEmpty) break;
-            rec = rc.kd_rec[c];
-            cur[r] = c;
-            dcur[r] += 1;
-            side[r] = kd_left(vx[r], vy[r], rec.x, rec.y, dcur[r]) ? 0u : 1u;
-        }
-    }
-    __syncthreads();
-    if (rc.dbg && threadIdx.x == 0) rc.dbg[b * 8 + 2] = wall_clock64();
     uint32_t rounds = 0;
-    // phase 2: claim rounds
+    // claim rounds
     for (;;) {
         ++rounds;
         bool any = false;
@@ -1166,12 +1167,14 @@ __global__ __launch_bounds__(1024) void k_kd_insert(const RunConst *__restrict__
                     else atomicOr(&rc.cnt->err, ERR_GPATH_OVERFLOW);
                     rc.kd_gexit[w] = dw | kOnG;
                     atomicMax(&rc.cnt->g_len, dw + 1);
+                    if (vx[r] == px && vy[r] == py) atomicMin(&rc.cnt->g_first_dup[dw & 1u], dw);
+                    else rc.g_nd[atomicAdd(&rc.cnt->g_nd_len, 1u)] = dw;
                 } else {
                     rc.kd_gexit[w] = gex[r];
                 }
                 todo[r] = false;
             } else {
-                // step below the winner (its coordinates were written by k_connect_rrt of this step)
+                // step below the winner (its coordinates were written by the connect kernel of this step)
                 const double wx = rc.nx[w], wy = rc.ny[w];
                 const bool vl = kd_left(vx[r], vy[r], wx, wy, dw);
                 if (onpath[r] && vl != kd_left(px, py, wx, wy, dw)) { onpath[r] = false; gex[r] = dw; }

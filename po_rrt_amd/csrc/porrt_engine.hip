@@ -99,24 +99,22 @@ struct Pcg64 {
     }
 };
 
+// All device buffers live in ONE allocation (2 MiB granules): few large pages instead of dozens of small
+// mappings keeps the dependent, scattered loads of the connect / kd kernels out of page-table walks.
+struct DevBufBase {
+    void *vp = nullptr;
+    size_t n = 0, want = 0, elem = 1;
+};
 template <class T>
-struct DevBuf {
+struct DevBuf : DevBufBase {
     T *p = nullptr;
-    size_t n = 0;
-    hipError_t reserve(size_t want) {
-        if (want <= n) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        n = 0;
-        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
-        if (e == hipSuccess) n = want;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        n = 0;
-    }
+    DevBuf() { elem = sizeof(T); }
+    hipError_t reserve(size_t w) { if (w > want) want = w; return hipSuccess; }
+    void release() {}
+};
+struct Arena {
+    void *base = nullptr;
+    size_t cap = 0;
 };
 
 uint64_t ones(int n) { return n >= 64 ? ~0ULL : ((1ULL << n) - 1); }
@@ -164,6 +162,8 @@ struct porrt_ctx {
     DevBuf<double> d_nx, d_ny, d_distA, d_distB, d_sx, d_sy, d_qx, d_qy, d_partD, d_candval, d_radT2, d_inj;
     DevBuf<int> d_parent, d_qnn, d_qvid, d_partid, d_candid, d_gid, d_kdup;
     DevBuf<KdRec> d_kdrec;
+    DevBuf<int> d_loccur;
+    DevBuf<uint32_t> d_locdcur, d_locgex, d_locflags, d_kdsurv;
     DevBuf<double> d_gx, d_gy;
     DevBuf<float> d_fx, d_fy, d_f2, d_qax, d_qay, d_qthr;
     DevBuf<int> d_rep;
@@ -175,6 +175,9 @@ struct porrt_ctx {
     DevBuf<Counters> d_cnt;
     DevBuf<RunConst> d_rc;
     DevBuf<PcgJump> d_jump;
+    Arena arena;
+    std::vector<DevBufBase *> all_bufs;
+    int layout_buffers();
     // radius table cache
     std::vector<double> radT2;
     double rad_max_step = -1, rad_search_radius = -1;
@@ -216,6 +219,59 @@ struct porrt_ctx {
 // ---------------------------------------------------------------------------------------------------------
 // Pre-classified raster: one byte per pixel holding what the raycast needs (map_shelves_io.rs:150-156;
 // map_io.rs:165-174,190-196).
+// (Re)lay out every buffer in the arena when one of them has to grow.  Contents are lost on a re-layout;
+// every grow re-initialises what it uses, and the cached uploads are marked stale.
+int porrt_ctx::layout_buffers() {
+    if (all_bufs.empty()) {
+        DevBufBase *list[] = {&d_nx, &d_ny, &d_distA, &d_distB, &d_sx, &d_sy, &d_qx, &d_qy, &d_partD, &d_candval, &d_radT2, &d_inj,
+                              &d_parent, &d_qnn, &d_qvid, &d_partid, &d_candid, &d_gid, &d_kdup, &d_kdrec, &d_gx, &d_gy, &d_fx, &d_fy,
+                              &d_f2, &d_qax, &d_qay, &d_qthr, &d_rep, &d_dbg, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB,
+                              &d_finalmask, &d_validmask, &d_vid, &d_finalflag, &d_cls, &d_nat, &d_sworld, &d_candcnt, &d_efrom,
+                              &d_eto, &d_etv, &d_heavy, &d_cnt, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags, &d_kdsurv};
+        for (DevBufBase *b2 : list) all_bufs.push_back(b2);
+    }
+    bool grow_needed = false;
+    for (DevBufBase *b2 : all_bufs) if (b2->want > b2->n) grow_needed = true;
+    if (!grow_needed) return PORRT_OK;
+    size_t total = 0;
+    for (DevBufBase *b2 : all_bufs) {
+        if (b2->want > b2->n) b2->n = b2->want + b2->want / 8;     // a little headroom
+        total += (b2->n * b2->elem + 4095) & ~(size_t)4095;
+    }
+    total = (total + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+    if (total > arena.cap) {
+        (void)hipStreamSynchronize(stream);
+        if (arena.base) (void)hipFree(arena.base);
+        arena.base = nullptr; arena.cap = 0;
+        HIPCHK(hipMalloc(&arena.base, total));
+        arena.cap = total;
+    }
+    size_t off = 0;
+    for (DevBufBase *b2 : all_bufs) { b2->vp = (char *)arena.base + off; off += (b2->n * b2->elem + 4095) & ~(size_t)4095; }
+    d_nx.p = (double *)d_nx.vp; d_ny.p = (double *)d_ny.vp; d_distA.p = (double *)d_distA.vp; d_distB.p = (double *)d_distB.vp;
+    d_sx.p = (double *)d_sx.vp; d_sy.p = (double *)d_sy.vp; d_qx.p = (double *)d_qx.vp; d_qy.p = (double *)d_qy.vp;
+    d_partD.p = (double *)d_partD.vp; d_candval.p = (double *)d_candval.vp; d_radT2.p = (double *)d_radT2.vp; d_inj.p = (double *)d_inj.vp;
+    d_parent.p = (int *)d_parent.vp; d_qnn.p = (int *)d_qnn.vp; d_qvid.p = (int *)d_qvid.vp; d_partid.p = (int *)d_partid.vp;
+    d_candid.p = (int *)d_candid.vp; d_gid.p = (int *)d_gid.vp; d_kdup.p = (int *)d_kdup.vp; d_kdrec.p = (KdRec *)d_kdrec.vp;
+    d_gx.p = (double *)d_gx.vp; d_gy.p = (double *)d_gy.vp; d_fx.p = (float *)d_fx.vp; d_fy.p = (float *)d_fy.vp; d_f2.p = (float *)d_f2.vp;
+    d_qax.p = (float *)d_qax.vp; d_qay.p = (float *)d_qay.vp; d_qthr.p = (float *)d_qthr.vp; d_rep.p = (int *)d_rep.vp;
+    d_dbg.p = (unsigned long long *)d_dbg.vp; d_kddepth.p = (uint32_t *)d_kddepth.vp; d_kdgexit.p = (uint32_t *)d_kdgexit.vp;
+    d_reachA.p = (unsigned long long *)d_reachA.vp; d_reachB.p = (unsigned long long *)d_reachB.vp;
+    d_finalmask.p = (unsigned long long *)d_finalmask.vp; d_validmask.p = (unsigned long long *)d_validmask.vp;
+    d_vid.p = (uint8_t *)d_vid.vp; d_finalflag.p = (uint8_t *)d_finalflag.vp; d_cls.p = (uint8_t *)d_cls.vp;
+    d_nat.p = (uint32_t *)d_nat.vp; d_sworld.p = (uint32_t *)d_sworld.vp; d_candcnt.p = (uint32_t *)d_candcnt.vp;
+    d_efrom.p = (uint32_t *)d_efrom.vp; d_eto.p = (uint32_t *)d_eto.vp; d_etv.p = (uint32_t *)d_etv.vp; d_heavy.p = (uint32_t *)d_heavy.vp;
+    d_loccur.p = (int *)d_loccur.vp; d_locdcur.p = (uint32_t *)d_locdcur.vp; d_locgex.p = (uint32_t *)d_locgex.vp;
+    d_locflags.p = (uint32_t *)d_locflags.vp; d_kdsurv.p = (uint32_t *)d_kdsurv.vp;
+    d_cnt.p = (Counters *)d_cnt.vp; d_rc.p = (RunConst *)d_rc.vp; d_jump.p = (PcgJump *)d_jump.vp;
+    // cached uploads are gone
+    rad_uploaded = 0;
+    cls_dirty = true;
+    inj_dirty = true;
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    return PORRT_OK;
+}
+
 int porrt_ctx::build_cls() {
     if (!has_grid) return PORRT_OK;
     if (!cls_dirty) return PORRT_OK;
@@ -234,7 +290,6 @@ int porrt_ctx::build_cls() {
         }
         cls[p] = c;
     }
-    HIPCHK(d_cls.reserve(n + 16));
     HIPCHK(hipMemcpyAsync(d_cls.p, cls.data(), n, hipMemcpyHostToDevice, stream));
     cls_dirty = false;
     return PORRT_OK;
@@ -302,6 +357,10 @@ __global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y
     rep_insert(rc, x, y, 0);
     rc.g_id[0] = 0;          // the root is on every kd descent path
     rc.cnt->g_len = 1;
+    rc.cnt->g_first_dup[0] = 0xFFFFFFFFu;
+    rc.cnt->g_first_dup[1] = 0xFFFFFFFFu;
+    if (x == rc.gp_x && y == rc.gp_y) { rc.cnt->g_first_dup[0] = 0; rc.cnt->g_nd_len = 0; }
+    else { rc.g_nd[0] = 0; rc.cnt->g_nd_len = 1; }
     KdRec rec;
     rec.x = x; rec.y = y; rec.child[0] = kEmpty; rec.child[1] = kEmpty;
     rc.kd_rec[0] = rec;
@@ -355,7 +414,8 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
         // order-exact kd insertion of this step's nodes runs beside the next step's bound / scans
         (void)hipEventRecord(ev_step_done, stream);
         (void)hipStreamWaitEvent(stream2, ev_step_done, 0);
-        hipLaunchKernelGGL(k_kd_insert, dim3(1), dim3(1024), 0, stream2, rcp, b);
+        hipLaunchKernelGGL(k_kd_locate, dim3((nb + 255) / 256), dim3(256), 0, stream2, rcp, b);
+        hipLaunchKernelGGL(k_kd_claim, dim3(1), dim3(1024), 0, stream2, rcp, b);
         (void)hipEventRecord(ev_kd_done, stream2);
         kd_pending = true;
     }
@@ -417,21 +477,26 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(d_sx.reserve(n_iter_max + 1)); HIPCHK(d_sy.reserve(n_iter_max + 1)); HIPCHK(d_sworld.reserve(n_iter_max + 1));
         HIPCHK(d_qx.reserve(K)); HIPCHK(d_qy.reserve(K)); HIPCHK(d_qnn.reserve(K)); HIPCHK(d_qvid.reserve(K));
         HIPCHK(d_partD.reserve((size_t)K * kMaxChunks)); HIPCHK(d_partid.reserve((size_t)K * kMaxChunks));
-        HIPCHK(d_candcnt.reserve(K)); HIPCHK(d_heavy.reserve(K)); HIPCHK(d_candid.reserve((size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
+        HIPCHK(d_candcnt.reserve(K)); HIPCHK(d_heavy.reserve(K));
+        HIPCHK(d_loccur.reserve(K)); HIPCHK(d_locdcur.reserve(K)); HIPCHK(d_locgex.reserve(K)); HIPCHK(d_locflags.reserve(K)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_candid.reserve((size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
         HIPCHK(d_gid.reserve(Nmax));
         HIPCHK(d_fx.reserve(Nmax + 64)); HIPCHK(d_fy.reserve(Nmax + 64)); HIPCHK(d_f2.reserve(Nmax + 64));
         HIPCHK(d_qax.reserve(K)); HIPCHK(d_qay.reserve(K)); HIPCHK(d_qthr.reserve(K)); HIPCHK(d_rep.reserve(kRepTotal));
         HIPCHK(d_kdrec.reserve(Nmax)); HIPCHK(d_gx.reserve(Nmax + 16)); HIPCHK(d_gy.reserve(Nmax + 16)); HIPCHK(d_kdup.reserve(Nmax)); HIPCHK(d_kddepth.reserve(Nmax)); HIPCHK(d_kdgexit.reserve(Nmax));
-        if (d_radT2.n < Nmax + 8) { HIPCHK(d_radT2.reserve(Nmax + 8)); rad_uploaded = 0; }
+        HIPCHK(d_radT2.reserve(Nmax + 8));
         HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_jump.reserve(1));
         if (mode == PORRT_MODE_PTO) {
             const uint64_t ecap = std::min<uint64_t>(Nmax * 256 + 4096, 1ull << 28);
             HIPCHK(d_efrom.reserve(ecap)); HIPCHK(d_eto.reserve(ecap)); HIPCHK(d_etv.reserve(ecap));
         }
-        int r = build_cls();
+        if (has_grid) HIPCHK(d_cls.reserve((size_t)W * H + 16));
+        if (has_inj) HIPCHK(d_inj.reserve(inj_xy.size() + 2));
+        HIPCHK(d_dbg.reserve((steps_max + 2) * 8));
+        int r = layout_buffers();
+        if (r) return r;
+        r = build_cls();
         if (r) return r;
         if (has_inj && inj_dirty) {
-            HIPCHK(d_inj.reserve(inj_xy.size() + 2));
             HIPCHK(hipMemcpyAsync(d_inj.p, inj_xy.data(), inj_xy.size() * sizeof(double), hipMemcpyHostToDevice, stream));
             inj_dirty = false;
         }
@@ -449,6 +514,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.inj_base = inj_pos; c.inj_n = inj_xy.size() / 2;
     c.q_x = d_qx.p; c.q_y = d_qy.p; c.q_nn = d_qnn.p; c.q_vid = d_qvid.p;
     c.part_D = d_partD.p; c.part_id = d_partid.p;
+    c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p;
     c.heavy_list = d_heavy.p; c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
     c.rad_T2 = d_radT2.p;
     c.e_from = d_efrom.p; c.e_to = d_eto.p; c.e_tv = d_etv.p; c.e_cap = (uint32_t)d_efrom.n;
@@ -464,7 +530,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         const double Rm = std::max(std::max(fabs(x0), fabs(x1)), std::max(fabs(y0), fabs(y1)));
         c.filt_E = 32.0 * ldexp(1.0, -24) * Rm * Rm + 1e-300;
     }
-    if (getenv("PORRT_DEBUG")) { if (d_dbg.reserve((steps_max + 2) * 8) == hipSuccess) { (void)hipMemsetAsync(d_dbg.p, 0, (steps_max + 2) * 64, stream); c.dbg = d_dbg.p; } }
+    if (getenv("PORRT_DEBUG")) { (void)hipMemsetAsync(d_dbg.p, 0, (steps_max + 2) * 64, stream); c.dbg = d_dbg.p; }
     c.kd_rec = d_kdrec.p; c.g_x = d_gx.p; c.g_y = d_gy.p; c.kd_up = d_kdup.p; c.kd_depth = d_kddepth.p; c.kd_gexit = d_kdgexit.p;
     c.g_id = d_gid.p; c.g_cap = (uint32_t)std::min<uint64_t>(d_gid.n, 0xFFFFFFFFull);
     c.cls = d_cls.p; c.W = W; c.H = H; c.low0 = low[0]; c.low1 = low[1]; c.ppm = ppm; c.domain = domain; c.has_grid = has_grid;
@@ -706,8 +772,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
             std::vector<unsigned long long> d((size_t)b * 8);
             (void)hipMemcpy(d.data(), d_dbg.p, d.size() * 8, hipMemcpyDeviceToHost);
             for (uint32_t s2 = 0; s2 < b; s2 += std::max(1u, b / 12))
-                fprintf(stderr, "[porrt] kd_insert step %3u: 1a %6.1f us  1b %6.1f us  rounds(%2llu) %6.1f us  glen %llu  clock %.0f MHz\n", s2,
-                        (d[s2 * 8 + 1] - d[s2 * 8 + 0]) * 0.01, (d[s2 * 8 + 2] - d[s2 * 8 + 1]) * 0.01, d[s2 * 8 + 4],
+                fprintf(stderr, "[porrt] kd_claim step %3u: rounds(%2llu) %6.1f us  glen %llu  clock %.0f MHz\n", s2, d[s2 * 8 + 4],
                         (d[s2 * 8 + 3] - d[s2 * 8 + 2]) * 0.01, d[s2 * 8 + 5], (double)d[s2 * 8 + 6] / ((d[s2 * 8 + 3] - d[s2 * 8 + 0]) * 0.01));
         }
     }
@@ -827,13 +892,7 @@ void porrt_destroy(porrt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->d_nx.release(); c->d_ny.release(); c->d_distA.release(); c->d_distB.release(); c->d_sx.release(); c->d_sy.release();
-    c->d_qx.release(); c->d_qy.release(); c->d_partD.release(); c->d_candval.release(); c->d_radT2.release(); c->d_inj.release();
-    c->d_parent.release(); c->d_qnn.release(); c->d_qvid.release(); c->d_partid.release(); c->d_candid.release(); c->d_gid.release(); c->d_fx.release(); c->d_fy.release(); c->d_f2.release(); c->d_qax.release(); c->d_qay.release(); c->d_qthr.release(); c->d_rep.release(); c->d_kdrec.release(); c->d_gx.release(); c->d_gy.release(); c->d_kdup.release(); c->d_kddepth.release(); c->d_kdgexit.release();
-    c->d_reachA.release(); c->d_reachB.release(); c->d_finalmask.release(); c->d_validmask.release();
-    c->d_vid.release(); c->d_finalflag.release(); c->d_cls.release();
-    c->d_nat.release(); c->d_sworld.release(); c->d_candcnt.release(); c->d_heavy.release(); c->d_efrom.release(); c->d_eto.release(); c->d_etv.release();
-    c->d_cnt.release(); c->d_rc.release(); c->d_jump.release();
+    if (c->arena.base) (void)hipFree(c->arena.base);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->ev_step_done) (void)hipEventDestroy(c->ev_step_done);
