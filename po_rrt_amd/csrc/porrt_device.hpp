@@ -137,6 +137,19 @@ struct RunConst {
     uint32_t part_stride;       // stride of the per-chunk NN partials ([chunk][sample] layout)
 };
 
+// Pointers read out of RunConst have no known address space, so hipcc emits flat_* accesses and drains both
+// memory counters around each of them.  Everything lives in hipMalloc'ed HBM: viewing a pointer as global
+// (address space 1) gives global_* instructions with exact vmcnt bookkeeping.
+#define GPTR(T) T __attribute__((address_space(1))) *
+template <class T>
+__device__ __forceinline__ GPTR(T) as_global(T *p) { return (GPTR(T))(uintptr_t)p; }
+template <class T>
+__device__ __forceinline__ T g_atomic_add(GPTR(T) p, T v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T>
+__device__ __forceinline__ T g_atomic_or(GPTR(T) p, T v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T>
+__device__ __forceinline__ T g_atomic_min(GPTR(T) p, T v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // ------------------------------------------------------------------ small helpers
 __device__ __forceinline__ unsigned long long f64_bits(double d) { return (unsigned long long)__double_as_longlong(d); }
 
@@ -422,12 +435,14 @@ __device__ __forceinline__ float key_threshold_inner(const RunConst &rc, double 
 
 // One thread per sample: upper bound of its nearest-neighbour distance from the pyramid (finest level whose
 // 3x3 neighbourhood holds a node that passes the world filter), turned into the scan's key threshold.
+// `b` is the step the bound is FOR; `bsnap` (<= b) is the step whose tree size limits the nodes that may be
+// used -- the kernel runs ahead of the main pipeline (bounds from a slightly older tree are still bounds).
 template <bool PTO>
-__global__ __launch_bounds__(256) void k_nn_bound(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb) {
+__global__ __launch_bounds__(256) void k_nn_bound(const RunConst *__restrict__ rcp, uint32_t b, uint32_t bsnap, uint32_t i0, uint32_t nb) {
     const RunConst &rc = *rcp;
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= nb) return;
-    const uint32_t N = rc.n_at[b];
+    const uint32_t N = rc.n_at[bsnap];
     const double qx = rc.sx[i0 + k], qy = rc.sy[i0 + k];
     uint32_t world = 0;
     if (PTO) world = rc.sworld[i0 + k];
@@ -463,9 +478,10 @@ __global__ __launch_bounds__(256) void k_nn_bound(const RunConst *__restrict__ r
         }
     }
     if (m == INF && !PTO) m = dist2(rc.nx[0], rc.ny[0], qx, qy);      // the root always exists
-    rc.q_ax[k] = (float)(-2.0 * qx);
-    rc.q_ay[k] = (float)(-2.0 * qy);
-    rc.q_thr[k] = m == INF ? __int_as_float(0x7F800000) : key_threshold(rc, m, qx, qy);
+    const uint32_t o = (b & 1u) * rc.part_stride + k;      // double-buffered by step parity
+    rc.q_ax[o] = (float)(-2.0 * qx);
+    rc.q_ay[o] = (float)(-2.0 * qy);
+    rc.q_thr[o] = m == INF ? __int_as_float(0x7F800000) : key_threshold(rc, m, qx, qy);
 }
 
 // ------------------------------------------------------------------ scans
@@ -486,61 +502,70 @@ __device__ __forceinline__ void chunk_range(uint32_t N, uint32_t NC, uint32_t c,
 }
 
 constexpr int kUnroll = 8;
-typedef const __attribute__((address_space(4))) float *cfloat_p;
-__device__ __forceinline__ cfloat_p as_constf(const float *p) { return (cfloat_p)(uintptr_t)p; }
+constexpr uint32_t kTile = 512;      // nodes staged in LDS per pass: 512 * (3*4 + 2*8) B = 14 KiB per workgroup
 
-// Stream the nodes [j0, j1) of one chunk past the lanes' samples.  Hot loop (all lanes, wave-uniform node):
+// LDS image of one tile of nodes: the f32 filter view for the hot loop and the exact f64 coordinates for
+// the rare path, so that neither touches global memory after the staging pass.
+struct NodeTile {
+    float fx[kTile], fy[kTile], f2[kTile];
+    double x[kTile], y[kTile];
+};
+
+// coalesced staging of nodes [base, base+n) by the whole workgroup
+__device__ __forceinline__ void stage_tile(const RunConst &rc, NodeTile &t, uint32_t base, uint32_t n) {
+    auto gfx = as_global(rc.fx) + base, gfy = as_global(rc.fy) + base, gf2 = as_global(rc.f2) + base;
+    auto gx = as_global(rc.nx) + base, gy = as_global(rc.ny) + base;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        t.fx[i] = gfx[i]; t.fy[i] = gfy[i]; t.f2[i] = gf2[i];
+        t.x[i] = gx[i]; t.y[i] = gy[i];
+    }
+}
+
+// Stream one staged tile past the lanes' samples.  Hot loop (all lanes, wave-uniform node, LDS broadcast):
 //     key = fma(fx, -2qx, fma(fy, -2qy, f2))        f32, 2 FMA
 //     hit = key <= thr                              1 compare
 // key approximates d2 - |q|^2 with absolute error < filt_E, and thr was rounded up past bound - |q|^2 +
 // filt_E, so a node whose exact squared distance is <= bound can never be rejected (DESIGN.md gives the
-// error budget).  `visit(j)` runs only for hits and redoes the arithmetic exactly in f64.  Eight nodes are
-// fetched per iteration with three 32-byte scalar loads, double-buffered.
+// error budget).  `visit(i, key)` runs only for hits (i = index in the tile) and redoes the arithmetic
+// exactly in f64.
 template <class Visit>
-__device__ __forceinline__ void scan_chunk(cfloat_p fx, cfloat_p fy, cfloat_p f2, uint32_t j0, uint32_t j1, float ax, float ay,
-                                           const float &thr, Visit visit) {
-    uint32_t j = j0;
-    cfloat_p px = fx + j0, py = fy + j0, p2 = f2 + j0;
-    if (j + kUnroll <= j1) {
-        float cx[kUnroll], cy[kUnroll], c2[kUnroll];
+__device__ __forceinline__ void scan_tile(const NodeTile &t, uint32_t n, float ax, float ay, const float &thr, Visit visit) {
+    uint32_t i = 0;
+    for (; i + kUnroll <= n; i += kUnroll) {
+        const float4 x0 = *(const float4 *)&t.fx[i], x1 = *(const float4 *)&t.fx[i + 4];
+        const float4 y0 = *(const float4 *)&t.fy[i], y1 = *(const float4 *)&t.fy[i + 4];
+        const float4 z0 = *(const float4 *)&t.f2[i], z1 = *(const float4 *)&t.f2[i + 4];
+        float key[kUnroll];
+        key[0] = __builtin_fmaf(x0.x, ax, __builtin_fmaf(y0.x, ay, z0.x));
+        key[1] = __builtin_fmaf(x0.y, ax, __builtin_fmaf(y0.y, ay, z0.y));
+        key[2] = __builtin_fmaf(x0.z, ax, __builtin_fmaf(y0.z, ay, z0.z));
+        key[3] = __builtin_fmaf(x0.w, ax, __builtin_fmaf(y0.w, ay, z0.w));
+        key[4] = __builtin_fmaf(x1.x, ax, __builtin_fmaf(y1.x, ay, z1.x));
+        key[5] = __builtin_fmaf(x1.y, ax, __builtin_fmaf(y1.y, ay, z1.y));
+        key[6] = __builtin_fmaf(x1.z, ax, __builtin_fmaf(y1.z, ay, z1.z));
+        key[7] = __builtin_fmaf(x1.w, ax, __builtin_fmaf(y1.w, ay, z1.w));
+        bool any = false;
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) { cx[u] = px[u]; cy[u] = py[u]; c2[u] = p2[u]; }
-        for (;;) {
-            const bool more = j + 2 * kUnroll <= j1;
-            float nx_[kUnroll], ny_[kUnroll], n2_[kUnroll];
-            if (more) {
+        for (int u = 0; u < kUnroll; ++u) any |= key[u] <= thr;
+        if (any) {                       // rare: one branch per eight nodes
 #pragma unroll
-                for (int u = 0; u < kUnroll; ++u) { nx_[u] = px[kUnroll + u]; ny_[u] = py[kUnroll + u]; n2_[u] = p2[kUnroll + u]; }
-            }
-            float key[kUnroll];
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) key[u] = __builtin_fmaf(cx[u], ax, __builtin_fmaf(cy[u], ay, c2[u]));
-            bool any = false;
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) any |= key[u] <= thr;
-            if (any) {                       // rare: one branch per eight nodes
-#pragma unroll
-                for (int u = 0; u < kUnroll; ++u)
-                    if (key[u] <= thr) visit(j + u);
-            }
-            j += kUnroll; px += kUnroll; py += kUnroll; p2 += kUnroll;
-            if (!more) break;
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) { cx[u] = nx_[u]; cy[u] = ny_[u]; c2[u] = n2_[u]; }
+            for (int u = 0; u < kUnroll; ++u)
+                if (key[u] <= thr) visit(i + u, key[u]);
         }
     }
-    for (; j < j1; ++j, ++px, ++py, ++p2) {
-        const float key = __builtin_fmaf(px[0], ax, __builtin_fmaf(py[0], ay, p2[0]));
-        if (key <= thr) visit(j);
+    for (; i < n; ++i) {
+        const float key = __builtin_fmaf(t.fx[i], ax, __builtin_fmaf(t.fy[i], ay, t.f2[i]));
+        if (key <= thr) visit(i, key);
     }
 }
 
-// K x N nearest-neighbour scan.  grid = (ceil(nb/256), NC); lane <-> sample, nodes broadcast.
+// K x N nearest-neighbour scan.  grid = (ceil(nb/256), NC); lane <-> sample, nodes broadcast from LDS.
 // Output per (sample, chunk): lexicographic min of (norm2, id) over the chunk's nodes that pass the world
 // filter (nearest_neighbor.rs:61-62: `d < dmin && validator(id)`, ascending id so the first wins ties).
 template <bool PTO>
 __global__ __launch_bounds__(kScanBlock) void k_nn_scan(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb,
                                                           uint32_t NC) {
+    __shared__ __attribute__((aligned(16))) NodeTile tile;
     const RunConst &rc = *rcp;
     const uint32_t k = blockIdx.x * kScanBlock + threadIdx.x;
     const uint32_t c = blockIdx.y;
@@ -549,34 +574,40 @@ __global__ __launch_bounds__(kScanBlock) void k_nn_scan(const RunConst *__restri
     chunk_range(N, NC, c, j0, j1);
     const bool live = k < nb;
     const double qx = live ? rc.sx[i0 + k] : 0.0, qy = live ? rc.sy[i0 + k] : 0.0;
-    const float ax = live ? rc.q_ax[k] : 0.0f, ay = live ? rc.q_ay[k] : 0.0f;
-    float thr = live ? rc.q_thr[k] : __int_as_float(0xFF800000);   // -inf: dead lanes never hit
+    const uint32_t qo = (b & 1u) * rc.part_stride + (live ? k : 0u);
+    const float ax = live ? rc.q_ax[qo] : 0.0f, ay = live ? rc.q_ay[qo] : 0.0f;
+    float thr = live ? rc.q_thr[qo] : __int_as_float(0xFF800000);   // -inf: dead lanes never hit
     uint32_t world = 0;
     if (PTO) world = live ? rc.sworld[i0 + k] : 0u;
     double m2 = __longlong_as_double(0x7FF0000000000000ll);   // +inf
     double bestD = m2;
     int best = -1;
-    const unsigned long long *reach = rc.reachA;
-    const double *nx = rc.nx, *ny = rc.ny;
-    scan_chunk(as_constf(rc.fx), as_constf(rc.fy), as_constf(rc.f2), j0, j1, ax, ay, thr,
-               [&](uint32_t j) {
-                   const double d2 = dist2(nx[j], ny[j], qx, qy);          // exact, as the reference computes it
-                   if (d2 < m2) {
-                       bool pass = true;
-                       if (PTO) pass = (reach[j] >> world) & 1ull;
-                       if (pass) {
-                           const double D = sqrt(d2);                       // the reference compares rounded distances
-                           if (D < bestD) {
-                               bestD = D; best = (int)j; m2 = d2;
-                               const float t = key_threshold(rc, d2, qx, qy);  // tighten the filter
-                               thr = t < thr ? t : thr;
-                           }
-                       }
-                   }
-               });
+    auto reach = as_global(rc.reachA);
+    for (uint32_t base = j0; base < j1; base += kTile) {
+        const uint32_t n = j1 - base < kTile ? j1 - base : kTile;
+        if (base != j0) __syncthreads();
+        stage_tile(rc, tile, base, n);
+        __syncthreads();
+        scan_tile(tile, n, ax, ay, thr,
+                  [&](uint32_t i, float) {
+                      const double d2 = dist2(tile.x[i], tile.y[i], qx, qy);   // exact, as the reference computes it
+                      if (d2 < m2) {
+                          bool pass = true;
+                          if (PTO) pass = (reach[base + i] >> world) & 1ull;
+                          if (pass) {
+                              const double D = sqrt(d2);                    // the reference compares rounded distances
+                              if (D < bestD) {
+                                  bestD = D; best = (int)(base + i); m2 = d2;
+                                  const float t2 = key_threshold(rc, d2, qx, qy);  // tighten the filter
+                                  thr = t2 < thr ? t2 : thr;
+                              }
+                          }
+                      }
+                  });
+    }
     if (live) {
-        rc.part_D[(size_t)c * rc.part_stride + k] = bestD;      // [chunk][sample]: coalesced
-        rc.part_id[(size_t)c * rc.part_stride + k] = best;
+        as_global(rc.part_D)[(size_t)c * rc.part_stride + k] = bestD;      // [chunk][sample]: coalesced
+        as_global(rc.part_id)[(size_t)c * rc.part_stride + k] = best;
     }
 }
 
@@ -645,7 +676,6 @@ __global__ __launch_bounds__(256) void k_nn_reduce_steer(const RunConst *__restr
     rc.q_nn[k] = nn;
     rc.q_vid[k] = valid ? vid : -1;
     rc.cand_cnt[k] = 0;
-    if (k == 0) rc.cnt->n_heavy = 0;
     if (valid) atomicOr(&rc.valid_mask[(size_t)b * vwords + (k >> 6)], 1ull << (k & 63u));
     if (err) atomicOr(&rc.cnt->err, err);
 }
@@ -656,6 +686,7 @@ __global__ __launch_bounds__(256) void k_nn_reduce_steer(const RunConst *__restr
 // appended with one atomic slot claim; the store of the id is deferred to the lane's next hit so that the
 // wave never waits for the atomic's round trip.
 __global__ __launch_bounds__(kScanBlock) void k_radius_scan(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t NC) {
+    __shared__ __attribute__((aligned(16))) NodeTile tile;
     const RunConst &rc = *rcp;
     const uint32_t k = blockIdx.x * kScanBlock + threadIdx.x;
     const uint32_t c = blockIdx.y;
@@ -670,32 +701,34 @@ __global__ __launch_bounds__(kScanBlock) void k_radius_scan(const RunConst *__re
     const float NEG_INF = __int_as_float(0xFF800000);
     const float thr = live ? key_threshold(rc, T2, qx, qy) : NEG_INF;
     const float thr_in = live ? key_threshold_inner(rc, T2, qx, qy) : NEG_INF;
-    uint32_t *cand_cnt = rc.cand_cnt;
-    int *cand_id = rc.cand_id + (size_t)(k < nb ? k : 0) * rc.cand_cap;
+    auto cand_cnt = as_global(rc.cand_cnt) + (k < nb ? k : 0);
+    auto cand_id = as_global(rc.cand_id) + (size_t)(k < nb ? k : 0) * rc.cand_cap;
     const uint32_t cap = rc.cand_cap;
-    Counters *cnt = rc.cnt;
-    const double *nx = rc.nx, *ny = rc.ny;
-    const cfloat_p fx = as_constf(rc.fx), fy = as_constf(rc.fy), f2 = as_constf(rc.f2);
+    auto errw = as_global(&rc.cnt->err);
     uint32_t pend_slot = 0;
     int pend_j = -1;
-    scan_chunk(fx, fy, f2, j0, j1, ax, ay, thr,
-               [&](uint32_t j) {
-                   // recompute the key of this node (cheaper than keeping eight of them live for the rare path)
-                   const float key = __builtin_fmaf(fx[j], ax, __builtin_fmaf(fy[j], ay, f2[j]));
-                   bool in = key <= thr_in;
-                   if (!in) in = dist2(nx[j], ny[j], qx, qy) <= T2;          // shell: exact test
-                   if (in) {
-                       if (pend_j >= 0) {
-                           if (pend_slot < cap) cand_id[pend_slot] = pend_j;
-                           else atomicOr(&cnt->err, ERR_CAND_OVERFLOW);
-                       }
-                       pend_slot = atomicAdd(&cand_cnt[k], 1u);
-                       pend_j = (int)j;
-                   }
-               });
+    for (uint32_t base = j0; base < j1; base += kTile) {
+        const uint32_t n = j1 - base < kTile ? j1 - base : kTile;
+        if (base != j0) __syncthreads();
+        stage_tile(rc, tile, base, n);
+        __syncthreads();
+        scan_tile(tile, n, ax, ay, thr,
+                  [&](uint32_t i, float key) {
+                      bool in = key <= thr_in;
+                      if (!in) in = dist2(tile.x[i], tile.y[i], qx, qy) <= T2;      // shell: exact test
+                      if (in) {
+                          if (pend_j >= 0) {
+                              if (pend_slot < cap) cand_id[pend_slot] = pend_j;
+                              else g_atomic_or(errw, (uint32_t)ERR_CAND_OVERFLOW);
+                          }
+                          pend_slot = g_atomic_add(cand_cnt, 1u);
+                          pend_j = (int)(base + i);
+                      }
+                  });
+    }
     if (pend_j >= 0) {
         if (pend_slot < cap) cand_id[pend_slot] = pend_j;
-        else atomicOr(&cnt->err, ERR_CAND_OVERFLOW);
+        else g_atomic_or(errw, (uint32_t)ERR_CAND_OVERFLOW);
     }
 }
 
@@ -965,10 +998,7 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunCon
     const uint32_t k = blockIdx.x * kConnectWaves + (threadIdx.x >> 6);
     if (k >= nb || rc.q_vid[k] < 0) return;
     const uint32_t cnt = rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap;
-    if (cnt > kHeavyCand) {
-        if (lane == 0) rc.heavy_list[atomicAdd(&rc.cnt->n_heavy, 1u)] = k;
-        return;
-    }
+    if (cnt > kHeavyCand) return;          // served by k_connect_rrt_heavy, which runs beside this kernel
     TileGrid grid;
     if (LDSGRID) {
         const uint32_t TW = 2u * rc.tile_R + 1u;
@@ -987,25 +1017,23 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunCon
 // heavy samples (hundreds of neighbours: the dense start of a tree, duplicates of the goal point): a
 // workgroup of four waves per sample
 template <bool LDSGRID>
-__global__ __launch_bounds__(256) void k_connect_rrt_heavy(const RunConst *__restrict__ rcp, uint32_t b, uint32_t vwords) {
+__global__ __launch_bounds__(256) void k_connect_rrt_heavy(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_tiles[];
     __shared__ double s_d[4];
     __shared__ int s_i[4];
     const RunConst &rc = *rcp;
-    const uint32_t n_heavy = rc.cnt->n_heavy;
+    const uint32_t k = blockIdx.x;          // one workgroup per sample; all but the heavy ones leave at once
+    if (k >= nb || rc.q_vid[k] < 0) return;
+    const uint32_t cnt = rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap;
+    if (cnt <= kHeavyCand) return;
     Team<4> tm;
     tm.scr_d = s_d; tm.scr_i = s_i; tm.wave = threadIdx.x >> 6; tm.lane = threadIdx.x & 63u;
     uint32_t err = 0;
-    for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
-        const uint32_t k = rc.heavy_list[h];
-        const uint32_t cnt = rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap;
-        TileGrid grid;
-        __syncthreads();
-        if (LDSGRID) grid = load_tile(rc, lds_tiles, rc.q_x[k], rc.q_y[k], threadIdx.x, 256u);
-        else { grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0; }
-        __syncthreads();
-        connect_rrt_sample<4>(rc, tm, grid, b, vwords, k, cnt, err);
-    }
+    TileGrid grid;
+    if (LDSGRID) grid = load_tile(rc, lds_tiles, rc.q_x[k], rc.q_y[k], threadIdx.x, 256u);
+    else { grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0; }
+    __syncthreads();
+    connect_rrt_sample<4>(rc, tm, grid, b, vwords, k, cnt, err);
     if (err) atomicOr(&rc.cnt->err, err);
 }
 

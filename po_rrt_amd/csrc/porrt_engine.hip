@@ -206,7 +206,11 @@ struct porrt_ctx {
     int grow_once(const double start[2], double max_step, double search_radius, uint64_t n_iter_min, uint64_t n_iter_max,
                   uint32_t K, int mode, bool host_samples);
     int download();
-    void launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, size_t lds_bytes, bool prof, size_t &ev_used);
+    void launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, size_t lds_bytes, bool prof, size_t &ev_used,
+                     uint32_t nxt2_i0, uint32_t nxt2_nb);
+    void launch_bound(hipStream_t st, uint32_t b, uint32_t bsnap, uint32_t i0, uint32_t nb);
+    hipStream_t stream3 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void join_side();
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_step_done = nullptr, ev_kd_done = nullptr;
@@ -371,7 +375,17 @@ __global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y
     rc.kd_gexit[0] = kOnG;
 }
 
-void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, size_t lds_bytes, bool prof, size_t &ev_used) {
+void porrt_ctx::launch_bound(hipStream_t st, uint32_t b, uint32_t bsnap, uint32_t i0, uint32_t nb) {
+    const dim3 kgrid((nb + 255) / 256);
+    if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_nn_bound<true>, kgrid, dim3(256), 0, st, (const RunConst *)d_rc.p, b, bsnap, i0, nb);
+    else hipLaunchKernelGGL(k_nn_bound<false>, kgrid, dim3(256), 0, st, (const RunConst *)d_rc.p, b, bsnap, i0, nb);
+}
+
+// One step.  Main stream: nn_scan, reduce+steer, radius_scan, connect (light and heavy side by side), commit.
+// Side stream (RRT*): kd insertion of this step's nodes and the NN bounds of the step after next, both needed
+// only later, so they run beside the next step's scans.  `nxt2_*` describe step b+2 (nb = 0: none).
+void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, size_t lds_bytes, bool prof, size_t &ev_used,
+                            uint32_t nxt2_i0, uint32_t nxt2_nb) {
     // at most one node per iteration so far (+ root): bound on the tree size at the start of this step
     const uint32_t n_ub = i0 + 1;
     uint32_t NC = (n_ub + 63) / 64;
@@ -383,9 +397,8 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     auto ev = [&](void) {
         if (prof && ev_used < ev_pool.size()) (void)hipEventRecord(ev_pool[ev_used++], stream);
     };
-    const dim3 kgrid((nb + 255) / 256);
-    if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_nn_bound<true>, kgrid, dim3(256), 0, stream, rcp, b, i0, nb);
-    else hipLaunchKernelGGL(k_nn_bound<false>, kgrid, dim3(256), 0, stream, rcp, b, i0, nb);
+    const bool rrt = mode == PORRT_MODE_RRT;
+    if (!rrt) launch_bound(stream, b, b, i0, nb);      // PTO: bounds in-stream (the world filter wants fresh reach masks)
     ev();
     if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_nn_scan<true>, scan_grid, dim3(kScanBlock), 0, stream, rcp, b, i0, nb, NC);
     else hipLaunchKernelGGL(k_nn_scan<false>, scan_grid, dim3(kScanBlock), 0, stream, rcp, b, i0, nb, NC);
@@ -396,29 +409,34 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     ev();
     const dim3 cgrid((nb + kConnectWaves - 1) / kConnectWaves), cblock(kConnectWaves * 64);
     // the kd structure of the previous step's nodes (side stream) is needed from here on
-    if (mode == PORRT_MODE_RRT && kd_pending) { (void)hipStreamWaitEvent(stream, ev_kd_done, 0); kd_pending = false; }
-    if (mode == PORRT_MODE_PTO) {
+    if (rrt && kd_pending) { (void)hipStreamWaitEvent(stream, ev_kd_done, 0); kd_pending = false; }
+    if (!rrt) {
         if (lds_bytes) hipLaunchKernelGGL(k_connect_pto<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
         else hipLaunchKernelGGL(k_connect_pto<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
         hipLaunchKernelGGL(k_commit_pto, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, nb, vwords);
-    } else {
-        const dim3 hgrid(std::min<uint32_t>(nb, 1024u));
-        if (lds_bytes) {
-            hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
-            hipLaunchKernelGGL(k_connect_rrt_heavy<true>, hgrid, dim3(256), lds_bytes / kConnectWaves, stream, rcp, b, vwords);
-        } else {
-            hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
-            hipLaunchKernelGGL(k_connect_rrt_heavy<false>, hgrid, dim3(256), 0, stream, rcp, b, vwords);
-        }
-        hipLaunchKernelGGL(k_commit_rrt, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, nb, vwords);
-        // order-exact kd insertion of this step's nodes runs beside the next step's bound / scans
-        (void)hipEventRecord(ev_step_done, stream);
-        (void)hipStreamWaitEvent(stream2, ev_step_done, 0);
-        hipLaunchKernelGGL(k_kd_locate, dim3((nb + 255) / 256), dim3(256), 0, stream2, rcp, b);
-        hipLaunchKernelGGL(k_kd_claim, dim3(1), dim3(1024), 0, stream2, rcp, b);
-        (void)hipEventRecord(ev_kd_done, stream2);
-        kd_pending = true;
+        return;
     }
+    // heavy samples on a third stream beside the light ones
+    (void)hipEventRecord(ev_fork, stream);
+    (void)hipStreamWaitEvent(stream3, ev_fork, 0);
+    if (lds_bytes) {
+        hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
+        hipLaunchKernelGGL(k_connect_rrt_heavy<true>, dim3(nb), dim3(256), lds_bytes / kConnectWaves, stream3, rcp, b, nb, vwords);
+    } else {
+        hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
+        hipLaunchKernelGGL(k_connect_rrt_heavy<false>, dim3(nb), dim3(256), 0, stream3, rcp, b, nb, vwords);
+    }
+    (void)hipEventRecord(ev_join, stream3);
+    (void)hipStreamWaitEvent(stream, ev_join, 0);
+    hipLaunchKernelGGL(k_commit_rrt, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, nb, vwords);
+    // side stream: order-exact kd insertion of this step's nodes, then the bounds of step b+2
+    (void)hipEventRecord(ev_step_done, stream);
+    (void)hipStreamWaitEvent(stream2, ev_step_done, 0);
+    hipLaunchKernelGGL(k_kd_locate, dim3((nb + 255) / 256), dim3(256), 0, stream2, rcp, b);
+    hipLaunchKernelGGL(k_kd_claim, dim3(1), dim3(1024), 0, stream2, rcp, b);
+    if (nxt2_nb) launch_bound(stream2, b + 2, b + 1, nxt2_i0, nxt2_nb);
+    (void)hipEventRecord(ev_kd_done, stream2);
+    kd_pending = true;
 }
 
 // join the side stream back into the main stream (end of a launch sequence / of a capture)
@@ -481,7 +499,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(d_loccur.reserve(K)); HIPCHK(d_locdcur.reserve(K)); HIPCHK(d_locgex.reserve(K)); HIPCHK(d_locflags.reserve(K)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_candid.reserve((size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
         HIPCHK(d_gid.reserve(Nmax));
         HIPCHK(d_fx.reserve(Nmax + 64)); HIPCHK(d_fy.reserve(Nmax + 64)); HIPCHK(d_f2.reserve(Nmax + 64));
-        HIPCHK(d_qax.reserve(K)); HIPCHK(d_qay.reserve(K)); HIPCHK(d_qthr.reserve(K)); HIPCHK(d_rep.reserve(kRepTotal));
+        HIPCHK(d_qax.reserve(2 * (size_t)K)); HIPCHK(d_qay.reserve(2 * (size_t)K)); HIPCHK(d_qthr.reserve(2 * (size_t)K)); HIPCHK(d_rep.reserve(kRepTotal));
         HIPCHK(d_kdrec.reserve(Nmax)); HIPCHK(d_gx.reserve(Nmax + 16)); HIPCHK(d_gy.reserve(Nmax + 16)); HIPCHK(d_kdup.reserve(Nmax)); HIPCHK(d_kddepth.reserve(Nmax)); HIPCHK(d_kdgexit.reserve(Nmax));
         HIPCHK(d_radT2.reserve(Nmax + 8));
         HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_jump.reserve(1));
@@ -694,9 +712,15 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
             HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
             uint64_t ci = 0;
             uint32_t cb = 0;
+            if (mode == PORRT_MODE_RRT) {       // the first two steps' bounds cannot come from the side stream
+                launch_bound(stream, 0, 0, 0, (uint32_t)std::min<uint64_t>(K, n_iter_min));
+                if (n_iter_min > K) launch_bound(stream, 1, 0, K, (uint32_t)std::min<uint64_t>(K, n_iter_min - K));
+            }
             while (ci < n_iter_min) {
                 uint32_t nb = (uint32_t)std::min<uint64_t>(K, n_iter_min - ci);
-                launch_step(cb, (uint32_t)ci, nb, vwords, lds_bytes, false, ev_used);
+                uint64_t i2 = ci + nb + std::min<uint64_t>(K, n_iter_min - ci - nb);      // start of step cb+2
+                uint32_t nb2 = i2 < n_iter_min ? (uint32_t)std::min<uint64_t>(K, n_iter_min - i2) : 0;
+                launch_step(cb, (uint32_t)ci, nb, vwords, lds_bytes, false, ev_used, (uint32_t)i2, nb2);
                 ci += nb;
                 ++cb;
             }
@@ -710,9 +734,15 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(hipGraphLaunch(graph_exec, stream));
         while (i < n_iter_min) { i += std::min<uint64_t>(K, n_iter_min - i); ++b; }
     } else {
+        if (mode == PORRT_MODE_RRT && n_iter_min > 0) {
+            launch_bound(stream, 0, 0, 0, (uint32_t)std::min<uint64_t>(K, n_iter_min));
+            if (n_iter_min > K) launch_bound(stream, 1, 0, K, (uint32_t)std::min<uint64_t>(K, n_iter_min - K));
+        }
         while (i < n_iter_min) {
             uint32_t nb = (uint32_t)std::min<uint64_t>(K, n_iter_min - i);
-            launch_step(b, (uint32_t)i, nb, vwords, lds_bytes, prof, ev_used);
+            uint64_t i2 = i + nb + std::min<uint64_t>(K, n_iter_min - i - nb);
+            uint32_t nb2 = i2 < n_iter_min ? (uint32_t)std::min<uint64_t>(K, n_iter_min - i2) : 0;
+            launch_step(b, (uint32_t)i, nb, vwords, lds_bytes, prof, ev_used, (uint32_t)i2, nb2);
             i += nb;
             ++b;
         }
@@ -740,7 +770,8 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         t_setup += now_s() - t0;
         r = make_samples(i, nb);
         if (r) return r;
-        launch_step(b, (uint32_t)i, nb, vwords, lds_bytes, prof, ev_used);
+        if (mode == PORRT_MODE_RRT) launch_bound(stream, b, b, (uint32_t)i, nb);     // beyond n_iter_min: in-stream
+        launch_step(b, (uint32_t)i, nb, vwords, lds_bytes, prof, ev_used, 0, 0);
         join_side();
         i += nb;
         ++b;
@@ -878,7 +909,10 @@ porrt_ctx *porrt_create(int device) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_step_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_kd_done, hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
+        hipEventCreateWithFlags(&c->ev_kd_done, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
     c->crng.seed_from_u64(0);   // sample_space.rs:18
     c->drng.seed_from_u64(0);   // sample_space.rs:47
     c->validities[0] = 1;       // map_io.rs:108-111 init_without_zones
@@ -898,6 +932,9 @@ void porrt_destroy(porrt_ctx *c) {
     if (c->ev_step_done) (void)hipEventDestroy(c->ev_step_done);
     if (c->ev_kd_done) (void)hipEventDestroy(c->ev_kd_done);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 #include <random>
+#include <cmath>
 
 using namespace porrt;
 
@@ -68,6 +69,31 @@ __global__ __launch_bounds__(256) void v_f32(const float *nxf, const float *nyf,
     out[(size_t)c * gridDim.x * 256 + k] = m;
 }
 
+// variant D: f32 keys, nodes staged once per block into LDS with coalesced vector loads, ds_read_b128 broadcast
+__global__ __launch_bounds__(256) void v_f32_lds(const float *nxf, const float *nyf, const float *nn2, const double *sx, const double *sy,
+                                                  float *out, uint32_t N, uint32_t NC) {
+    __shared__ __attribute__((aligned(16))) float lx[1024], ly[1024], l2[1024];
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    uint32_t j0, j1;
+    chunk_range(N, NC, c, j0, j1);
+    const uint32_t n = j1 - j0;
+    for (uint32_t t = threadIdx.x; t < n; t += 256) { lx[t] = nxf[j0 + t]; ly[t] = nyf[j0 + t]; l2[t] = nn2[j0 + t]; }
+    __syncthreads();
+    const float ax = -2.0f * (float)sx[k], ay = -2.0f * (float)sy[k];
+    float m = 1e30f;
+    for (uint32_t t = 0; t + 8 <= n; t += 8) {
+        const float4 x0 = *(const float4 *)&lx[t], x1 = *(const float4 *)&lx[t + 4];
+        const float4 y0 = *(const float4 *)&ly[t], y1 = *(const float4 *)&ly[t + 4];
+        const float4 z0 = *(const float4 *)&l2[t], z1 = *(const float4 *)&l2[t + 4];
+        float k0 = __builtin_fmaf(x0.x, ax, __builtin_fmaf(y0.x, ay, z0.x)), k1 = __builtin_fmaf(x0.y, ax, __builtin_fmaf(y0.y, ay, z0.y));
+        float k2 = __builtin_fmaf(x0.z, ax, __builtin_fmaf(y0.z, ay, z0.z)), k3 = __builtin_fmaf(x0.w, ax, __builtin_fmaf(y0.w, ay, z0.w));
+        float k4 = __builtin_fmaf(x1.x, ax, __builtin_fmaf(y1.x, ay, z1.x)), k5 = __builtin_fmaf(x1.y, ax, __builtin_fmaf(y1.y, ay, z1.y));
+        float k6 = __builtin_fmaf(x1.z, ax, __builtin_fmaf(y1.z, ay, z1.z)), k7 = __builtin_fmaf(x1.w, ax, __builtin_fmaf(y1.w, ay, z1.w));
+        m = fminf(m, fminf(fminf(fminf(k0, k1), fminf(k2, k3)), fminf(fminf(k4, k5), fminf(k6, k7))));
+    }
+    out[(size_t)c * gridDim.x * 256 + k] = m;
+}
+
 int main(int argc, char **argv) {
     uint32_t N = argc > 1 ? atoi(argv[1]) : 100000, K = argc > 2 ? atoi(argv[2]) : 1024;
     std::mt19937_64 rng(1);
@@ -82,10 +108,10 @@ int main(int argc, char **argv) {
     uint32_t nat[2] = {N, N};
     float *dfx, *dfy, *dfn, *dof;
     CK(hipMalloc(&rc.nx, (N + 64) * 8)); CK(hipMalloc(&rc.ny, (N + 64) * 8)); CK(hipMalloc(&rc.sx, K * 8)); CK(hipMalloc(&rc.sy, K * 8));
-    CK(hipMalloc(&rc.n_at, 8)); CK(hipMalloc(&rc.part_D, (size_t)K * kMaxChunks * 8)); CK(hipMalloc(&rc.part_id, (size_t)K * kMaxChunks * 4));
+    CK(hipMalloc(&rc.n_at, 8)); CK(hipMalloc(&rc.part_D, (size_t)K * 512 * 8)); CK(hipMalloc(&rc.part_id, (size_t)K * 512 * 4));
     CK(hipMalloc(&rc.q_x, K * 8)); CK(hipMalloc(&rc.q_y, K * 8)); CK(hipMalloc(&rc.q_vid, K * 4)); CK(hipMalloc(&rc.cand_cnt, K * 4));
     CK(hipMalloc(&rc.cand_id, (size_t)K * 4096 * 4)); CK(hipMalloc(&rc.cnt, sizeof(Counters))); CK(hipMalloc((void **)&rc.rad_T2, (N + 8) * 8));
-    CK(hipMalloc(&dfx, (N + 64) * 4)); CK(hipMalloc(&dfy, (N + 64) * 4)); CK(hipMalloc(&dfn, (N + 64) * 4)); CK(hipMalloc(&dof, (size_t)K * kMaxChunks * 4));
+    CK(hipMalloc(&dfx, (N + 64) * 4)); CK(hipMalloc(&dfy, (N + 64) * 4)); CK(hipMalloc(&dfn, (N + 64) * 4)); CK(hipMalloc(&dof, (size_t)K * 512 * 4));
     rc.cand_cap = 4096; rc.part_stride = K;
     CK(hipMemcpy(rc.nx, hx.data(), (N + 64) * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(rc.ny, hy.data(), (N + 64) * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(rc.sx, qx.data(), K * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(rc.sy, qy.data(), K * 8, hipMemcpyHostToDevice));
@@ -98,6 +124,20 @@ int main(int argc, char **argv) {
     // radius threshold: expect ~36 neighbours per sample
     std::vector<double> t2(N + 8, 36.0 * 4.0 / (3.14159265 * N));
     CK(hipMemcpy((void *)rc.rad_T2, t2.data(), (N + 8) * 8, hipMemcpyHostToDevice));
+    // filter operands: threshold from a bound 4x the true nearest squared distance (what the pyramid gives)
+    rc.fx = dfx; rc.fy = dfy; rc.f2 = dfn;
+    rc.filt_E = 32.0 * ldexp(1.0, -24);
+    std::vector<float> hax(2 * K), hay(2 * K), hthr(2 * K);
+    for (uint32_t k = 0; k < K; ++k) {
+        double m = 1e300;
+        for (uint32_t j = 0; j < N; ++j) { double dx = hx[j] - qx[k], dy = hy[j] - qy[k]; double d = dx * dx + dy * dy; m = d < m ? d : m; }
+        double t = 4.0 * m - (qx[k] * qx[k] + qy[k] * qy[k]) + rc.filt_E;
+        hax[k] = hax[K + k] = (float)(-2.0 * qx[k]); hay[k] = hay[K + k] = (float)(-2.0 * qy[k]);
+        hthr[k] = hthr[K + k] = nextafterf((float)t, 1e30f);
+    }
+    CK(hipMalloc(&rc.q_ax, 2 * K * 4)); CK(hipMalloc(&rc.q_ay, 2 * K * 4)); CK(hipMalloc(&rc.q_thr, 2 * K * 4));
+    CK(hipMemcpy(rc.q_ax, hax.data(), 2 * K * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(rc.q_ay, hay.data(), 2 * K * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(rc.q_thr, hthr.data(), 2 * K * 4, hipMemcpyHostToDevice));
     RunConst *drc;
     CK(hipMalloc(&drc, sizeof rc));
     CK(hipMemcpy(drc, &rc, sizeof rc, hipMemcpyHostToDevice));
@@ -116,12 +156,13 @@ int main(int argc, char **argv) {
         double us = ms * 1e3 / reps, pairs = (double)N * K;
         printf("%-22s N=%u NC=%3u  %8.2f us  %7.2f Gpair/s  (6 flop/pair: %6.2f TF)\n", name, N, NC, us, pairs / us * 1e-3, 6 * pairs / us * 1e-6);
     };
-    for (uint32_t NC : {32u, 64u, 128u, 256u}) {
+    for (uint32_t NC : {128u, 256u, 512u}) {
         dim3 grid(K / 256, NC);
         timeit("nn_scan", NC, [&] { hipLaunchKernelGGL(k_nn_scan<false>, grid, dim3(256), 0, 0, (const RunConst *)drc, 0u, 0u, K, NC); });
         timeit("radius_scan", NC, [&] { CK(hipMemsetAsync(rc.cand_cnt, 0, K * 4)); hipLaunchKernelGGL(k_radius_scan, grid, dim3(256), 0, 0, (const RunConst *)drc, 0u, K, NC); });
         timeit("minonly(sload)", NC, [&] { hipLaunchKernelGGL(v_minonly, grid, dim3(256), 0, 0, (const double *)rc.nx, (const double *)rc.ny, (const double *)rc.sx, (const double *)rc.sy, rc.part_D, N, NC); });
         timeit("minonly(lds)", NC, [&] { hipLaunchKernelGGL(v_lds, grid, dim3(256), 0, 0, (const double *)rc.nx, (const double *)rc.ny, (const double *)rc.sx, (const double *)rc.sy, rc.part_D, N, NC); });
+        timeit("f32key(lds)", NC, [&] { hipLaunchKernelGGL(v_f32_lds, grid, dim3(256), 0, 0, (const float *)dfx, (const float *)dfy, (const float *)dfn, (const double *)rc.sx, (const double *)rc.sy, dof, N, NC); });
         timeit("f32key(sload)", NC, [&] { hipLaunchKernelGGL(v_f32, grid, dim3(256), 0, 0, (const float *)dfx, (const float *)dfy, (const float *)dfn, (const double *)rc.sx, (const double *)rc.sy, dof, N, NC); });
     }
     return 0;
