@@ -1,0 +1,34 @@
+// Plans one RRT* query with the C++ mirror of the reference interface (cf. src/rrt.rs:269-303,
+// test_plan_on_map7_prefefined_goal) and prints a digest the tests compare with the CPU oracle.
+// usage: plan_rrt <map.pgm> <n_iter_min> <n_iter_max> <batch_K> <seed>
+#include "../include/porrt.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+int main(int argc, char **argv) {
+    if (argc < 6) { std::fprintf(stderr, "usage: %s map.pgm n_iter_min n_iter_max batch_K seed\n", argv[0]); return 2; }
+    using namespace po_rrt;
+    try {
+        auto m = MapShelfDomain::open(argv[1], {-1.0, -1.0}, {1.0, 1.0});
+        SquareGoal goal({{{0.9, 0.0}, 1}}, 0.05);
+        RRT rrt(ContinuousSampler({-1.0, -1.0}, {1.0, 1.0}, std::strtoull(argv[5], nullptr, 10)), &m);
+        rrt.batch_K = (uint32_t)std::atoi(argv[4]);
+        auto [result, tree] = rrt.plan({0.0, -1.0}, goal, 0.1, 2.0, std::strtoull(argv[2], nullptr, 10), std::strtoull(argv[3], nullptr, 10));
+        uint64_t h = 1469598103934665603ull;                 // FNV-1a over parents and coordinate bits
+        for (auto &n : tree.nodes) {
+            uint64_t v[3];
+            v[0] = n.parent_id ? *n.parent_id : ~0ull;
+            std::memcpy(&v[1], &n.state[0], 8);
+            std::memcpy(&v[2], &n.state[1], 8);
+            for (uint64_t x : v) for (int b = 0; b < 8; ++b) { h ^= (x >> (8 * b)) & 0xff; h *= 1099511628211ull; }
+        }
+        std::printf("nodes %zu digest %016llx ", tree.nodes.size(), (unsigned long long)h);
+        if (result) std::printf("path %zu cost %.17g\n", result->first.size(), result->second);
+        else std::printf("No solution found\n");
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

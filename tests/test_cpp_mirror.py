@@ -1,0 +1,69 @@
+"""The C++ host mirror (include/porrt.hpp) of the reference's RRT / PTO interface.
+
+CPU: the header and the example compile with plain g++ against the C ABI and the program fails loudly
+without a GPU.  GPU: the example's tree digest equals the oracle's for the same map / seed / batch."""
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "build_tools", "plan_rrt")
+MAP = os.path.join(ROOT, "tests", "golden", "maps", "map_benchmark_like.pgm")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    from po_rrt_amd import build
+    build.build()
+    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < os.path.getmtime(os.path.join(ROOT, "include", "porrt.hpp")):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-o", EXE, os.path.join(ROOT, "examples", "plan_rrt.cpp"),
+                        "-L" + os.path.join(ROOT, "po_rrt_amd"), "-lporrt_hip", "-Wl,-rpath," + os.path.join(ROOT, "po_rrt_amd")],
+                       check=True)
+    return EXE
+
+
+def test_cpp_example_builds_and_needs_a_gpu(exe):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    out = subprocess.run([exe, MAP, "100", "100", "16", "0"], capture_output=True, text=True)
+    assert out.returncode == 1 and "no usable HIP device" in out.stderr
+
+
+def fnv_digest(xy, parent):
+    h = 1469598103934665603
+    for j in range(len(parent)):
+        p = parent[j] if parent[j] >= 0 else -1
+        for v in (p & (2 ** 64 - 1), struct.unpack("<Q", struct.pack("<d", xy[j, 0]))[0], struct.unpack("<Q", struct.pack("<d", xy[j, 1]))[0]):
+            for b in range(8):
+                h ^= (v >> (8 * b)) & 0xFF
+                h = (h * 1099511628211) & (2 ** 64 - 1)
+    return h
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [1, 256])
+def test_cpp_rrt_plan_matches_oracle(exe, K):
+    n = 400 if K == 1 else 3000
+    out = subprocess.run([exe, MAP, str(n), str(n), str(K), "5"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    tok = out.stdout.split()
+    case = cases.cfg2(n, seed=5)
+    o = cases.configure(orc.Oracle(), case)
+    cases.grow(o, case, K=K, algo=orc.ALGO_BATCHED_KD)
+    xy, parent, _ = o.tree()
+    assert int(tok[1]) == len(parent)
+    assert int(tok[3], 16) == fnv_digest(xy, parent)
+    sol = o.best_solution()
+    if sol is None:
+        assert "No solution found" in out.stdout
+    else:
+        assert int(tok[5]) == len(sol[0]) and float(tok[7]) == sol[1]
