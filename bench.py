@@ -153,6 +153,18 @@ def main():
             agg.update(prof)
             achieved = agg["scan_bytes"] / agg["scan_s"] / 1e9
             tflops = FLOP_PER_PAIR * agg["scan_pairs"] / agg["scan_s"] / 1e12
+            traffic, traffic_note = None, None
+            try:    # HBM traffic per launch from the committed rocprofv3 --pmc passes (profiles/r1_pmc_traffic.json)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+                ks = [pm[k] for k in pm if k.startswith("k_nn_scan") or k.startswith("k_radius_scan")]
+                if ks:
+                    traffic = sum(2.0 * k["fetch_bytes_per_launch_raw"] + k["write_bytes_per_launch"] for k in ks) / len(ks)
+                    traffic_note = ("bytes per scan launch = 2 x FETCH_SIZE (gfx950 under-reports streaming reads) + WRITE_SIZE, "
+                                    "separate --pmc passes of this command; raw fetch %.0f B, write %.0f B"
+                                    % (sum(k["fetch_bytes_per_launch_raw"] for k in ks) / len(ks),
+                                       sum(k["write_bytes_per_launch"] for k in ks) / len(ks)))
+            except Exception:
+                pass
             out["roofline"] = {
                 "bound": "hbm",
                 "kernel": "k_nn_scan + k_radius_scan (same loop body; K x N_b sample-node pairs per launch)",
@@ -160,7 +172,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": traffic_note,
                 "avg_launch_us": 1e6 * agg["scan_s"] / max(agg["scan_launches"], 1),
                 "launches": agg["scan_launches"],
                 "algorithmic_bytes_per_launch": agg["scan_bytes"] / max(agg["scan_launches"], 1),

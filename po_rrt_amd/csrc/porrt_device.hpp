@@ -26,7 +26,7 @@
 
 namespace porrt {
 
-constexpr int kScanBlock = 256;      // lanes = samples per scan workgroup
+constexpr int kScanBlock = 1024;     // lanes = samples per scan workgroup: one workgroup streams a node chunk past ALL samples
 constexpr int kMaxChunks = 256;      // node chunks per scan (grid.y)
 constexpr int kConnectWaves = 4;     // samples per connect workgroup (one wave each)
 constexpr uint32_t kTileRMax = 31;             // LDS tile half-width limit (pixels); above it rays read global
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(kScanBlock) void k_nn_scan(const RunConst *__restri
                                                           uint32_t NC) {
     __shared__ __attribute__((aligned(16))) NodeTile tile;
     const RunConst &rc = *rcp;
-    const uint32_t k = blockIdx.x * kScanBlock + threadIdx.x;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t c = blockIdx.y;
     const uint32_t N = __builtin_amdgcn_readfirstlane(rc.n_at[b]);
     uint32_t j0, j1;
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256) void k_nn_reduce_steer(const RunConst *__restr
 __global__ __launch_bounds__(kScanBlock) void k_radius_scan(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t NC) {
     __shared__ __attribute__((aligned(16))) NodeTile tile;
     const RunConst &rc = *rcp;
-    const uint32_t k = blockIdx.x * kScanBlock + threadIdx.x;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t c = blockIdx.y;
     const uint32_t N = __builtin_amdgcn_readfirstlane(rc.n_at[b]);
     uint32_t j0, j1;

@@ -390,7 +390,8 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     const uint32_t n_ub = i0 + 1;
     uint32_t NC = (n_ub + 63) / 64;
     NC = std::max(1u, std::min<uint32_t>(NC, kMaxChunks));
-    const dim3 scan_grid((nb + kScanBlock - 1) / kScanBlock, NC);
+    const uint32_t sblock = std::min<uint32_t>(kScanBlock, (nb + 63u) & ~63u);   // all samples of the step in one workgroup when they fit
+    const dim3 scan_grid((nb + sblock - 1) / sblock, NC);
     const uint32_t wave_blocks = (nb * 64 + 255) / 256;
     const uint32_t red_blocks = (nb + 63) / 64;
     const RunConst *rcp = d_rc.p;
@@ -400,12 +401,12 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     const bool rrt = mode == PORRT_MODE_RRT;
     if (!rrt) launch_bound(stream, b, b, i0, nb);      // PTO: bounds in-stream (the world filter wants fresh reach masks)
     ev();
-    if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_nn_scan<true>, scan_grid, dim3(kScanBlock), 0, stream, rcp, b, i0, nb, NC);
-    else hipLaunchKernelGGL(k_nn_scan<false>, scan_grid, dim3(kScanBlock), 0, stream, rcp, b, i0, nb, NC);
+    if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_nn_scan<true>, scan_grid, dim3(sblock), 0, stream, rcp, b, i0, nb, NC);
+    else hipLaunchKernelGGL(k_nn_scan<false>, scan_grid, dim3(sblock), 0, stream, rcp, b, i0, nb, NC);
     ev();
     hipLaunchKernelGGL(k_nn_reduce_steer, dim3(red_blocks), dim3(256), 0, stream, rcp, b, i0, nb, NC, vwords);
     ev();
-    hipLaunchKernelGGL(k_radius_scan, scan_grid, dim3(kScanBlock), 0, stream, rcp, b, nb, NC);
+    hipLaunchKernelGGL(k_radius_scan, scan_grid, dim3(sblock), 0, stream, rcp, b, nb, NC);
     ev();
     const dim3 cgrid((nb + kConnectWaves - 1) / kConnectWaves), cblock(kConnectWaves * 64);
     // the kd structure of the previous step's nodes (side stream) is needed from here on

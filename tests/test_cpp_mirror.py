@@ -41,7 +41,7 @@ def test_cpp_example_builds_and_needs_a_gpu(exe):
 def fnv_digest(xy, parent):
     h = 1469598103934665603
     for j in range(len(parent)):
-        p = parent[j] if parent[j] >= 0 else -1
+        p = int(parent[j]) if parent[j] >= 0 else -1
         for v in (p & (2 ** 64 - 1), struct.unpack("<Q", struct.pack("<d", xy[j, 0]))[0], struct.unpack("<Q", struct.pack("<d", xy[j, 1]))[0]):
             for b in range(8):
                 h ^= (v >> (8 * b)) & 0xFF

@@ -193,3 +193,18 @@ def test_size_independent_properties(eng_mod):
     assert not (cur >= 0).any(), "cycle in parents"
     straight = np.sqrt(((xy - xy[0]) ** 2).sum(axis=1))
     assert (dist + 1e-9 >= straight).all()
+
+
+def test_cfg5_maps_and_seeds(eng_mod):
+    """BASELINE.json configs[4]: the nine map_benchmark_{a..i} stand-ins x several seeds, one context reused
+    for all queries of a map (the reference reuses one RRT object, tamp_rrt.rs:196-232)."""
+    for letter in "abcdefghi":
+        case = cases.cfg2(6000, grid="map_benchmark_like_%s" % letter)
+        e = cases.configure(eng_mod.Engine(), case)
+        o = cases.configure(orc.Oracle(), case)
+        for seed in (0, 7):
+            e.set_sampler((-1.0, -1.0), (1.0, 1.0), seed)
+            o.set_sampler((-1.0, -1.0), (1.0, 1.0), seed)
+            cases.grow(e, case, K=1024)
+            cases.grow(o, case, K=1024, algo=orc.ALGO_BATCHED_KD)
+            assert_same(e, o)

@@ -158,8 +158,9 @@ int main(int argc, char **argv) {
     };
     for (uint32_t NC : {128u, 256u, 512u}) {
         dim3 grid(K / 256, NC);
-        timeit("nn_scan", NC, [&] { hipLaunchKernelGGL(k_nn_scan<false>, grid, dim3(256), 0, 0, (const RunConst *)drc, 0u, 0u, K, NC); });
-        timeit("radius_scan", NC, [&] { CK(hipMemsetAsync(rc.cand_cnt, 0, K * 4)); hipLaunchKernelGGL(k_radius_scan, grid, dim3(256), 0, 0, (const RunConst *)drc, 0u, K, NC); });
+        dim3 sgrid(K / 1024, NC);
+        timeit("nn_scan", NC, [&] { hipLaunchKernelGGL(k_nn_scan<false>, sgrid, dim3(1024), 0, 0, (const RunConst *)drc, 0u, 0u, K, NC); });
+        timeit("radius_scan", NC, [&] { CK(hipMemsetAsync(rc.cand_cnt, 0, K * 4)); hipLaunchKernelGGL(k_radius_scan, sgrid, dim3(1024), 0, 0, (const RunConst *)drc, 0u, K, NC); });
         timeit("minonly(sload)", NC, [&] { hipLaunchKernelGGL(v_minonly, grid, dim3(256), 0, 0, (const double *)rc.nx, (const double *)rc.ny, (const double *)rc.sx, (const double *)rc.sy, rc.part_D, N, NC); });
         timeit("minonly(lds)", NC, [&] { hipLaunchKernelGGL(v_lds, grid, dim3(256), 0, 0, (const double *)rc.nx, (const double *)rc.ny, (const double *)rc.sx, (const double *)rc.sy, rc.part_D, N, NC); });
         timeit("f32key(lds)", NC, [&] { hipLaunchKernelGGL(v_f32_lds, grid, dim3(256), 0, 0, (const float *)dfx, (const float *)dfy, (const float *)dfn, (const double *)rc.sx, (const double *)rc.sy, dof, N, NC); });
