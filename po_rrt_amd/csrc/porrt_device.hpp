@@ -86,10 +86,13 @@ struct RunConst {
     unsigned long long inj_base, inj_n;
     // per-sample step scratch
     double *q_x, *q_y;          // steered state
+    double *kq_x, *kq_y;        // copy for the kd insertion (two step parities)
+    int *kq_vid;
     int *q_nn;
     int *q_vid;
     double *part_D;
     int *part_id;
+    unsigned long long *part_mask;   // [chunk][sample/64]: which partial slots hold a candidate
     unsigned long long *dbg;    // optional per-step phase stamps (diagnostic builds of the host only)
     uint32_t *heavy_list;       // samples routed to the team connect kernel this step
     uint32_t *cand_cnt;
@@ -109,6 +112,7 @@ struct RunConst {
     uint32_t *kd_gexit;
     int *loc_cur;               // per new node of the step: where k_kd_locate stopped (node, depth, G exit, flags)
     uint32_t *loc_dcur, *loc_gex, *loc_flags, *g_nd;
+    double *g_nd_x, *g_nd_y;    // coordinates of the non-duplicate levels of G (contiguous, no indirection)
     int *g_id;                  // G[i] = node at depth i on the kd descent path of the goal point
     double *g_x, *g_y;          // its coordinates, contiguous (the path is scanned, not chased)
     uint32_t g_cap;
@@ -435,14 +439,10 @@ __device__ __forceinline__ float key_threshold_inner(const RunConst &rc, double 
 
 // One thread per sample: upper bound of its nearest-neighbour distance from the pyramid (finest level whose
 // 3x3 neighbourhood holds a node that passes the world filter), turned into the scan's key threshold.
-// `b` is the step the bound is FOR; `bsnap` (<= b) is the step whose tree size limits the nodes that may be
-// used -- the kernel runs ahead of the main pipeline (bounds from a slightly older tree are still bounds).
+// Upper bound of sample k's nearest-neighbour distance from the pyramid (finest level whose 3x3 neighbourhood
+// holds a node with id < N that passes the world filter), turned into the scan's key threshold for step b.
 template <bool PTO>
-__global__ __launch_bounds__(256) void k_nn_bound(const RunConst *__restrict__ rcp, uint32_t b, uint32_t bsnap, uint32_t i0, uint32_t nb) {
-    const RunConst &rc = *rcp;
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= nb) return;
-    const uint32_t N = rc.n_at[bsnap];
+__device__ __forceinline__ void nn_bound_sample(const RunConst &rc, uint32_t b, uint32_t N, uint32_t i0, uint32_t k) {
     const double qx = rc.sx[i0 + k], qy = rc.sy[i0 + k];
     uint32_t world = 0;
     if (PTO) world = rc.sworld[i0 + k];
@@ -482,6 +482,15 @@ __global__ __launch_bounds__(256) void k_nn_bound(const RunConst *__restrict__ r
     rc.q_ax[o] = (float)(-2.0 * qx);
     rc.q_ay[o] = (float)(-2.0 * qy);
     rc.q_thr[o] = m == INF ? __int_as_float(0x7F800000) : key_threshold(rc, m, qx, qy);
+}
+
+// stand-alone form: first step of a run, PTO steps (fresh reach masks), steps beyond n_iter_min
+template <bool PTO>
+__global__ __launch_bounds__(256) void k_nn_bound(const RunConst *__restrict__ rcp, uint32_t b, uint32_t bsnap, uint32_t i0, uint32_t nb) {
+    const RunConst &rc = *rcp;
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nb) return;
+    nn_bound_sample<PTO>(rc, b, rc.n_at[bsnap], i0, k);
 }
 
 // ------------------------------------------------------------------ scans
@@ -624,18 +633,20 @@ __global__ __launch_bounds__(256) void k_nn_reduce_steer(const RunConst *__restr
     double D = __longlong_as_double(0x7FF0000000000000ll);
     int id = 0x7FFFFFFF;
     if (k < nb) {
-        for (uint32_t c0 = wv; c0 < NC; c0 += 32) {      // 8 independent loads in flight per lane
-            double d[8];
-            int i[8];
+        auto pD = as_global(rc.part_D) + k;
+        auto pI = as_global(rc.part_id) + k;
+        for (uint32_t c0 = wv; c0 < NC; c0 += 64) {      // 16 independent coalesced loads in flight per lane
+            double d[16];
+            int i[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const uint32_t c = c0 + 4u * u;
                 const bool ok = c < NC;
-                i[u] = ok ? rc.part_id[(size_t)c * rc.part_stride + k] : -1;
-                d[u] = ok ? rc.part_D[(size_t)c * rc.part_stride + k] : 0.0;
+                i[u] = ok ? pI[(size_t)c * rc.part_stride] : -1;
+                d[u] = ok ? pD[(size_t)c * rc.part_stride] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 16; ++u)
                 if (i[u] >= 0 && (d[u] < D || (d[u] == D && i[u] < id))) { D = d[u]; id = i[u]; }
         }
     }
@@ -673,6 +684,10 @@ __global__ __launch_bounds__(256) void k_nn_reduce_steer(const RunConst *__restr
     }
     rc.q_x[k] = tx;
     rc.q_y[k] = ty;
+    {   // copy for the kd insertion, which runs beside the next steps (double-buffered by step parity)
+        const uint32_t o2 = (b & 1u) * rc.part_stride + k;
+        rc.kq_x[o2] = tx; rc.kq_y[o2] = ty; rc.kq_vid[o2] = valid ? vid : -1;
+    }
     rc.q_nn[k] = nn;
     rc.q_vid[k] = valid ? vid : -1;
     rc.cand_cnt[k] = 0;
@@ -705,8 +720,21 @@ __global__ __launch_bounds__(kScanBlock) void k_radius_scan(const RunConst *__re
     auto cand_id = as_global(rc.cand_id) + (size_t)(k < nb ? k : 0) * rc.cand_cap;
     const uint32_t cap = rc.cand_cap;
     auto errw = as_global(&rc.cnt->err);
-    uint32_t pend_slot = 0;
-    int pend_j = -1;
+    // A lane's hits are parked in LDS and flushed with ONE slot claim (atomicAdd of the count) -- vmcnt is per
+    // wave, so claiming a slot per hit would stall every lane of the wave on each other's atomics.
+    constexpr uint32_t kHits = 8;
+    __shared__ int s_hits[kHits * kScanBlock];
+    uint32_t nh = 0;
+    auto flush = [&]() {
+        if (nh) {
+            const uint32_t slot = g_atomic_add(cand_cnt, nh);
+            for (uint32_t h = 0; h < nh; ++h) {
+                if (slot + h < cap) cand_id[slot + h] = s_hits[h * kScanBlock + threadIdx.x];
+                else g_atomic_or(errw, (uint32_t)ERR_CAND_OVERFLOW);
+            }
+            nh = 0;
+        }
+    };
     for (uint32_t base = j0; base < j1; base += kTile) {
         const uint32_t n = j1 - base < kTile ? j1 - base : kTile;
         if (base != j0) __syncthreads();
@@ -717,19 +745,13 @@ __global__ __launch_bounds__(kScanBlock) void k_radius_scan(const RunConst *__re
                       bool in = key <= thr_in;
                       if (!in) in = dist2(tile.x[i], tile.y[i], qx, qy) <= T2;      // shell: exact test
                       if (in) {
-                          if (pend_j >= 0) {
-                              if (pend_slot < cap) cand_id[pend_slot] = pend_j;
-                              else g_atomic_or(errw, (uint32_t)ERR_CAND_OVERFLOW);
-                          }
-                          pend_slot = g_atomic_add(cand_cnt, 1u);
-                          pend_j = (int)(base + i);
+                          if (nh == kHits) flush();                                 // rare: dense neighbourhoods
+                          s_hits[nh * kScanBlock + threadIdx.x] = (int)(base + i);
+                          ++nh;
                       }
                   });
     }
-    if (pend_j >= 0) {
-        if (pend_slot < cap) cand_id[pend_slot] = pend_j;
-        else g_atomic_or(errw, (uint32_t)ERR_CAND_OVERFLOW);
-    }
+    flush();
 }
 
 // ------------------------------------------------------------------ connect
@@ -988,62 +1010,73 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
 
 constexpr uint32_t kHeavyCand = 128;     // samples with more neighbours than this go to the 4-wave team kernel
 
-// light samples: one wave each; heavy ones are queued for k_connect_rrt_heavy
+// One workgroup = kConnectWaves samples.  Phase 1: every wave serves its own sample if it is light.  Phase 2:
+// samples with more than kHeavyCand neighbours (the dense start of a tree, duplicates of the goal point) are
+// served one after the other by the whole workgroup as a 4-wave team.
 template <bool LDSGRID>
 __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
                                                                      uint32_t vwords) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_tiles[];
+    __shared__ double s_d[kConnectWaves];
+    __shared__ int s_i[kConnectWaves];
+    __shared__ uint32_t s_heavy[kConnectWaves];
     const RunConst &rc = *rcp;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t k = blockIdx.x * kConnectWaves + (threadIdx.x >> 6);
-    if (k >= nb || rc.q_vid[k] < 0) return;
-    const uint32_t cnt = rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap;
-    if (cnt > kHeavyCand) return;          // served by k_connect_rrt_heavy, which runs beside this kernel
-    TileGrid grid;
-    if (LDSGRID) {
-        const uint32_t TW = 2u * rc.tile_R + 1u;
-        grid = load_tile(rc, lds_tiles + (threadIdx.x >> 6) * ((TW * TW + 15u) & ~15u), rc.q_x[k], rc.q_y[k], lane, 64u);
-        __builtin_amdgcn_wave_barrier();
-    } else {
-        grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t k = blockIdx.x * kConnectWaves + wv;
+    const bool active = k < nb && rc.q_vid[k < nb ? k : 0] >= 0;
+    const uint32_t cnt = active ? (rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap) : 0u;
+    const bool heavy = active && cnt > kHeavyCand;
+    if (lane == 0) s_heavy[wv] = heavy ? cnt : 0u;
+    const uint32_t TW = 2u * rc.tile_R + 1u;
+    const uint32_t tile_bytes = (TW * TW + 15u) & ~15u;
+    uint32_t err = 0;
+    if (active && !heavy) {
+        TileGrid grid;
+        if (LDSGRID) {
+            grid = load_tile(rc, lds_tiles + wv * tile_bytes, rc.q_x[k], rc.q_y[k], lane, 64u);
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0;
+        }
+        Team<1> tm;
+        tm.scr_d = nullptr; tm.scr_i = nullptr; tm.wave = 0; tm.lane = lane;
+        connect_rrt_sample<1>(rc, tm, grid, b, vwords, k, cnt, err);
     }
-    Team<1> tm;
-    tm.scr_d = nullptr; tm.scr_i = nullptr; tm.wave = 0; tm.lane = lane;
-    uint32_t err = 0;
-    connect_rrt_sample<1>(rc, tm, grid, b, vwords, k, cnt, err);
-    if (err) atomicOr(&rc.cnt->err, err);
-}
-
-// heavy samples (hundreds of neighbours: the dense start of a tree, duplicates of the goal point): a
-// workgroup of four waves per sample
-template <bool LDSGRID>
-__global__ __launch_bounds__(256) void k_connect_rrt_heavy(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_tiles[];
-    __shared__ double s_d[4];
-    __shared__ int s_i[4];
-    const RunConst &rc = *rcp;
-    const uint32_t k = blockIdx.x;          // one workgroup per sample; all but the heavy ones leave at once
-    if (k >= nb || rc.q_vid[k] < 0) return;
-    const uint32_t cnt = rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap;
-    if (cnt <= kHeavyCand) return;
-    Team<4> tm;
-    tm.scr_d = s_d; tm.scr_i = s_i; tm.wave = threadIdx.x >> 6; tm.lane = threadIdx.x & 63u;
-    uint32_t err = 0;
-    TileGrid grid;
-    if (LDSGRID) grid = load_tile(rc, lds_tiles, rc.q_x[k], rc.q_y[k], threadIdx.x, 256u);
-    else { grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0; }
     __syncthreads();
-    connect_rrt_sample<4>(rc, tm, grid, b, vwords, k, cnt, err);
+    Team<kConnectWaves> tmh;
+    tmh.scr_d = s_d; tmh.scr_i = s_i; tmh.wave = wv; tmh.lane = lane;
+    for (uint32_t w = 0; w < kConnectWaves; ++w) {
+        const uint32_t hc = s_heavy[w];            // workgroup-uniform
+        if (!hc) continue;
+        const uint32_t kh = blockIdx.x * kConnectWaves + w;
+        TileGrid grid;
+        __syncthreads();
+        if (LDSGRID) grid = load_tile(rc, lds_tiles, rc.q_x[kh], rc.q_y[kh], threadIdx.x, kConnectWaves * 64u);
+        else { grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0; }
+        __syncthreads();
+        connect_rrt_sample<kConnectWaves>(rc, tmh, grid, b, vwords, kh, hc, err);
+    }
     if (err) atomicOr(&rc.cnt->err, err);
 }
 
 // RRT*: rewire phase 2.  A pair wins iff its candidate equals the accumulated minimum; among equal
 // candidates the lowest new id wins (sequential order of the reference, strict `<`, rrt.rs:157).
-__global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
+__global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords,
+                                                     uint32_t nxt_i0, uint32_t nxt_nb) {
     const RunConst &rc = *rcp;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t N = rc.n_at[b];
+    {
+        // NN bounds of the NEXT step (its samples are known since the start of the run; every node written by
+        // this step's connect kernel may serve as a bound)
+        const uint32_t kb = blockIdx.x * 256u + threadIdx.x;
+        if (kb < nxt_nb) {
+            uint32_t add = 0;
+            for (uint32_t w = 0; w < vwords; ++w) add += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
+            nn_bound_sample<false>(rc, b + 1, N + add, nxt_i0, kb);
+        }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         uint32_t add = 0;
         for (uint32_t w = 0; w < vwords; ++w) add += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
@@ -1082,41 +1115,86 @@ __global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__
 //                the same round because they share the whole path above it, so this equals sequential insertion.
 enum : uint32_t { LOC_SIDE = 1u, LOC_ONPATH = 2u };
 
-// descend from node `cur` (depth dcur, taking `side`) to an empty slot of the old tree
-__device__ __forceinline__ void kd_descend(const RunConst &rc, double vx, double vy, int &cur, uint32_t &dcur, uint32_t &side) {
-    KdRec rec = rc.kd_rec[cur];
+constexpr int kKdTop = 2048;         // oldest nodes = top of the tree (ids grow downwards): staged in LDS by k_kd_locate
+
+// descend from node `cur` (depth dcur, taking `side`) to an empty slot of the old tree.  Records of the kKdTop
+// oldest nodes come from the LDS copy `top` (a descent spends ~2 ln(kKdTop) of its ~2 ln(N) levels there).
+__device__ __forceinline__ void kd_descend(const RunConst &rc, const KdRec *top, uint32_t n_top, double vx, double vy, int &cur,
+                                           uint32_t &dcur, uint32_t &side) {
+    auto grec = as_global(rc.kd_rec);
+    KdRec rec;
+    if ((uint32_t)cur < n_top) rec = top[cur];
+    else { rec.x = grec[cur].x; rec.y = grec[cur].y; rec.child[0] = grec[cur].child[0]; rec.child[1] = grec[cur].child[1]; }
     for (;;) {                          // one dependent 24-byte load per level
         const int c = side ? rec.child[1] : rec.child[0];
         if (c == kEmpty) break;
-        rec = rc.kd_rec[c];
+        if ((uint32_t)c < n_top) rec = top[c];
+        else { rec.x = grec[c].x; rec.y = grec[c].y; rec.child[0] = grec[c].child[0]; rec.child[1] = grec[c].child[1]; }
         cur = c;
         dcur += 1;
         side = kd_left(vx, vy, rec.x, rec.y, dcur) ? 0u : 1u;
     }
 }
 
-__global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ rcp, uint32_t b) {
+__global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
     const RunConst &rc = *rcp;
     const uint32_t N = rc.n_at[b];
-    const uint32_t n_new = rc.n_at[b + 1] - N;       // written by the commit kernel of step b
     const uint32_t glen0 = __builtin_amdgcn_readfirstlane(rc.cnt->g_len);
     const uint32_t n_nd = __builtin_amdgcn_readfirstlane(rc.cnt->g_nd_len);
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n_new) return;
+    const bool dbgt = rc.dbg && blockIdx.x == 0 && threadIdx.x == 0;
+    if (dbgt) rc.dbg[b * 8 + 1] = wall_clock64();
+    __shared__ __attribute__((aligned(16))) KdRec s_top[kKdTop];
+    const uint32_t n_top = N < (uint32_t)kKdTop ? N : (uint32_t)kKdTop;
+    constexpr uint32_t kNdLds = 1024;
+    __shared__ double s_ndx[kNdLds], s_ndy[kNdLds];
+    __shared__ uint32_t s_ndi[kNdLds];
+    {
+        // 24-byte records as 16-byte words, eight loads in flight per lane; then the non-duplicate G levels
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        auto src = reinterpret_cast<GPTR(const u32x4)>(as_global(rc.kd_rec));
+        u32x4 *dst = reinterpret_cast<u32x4 *>(s_top);
+        const uint32_t nw = (n_top * 24u + 15u) / 16u;
+        for (uint32_t w0 = threadIdx.x; w0 < nw; w0 += 8u * 256u) {
+            u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const uint32_t w = w0 + u * 256u; v[u] = src[w < nw ? w : 0u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const uint32_t w = w0 + u * 256u; if (w < nw) dst[w] = v[u]; }
+        }
+        for (uint32_t t2 = threadIdx.x; t2 < n_nd && t2 < kNdLds; t2 += 256u) {
+            s_ndi[t2] = rc.g_nd[t2]; s_ndx[t2] = rc.g_nd_x[t2]; s_ndy[t2] = rc.g_nd_y[t2];
+        }
+    }
+    __syncthreads();
+    if (dbgt) rc.dbg[b * 8 + 7] = wall_clock64();
+    // The step's new nodes are the valid samples (positions known since k_nn_reduce_steer), id = N + rank: this
+    // kernel runs beside the step's radius scan and connect.
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t o2 = (b & 1u) * rc.part_stride + (k < nb ? k : 0u);
+    if (k >= nb || rc.kq_vid[o2] < 0) return;
+    const uint32_t t = rank_before(rc, b, vwords, k);
     const double px = rc.gp_x, py = rc.gp_y;
-    const double vx = rc.nx[N + t], vy = rc.ny[N + t];
+    const double vx = rc.kq_x[o2], vy = rc.kq_y[o2];
+    {   // the node's kd record exists from here on (k_kd_claim only links it)
+        KdRec rec;
+        rec.x = vx; rec.y = vy; rec.child[0] = kEmpty; rec.child[1] = kEmpty;
+        rc.kd_rec[N + t] = rec;
+    }
     // Where does this node's descent leave the goal path G?  At the first level whose test it fails.  A level
     // held by an exact duplicate of the goal point tests `x < p.x` (even depth) or `y < p.y` (odd depth), and
     // the goal point itself always goes right there, so all duplicate levels reduce to two comparisons against
-    // the first duplicate of each parity; only the few non-duplicate levels (g_nd) are real tests.
+    // the first duplicate of each parity; only the few non-duplicate levels (g_nd*) are real tests.
     uint32_t E = 0xFFFFFFFFu;
     bool leftE = false;
-    for (uint32_t s = 0; s < n_nd; ++s) {             // wave-uniform: scalar loads
-        const uint32_t i = rc.g_nd[s];
-        const double wx = rc.g_x[i], wy = rc.g_y[i];
-        const bool gl = kd_left(px, py, wx, wy, i), vl = kd_left(vx, vy, wx, wy, i);
-        if (vl != gl && i < E) { E = i; leftE = vl; }
+    for (uint32_t s0 = 0; s0 < n_nd; ++s0) {
+        uint32_t ii;
+        double wx, wy;
+        if (s0 < kNdLds) { ii = s_ndi[s0]; wx = s_ndx[s0]; wy = s_ndy[s0]; }
+        else { ii = rc.g_nd[s0]; wx = rc.g_nd_x[s0]; wy = rc.g_nd_y[s0]; }
+        const bool gl = kd_left(px, py, wx, wy, ii), vl = kd_left(vx, vy, wx, wy, ii);
+        if (vl != gl && ii < E) { E = ii; leftE = vl; }
     }
+    if (dbgt) rc.dbg[b * 8 + 5] = wall_clock64();
     const uint32_t d0 = rc.cnt->g_first_dup[0], d1 = rc.cnt->g_first_dup[1];
     if (vx < px && d0 < E) { E = d0; leftE = true; }
     if (vy < py && d1 < E) { E = d1; leftE = true; }
@@ -1132,22 +1210,24 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
         gex = E;
         cur = rc.g_id[E];
         side = leftE ? 0u : 1u;
-        kd_descend(rc, vx, vy, cur, dcur, side);
+        kd_descend(rc, s_top, n_top, vx, vy, cur, dcur, side);
     }
     rc.loc_cur[t] = cur;
     rc.loc_dcur[t] = dcur;
     rc.loc_gex[t] = gex;
     rc.loc_flags[t] = flags | (side ? LOC_SIDE : 0u);
+    if (dbgt) { rc.dbg[b * 8 + 4] = wall_clock64(); rc.dbg[b * 8 + 6] = dcur; }
 }
 
 // One workgroup; a thread owns up to kPer nodes (batch_K <= 4096).
-__global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ rcp, uint32_t b) {
+__global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ rcp, uint32_t b, uint32_t vwords) {
     const RunConst &rc = *rcp;
     const uint32_t N = rc.n_at[b];
-    const uint32_t n_new = rc.n_at[b + 1] - N;
+    uint32_t n_new = 0;
+    for (uint32_t w = 0; w < vwords; ++w) n_new += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
     const uint32_t glen0 = __builtin_amdgcn_readfirstlane(rc.cnt->g_len);
     const double px = rc.gp_x, py = rc.gp_y;
-    if (rc.dbg && threadIdx.x == 0) { rc.dbg[b * 8 + 0] = wall_clock64(); rc.dbg[b * 8 + 6] = clock64(); }
+    if (rc.dbg && threadIdx.x == 0) rc.dbg[b * 8 + 0] = wall_clock64();
     if (rc.dbg && threadIdx.x == 0) rc.dbg[b * 8 + 2] = wall_clock64();
     constexpr int kPer = 4;
     bool todo[kPer], onpath[kPer];
@@ -1166,8 +1246,8 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
         dcur[r] = rc.loc_dcur[tt];
         gex[r] = rc.loc_gex[tt];
         vidn[r] = todo[r] ? (int)(N + t) : kEmpty;
-        vx[r] = todo[r] ? rc.nx[N + t] : 0.0;
-        vy[r] = todo[r] ? rc.ny[N + t] : 0.0;
+        vx[r] = todo[r] ? rc.kd_rec[N + tt].x : 0.0;
+        vy[r] = todo[r] ? rc.kd_rec[N + tt].y : 0.0;
     }
     uint32_t rounds = 0;
     // claim rounds
@@ -1185,9 +1265,6 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
             const int w = atomicMin(&rc.kd_rec[cur[r]].child[side[r]], kEmpty);   // read the winner at L2
             const uint32_t dw = dcur[r] + 1;
             if (w == vidn[r]) {
-                KdRec rec;
-                rec.x = vx[r]; rec.y = vy[r]; rec.child[0] = kEmpty; rec.child[1] = kEmpty;
-                rc.kd_rec[w] = rec;
                 rc.kd_up[w] = cur[r];
                 rc.kd_depth[w] = dw;
                 if (onpath[r]) {
@@ -1196,14 +1273,17 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
                     rc.kd_gexit[w] = dw | kOnG;
                     atomicMax(&rc.cnt->g_len, dw + 1);
                     if (vx[r] == px && vy[r] == py) atomicMin(&rc.cnt->g_first_dup[dw & 1u], dw);
-                    else rc.g_nd[atomicAdd(&rc.cnt->g_nd_len, 1u)] = dw;
+                    else {
+                        const uint32_t sl = atomicAdd(&rc.cnt->g_nd_len, 1u);
+                        rc.g_nd[sl] = dw; rc.g_nd_x[sl] = vx[r]; rc.g_nd_y[sl] = vy[r];
+                    }
                 } else {
                     rc.kd_gexit[w] = gex[r];
                 }
                 todo[r] = false;
             } else {
-                // step below the winner (its coordinates were written by the connect kernel of this step)
-                const double wx = rc.nx[w], wy = rc.ny[w];
+                // step below the winner (k_kd_locate wrote its record)
+                const double wx = rc.kd_rec[w].x, wy = rc.kd_rec[w].y;
                 const bool vl = kd_left(vx[r], vy[r], wx, wy, dw);
                 if (onpath[r] && vl != kd_left(px, py, wx, wy, dw)) { onpath[r] = false; gex[r] = dw; }
                 cur[r] = w; dcur[r] = dw; side[r] = vl ? 0u : 1u;
@@ -1211,7 +1291,7 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
         }
         __syncthreads();
     }
-    if (rc.dbg && threadIdx.x == 0) { rc.dbg[b * 8 + 3] = wall_clock64(); rc.dbg[b * 8 + 4] = rounds; rc.dbg[b * 8 + 5] = glen0; rc.dbg[b * 8 + 6] = clock64() - rc.dbg[b * 8 + 6]; }
+    if (rc.dbg && threadIdx.x == 0) rc.dbg[b * 8 + 3] = wall_clock64() | ((unsigned long long)rounds << 56);
 }
 
 // PTO: edges to every neighbour with a valid transition, reachability phase 1 and 2 (pto.rs:95-124)

@@ -164,10 +164,11 @@ struct porrt_ctx {
     DevBuf<KdRec> d_kdrec;
     DevBuf<int> d_loccur;
     DevBuf<uint32_t> d_locdcur, d_locgex, d_locflags, d_kdsurv;
-    DevBuf<double> d_gx, d_gy;
+    DevBuf<double> d_gx, d_gy, d_gndx, d_gndy, d_kqx, d_kqy;
+    DevBuf<int> d_kqvid;
     DevBuf<float> d_fx, d_fy, d_f2, d_qax, d_qay, d_qthr;
     DevBuf<int> d_rep;
-    DevBuf<unsigned long long> d_dbg;
+    DevBuf<unsigned long long> d_dbg, d_partmask;
     DevBuf<uint32_t> d_kddepth, d_kdgexit;
     DevBuf<unsigned long long> d_reachA, d_reachB, d_finalmask, d_validmask;
     DevBuf<uint8_t> d_vid, d_finalflag, d_cls;
@@ -210,11 +211,12 @@ struct porrt_ctx {
                      uint32_t nxt2_i0, uint32_t nxt2_nb);
     void launch_bound(hipStream_t st, uint32_t b, uint32_t bsnap, uint32_t i0, uint32_t nb);
     hipStream_t stream3 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bound[2] = {nullptr, nullptr};
+    bool bound_pending[2] = {false, false};
     void join_side();
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev_step_done = nullptr, ev_kd_done = nullptr;
-    bool kd_pending = false;
+    hipEvent_t ev_step_done = nullptr, ev_kd[2] = {nullptr, nullptr}, ev_steered = nullptr, ev_located = nullptr;
+    bool kd_pend[2] = {false, false}, loc_pending = false;
     // cached hipGraph of the steps up to n_iter_min
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_key[6] = {0, 0, 0, 0, 0, 0};
@@ -231,7 +233,7 @@ int porrt_ctx::layout_buffers() {
                               &d_parent, &d_qnn, &d_qvid, &d_partid, &d_candid, &d_gid, &d_kdup, &d_kdrec, &d_gx, &d_gy, &d_fx, &d_fy,
                               &d_f2, &d_qax, &d_qay, &d_qthr, &d_rep, &d_dbg, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB,
                               &d_finalmask, &d_validmask, &d_vid, &d_finalflag, &d_cls, &d_nat, &d_sworld, &d_candcnt, &d_efrom,
-                              &d_eto, &d_etv, &d_heavy, &d_cnt, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags, &d_kdsurv};
+                              &d_eto, &d_etv, &d_heavy, &d_cnt, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags, &d_kdsurv, &d_partmask, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid};
         for (DevBufBase *b2 : list) all_bufs.push_back(b2);
     }
     bool grow_needed = false;
@@ -267,6 +269,8 @@ int porrt_ctx::layout_buffers() {
     d_efrom.p = (uint32_t *)d_efrom.vp; d_eto.p = (uint32_t *)d_eto.vp; d_etv.p = (uint32_t *)d_etv.vp; d_heavy.p = (uint32_t *)d_heavy.vp;
     d_loccur.p = (int *)d_loccur.vp; d_locdcur.p = (uint32_t *)d_locdcur.vp; d_locgex.p = (uint32_t *)d_locgex.vp;
     d_locflags.p = (uint32_t *)d_locflags.vp; d_kdsurv.p = (uint32_t *)d_kdsurv.vp;
+    d_partmask.p = (unsigned long long *)d_partmask.vp; d_gndx.p = (double *)d_gndx.vp; d_gndy.p = (double *)d_gndy.vp;
+    d_kqx.p = (double *)d_kqx.vp; d_kqy.p = (double *)d_kqy.vp; d_kqvid.p = (int *)d_kqvid.vp;
     d_cnt.p = (Counters *)d_cnt.vp; d_rc.p = (RunConst *)d_rc.vp; d_jump.p = (PcgJump *)d_jump.vp;
     // cached uploads are gone
     rad_uploaded = 0;
@@ -364,7 +368,7 @@ __global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y
     rc.cnt->g_first_dup[0] = 0xFFFFFFFFu;
     rc.cnt->g_first_dup[1] = 0xFFFFFFFFu;
     if (x == rc.gp_x && y == rc.gp_y) { rc.cnt->g_first_dup[0] = 0; rc.cnt->g_nd_len = 0; }
-    else { rc.g_nd[0] = 0; rc.cnt->g_nd_len = 1; }
+    else { rc.g_nd[0] = 0; rc.g_nd_x[0] = x; rc.g_nd_y[0] = y; rc.cnt->g_nd_len = 1; }
     KdRec rec;
     rec.x = x; rec.y = y; rec.child[0] = kEmpty; rec.child[1] = kEmpty;
     rc.kd_rec[0] = rec;
@@ -381,11 +385,11 @@ void porrt_ctx::launch_bound(hipStream_t st, uint32_t b, uint32_t bsnap, uint32_
     else hipLaunchKernelGGL(k_nn_bound<false>, kgrid, dim3(256), 0, st, (const RunConst *)d_rc.p, b, bsnap, i0, nb);
 }
 
-// One step.  Main stream: nn_scan, reduce+steer, radius_scan, connect (light and heavy side by side), commit.
-// Side stream (RRT*): kd insertion of this step's nodes and the NN bounds of the step after next, both needed
-// only later, so they run beside the next step's scans.  `nxt2_*` describe step b+2 (nb = 0: none).
+// One step.  Main stream: nn_scan, reduce+steer, radius_scan, connect, commit (which also bounds the next step's
+// samples).  Side stream (RRT*): order-exact kd insertion of this step's nodes, started as soon as their positions
+// are final and needed only by the NEXT step's connect -- two cross-stream edges per step.
 void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, size_t lds_bytes, bool prof, size_t &ev_used,
-                            uint32_t nxt2_i0, uint32_t nxt2_nb) {
+                            uint32_t nxt_i0, uint32_t nxt_nb) {
     // at most one node per iteration so far (+ root): bound on the tree size at the start of this step
     const uint32_t n_ub = i0 + 1;
     uint32_t NC = (n_ub + 63) / 64;
@@ -406,43 +410,35 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     ev();
     hipLaunchKernelGGL(k_nn_reduce_steer, dim3(red_blocks), dim3(256), 0, stream, rcp, b, i0, nb, NC, vwords);
     ev();
+    if (rrt) {
+        (void)hipEventRecord(ev_steered, stream);
+        (void)hipStreamWaitEvent(stream2, ev_steered, 0);
+        hipLaunchKernelGGL(k_kd_locate, dim3((nb + 255) / 256), dim3(256), 0, stream2, rcp, b, nb, vwords);
+        hipLaunchKernelGGL(k_kd_claim, dim3(1), dim3(1024), 0, stream2, rcp, b, vwords);
+        (void)hipEventRecord(ev_kd[b & 1u], stream2);
+        kd_pend[b & 1u] = true;
+    }
     hipLaunchKernelGGL(k_radius_scan, scan_grid, dim3(sblock), 0, stream, rcp, b, nb, NC);
     ev();
     const dim3 cgrid((nb + kConnectWaves - 1) / kConnectWaves), cblock(kConnectWaves * 64);
-    // the kd structure of the previous step's nodes (side stream) is needed from here on
-    if (rrt && kd_pending) { (void)hipStreamWaitEvent(stream, ev_kd_done, 0); kd_pending = false; }
     if (!rrt) {
         if (lds_bytes) hipLaunchKernelGGL(k_connect_pto<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
         else hipLaunchKernelGGL(k_connect_pto<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
         hipLaunchKernelGGL(k_commit_pto, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, nb, vwords);
         return;
     }
-    // heavy samples on a third stream beside the light ones
-    (void)hipEventRecord(ev_fork, stream);
-    (void)hipStreamWaitEvent(stream3, ev_fork, 0);
-    if (lds_bytes) {
-        hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
-        hipLaunchKernelGGL(k_connect_rrt_heavy<true>, dim3(nb), dim3(256), lds_bytes / kConnectWaves, stream3, rcp, b, nb, vwords);
-    } else {
-        hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
-        hipLaunchKernelGGL(k_connect_rrt_heavy<false>, dim3(nb), dim3(256), 0, stream3, rcp, b, nb, vwords);
-    }
-    (void)hipEventRecord(ev_join, stream3);
-    (void)hipStreamWaitEvent(stream, ev_join, 0);
-    hipLaunchKernelGGL(k_commit_rrt, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, nb, vwords);
-    // side stream: order-exact kd insertion of this step's nodes, then the bounds of step b+2
-    (void)hipEventRecord(ev_step_done, stream);
-    (void)hipStreamWaitEvent(stream2, ev_step_done, 0);
-    hipLaunchKernelGGL(k_kd_locate, dim3((nb + 255) / 256), dim3(256), 0, stream2, rcp, b);
-    hipLaunchKernelGGL(k_kd_claim, dim3(1), dim3(1024), 0, stream2, rcp, b);
-    if (nxt2_nb) launch_bound(stream2, b + 2, b + 1, nxt2_i0, nxt2_nb);
-    (void)hipEventRecord(ev_kd_done, stream2);
-    kd_pending = true;
+    // this step's connect orders tied parents by the kd structure of the tree before the step: the previous step's
+    // insertion must be complete (this step's own insertion may run concurrently)
+    if (kd_pend[(b + 1u) & 1u]) { (void)hipStreamWaitEvent(stream, ev_kd[(b + 1u) & 1u], 0); kd_pend[(b + 1u) & 1u] = false; }
+    if (lds_bytes) hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
+    else hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
+    hipLaunchKernelGGL(k_commit_rrt, dim3(std::max(wave_blocks, (nxt_nb + 255) / 256)), dim3(256), 0, stream, rcp, b, nb, vwords, nxt_i0, nxt_nb);
 }
 
 // join the side stream back into the main stream (end of a launch sequence / of a capture)
 void porrt_ctx::join_side() {
-    if (kd_pending) { (void)hipStreamWaitEvent(stream, ev_kd_done, 0); kd_pending = false; }
+    for (int p2 = 0; p2 < 2; ++p2)
+        if (kd_pend[p2]) { (void)hipStreamWaitEvent(stream, ev_kd[p2], 0); kd_pend[p2] = false; }
 }
 
 int porrt_ctx::grow(const double start[2], double max_step, double search_radius, uint64_t n_iter_min, uint64_t n_iter_max,
@@ -486,6 +482,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     const uint64_t Nmax = n_iter_max + 2;
     const uint64_t steps_max = n_iter_max / K + 4;
     const uint32_t vwords = (K + 63) / 64;
+    const uint32_t Kpad = vwords * 64;       // sample stride of the per-chunk arrays (multiple of the wave size)
     const uint32_t cand_cap = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(opt_cand_cap, 64), Nmax);
     {
         double t0 = now_s();
@@ -495,12 +492,13 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(d_nat.reserve(steps_max + 2)); HIPCHK(d_validmask.reserve((steps_max + 2) * vwords));
         HIPCHK(d_sx.reserve(n_iter_max + 1)); HIPCHK(d_sy.reserve(n_iter_max + 1)); HIPCHK(d_sworld.reserve(n_iter_max + 1));
         HIPCHK(d_qx.reserve(K)); HIPCHK(d_qy.reserve(K)); HIPCHK(d_qnn.reserve(K)); HIPCHK(d_qvid.reserve(K));
-        HIPCHK(d_partD.reserve((size_t)K * kMaxChunks)); HIPCHK(d_partid.reserve((size_t)K * kMaxChunks));
+        HIPCHK(d_partD.reserve((size_t)Kpad * kMaxChunks)); HIPCHK(d_partid.reserve((size_t)Kpad * kMaxChunks)); HIPCHK(d_partmask.reserve((size_t)(Kpad / 64) * kMaxChunks));
         HIPCHK(d_candcnt.reserve(K)); HIPCHK(d_heavy.reserve(K));
-        HIPCHK(d_loccur.reserve(K)); HIPCHK(d_locdcur.reserve(K)); HIPCHK(d_locgex.reserve(K)); HIPCHK(d_locflags.reserve(K)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_candid.reserve((size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
+        HIPCHK(d_loccur.reserve(K)); HIPCHK(d_locdcur.reserve(K)); HIPCHK(d_locgex.reserve(K)); HIPCHK(d_locflags.reserve(K)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_gndx.reserve(Nmax)); HIPCHK(d_gndy.reserve(Nmax));
+        HIPCHK(d_kqx.reserve(2 * (size_t)Kpad)); HIPCHK(d_kqy.reserve(2 * (size_t)Kpad)); HIPCHK(d_kqvid.reserve(2 * (size_t)Kpad)); HIPCHK(d_candid.reserve((size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
         HIPCHK(d_gid.reserve(Nmax));
         HIPCHK(d_fx.reserve(Nmax + 64)); HIPCHK(d_fy.reserve(Nmax + 64)); HIPCHK(d_f2.reserve(Nmax + 64));
-        HIPCHK(d_qax.reserve(2 * (size_t)K)); HIPCHK(d_qay.reserve(2 * (size_t)K)); HIPCHK(d_qthr.reserve(2 * (size_t)K)); HIPCHK(d_rep.reserve(kRepTotal));
+        HIPCHK(d_qax.reserve(2 * (size_t)Kpad)); HIPCHK(d_qay.reserve(2 * (size_t)Kpad)); HIPCHK(d_qthr.reserve(2 * (size_t)Kpad)); HIPCHK(d_rep.reserve(kRepTotal));
         HIPCHK(d_kdrec.reserve(Nmax)); HIPCHK(d_gx.reserve(Nmax + 16)); HIPCHK(d_gy.reserve(Nmax + 16)); HIPCHK(d_kdup.reserve(Nmax)); HIPCHK(d_kddepth.reserve(Nmax)); HIPCHK(d_kdgexit.reserve(Nmax));
         HIPCHK(d_radT2.reserve(Nmax + 8));
         HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_jump.reserve(1));
@@ -532,8 +530,8 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.inj_xy = (has_inj && !host_samples) ? d_inj.p : nullptr;
     c.inj_base = inj_pos; c.inj_n = inj_xy.size() / 2;
     c.q_x = d_qx.p; c.q_y = d_qy.p; c.q_nn = d_qnn.p; c.q_vid = d_qvid.p;
-    c.part_D = d_partD.p; c.part_id = d_partid.p;
-    c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p;
+    c.part_D = d_partD.p; c.part_id = d_partid.p; c.part_mask = d_partmask.p;
+    c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p;
     c.heavy_list = d_heavy.p; c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
     c.rad_T2 = d_radT2.p;
     c.e_from = d_efrom.p; c.e_to = d_eto.p; c.e_tv = d_etv.p; c.e_cap = (uint32_t)d_efrom.n;
@@ -566,7 +564,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     else if (goal_kind == 2) { c.gp_x = c.zone_x; c.gp_y = c.zone_y; }
     c.s_low0 = s_low[0]; c.s_low1 = s_low[1]; c.s_up0 = s_up[0]; c.s_up1 = s_up[1];
     c.max_step = max_step; c.mode = mode;
-    c.part_stride = K;
+    c.part_stride = Kpad;
 
     // ---- root (rrt.rs:105-106 / pto.rs:61-64)
     uint64_t root_reach = 0;
@@ -701,7 +699,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         if (r) return r;
     }
     HIPCHK(hipEventRecord(ev_first, stream));
-    kd_pending = false;
+    kd_pend[0] = kd_pend[1] = false;
     if (opt_graph && !prof && n_iter_min > 0) {
         // all steps up to n_iter_min as one hipGraph (two branches: main pipeline + kd insertion); the graph
         // only depends on the launch geometry, so it is instantiated once and replayed by later grows
@@ -713,13 +711,10 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
             HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
             uint64_t ci = 0;
             uint32_t cb = 0;
-            if (mode == PORRT_MODE_RRT) {       // the first two steps' bounds cannot come from the side stream
-                launch_bound(stream, 0, 0, 0, (uint32_t)std::min<uint64_t>(K, n_iter_min));
-                if (n_iter_min > K) launch_bound(stream, 1, 0, K, (uint32_t)std::min<uint64_t>(K, n_iter_min - K));
-            }
+            if (mode == PORRT_MODE_RRT) launch_bound(stream, 0, 0, 0, (uint32_t)std::min<uint64_t>(K, n_iter_min));
             while (ci < n_iter_min) {
                 uint32_t nb = (uint32_t)std::min<uint64_t>(K, n_iter_min - ci);
-                uint64_t i2 = ci + nb + std::min<uint64_t>(K, n_iter_min - ci - nb);      // start of step cb+2
+                uint64_t i2 = ci + nb;                                                       // start of step cb+1
                 uint32_t nb2 = i2 < n_iter_min ? (uint32_t)std::min<uint64_t>(K, n_iter_min - i2) : 0;
                 launch_step(cb, (uint32_t)ci, nb, vwords, lds_bytes, false, ev_used, (uint32_t)i2, nb2);
                 ci += nb;
@@ -735,13 +730,10 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(hipGraphLaunch(graph_exec, stream));
         while (i < n_iter_min) { i += std::min<uint64_t>(K, n_iter_min - i); ++b; }
     } else {
-        if (mode == PORRT_MODE_RRT && n_iter_min > 0) {
-            launch_bound(stream, 0, 0, 0, (uint32_t)std::min<uint64_t>(K, n_iter_min));
-            if (n_iter_min > K) launch_bound(stream, 1, 0, K, (uint32_t)std::min<uint64_t>(K, n_iter_min - K));
-        }
+        if (mode == PORRT_MODE_RRT && n_iter_min > 0) launch_bound(stream, 0, 0, 0, (uint32_t)std::min<uint64_t>(K, n_iter_min));
         while (i < n_iter_min) {
             uint32_t nb = (uint32_t)std::min<uint64_t>(K, n_iter_min - i);
-            uint64_t i2 = i + nb + std::min<uint64_t>(K, n_iter_min - i - nb);
+            uint64_t i2 = i + nb;
             uint32_t nb2 = i2 < n_iter_min ? (uint32_t)std::min<uint64_t>(K, n_iter_min - i2) : 0;
             launch_step(b, (uint32_t)i, nb, vwords, lds_bytes, prof, ev_used, (uint32_t)i2, nb2);
             i += nb;
@@ -804,8 +796,9 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
             std::vector<unsigned long long> d((size_t)b * 8);
             (void)hipMemcpy(d.data(), d_dbg.p, d.size() * 8, hipMemcpyDeviceToHost);
             for (uint32_t s2 = 0; s2 < b; s2 += std::max(1u, b / 12))
-                fprintf(stderr, "[porrt] kd_claim step %3u: rounds(%2llu) %6.1f us  glen %llu  clock %.0f MHz\n", s2, d[s2 * 8 + 4],
-                        (d[s2 * 8 + 3] - d[s2 * 8 + 2]) * 0.01, d[s2 * 8 + 5], (double)d[s2 * 8 + 6] / ((d[s2 * 8 + 3] - d[s2 * 8 + 0]) * 0.01));
+                fprintf(stderr, "[porrt] step %3u locate: stage %5.1f  nd %5.1f  descent+store %5.1f us (depth %llu) | claim: %5.1f us rounds %llu\n", s2,
+                        (d[s2 * 8 + 7] - d[s2 * 8 + 1]) * 0.01, (d[s2 * 8 + 5] - d[s2 * 8 + 7]) * 0.01, (d[s2 * 8 + 4] - d[s2 * 8 + 5]) * 0.01,
+                        d[s2 * 8 + 6], ((d[s2 * 8 + 3] & 0xFFFFFFFFFFFFFFull) - d[s2 * 8 + 0]) * 0.01, d[s2 * 8 + 3] >> 56);
         }
     }
     n_iter = i;
@@ -910,10 +903,15 @@ porrt_ctx *porrt_create(int device) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_step_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_kd_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_kd[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_kd[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_steered, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_located, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_bound[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_bound[1], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
     c->crng.seed_from_u64(0);   // sample_space.rs:18
     c->drng.seed_from_u64(0);   // sample_space.rs:47
     c->validities[0] = 1;       // map_io.rs:108-111 init_without_zones
@@ -931,10 +929,13 @@ void porrt_destroy(porrt_ctx *c) {
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->ev_step_done) (void)hipEventDestroy(c->ev_step_done);
-    if (c->ev_kd_done) (void)hipEventDestroy(c->ev_kd_done);
+    for (int p2 = 0; p2 < 2; ++p2) if (c->ev_kd[p2]) (void)hipEventDestroy(c->ev_kd[p2]);
+    if (c->ev_steered) (void)hipEventDestroy(c->ev_steered);
+    if (c->ev_located) (void)hipEventDestroy(c->ev_located);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (int p2 = 0; p2 < 2; ++p2) if (c->ev_bound[p2]) (void)hipEventDestroy(c->ev_bound[p2]);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     (void)hipStreamDestroy(c->stream);
     delete c;

@@ -113,6 +113,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&rc.cand_id, (size_t)K * 4096 * 4)); CK(hipMalloc(&rc.cnt, sizeof(Counters))); CK(hipMalloc((void **)&rc.rad_T2, (N + 8) * 8));
     CK(hipMalloc(&dfx, (N + 64) * 4)); CK(hipMalloc(&dfy, (N + 64) * 4)); CK(hipMalloc(&dfn, (N + 64) * 4)); CK(hipMalloc(&dof, (size_t)K * 512 * 4));
     rc.cand_cap = 4096; rc.part_stride = K;
+    CK(hipMalloc(&rc.part_mask, (size_t)(K / 64) * 512 * 8));
     CK(hipMemcpy(rc.nx, hx.data(), (N + 64) * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(rc.ny, hy.data(), (N + 64) * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(rc.sx, qx.data(), K * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(rc.sy, qy.data(), K * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(rc.q_x, qx.data(), K * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(rc.q_y, qy.data(), K * 8, hipMemcpyHostToDevice));
