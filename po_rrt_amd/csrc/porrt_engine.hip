@@ -410,14 +410,6 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     ev();
     hipLaunchKernelGGL(k_nn_reduce_steer, dim3(red_blocks), dim3(256), 0, stream, rcp, b, i0, nb, NC, vwords);
     ev();
-    if (rrt) {
-        (void)hipEventRecord(ev_steered, stream);
-        (void)hipStreamWaitEvent(stream2, ev_steered, 0);
-        hipLaunchKernelGGL(k_kd_locate, dim3((nb + 255) / 256), dim3(256), 0, stream2, rcp, b, nb, vwords);
-        hipLaunchKernelGGL(k_kd_claim, dim3(1), dim3(1024), 0, stream2, rcp, b, vwords);
-        (void)hipEventRecord(ev_kd[b & 1u], stream2);
-        kd_pend[b & 1u] = true;
-    }
     hipLaunchKernelGGL(k_radius_scan, scan_grid, dim3(sblock), 0, stream, rcp, b, nb, NC);
     ev();
     const dim3 cgrid((nb + kConnectWaves - 1) / kConnectWaves), cblock(kConnectWaves * 64);
@@ -429,6 +421,14 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     }
     // this step's connect orders tied parents by the kd structure of the tree before the step: the previous step's
     // insertion must be complete (this step's own insertion may run concurrently)
+    // One sync point per step: fork this step's kd insertion (positions are final since reduce_steer; it runs beside
+    // connect, commit and the next step's scans) and join the previous step's.
+    (void)hipEventRecord(ev_steered, stream);
+    (void)hipStreamWaitEvent(stream2, ev_steered, 0);
+    hipLaunchKernelGGL(k_kd_locate, dim3((nb + 255) / 256), dim3(256), 0, stream2, rcp, b, nb, vwords);
+    hipLaunchKernelGGL(k_kd_claim, dim3(1), dim3(1024), 0, stream2, rcp, b, vwords);
+    (void)hipEventRecord(ev_kd[b & 1u], stream2);
+    kd_pend[b & 1u] = true;
     if (kd_pend[(b + 1u) & 1u]) { (void)hipStreamWaitEvent(stream, ev_kd[(b + 1u) & 1u], 0); kd_pend[(b + 1u) & 1u] = false; }
     if (lds_bytes) hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
     else hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
