@@ -503,7 +503,7 @@ __device__ __forceinline__ cdouble_p as_const(const double *p) { return (cdouble
 
 __device__ __forceinline__ void chunk_range(uint32_t N, uint32_t NC, uint32_t c, uint32_t &j0, uint32_t &j1) {
     uint32_t C = (N + NC - 1) / NC;
-    C = (C + 7u) & ~7u;                 // chunks start on 64-byte boundaries of the x / y arrays
+    C = (C + 15u) & ~15u;               // whole 16-node trips; chunks start on 64-byte boundaries of the arrays
     j0 = c * C;
     uint32_t e = j0 + C;
     j1 = e < N ? e : N;
@@ -540,25 +540,25 @@ __device__ __forceinline__ void stage_tile(const RunConst &rc, NodeTile &t, uint
 template <class Visit>
 __device__ __forceinline__ void scan_tile(const NodeTile &t, uint32_t n, float ax, float ay, const float &thr, Visit visit) {
     uint32_t i = 0;
-    for (; i + kUnroll <= n; i += kUnroll) {
-        const float4 x0 = *(const float4 *)&t.fx[i], x1 = *(const float4 *)&t.fx[i + 4];
-        const float4 y0 = *(const float4 *)&t.fy[i], y1 = *(const float4 *)&t.fy[i + 4];
-        const float4 z0 = *(const float4 *)&t.f2[i], z1 = *(const float4 *)&t.f2[i + 4];
-        float key[kUnroll];
-        key[0] = __builtin_fmaf(x0.x, ax, __builtin_fmaf(y0.x, ay, z0.x));
-        key[1] = __builtin_fmaf(x0.y, ax, __builtin_fmaf(y0.y, ay, z0.y));
-        key[2] = __builtin_fmaf(x0.z, ax, __builtin_fmaf(y0.z, ay, z0.z));
-        key[3] = __builtin_fmaf(x0.w, ax, __builtin_fmaf(y0.w, ay, z0.w));
-        key[4] = __builtin_fmaf(x1.x, ax, __builtin_fmaf(y1.x, ay, z1.x));
-        key[5] = __builtin_fmaf(x1.y, ax, __builtin_fmaf(y1.y, ay, z1.y));
-        key[6] = __builtin_fmaf(x1.z, ax, __builtin_fmaf(y1.z, ay, z1.z));
-        key[7] = __builtin_fmaf(x1.w, ax, __builtin_fmaf(y1.w, ay, z1.w));
-        bool any = false;
+    constexpr int U = 16;                // nodes per trip: 12 ds_read_b128, 32 FMA, a min tree, ONE compare + branch
+    for (; i + U <= n; i += U) {
+        float key[U];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) any |= key[u] <= thr;
-        if (any) {                       // rare: one branch per eight nodes
+        for (int g = 0; g < U / 4; ++g) {
+            const float4 x = *(const float4 *)&t.fx[i + 4 * g];
+            const float4 y = *(const float4 *)&t.fy[i + 4 * g];
+            const float4 z = *(const float4 *)&t.f2[i + 4 * g];
+            key[4 * g + 0] = __builtin_fmaf(x.x, ax, __builtin_fmaf(y.x, ay, z.x));
+            key[4 * g + 1] = __builtin_fmaf(x.y, ax, __builtin_fmaf(y.y, ay, z.y));
+            key[4 * g + 2] = __builtin_fmaf(x.z, ax, __builtin_fmaf(y.z, ay, z.z));
+            key[4 * g + 3] = __builtin_fmaf(x.w, ax, __builtin_fmaf(y.w, ay, z.w));
+        }
+        float m = key[0];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
+        for (int u = 1; u < U; ++u) m = __builtin_fminf(m, key[u]);      // v_min3_f32 tree
+        if (m <= thr) {                  // rare: one branch per sixteen nodes
+#pragma unroll
+            for (int u = 0; u < U; ++u)
                 if (key[u] <= thr) visit(i + u, key[u]);
         }
     }

@@ -157,7 +157,21 @@ int main(int argc, char **argv) {
         double us = ms * 1e3 / reps, pairs = (double)N * K;
         printf("%-22s N=%u NC=%3u  %8.2f us  %7.2f Gpair/s  (6 flop/pair: %6.2f TF)\n", name, N, NC, us, pairs / us * 1e-3, 6 * pairs / us * 1e-6);
     };
-    for (uint32_t NC : {128u, 256u, 512u}) {
+    // radius scan with NO neighbours at all (threshold 0): cost of staging + filter loop alone
+    {
+        std::vector<double> z(N + 8, 0.0);
+        double *dz;
+        CK(hipMalloc(&dz, (N + 8) * 8));
+        CK(hipMemcpy(dz, z.data(), (N + 8) * 8, hipMemcpyHostToDevice));
+        RunConst rc0 = rc;
+        rc0.rad_T2 = dz;
+        RunConst *drc0;
+        CK(hipMalloc(&drc0, sizeof rc0));
+        CK(hipMemcpy(drc0, &rc0, sizeof rc0, hipMemcpyHostToDevice));
+        dim3 sgrid(K / 1024, 256);
+        timeit("radius_scan(no hits)", 256, [&] { hipLaunchKernelGGL(k_radius_scan, sgrid, dim3(1024), 0, 0, (const RunConst *)drc0, 0u, K, 256u); });
+    }
+    for (uint32_t NC : {256u}) {
         dim3 grid(K / 256, NC);
         dim3 sgrid(K / 1024, NC);
         timeit("nn_scan", NC, [&] { hipLaunchKernelGGL(k_nn_scan<false>, sgrid, dim3(1024), 0, 0, (const RunConst *)drc, 0u, 0u, K, NC); });
