@@ -908,6 +908,8 @@ struct Team {
 };
 
 // RRT*: validated neighbours, best parent, new node, rewire phase 1 for sample k by a team of W waves.
+// A lane keeps its first candidate in registers through all three passes (that is every candidate when the
+// sample has at most 64 * W neighbours, the common case); further candidates go through the scratch lists.
 template <int W, class Grid>
 __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const Grid &grid, uint32_t b, uint32_t vwords, uint32_t k,
                                    uint32_t cnt, uint32_t &err) {
@@ -915,8 +917,9 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     const uint32_t N = rc.n_at[b];
     const uint32_t id = N + rank_before(rc, b, vwords, k);
     const double px = rc.q_x[k], py = rc.q_y[k];
-    int *cid = rc.cand_id + (size_t)k * rc.cand_cap;
-    double *cval = rc.cand_val + (size_t)k * rc.cand_cap;
+    auto cid = as_global(rc.cand_id) + (size_t)k * rc.cand_cap;
+    auto cval = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
+    auto gnx = as_global(rc.nx), gny = as_global(rc.ny), gdA = as_global(rc.distA);
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
     GlobalGrid ggrid;
     ggrid.p = rc.cls; ggrid.W = rc.W;
@@ -925,16 +928,19 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     double bt = INF;
     int bj = 0x7FFFFFFF;
     uint32_t nvalid = 0;
+    int j0 = -1;                // first candidate of this lane, register resident
+    double cost0 = -1.0, tot0 = INF, dA0 = 0.0;
     for (uint32_t a = tl; a < cnt; a += TS) {
         const int j = cid[a];
-        const double ax = rc.nx[j], ay = rc.ny[j];
+        const double ax = gnx[j], ay = gny[j], dA = gdA[j];
         const double cost = sqrt(dist2(ax, ay, px, py));
         bool ok = true;
         if (rc.has_grid) ok = traversed_class(rc, grid, ax, ay, px, py, &err) == CLS_FREE;
-        cval[a] = ok ? cost : -1.0;
+        const double total = dA + cost;
+        if (a == tl) { j0 = j; cost0 = ok ? cost : -1.0; tot0 = total; dA0 = dA; }
+        else cval[a] = ok ? cost : -1.0;
         if (ok) {
             ++nvalid;
-            const double total = rc.distA[j] + cost;
             if (total < bt || (total == bt && j < bj)) { bt = total; bj = j; }
         }
     }
@@ -945,22 +951,24 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     if (nvalid == 0) {
         // rrt.rs:132-134: fall back to the nearest node, not collision-checked
         best = rc.q_nn[k];
-        best_cost = sqrt(dist2(rc.nx[best], rc.ny[best], px, py));
-        dnew = rc.distA[best] + best_cost;
+        best_cost = sqrt(dist2(gnx[best], gny[best], px, py));
+        dnew = gdA[best] + best_cost;
     } else {
         // equal totals: the reference keeps the first in kd-tree pre-order (rrt.rs:143-145)
         uint32_t n_tie = 0;
         int on_min = kEmpty;        // tied nodes ON the goal path: an ancestor chain, the lowest id is first
         int off_best = kEmpty;      // pre-order-first tied node off the goal path
-        for (uint32_t a = tl; a < cnt; a += TS) {
+        auto tie_visit = [&](int j) {
+            ++n_tie;
+            if (rc.kd_gexit[j] & kOnG) on_min = j < on_min ? j : on_min;
+            else if (off_best == kEmpty || kd_preorder_less(rc, j, off_best)) off_best = j;
+        };
+        if (j0 >= 0 && cost0 >= 0.0 && tot0 == bt) tie_visit(j0);
+        for (uint32_t a = tl + TS; a < cnt; a += TS) {
             const double cost = cval[a];
             if (cost >= 0.0) {
                 const int j = cid[a];
-                if (rc.distA[j] + cost == bt) {
-                    ++n_tie;
-                    if (rc.kd_gexit[j] & kOnG) on_min = j < on_min ? j : on_min;
-                    else if (off_best == kEmpty || kd_preorder_less(rc, j, off_best)) off_best = j;
-                }
+                if (gdA[j] + cost == bt) tie_visit(j);
             }
         }
         n_tie = tm.sum(n_tie);
@@ -972,8 +980,8 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
             else if (on_min == kEmpty) best = off_best;
             else best = kd_preorder_less(rc, on_min, off_best) ? on_min : off_best;
         }
-        best_cost = sqrt(dist2(rc.nx[best], rc.ny[best], px, py));
-        dnew = rc.distA[best] + best_cost;
+        best_cost = sqrt(dist2(gnx[best], gny[best], px, py));
+        dnew = gdA[best] + best_cost;
     }
 
     // new node (rrt.rs:148, 30-37) and goal test (rrt.rs:165-167)
@@ -992,14 +1000,27 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
         if (fin) atomicAdd(&rc.cnt->n_final, 1u);
     }
     // rewire phase 1 (rrt.rs:152-161): dist_root candidates, min wins
-    for (uint32_t a = tl; a < cnt; a += TS) {
+    auto gdB = as_global(reinterpret_cast<unsigned long long *>(rc.distB));
+    if (j0 >= 0) {
+        int keep = -1;
+        if (nvalid != 0 && cost0 >= 0.0 && j0 != best) {
+            const double via = dnew + cost0;
+            if (via < dA0) {
+                g_atomic_min(gdB + j0, f64_bits(via));
+                cval[tl] = via;
+                keep = j0;
+            }
+        }
+        cid[tl] = keep;
+    }
+    for (uint32_t a = tl + TS; a < cnt; a += TS) {
         const double cost = cval[a];
         const int j = cid[a];
         int keep = -1;
         if (nvalid != 0 && cost >= 0.0 && j != best) {
             const double via = dnew + cost;
-            if (via < rc.distA[j]) {
-                atomicMin(reinterpret_cast<unsigned long long *>(&rc.distB[j]), f64_bits(via));
+            if (via < gdA[j]) {
+                g_atomic_min(gdB + j, f64_bits(via));
                 cval[a] = via;
                 keep = j;
             }
@@ -1008,7 +1029,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     }
 }
 
-constexpr uint32_t kHeavyCand = 128;     // samples with more neighbours than this go to the 4-wave team kernel
+constexpr uint32_t kHeavyCand = 256;     // samples with more neighbours than this are served by the 4-wave team
 
 // One workgroup = kConnectWaves samples.  Phase 1: every wave serves its own sample if it is light.  Phase 2:
 // samples with more than kHeavyCand neighbours (the dense start of a tree, duplicates of the goal point) are
