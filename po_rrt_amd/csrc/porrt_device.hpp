@@ -620,14 +620,15 @@ __global__ __launch_bounds__(kScanBlock) void k_nn_scan(const RunConst *__restri
     }
 }
 
-// argmin over node chunks, steer (L1 step length), point validity.  A workgroup of 4 waves serves 64
-// samples: wave r reduces chunks r, r+4, ... for all 64 (coalesced reads of the [chunk][sample] partials),
-// the four candidates meet in LDS and a quad of lanes finishes with a shuffle argmin.
-__global__ __launch_bounds__(256) void k_nn_reduce_steer(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb,
-                                                          uint32_t NC, uint32_t vwords) {
+// argmin over node chunks, steer (L1 step length), point validity.  A workgroup of 16 waves serves 64
+// samples: wave r reduces chunks r, r+16, ... for all 64 (coalesced reads of the [chunk][sample] partials, all
+// sixteen loads of a lane in flight at once), the sixteen candidates meet in LDS and wave 0 finishes.
+constexpr uint32_t kRedWaves = 16;
+__global__ __launch_bounds__(kRedWaves * 64) void k_nn_reduce_steer(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb,
+                                                                    uint32_t NC, uint32_t vwords) {
     const RunConst &rc = *rcp;
-    __shared__ double s_D[4][64];
-    __shared__ int s_id[4][64];
+    __shared__ double s_D[kRedWaves][64];
+    __shared__ int s_id[kRedWaves][64];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t k = blockIdx.x * 64u + lane;
     double D = __longlong_as_double(0x7FF0000000000000ll);
@@ -635,12 +636,12 @@ __global__ __launch_bounds__(256) void k_nn_reduce_steer(const RunConst *__restr
     if (k < nb) {
         auto pD = as_global(rc.part_D) + k;
         auto pI = as_global(rc.part_id) + k;
-        for (uint32_t c0 = wv; c0 < NC; c0 += 64) {      // 16 independent coalesced loads in flight per lane
+        for (uint32_t c0 = wv; c0 < NC; c0 += 16u * kRedWaves) {
             double d[16];
             int i[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const uint32_t c = c0 + 4u * u;
+                const uint32_t c = c0 + kRedWaves * u;
                 const bool ok = c < NC;
                 i[u] = ok ? pI[(size_t)c * rc.part_stride] : -1;
                 d[u] = ok ? pD[(size_t)c * rc.part_stride] : 0.0;
@@ -654,9 +655,8 @@ __global__ __launch_bounds__(256) void k_nn_reduce_steer(const RunConst *__restr
     s_id[wv][lane] = id;
     __syncthreads();
     if (wv != 0 || k >= nb) return;
-    // wavefront shuffle argmin over the four slices (lanes q*16.. hold slice q of 16 samples each pass)
 #pragma unroll
-    for (int r = 1; r < 4; ++r) {
+    for (uint32_t r = 1; r < kRedWaves; ++r) {
         const double d = s_D[r][lane];
         const int i = s_id[r][lane];
         if (d < D || (d == D && i < id)) { D = d; id = i; }

@@ -408,7 +408,7 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_nn_scan<true>, scan_grid, dim3(sblock), 0, stream, rcp, b, i0, nb, NC);
     else hipLaunchKernelGGL(k_nn_scan<false>, scan_grid, dim3(sblock), 0, stream, rcp, b, i0, nb, NC);
     ev();
-    hipLaunchKernelGGL(k_nn_reduce_steer, dim3(red_blocks), dim3(256), 0, stream, rcp, b, i0, nb, NC, vwords);
+    hipLaunchKernelGGL(k_nn_reduce_steer, dim3(red_blocks), dim3(kRedWaves * 64), 0, stream, rcp, b, i0, nb, NC, vwords);
     ev();
     hipLaunchKernelGGL(k_radius_scan, scan_grid, dim3(sblock), 0, stream, rcp, b, nb, NC);
     ev();
