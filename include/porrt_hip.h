@@ -129,11 +129,12 @@ typedef struct {
     double   total_s;         /* wall time of porrt_grow */
     double   setup_s;         /* part of total_s: host tables + uploads (radius table, worlds) */
     double   device_s;        /* HIP-event time from first to last kernel of the growth loop */
-    double   scan_s;          /* HIP-event time summed over the nn_scan + radius_scan kernels
-                                 (only filled when profiling is enabled) */
+    double   scan_s;          /* HIP-event time summed over the near-search kernel (NN + steer + radius search;
+                                 only filled when profiling is enabled) */
     uint64_t scan_launches;
-    double   scan_pairs;      /* sample x node pairs evaluated by those kernels */
-    double   scan_bytes;      /* algorithmic bytes of those kernels */
+    double   scan_pairs;      /* sample x node pairs those searches answer (2 * K * N_b per step) */
+    double   scan_bytes;      /* algorithmic bytes of those searches */
+    double   connect_s;       /* HIP-event time summed over the connect kernel (profiling only) */
 } porrt_metrics;
 int porrt_get_metrics(const porrt_ctx *ctx, porrt_metrics *out);
 /* options: "profile" (0/1 per-kernel HIP events), "cand_cap" (initial neighbour-list

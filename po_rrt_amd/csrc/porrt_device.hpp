@@ -1,33 +1,29 @@
 // porrt_device.hpp -- gfx950 kernels of the batched RRT*/PTO expansion engine.
 //
-// One grow step ("batch") of K samples runs five kernels on one stream:
-//   k_nn_scan        K x N_b brute-force nearest-neighbour scan   (replaces KdTree::nearest_neighbor[_filtered],
-//                                                                  src/nearest_neighbor.rs:48-92)
-//   k_nn_reduce_steer  argmin over node chunks (wave shfl), steer, point validity
-//                                                                 (src/common.rs:215-225, map_shelves_io.rs:158-170,
-//                                                                  map_io.rs:165-181)
-//   k_radius_scan    K x N_b radius scan, neighbour lists          (replaces KdTree::nearest_neighbors,
-//                                                                  src/nearest_neighbor.rs:94-126)
+// One grow step ("batch") of K samples runs three kernels on the main stream:
+//   k_near           one wave per sample: nearest neighbour, steer, point validity, radius search -- exact f64
+//                    brute force over the region pages the query disc touches (replaces
+//                    KdTree::nearest_neighbor[_filtered] / nearest_neighbors, src/nearest_neighbor.rs:48-126;
+//                    src/common.rs:215-225, map_shelves_io.rs:158-170, map_io.rs:165-181)
 //   k_connect_rrt / k_connect_pto   Bresenham raycasts on the LDS-resident grid, best parent (wave argmin),
 //                    new node, rewire phase 1 / reachability        (src/rrt.rs:123-161, src/pto.rs:95-124,
 //                                                                  map_shelves_io.rs:187-203, map_io.rs:216-241,
 //                                                                  pto_reachability.rs:42-52)
-//   k_commit_rrt / k_commit_pto     rewire phase 2 (deterministic winner) / reach sync, step counter
-// plus k_gen_samples (Pcg64 + gen_range on the device, sample_space.rs:30-36, rrt.rs:176-181) once per grow
-// and k_goal_path (kd pre-order bookkeeping for equal-cost parents) once per RRT* step.
+//                    + one extra workgroup that files the step's new nodes into the region pages
+//   k_commit_rrt / k_commit_pto     rewire phase 2 (deterministic winner) / reach sync, step counter, NN bounds
+//                    of the next step's samples
+// plus k_gen_samples (Pcg64 + gen_range on the device, sample_space.rs:30-36, rrt.rs:176-181) once per grow,
+// and on a side stream (RRT*) k_kd_locate / k_kd_claim: the STRUCTURE of the reference's kd-tree, kept only to
+// resolve equal-cost parents in its pre-order.
 //
-// Scan layout: one LANE per sample, the node stream is wave-uniform (scalar loads broadcast x,y to all 64
-// lanes), so the hot loop is pure FP64 VALU: 2 sub, 2 mul, 1 add, 1 compare per (sample, node) pair -- no
-// cross-lane traffic, no LDS.  Arithmetic is IEEE f64 without contraction (-ffp-contract=off): it has to
-// reproduce the reference's rounding exactly (integer parents bit-exact, coordinates bit-exact).
+// Arithmetic is IEEE f64 without contraction (-ffp-contract=off): it has to reproduce the reference's rounding
+// exactly (integer parents bit-exact, coordinates bit-exact).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace porrt {
 
-constexpr int kScanBlock = 1024;     // lanes = samples per scan workgroup: one workgroup streams a node chunk past ALL samples
-constexpr int kMaxChunks = 256;      // node chunks per scan (grid.y)
 constexpr int kConnectWaves = 4;     // samples per connect workgroup (one wave each)
 constexpr uint32_t kTileRMax = 31;             // LDS tile half-width limit (pixels); above it rays read global
 constexpr int kEmpty = 0x7FFFFFFF;       // empty kd child slot (atomicMin claims it)
@@ -38,7 +34,8 @@ enum : uint32_t {
     ERR_CAND_OVERFLOW = 2u, // neighbour list capacity
     ERR_RNG_RETRY = 4u,     // gen_range would have redrawn (host regenerates the stream exactly)
     ERR_EDGE_OVERFLOW = 8u,
-    ERR_GPATH_OVERFLOW = 16u
+    ERR_GPATH_OVERFLOW = 16u,
+    ERR_PAGE_OVERFLOW = 32u
 };
 
 // pixel classes of the pre-classified raster (host builds it in set_grid/set_zones)
@@ -59,17 +56,21 @@ struct Counters {
     uint32_t n_heavy;
     uint32_t g_nd_len;          // non-duplicate levels of G
     uint32_t g_first_dup[2];    // first level of even / odd depth held by a duplicate of the goal point
-    uint32_t pad;
+    uint32_t n_pages;           // pool pages handed out (region pages)
 };
 
 struct RunConst {
     // node SoA
     double *nx, *ny;
-    float *fx, *fy, *f2;        // f32 filter view of the nodes: fl(x), fl(y), fl(x^2+y^2) (see scan_chunk)
     int *rep;                   // cell -> some node in that cell (3-level pyramid), only ever used for bounds
     double bx0, by0, binv_w, binv_h;   // box the pyramid covers
-    double filt_E;              // absolute error bound of the f32 key
-    float *q_ax, *q_ay, *q_thr; // per-sample filter operands: -2qx, -2qy, threshold on the key
+    double *q_bound;            // per sample (two step parities): upper bound of its squared NN distance
+    // region pages (see scan_disc)
+    uint32_t *rg_cnt;           // nodes per region
+    uint32_t *rg_dir;           // [region][j]: j-th page of the region, j >= 1
+    double *pg_xy;              // [page][slot] (x, y)
+    int *pg_id;                 // [page][slot] node id
+    uint32_t rg_maxp, pg_cap;   // directory stride, pages in the pool
     double *distA, *distB;      // dist_root: A = snapshot read by the step, B = rewire accumulator
     int *parent;
     unsigned long long *reachA, *reachB;
@@ -90,9 +91,6 @@ struct RunConst {
     int *kq_vid;
     int *q_nn;
     int *q_vid;
-    double *part_D;
-    int *part_id;
-    unsigned long long *part_mask;   // [chunk][sample/64]: which partial slots hold a candidate
     unsigned long long *dbg;    // optional per-step phase stamps (diagnostic builds of the host only)
     uint32_t *heavy_list;       // samples routed to the team connect kernel this step
     uint32_t *cand_cnt;
@@ -138,7 +136,7 @@ struct RunConst {
     double max_step;
     int mode;
     uint32_t tile_R;            // LDS tile half-width in pixels (0 = no tile: read the raster from global)
-    uint32_t part_stride;       // stride of the per-chunk NN partials ([chunk][sample] layout)
+    uint32_t part_stride;       // sample stride of the arrays double-buffered by step parity
 };
 
 // Pointers read out of RunConst have no known address space, so hipcc emits flat_* accesses and drains both
@@ -411,32 +409,6 @@ __device__ __forceinline__ void rep_insert(const RunConst &rc, double x, double 
     }
 }
 
-// f32 filter view of one node
-__device__ __forceinline__ void write_filter_view(const RunConst &rc, int id, double x, double y) {
-    rc.fx[id] = (float)x;
-    rc.fy[id] = (float)y;
-    const double xx = x * x, yy = y * y;
-    rc.f2[id] = (float)(xx + yy);
-}
-
-// threshold on the f32 key  key(n) = fl32(|n|^2 - 2 q.n)  that no node with exact d2 <= bound can exceed
-__device__ __forceinline__ float key_threshold(const RunConst &rc, double bound_d2, double qx, double qy) {
-    const double q2 = qx * qx + qy * qy;
-    const double t = bound_d2 * (1.0 + 1e-15) - q2 + rc.filt_E;
-    float f = (float)t;
-    if ((double)f < t) f = __int_as_float(__float_as_int(f) + (f >= 0.0f ? 1 : -1));   // round up
-    return __int_as_float(__float_as_int(f) + (f >= 0.0f ? 1 : -1)) ;                    // one more ulp of slack
-}
-
-// threshold below which a node's exact d2 is certainly <= bound (so no exact re-evaluation is needed)
-__device__ __forceinline__ float key_threshold_inner(const RunConst &rc, double bound_d2, double qx, double qy) {
-    const double q2 = qx * qx + qy * qy;
-    const double t = bound_d2 * (1.0 - 1e-15) - q2 - rc.filt_E;
-    float f = (float)t;
-    if ((double)f > t) f = __int_as_float(__float_as_int(f) + (f > 0.0f ? -1 : 1));     // round down
-    return __int_as_float(__float_as_int(f) + (f > 0.0f ? -1 : 1));                      // one more ulp of slack
-}
-
 // One thread per sample: upper bound of its nearest-neighbour distance from the pyramid (finest level whose
 // 3x3 neighbourhood holds a node that passes the world filter), turned into the scan's key threshold.
 // Upper bound of sample k's nearest-neighbour distance from the pyramid (finest level whose 3x3 neighbourhood
@@ -478,10 +450,7 @@ __device__ __forceinline__ void nn_bound_sample(const RunConst &rc, uint32_t b, 
         }
     }
     if (m == INF && !PTO) m = dist2(rc.nx[0], rc.ny[0], qx, qy);      // the root always exists
-    const uint32_t o = (b & 1u) * rc.part_stride + k;      // double-buffered by step parity
-    rc.q_ax[o] = (float)(-2.0 * qx);
-    rc.q_ay[o] = (float)(-2.0 * qy);
-    rc.q_thr[o] = m == INF ? __int_as_float(0x7F800000) : key_threshold(rc, m, qx, qy);
+    rc.q_bound[(b & 1u) * rc.part_stride + k] = m;         // double-buffered by step parity
 }
 
 // stand-alone form: first step of a run, PTO steps (fresh reach masks), steps beyond n_iter_min
@@ -493,177 +462,126 @@ __global__ __launch_bounds__(256) void k_nn_bound(const RunConst *__restrict__ r
     nn_bound_sample<PTO>(rc, b, rc.n_at[bsnap], i0, k);
 }
 
-// ------------------------------------------------------------------ scans
-// The node arrays are read-only inside a scan kernel and indexed wave-uniformly.  Viewing them through the
-// constant address space makes hipcc emit scalar loads (s_load_dwordx2/x4 into SGPRs) that feed the VALU
-// directly as broadcast operands; the scalar cache is invalidated at every kernel start, so nodes written
-// by the previous step's kernels are seen.
-typedef const __attribute__((address_space(4))) double *cdouble_p;
-__device__ __forceinline__ cdouble_p as_const(const double *p) { return (cdouble_p)(uintptr_t)p; }
+// ------------------------------------------------------------------ region pages + near search
+// The node coordinates the searches read are kept a second time, bucketed by REGION: a kRG x kRG grid over the
+// box of the run, every region owning a list of 64-slot pages (x, y, id per slot; page 0 of region r is page r,
+// further pages come from a pool through the directory rg_dir).  A search is still a brute-force scan with the
+// reference's exact f64 arithmetic -- over the pages of the regions that meet the query disc's bounding box
+// instead of over the whole array.  The cell function is monotone in each coordinate (clamped at the borders), so
+// a node within rho of the query in either coordinate lies in a region between cell(q - rho) and cell(q + rho):
+// nothing inside the disc is ever skipped, whatever the box is.
+// One WAVE serves one sample: lanes <-> the 64 slots of a page (coalesced 1 KiB + 256 B loads, four pages in
+// flight), hits are compacted with a ballot.
+__device__ __forceinline__ uint32_t rank_before(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k);
+constexpr int kRG = 64;
+constexpr uint32_t kRegions = kRG * kRG;
+constexpr uint32_t kPage = 64;
+typedef double dbl2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void chunk_range(uint32_t N, uint32_t NC, uint32_t c, uint32_t &j0, uint32_t &j1) {
-    uint32_t C = (N + NC - 1) / NC;
-    C = (C + 15u) & ~15u;               // whole 16-node trips; chunks start on 64-byte boundaries of the arrays
-    j0 = c * C;
-    uint32_t e = j0 + C;
-    j1 = e < N ? e : N;
-    if (j0 > N) j0 = N;
+__device__ __forceinline__ uint32_t region_of(const RunConst &rc, double x, double y) {
+    int cx, cy;
+    rep_cell(rc, x, y, kRG, cx, cy);
+    return (uint32_t)(cy * kRG + cx);
 }
 
-constexpr int kUnroll = 8;
-constexpr uint32_t kTile = 512;      // nodes staged in LDS per pass: 512 * (3*4 + 2*8) B = 14 KiB per workgroup
-
-// LDS image of one tile of nodes: the f32 filter view for the hot loop and the exact f64 coordinates for
-// the rare path, so that neither touches global memory after the staging pass.
-struct NodeTile {
-    float fx[kTile], fy[kTile], f2[kTile];
-    double x[kTile], y[kTile];
-};
-
-// coalesced staging of nodes [base, base+n) by the whole workgroup
-__device__ __forceinline__ void stage_tile(const RunConst &rc, NodeTile &t, uint32_t base, uint32_t n) {
-    auto gfx = as_global(rc.fx) + base, gfy = as_global(rc.fy) + base, gf2 = as_global(rc.f2) + base;
-    auto gx = as_global(rc.nx) + base, gy = as_global(rc.ny) + base;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        t.fx[i] = gfx[i]; t.fy[i] = gfy[i]; t.f2[i] = gf2[i];
-        t.x[i] = gx[i]; t.y[i] = gy[i];
-    }
+// conservative search radius for a threshold on the squared distance (relative + absolute slack cover the
+// roundings of d2 and of q -+ rho)
+__device__ __forceinline__ double disc_radius(double bound_d2, double qx, double qy) {
+    return sqrt(bound_d2) * (1.0 + 1e-9) + 1e-12 * (1.0 + fabs(qx) + fabs(qy));
 }
 
-// Stream one staged tile past the lanes' samples.  Hot loop (all lanes, wave-uniform node, LDS broadcast):
-//     key = fma(fx, -2qx, fma(fy, -2qy, f2))        f32, 2 FMA
-//     hit = key <= thr                              1 compare
-// key approximates d2 - |q|^2 with absolute error < filt_E, and thr was rounded up past bound - |q|^2 +
-// filt_E, so a node whose exact squared distance is <= bound can never be rejected (DESIGN.md gives the
-// error budget).  `visit(i, key)` runs only for hits (i = index in the tile) and redoes the arithmetic
-// exactly in f64.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// visit(x, y, id, ok): called by all 64 lanes for every page of every region meeting the box of the disc;
+// ok = this lane's slot holds a node.  q and rho are wave-uniform.
 template <class Visit>
-__device__ __forceinline__ void scan_tile(const NodeTile &t, uint32_t n, float ax, float ay, const float &thr, Visit visit) {
-    uint32_t i = 0;
-    constexpr int U = 16;                // nodes per trip: 12 ds_read_b128, 32 FMA, a min tree, ONE compare + branch
-    for (; i + U <= n; i += U) {
-        float key[U];
-#pragma unroll
-        for (int g = 0; g < U / 4; ++g) {
-            const float4 x = *(const float4 *)&t.fx[i + 4 * g];
-            const float4 y = *(const float4 *)&t.fy[i + 4 * g];
-            const float4 z = *(const float4 *)&t.f2[i + 4 * g];
-            key[4 * g + 0] = __builtin_fmaf(x.x, ax, __builtin_fmaf(y.x, ay, z.x));
-            key[4 * g + 1] = __builtin_fmaf(x.y, ax, __builtin_fmaf(y.y, ay, z.y));
-            key[4 * g + 2] = __builtin_fmaf(x.z, ax, __builtin_fmaf(y.z, ay, z.z));
-            key[4 * g + 3] = __builtin_fmaf(x.w, ax, __builtin_fmaf(y.w, ay, z.w));
+__device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double qy, double rho, uint32_t lane, Visit visit) {
+    int cx0, cy0, cx1, cy1;
+    rep_cell(rc, qx - rho, qy - rho, kRG, cx0, cy0);
+    rep_cell(rc, qx + rho, qy + rho, kRG, cx1, cy1);
+    const uint32_t x0 = uni((uint32_t)cx0), y0 = uni((uint32_t)cy0);
+    const uint32_t w = uni((uint32_t)(cx1 - cx0 + 1)), nreg = w * uni((uint32_t)(cy1 - cy0 + 1));
+    auto gcnt = as_global(rc.rg_cnt);
+    auto gdir = as_global(rc.rg_dir);
+    auto gxy = as_global(reinterpret_cast<const dbl2 *>(rc.pg_xy));
+    auto gid = as_global(rc.pg_id);
+    for (uint32_t r0 = 0; r0 < nreg; r0 += 64) {
+        const uint32_t r = r0 + lane;
+        uint32_t reg = 0, cnt = 0;
+        if (r < nreg) {
+            const uint32_t ry = r / w;
+            reg = (y0 + ry) * kRG + x0 + (r - ry * w);
+            cnt = gcnt[reg];
         }
-        float m = key[0];
+        uint32_t page = reg;                                 // the first page of a region is static
+        for (uint32_t j = 0;; ++j) {
+            unsigned long long m = __ballot(cnt > j * kPage);
+            if (!m) break;
+            if (j && cnt > j * kPage) page = gdir[(size_t)reg * rc.rg_maxp + j];
+            while (m) {
+                uint32_t pg[4], pc[4];
 #pragma unroll
-        for (int u = 1; u < U; ++u) m = __builtin_fminf(m, key[u]);      // v_min3_f32 tree
-        if (m <= thr) {                  // rare: one branch per sixteen nodes
+                for (int u = 0; u < 4; ++u) {
+                    pg[u] = 0; pc[u] = 0;
+                    if (m) {
+                        const uint32_t l = (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1;
+                        pg[u] = (uint32_t)__builtin_amdgcn_readlane((int)page, (int)l);
+                        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)l) - j * kPage;
+                        pc[u] = c < kPage ? c : kPage;
+                    }
+                }
+                dbl2 v[4];
+                int id[4];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (key[u] <= thr) visit(i + u, key[u]);
-        }
-    }
-    for (; i < n; ++i) {
-        const float key = __builtin_fmaf(t.fx[i], ax, __builtin_fmaf(t.fy[i], ay, t.f2[i]));
-        if (key <= thr) visit(i, key);
-    }
-}
-
-// K x N nearest-neighbour scan.  grid = (ceil(nb/256), NC); lane <-> sample, nodes broadcast from LDS.
-// Output per (sample, chunk): lexicographic min of (norm2, id) over the chunk's nodes that pass the world
-// filter (nearest_neighbor.rs:61-62: `d < dmin && validator(id)`, ascending id so the first wins ties).
-template <bool PTO>
-__global__ __launch_bounds__(kScanBlock) void k_nn_scan(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb,
-                                                          uint32_t NC) {
-    __shared__ __attribute__((aligned(16))) NodeTile tile;
-    const RunConst &rc = *rcp;
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t c = blockIdx.y;
-    const uint32_t N = __builtin_amdgcn_readfirstlane(rc.n_at[b]);
-    uint32_t j0, j1;
-    chunk_range(N, NC, c, j0, j1);
-    const bool live = k < nb;
-    const double qx = live ? rc.sx[i0 + k] : 0.0, qy = live ? rc.sy[i0 + k] : 0.0;
-    const uint32_t qo = (b & 1u) * rc.part_stride + (live ? k : 0u);
-    const float ax = live ? rc.q_ax[qo] : 0.0f, ay = live ? rc.q_ay[qo] : 0.0f;
-    float thr = live ? rc.q_thr[qo] : __int_as_float(0xFF800000);   // -inf: dead lanes never hit
-    uint32_t world = 0;
-    if (PTO) world = live ? rc.sworld[i0 + k] : 0u;
-    double m2 = __longlong_as_double(0x7FF0000000000000ll);   // +inf
-    double bestD = m2;
-    int best = -1;
-    auto reach = as_global(rc.reachA);
-    for (uint32_t base = j0; base < j1; base += kTile) {
-        const uint32_t n = j1 - base < kTile ? j1 - base : kTile;
-        if (base != j0) __syncthreads();
-        stage_tile(rc, tile, base, n);
-        __syncthreads();
-        scan_tile(tile, n, ax, ay, thr,
-                  [&](uint32_t i, float) {
-                      const double d2 = dist2(tile.x[i], tile.y[i], qx, qy);   // exact, as the reference computes it
-                      if (d2 < m2) {
-                          bool pass = true;
-                          if (PTO) pass = (reach[base + i] >> world) & 1ull;
-                          if (pass) {
-                              const double D = sqrt(d2);                    // the reference compares rounded distances
-                              if (D < bestD) {
-                                  bestD = D; best = (int)(base + i); m2 = d2;
-                                  const float t2 = key_threshold(rc, d2, qx, qy);  // tighten the filter
-                                  thr = t2 < thr ? t2 : thr;
-                              }
-                          }
-                      }
-                  });
-    }
-    if (live) {
-        as_global(rc.part_D)[(size_t)c * rc.part_stride + k] = bestD;      // [chunk][sample]: coalesced
-        as_global(rc.part_id)[(size_t)c * rc.part_stride + k] = best;
-    }
-}
-
-// argmin over node chunks, steer (L1 step length), point validity.  A workgroup of 16 waves serves 64
-// samples: wave r reduces chunks r, r+16, ... for all 64 (coalesced reads of the [chunk][sample] partials, all
-// sixteen loads of a lane in flight at once), the sixteen candidates meet in LDS and wave 0 finishes.
-constexpr uint32_t kRedWaves = 16;
-__global__ __launch_bounds__(kRedWaves * 64) void k_nn_reduce_steer(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb,
-                                                                    uint32_t NC, uint32_t vwords) {
-    const RunConst &rc = *rcp;
-    __shared__ double s_D[kRedWaves][64];
-    __shared__ int s_id[kRedWaves][64];
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t k = blockIdx.x * 64u + lane;
-    double D = __longlong_as_double(0x7FF0000000000000ll);
-    int id = 0x7FFFFFFF;
-    if (k < nb) {
-        auto pD = as_global(rc.part_D) + k;
-        auto pI = as_global(rc.part_id) + k;
-        for (uint32_t c0 = wv; c0 < NC; c0 += 16u * kRedWaves) {
-            double d[16];
-            int i[16];
+                for (int u = 0; u < 4; ++u) {                 // unused slots read page 0 (valid memory, ignored)
+                    v[u] = gxy[(size_t)pg[u] * kPage + lane];
+                    id[u] = gid[(size_t)pg[u] * kPage + lane];
+                }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const uint32_t c = c0 + kRedWaves * u;
-                const bool ok = c < NC;
-                i[u] = ok ? pI[(size_t)c * rc.part_stride] : -1;
-                d[u] = ok ? pD[(size_t)c * rc.part_stride] : 0.0;
+                for (int u = 0; u < 4; ++u)
+                    if (pc[u]) visit(v[u].x, v[u].y, id[u], lane < pc[u]);
             }
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (i[u] >= 0 && (d[u] < D || (d[u] == D && i[u] < id))) { D = d[u]; id = i[u]; }
         }
     }
-    s_D[wv][lane] = D;
-    s_id[wv][lane] = id;
-    __syncthreads();
-    if (wv != 0 || k >= nb) return;
-#pragma unroll
-    for (uint32_t r = 1; r < kRedWaves; ++r) {
-        const double d = s_D[r][lane];
-        const int i = s_id[r][lane];
-        if (d < D || (d == D && i < id)) { D = d; id = i; }
+}
+
+// One wave per sample: nearest neighbour (nearest_neighbor.rs:48-92: minimum of (norm2, id), world filter applied
+// after the distance test), steer + point validity (common.rs:215-225, map_shelves_io.rs:158-170,
+// map_io.rs:165-181), then the radius search around the steered state (nearest_neighbor.rs:94-126:
+// norm2 <= radius  <=>  d2 <= T2 with T2 from the host table) into the sample's neighbour list.
+template <bool PTO>
+__global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords) {
+    const RunConst &rc = *rcp;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (k >= nb) return;
+    const uint32_t N = uni(rc.n_at[b]);
+    const double sqx = rc.sx[i0 + k], sqy = rc.sy[i0 + k];
+    uint32_t world = 0;
+    if (PTO) world = rc.sworld[i0 + k];
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    double bestD = INF;
+    int best = 0x7FFFFFFF;
+    {
+        const double m = rc.q_bound[(b & 1u) * rc.part_stride + k];
+        auto reach = as_global(rc.reachA);
+        scan_disc(rc, sqx, sqy, disc_radius(m, sqx, sqy), lane, [&](double x, double y, int id, bool ok) {
+            if (!ok) return;
+            const double D = sqrt(dist2(x, y, sqx, sqy));        // the reference compares rounded distances
+            bool pass = true;
+            if (PTO) pass = (reach[id] >> world) & 1ull;
+            if (pass && (D < bestD || (D == bestD && id < best))) { bestD = D; best = id; }
+        });
+        for (int off = 32; off > 0; off >>= 1) {
+            const double od = __shfl_xor(bestD, off);
+            const int oi = __shfl_xor(best, off);
+            if (od < bestD || (od == bestD && oi < best)) { bestD = od; best = oi; }
+        }
     }
-    const int nn = id == 0x7FFFFFFF ? 0 : id;   // nothing passed the filter: the root (nearest_neighbor.rs:90)
+    const int nn = best == 0x7FFFFFFF ? 0 : best;   // nothing passed the filter: the root (nearest_neighbor.rs:90)
     const double fx = rc.nx[nn], fy = rc.ny[nn];
-    double tx = rc.sx[i0 + k], ty = rc.sy[i0 + k];
+    double tx = sqx, ty = sqy;
     // common.rs:215-225
     double step = fabs(tx - fx);
     step += fabs(ty - fy);
@@ -682,76 +600,83 @@ __global__ __launch_bounds__(kRedWaves * 64) void k_nn_reduce_steer(const RunCon
         else { vid = class_to_validity(rc, cls); valid = vid >= 0; }
         if (err) valid = false;
     }
-    rc.q_x[k] = tx;
-    rc.q_y[k] = ty;
-    {   // copy for the kd insertion, which runs beside the next steps (double-buffered by step parity)
+    if (lane == 0) {
+        rc.q_x[k] = tx;
+        rc.q_y[k] = ty;
+        // copy for the kd insertion, which runs beside the next steps (double-buffered by step parity)
         const uint32_t o2 = (b & 1u) * rc.part_stride + k;
         rc.kq_x[o2] = tx; rc.kq_y[o2] = ty; rc.kq_vid[o2] = valid ? vid : -1;
+        rc.q_nn[k] = nn;
+        rc.q_vid[k] = valid ? vid : -1;
+        if (valid) atomicOr(&rc.valid_mask[(size_t)b * vwords + (k >> 6)], 1ull << (k & 63u));
+        if (err) atomicOr(&rc.cnt->err, err);
     }
-    rc.q_nn[k] = nn;
-    rc.q_vid[k] = valid ? vid : -1;
-    rc.cand_cnt[k] = 0;
-    if (valid) atomicOr(&rc.valid_mask[(size_t)b * vwords + (k >> 6)], 1ull << (k & 63u));
-    if (err) atomicOr(&rc.cnt->err, err);
-}
-
-// K x N radius scan: neighbour ids with norm2 <= radius  <=>  d2 <= T2 (T2 from the host table).
-// The f32 key settles almost every node: key > thr_out rejects, key <= thr_in accepts (both margins are the
-// key's error bound), and only the thin shell in between is re-evaluated exactly in f64.  An accepted id is
-// appended with one atomic slot claim; the store of the id is deferred to the lane's next hit so that the
-// wave never waits for the atomic's round trip.
-__global__ __launch_bounds__(kScanBlock) void k_radius_scan(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t NC) {
-    __shared__ __attribute__((aligned(16))) NodeTile tile;
-    const RunConst &rc = *rcp;
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t c = blockIdx.y;
-    const uint32_t N = __builtin_amdgcn_readfirstlane(rc.n_at[b]);
-    uint32_t j0, j1;
-    chunk_range(N, NC, c, j0, j1);
-    const bool live = k < nb && rc.q_vid[k < nb ? k : 0] >= 0;
-    const double qx = live ? rc.q_x[k] : 0.0, qy = live ? rc.q_y[k] : 0.0;
+    if (!valid) return;
     // rrt.rs:121 uses the size before insertion, pto.rs:88 after it
     const double T2 = rc.rad_T2[N + (rc.mode == 1 ? 1u : 0u)];
-    const float ax = (float)(-2.0 * qx), ay = (float)(-2.0 * qy);
-    const float NEG_INF = __int_as_float(0xFF800000);
-    const float thr = live ? key_threshold(rc, T2, qx, qy) : NEG_INF;
-    const float thr_in = live ? key_threshold_inner(rc, T2, qx, qy) : NEG_INF;
-    auto cand_cnt = as_global(rc.cand_cnt) + (k < nb ? k : 0);
-    auto cand_id = as_global(rc.cand_id) + (size_t)(k < nb ? k : 0) * rc.cand_cap;
+    auto cid = as_global(rc.cand_id) + (size_t)k * rc.cand_cap;
     const uint32_t cap = rc.cand_cap;
-    auto errw = as_global(&rc.cnt->err);
-    // A lane's hits are parked in LDS and flushed with ONE slot claim (atomicAdd of the count) -- vmcnt is per
-    // wave, so claiming a slot per hit would stall every lane of the wave on each other's atomics.
-    constexpr uint32_t kHits = 8;
-    __shared__ int s_hits[kHits * kScanBlock];
-    uint32_t nh = 0;
-    auto flush = [&]() {
-        if (nh) {
-            const uint32_t slot = g_atomic_add(cand_cnt, nh);
-            for (uint32_t h = 0; h < nh; ++h) {
-                if (slot + h < cap) cand_id[slot + h] = s_hits[h * kScanBlock + threadIdx.x];
-                else g_atomic_or(errw, (uint32_t)ERR_CAND_OVERFLOW);
-            }
-            nh = 0;
+    uint32_t tot = 0;
+    bool over = false;
+    scan_disc(rc, tx, ty, disc_radius(T2, tx, ty), lane, [&](double x, double y, int id, bool ok) {
+        const bool in = ok && dist2(x, y, tx, ty) <= T2;
+        const unsigned long long hm = __ballot(in);
+        const uint32_t pos = tot + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+        if (in) {
+            if (pos < cap) cid[pos] = id;
+            else over = true;
         }
-    };
-    for (uint32_t base = j0; base < j1; base += kTile) {
-        const uint32_t n = j1 - base < kTile ? j1 - base : kTile;
-        if (base != j0) __syncthreads();
-        stage_tile(rc, tile, base, n);
-        __syncthreads();
-        scan_tile(tile, n, ax, ay, thr,
-                  [&](uint32_t i, float key) {
-                      bool in = key <= thr_in;
-                      if (!in) in = dist2(tile.x[i], tile.y[i], qx, qy) <= T2;      // shell: exact test
-                      if (in) {
-                          if (nh == kHits) flush();                                 // rare: dense neighbourhoods
-                          s_hits[nh * kScanBlock + threadIdx.x] = (int)(base + i);
-                          ++nh;
-                      }
-                  });
+        tot += (uint32_t)__popcll(hm);
+    });
+    if (lane == 0) rc.cand_cnt[k] = tot;
+    if (over) atomicOr(&rc.cnt->err, (uint32_t)ERR_CAND_OVERFLOW);
+}
+
+// Add the step's new nodes to the region pages (run by ONE workgroup, an extra block of the connect kernels:
+// positions and validity are final since k_near, ids follow from the valid mask).  Nothing reads the pages
+// between k_near of this step and k_near of the next.
+__device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords) {
+    __shared__ uint32_t s_add[kRegions];
+    __shared__ uint16_t s_off[4096];
+    __shared__ uint32_t s_np, s_base;
+    const uint32_t T = blockDim.x;
+    for (uint32_t r = threadIdx.x; r < kRegions; r += T) s_add[r] = 0;
+    if (threadIdx.x == 0) { s_np = 0; s_base = kRegions + rc.cnt->n_pages; }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nb; k += T)
+        if (rc.q_vid[k] >= 0) s_off[k] = (uint16_t)atomicAdd(&s_add[region_of(rc, rc.q_x[k], rc.q_y[k])], 1u);
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < kRegions; r += T) {
+        const uint32_t add = s_add[r];
+        if (!add) continue;
+        const uint32_t old = rc.rg_cnt[r];
+        const uint32_t p_old = old ? (old + kPage - 1) / kPage : 1u, p_new = (old + add + kPage - 1) / kPage;
+        if (p_new > p_old) {
+            const uint32_t need = p_new - p_old;
+            const uint32_t at = s_base + atomicAdd(&s_np, need);
+            if (at + need > rc.pg_cap || p_new > rc.rg_maxp) { atomicOr(&rc.cnt->err, (uint32_t)ERR_PAGE_OVERFLOW); continue; }
+            for (uint32_t i = 0; i < need; ++i) rc.rg_dir[(size_t)r * rc.rg_maxp + p_old + i] = at + i;
+        }
     }
-    flush();
+    __syncthreads();
+    if (rc.cnt->err & ERR_PAGE_OVERFLOW) return;
+    const uint32_t N = rc.n_at[b];
+    dbl2 *pxy = reinterpret_cast<dbl2 *>(rc.pg_xy);
+    for (uint32_t k = threadIdx.x; k < nb; k += T) {
+        if (rc.q_vid[k] < 0) continue;
+        const double x = rc.q_x[k], y = rc.q_y[k];
+        const uint32_t r = region_of(rc, x, y);
+        const uint32_t slot = rc.rg_cnt[r] + s_off[k], j = slot / kPage;
+        const uint32_t page = j ? __hip_atomic_load(&rc.rg_dir[(size_t)r * rc.rg_maxp + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : r;
+        dbl2 v;
+        v.x = x; v.y = y;
+        pxy[(size_t)page * kPage + (slot % kPage)] = v;
+        rc.pg_id[(size_t)page * kPage + (slot % kPage)] = (int)(N + rank_before(rc, b, vwords, k));
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < kRegions; r += T)
+        if (s_add[r]) rc.rg_cnt[r] += s_add[r];
+    if (threadIdx.x == 0) rc.cnt->n_pages += s_np;
 }
 
 // ------------------------------------------------------------------ connect
@@ -988,7 +913,6 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     if (tl == 0) {
         rc.nx[id] = px;
         rc.ny[id] = py;
-        write_filter_view(rc, (int)id, px, py);
         rep_insert(rc, px, py, (int)id);
         rc.parent[id] = best;
         rc.distA[id] = dnew;
@@ -1042,6 +966,7 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunCon
     __shared__ int s_i[kConnectWaves];
     __shared__ uint32_t s_heavy[kConnectWaves];
     const RunConst &rc = *rcp;
+    if (blockIdx.x == gridDim.x - 1) { insert_step_pages(rc, b, nb, vwords); return; }    // the extra block
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t k = blockIdx.x * kConnectWaves + wv;
     const bool active = k < nb && rc.q_vid[k < nb ? k : 0] >= 0;
@@ -1321,6 +1246,7 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
                                                                      uint32_t vwords) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_tiles[];
     const RunConst &rc = *rcp;
+    if (blockIdx.x == gridDim.x - 1) { insert_step_pages(rc, b, nb, vwords); return; }    // the extra block
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = blockIdx.x * kConnectWaves + (threadIdx.x >> 6);
     if (k >= nb || rc.q_vid[k] < 0) return;
@@ -1387,7 +1313,6 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
     if (lane == 0) {
         rc.nx[id] = px;
         rc.ny[id] = py;
-        write_filter_view(rc, (int)id, px, py);
         rep_insert(rc, px, py, (int)id);
         rc.parent[id] = -1;
         rc.distA[id] = 0.0;

@@ -159,16 +159,16 @@ struct porrt_ctx {
     bool opt_graph = true;
     uint32_t opt_cand_cap = 2048;
     // ---- device buffers
-    DevBuf<double> d_nx, d_ny, d_distA, d_distB, d_sx, d_sy, d_qx, d_qy, d_partD, d_candval, d_radT2, d_inj;
-    DevBuf<int> d_parent, d_qnn, d_qvid, d_partid, d_candid, d_gid, d_kdup;
+    DevBuf<double> d_nx, d_ny, d_distA, d_distB, d_sx, d_sy, d_qx, d_qy, d_qbound, d_pgxy, d_candval, d_radT2, d_inj;
+    DevBuf<int> d_parent, d_qnn, d_qvid, d_pgid, d_candid, d_gid, d_kdup;
     DevBuf<KdRec> d_kdrec;
     DevBuf<int> d_loccur;
     DevBuf<uint32_t> d_locdcur, d_locgex, d_locflags, d_kdsurv;
     DevBuf<double> d_gx, d_gy, d_gndx, d_gndy, d_kqx, d_kqy;
     DevBuf<int> d_kqvid;
-    DevBuf<float> d_fx, d_fy, d_f2, d_qax, d_qay, d_qthr;
+    DevBuf<uint32_t> d_rgcnt, d_rgdir;
     DevBuf<int> d_rep;
-    DevBuf<unsigned long long> d_dbg, d_partmask;
+    DevBuf<unsigned long long> d_dbg;
     DevBuf<uint32_t> d_kddepth, d_kdgexit;
     DevBuf<unsigned long long> d_reachA, d_reachB, d_finalmask, d_validmask;
     DevBuf<uint8_t> d_vid, d_finalflag, d_cls;
@@ -229,11 +229,11 @@ struct porrt_ctx {
 // every grow re-initialises what it uses, and the cached uploads are marked stale.
 int porrt_ctx::layout_buffers() {
     if (all_bufs.empty()) {
-        DevBufBase *list[] = {&d_nx, &d_ny, &d_distA, &d_distB, &d_sx, &d_sy, &d_qx, &d_qy, &d_partD, &d_candval, &d_radT2, &d_inj,
-                              &d_parent, &d_qnn, &d_qvid, &d_partid, &d_candid, &d_gid, &d_kdup, &d_kdrec, &d_gx, &d_gy, &d_fx, &d_fy,
-                              &d_f2, &d_qax, &d_qay, &d_qthr, &d_rep, &d_dbg, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB,
+        DevBufBase *list[] = {&d_nx, &d_ny, &d_distA, &d_distB, &d_sx, &d_sy, &d_qx, &d_qy, &d_qbound, &d_pgxy, &d_candval, &d_radT2, &d_inj,
+                              &d_parent, &d_qnn, &d_qvid, &d_pgid, &d_candid, &d_gid, &d_kdup, &d_kdrec, &d_gx, &d_gy, &d_rgcnt,
+                              &d_rgdir, &d_rep, &d_dbg, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB,
                               &d_finalmask, &d_validmask, &d_vid, &d_finalflag, &d_cls, &d_nat, &d_sworld, &d_candcnt, &d_efrom,
-                              &d_eto, &d_etv, &d_heavy, &d_cnt, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags, &d_kdsurv, &d_partmask, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid};
+                              &d_eto, &d_etv, &d_heavy, &d_cnt, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags, &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid};
         for (DevBufBase *b2 : list) all_bufs.push_back(b2);
     }
     bool grow_needed = false;
@@ -256,11 +256,11 @@ int porrt_ctx::layout_buffers() {
     for (DevBufBase *b2 : all_bufs) { b2->vp = (char *)arena.base + off; off += (b2->n * b2->elem + 4095) & ~(size_t)4095; }
     d_nx.p = (double *)d_nx.vp; d_ny.p = (double *)d_ny.vp; d_distA.p = (double *)d_distA.vp; d_distB.p = (double *)d_distB.vp;
     d_sx.p = (double *)d_sx.vp; d_sy.p = (double *)d_sy.vp; d_qx.p = (double *)d_qx.vp; d_qy.p = (double *)d_qy.vp;
-    d_partD.p = (double *)d_partD.vp; d_candval.p = (double *)d_candval.vp; d_radT2.p = (double *)d_radT2.vp; d_inj.p = (double *)d_inj.vp;
-    d_parent.p = (int *)d_parent.vp; d_qnn.p = (int *)d_qnn.vp; d_qvid.p = (int *)d_qvid.vp; d_partid.p = (int *)d_partid.vp;
+    d_qbound.p = (double *)d_qbound.vp; d_pgxy.p = (double *)d_pgxy.vp; d_candval.p = (double *)d_candval.vp; d_radT2.p = (double *)d_radT2.vp; d_inj.p = (double *)d_inj.vp;
+    d_parent.p = (int *)d_parent.vp; d_qnn.p = (int *)d_qnn.vp; d_qvid.p = (int *)d_qvid.vp; d_pgid.p = (int *)d_pgid.vp;
     d_candid.p = (int *)d_candid.vp; d_gid.p = (int *)d_gid.vp; d_kdup.p = (int *)d_kdup.vp; d_kdrec.p = (KdRec *)d_kdrec.vp;
-    d_gx.p = (double *)d_gx.vp; d_gy.p = (double *)d_gy.vp; d_fx.p = (float *)d_fx.vp; d_fy.p = (float *)d_fy.vp; d_f2.p = (float *)d_f2.vp;
-    d_qax.p = (float *)d_qax.vp; d_qay.p = (float *)d_qay.vp; d_qthr.p = (float *)d_qthr.vp; d_rep.p = (int *)d_rep.vp;
+    d_gx.p = (double *)d_gx.vp; d_gy.p = (double *)d_gy.vp; d_rgcnt.p = (uint32_t *)d_rgcnt.vp; d_rgdir.p = (uint32_t *)d_rgdir.vp;
+    d_rep.p = (int *)d_rep.vp;
     d_dbg.p = (unsigned long long *)d_dbg.vp; d_kddepth.p = (uint32_t *)d_kddepth.vp; d_kdgexit.p = (uint32_t *)d_kdgexit.vp;
     d_reachA.p = (unsigned long long *)d_reachA.vp; d_reachB.p = (unsigned long long *)d_reachB.vp;
     d_finalmask.p = (unsigned long long *)d_finalmask.vp; d_validmask.p = (unsigned long long *)d_validmask.vp;
@@ -269,7 +269,7 @@ int porrt_ctx::layout_buffers() {
     d_efrom.p = (uint32_t *)d_efrom.vp; d_eto.p = (uint32_t *)d_eto.vp; d_etv.p = (uint32_t *)d_etv.vp; d_heavy.p = (uint32_t *)d_heavy.vp;
     d_loccur.p = (int *)d_loccur.vp; d_locdcur.p = (uint32_t *)d_locdcur.vp; d_locgex.p = (uint32_t *)d_locgex.vp;
     d_locflags.p = (uint32_t *)d_locflags.vp; d_kdsurv.p = (uint32_t *)d_kdsurv.vp;
-    d_partmask.p = (unsigned long long *)d_partmask.vp; d_gndx.p = (double *)d_gndx.vp; d_gndy.p = (double *)d_gndy.vp;
+    d_gndx.p = (double *)d_gndx.vp; d_gndy.p = (double *)d_gndy.vp;
     d_kqx.p = (double *)d_kqx.vp; d_kqy.p = (double *)d_kqy.vp; d_kqvid.p = (int *)d_kqvid.vp;
     d_cnt.p = (Counters *)d_cnt.vp; d_rc.p = (RunConst *)d_rc.vp; d_jump.p = (PcgJump *)d_jump.vp;
     // cached uploads are gone
@@ -361,8 +361,13 @@ __global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y
     rc.final_flag[0] = 0;
     rc.final_mask[0] = 0;
     rc.n_at[0] = 1;
-    write_filter_view(rc, 0, x, y);
     rep_insert(rc, x, y, 0);
+    {   // region pages
+        const uint32_t r = region_of(rc, x, y);
+        rc.pg_xy[2 * ((size_t)r * kPage)] = x; rc.pg_xy[2 * ((size_t)r * kPage) + 1] = y;
+        rc.pg_id[(size_t)r * kPage] = 0;
+        rc.rg_cnt[r] = 1;
+    }
     rc.g_id[0] = 0;          // the root is on every kd descent path
     rc.cnt->g_len = 1;
     rc.cnt->g_first_dup[0] = 0xFFFFFFFFu;
@@ -385,19 +390,12 @@ void porrt_ctx::launch_bound(hipStream_t st, uint32_t b, uint32_t bsnap, uint32_
     else hipLaunchKernelGGL(k_nn_bound<false>, kgrid, dim3(256), 0, st, (const RunConst *)d_rc.p, b, bsnap, i0, nb);
 }
 
-// One step.  Main stream: nn_scan, reduce+steer, radius_scan, connect, commit (which also bounds the next step's
+// One step.  Main stream: near (NN + steer + radius search), connect, commit (which also bounds the next step's
 // samples).  Side stream (RRT*): order-exact kd insertion of this step's nodes, started as soon as their positions
 // are final and needed only by the NEXT step's connect -- two cross-stream edges per step.
 void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, size_t lds_bytes, bool prof, size_t &ev_used,
                             uint32_t nxt_i0, uint32_t nxt_nb) {
-    // at most one node per iteration so far (+ root): bound on the tree size at the start of this step
-    const uint32_t n_ub = i0 + 1;
-    uint32_t NC = (n_ub + 63) / 64;
-    NC = std::max(1u, std::min<uint32_t>(NC, kMaxChunks));
-    const uint32_t sblock = std::min<uint32_t>(kScanBlock, (nb + 63u) & ~63u);   // all samples of the step in one workgroup when they fit
-    const dim3 scan_grid((nb + sblock - 1) / sblock, NC);
     const uint32_t wave_blocks = (nb * 64 + 255) / 256;
-    const uint32_t red_blocks = (nb + 63) / 64;
     const RunConst *rcp = d_rc.p;
     auto ev = [&](void) {
         if (prof && ev_used < ev_pool.size()) (void)hipEventRecord(ev_pool[ev_used++], stream);
@@ -405,24 +403,23 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     const bool rrt = mode == PORRT_MODE_RRT;
     if (!rrt) launch_bound(stream, b, b, i0, nb);      // PTO: bounds in-stream (the world filter wants fresh reach masks)
     ev();
-    if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_nn_scan<true>, scan_grid, dim3(sblock), 0, stream, rcp, b, i0, nb, NC);
-    else hipLaunchKernelGGL(k_nn_scan<false>, scan_grid, dim3(sblock), 0, stream, rcp, b, i0, nb, NC);
+    if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_near<true>, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, i0, nb, vwords);
+    else hipLaunchKernelGGL(k_near<false>, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, i0, nb, vwords);
     ev();
-    hipLaunchKernelGGL(k_nn_reduce_steer, dim3(red_blocks), dim3(kRedWaves * 64), 0, stream, rcp, b, i0, nb, NC, vwords);
-    ev();
-    hipLaunchKernelGGL(k_radius_scan, scan_grid, dim3(sblock), 0, stream, rcp, b, nb, NC);
-    ev();
-    const dim3 cgrid((nb + kConnectWaves - 1) / kConnectWaves), cblock(kConnectWaves * 64);
+    // + 1: the workgroup that files the new nodes into the region pages
+    const dim3 cgrid((nb + kConnectWaves - 1) / kConnectWaves + 1), cblock(kConnectWaves * 64);
     if (!rrt) {
+        ev();
         if (lds_bytes) hipLaunchKernelGGL(k_connect_pto<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
         else hipLaunchKernelGGL(k_connect_pto<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
+        ev();
         hipLaunchKernelGGL(k_commit_pto, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, nb, vwords);
         return;
     }
     // this step's connect orders tied parents by the kd structure of the tree before the step: the previous step's
     // insertion must be complete (this step's own insertion may run concurrently)
-    // One sync point per step: fork this step's kd insertion (positions are final since reduce_steer; it runs beside
-    // connect, commit and the next step's scans) and join the previous step's.
+    // One sync point per step: fork this step's kd insertion (positions are final since k_near; it runs beside
+    // connect, commit and the next step's search) and join the previous step's.
     (void)hipEventRecord(ev_steered, stream);
     (void)hipStreamWaitEvent(stream2, ev_steered, 0);
     hipLaunchKernelGGL(k_kd_locate, dim3((nb + 255) / 256), dim3(256), 0, stream2, rcp, b, nb, vwords);
@@ -430,8 +427,10 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     (void)hipEventRecord(ev_kd[b & 1u], stream2);
     kd_pend[b & 1u] = true;
     if (kd_pend[(b + 1u) & 1u]) { (void)hipStreamWaitEvent(stream, ev_kd[(b + 1u) & 1u], 0); kd_pend[(b + 1u) & 1u] = false; }
+    ev();
     if (lds_bytes) hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
     else hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
+    ev();
     hipLaunchKernelGGL(k_commit_rrt, dim3(std::max(wave_blocks, (nxt_nb + 255) / 256)), dim3(256), 0, stream, rcp, b, nb, vwords, nxt_i0, nxt_nb);
 }
 
@@ -492,13 +491,15 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(d_nat.reserve(steps_max + 2)); HIPCHK(d_validmask.reserve((steps_max + 2) * vwords));
         HIPCHK(d_sx.reserve(n_iter_max + 1)); HIPCHK(d_sy.reserve(n_iter_max + 1)); HIPCHK(d_sworld.reserve(n_iter_max + 1));
         HIPCHK(d_qx.reserve(K)); HIPCHK(d_qy.reserve(K)); HIPCHK(d_qnn.reserve(K)); HIPCHK(d_qvid.reserve(K));
-        HIPCHK(d_partD.reserve((size_t)Kpad * kMaxChunks)); HIPCHK(d_partid.reserve((size_t)Kpad * kMaxChunks)); HIPCHK(d_partmask.reserve((size_t)(Kpad / 64) * kMaxChunks));
+        // region pages: one static page per region + a pool that cannot run out (sum of ceil(n_r / 64) <= N / 64 + regions)
+        const uint64_t rg_maxp = Nmax / kPage + 2, pg_cap = 2ull * kRegions + Nmax / kPage + 8;
+        HIPCHK(d_rgcnt.reserve(kRegions)); HIPCHK(d_rgdir.reserve((size_t)kRegions * rg_maxp));
+        HIPCHK(d_pgxy.reserve(2 * (size_t)pg_cap * kPage)); HIPCHK(d_pgid.reserve((size_t)pg_cap * kPage)); HIPCHK(d_qbound.reserve(2 * (size_t)Kpad));
         HIPCHK(d_candcnt.reserve(K)); HIPCHK(d_heavy.reserve(K));
         HIPCHK(d_loccur.reserve(K)); HIPCHK(d_locdcur.reserve(K)); HIPCHK(d_locgex.reserve(K)); HIPCHK(d_locflags.reserve(K)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_gndx.reserve(Nmax)); HIPCHK(d_gndy.reserve(Nmax));
         HIPCHK(d_kqx.reserve(2 * (size_t)Kpad)); HIPCHK(d_kqy.reserve(2 * (size_t)Kpad)); HIPCHK(d_kqvid.reserve(2 * (size_t)Kpad)); HIPCHK(d_candid.reserve((size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
         HIPCHK(d_gid.reserve(Nmax));
-        HIPCHK(d_fx.reserve(Nmax + 64)); HIPCHK(d_fy.reserve(Nmax + 64)); HIPCHK(d_f2.reserve(Nmax + 64));
-        HIPCHK(d_qax.reserve(2 * (size_t)Kpad)); HIPCHK(d_qay.reserve(2 * (size_t)Kpad)); HIPCHK(d_qthr.reserve(2 * (size_t)Kpad)); HIPCHK(d_rep.reserve(kRepTotal));
+        HIPCHK(d_rep.reserve(kRepTotal));
         HIPCHK(d_kdrec.reserve(Nmax)); HIPCHK(d_gx.reserve(Nmax + 16)); HIPCHK(d_gy.reserve(Nmax + 16)); HIPCHK(d_kdup.reserve(Nmax)); HIPCHK(d_kddepth.reserve(Nmax)); HIPCHK(d_kdgexit.reserve(Nmax));
         HIPCHK(d_radT2.reserve(Nmax + 8));
         HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_jump.reserve(1));
@@ -530,22 +531,21 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.inj_xy = (has_inj && !host_samples) ? d_inj.p : nullptr;
     c.inj_base = inj_pos; c.inj_n = inj_xy.size() / 2;
     c.q_x = d_qx.p; c.q_y = d_qy.p; c.q_nn = d_qnn.p; c.q_vid = d_qvid.p;
-    c.part_D = d_partD.p; c.part_id = d_partid.p; c.part_mask = d_partmask.p;
+    c.q_bound = d_qbound.p; c.rg_cnt = d_rgcnt.p; c.rg_dir = d_rgdir.p; c.pg_xy = d_pgxy.p; c.pg_id = d_pgid.p;
+    c.rg_maxp = (uint32_t)(Nmax / kPage + 2); c.pg_cap = (uint32_t)(2ull * kRegions + Nmax / kPage + 8);
     c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p;
     c.heavy_list = d_heavy.p; c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
     c.rad_T2 = d_radT2.p;
     c.e_from = d_efrom.p; c.e_to = d_eto.p; c.e_tv = d_etv.p; c.e_cap = (uint32_t)d_efrom.n;
-    c.fx = d_fx.p; c.fy = d_fy.p; c.f2 = d_f2.p; c.rep = d_rep.p; c.q_ax = d_qax.p; c.q_ay = d_qay.p; c.q_thr = d_qthr.p;
+    c.rep = d_rep.p;
     {
-        // box of the bound pyramid and the error budget of the f32 key: every node and every sample lies in it
+        // box of the bound pyramid and of the region grid (points outside it fall into the border cells)
         double x0 = std::min(s_low[0], start[0]), x1 = std::max(s_up[0], start[0]);
         double y0 = std::min(s_low[1], start[1]), y1 = std::max(s_up[1], start[1]);
         if (has_inj) for (size_t t = 0; t + 1 < inj_xy.size(); t += 2) { x0 = std::min(x0, inj_xy[t]); x1 = std::max(x1, inj_xy[t]); y0 = std::min(y0, inj_xy[t + 1]); y1 = std::max(y1, inj_xy[t + 1]); }
         for (uint32_t g = 0; g < G; ++g) { x0 = std::min(x0, gcx[g]); x1 = std::max(x1, gcx[g]); y0 = std::min(y0, gcy[g]); y1 = std::max(y1, gcy[g]); }
         for (int z = 0; z < n_zones; ++z) { x0 = std::min(x0, zone_pos[z][0]); x1 = std::max(x1, zone_pos[z][0]); y0 = std::min(y0, zone_pos[z][1]); y1 = std::max(y1, zone_pos[z][1]); }
         c.bx0 = x0; c.by0 = y0; c.binv_w = 1.0 / (x1 - x0); c.binv_h = 1.0 / (y1 - y0);
-        const double Rm = std::max(std::max(fabs(x0), fabs(x1)), std::max(fabs(y0), fabs(y1)));
-        c.filt_E = 32.0 * ldexp(1.0, -24) * Rm * Rm + 1e-300;
     }
     if (getenv("PORRT_DEBUG")) { (void)hipMemsetAsync(d_dbg.p, 0, (steps_max + 2) * 64, stream); c.dbg = d_dbg.p; }
     c.kd_rec = d_kdrec.p; c.g_x = d_gx.p; c.g_y = d_gy.p; c.kd_up = d_kdup.p; c.kd_depth = d_kddepth.p; c.kd_gexit = d_kdgexit.p;
@@ -603,6 +603,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(hipMemcpyAsync(d_jump.p, &jt, sizeof jt, hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemsetAsync(d_cnt.p, 0, sizeof(Counters), stream));
         HIPCHK(hipMemsetAsync(d_rep.p, 0xFF, kRepTotal * sizeof(int), stream));
+        HIPCHK(hipMemsetAsync(d_rgcnt.p, 0, kRegions * sizeof(uint32_t), stream));
         HIPCHK(hipMemsetAsync(d_validmask.p, 0, (steps_max + 2) * vwords * sizeof(unsigned long long), stream));
         t_setup += now_s() - t0;
     }
@@ -820,24 +821,28 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     metrics.n_tie_fallbacks = hc.tie_fallbacks + ((hc.err & ERR_GPATH_OVERFLOW) ? 1 : 0);
     metrics.device_s = ms * 1e-3;
     if (prof) {
-        // events were recorded around nn_scan [0,1], reduce [1,2], radius_scan [2,3] of every step
+        // events were recorded around k_near [0,1] and the connect kernel [2,3] of every step
         std::vector<uint32_t> nat(b + 1);
         HIPCHK(hipMemcpy(nat.data(), d_nat.p, (b + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        double scan = 0, pairs = 0, bytes = 0;
+        double scan = 0, conn = 0, pairs = 0, bytes = 0;
         uint64_t launches = 0;
         uint64_t it = 0;
         for (uint32_t s = 0; s < b && (size_t)(4 * s + 3) < ev_used; ++s) {
             float a = 0, r2 = 0;
             (void)hipEventElapsedTime(&a, ev_pool[4 * s + 0], ev_pool[4 * s + 1]);
             (void)hipEventElapsedTime(&r2, ev_pool[4 * s + 2], ev_pool[4 * s + 3]);
-            scan += (a + r2) * 1e-3;
-            launches += 2;
+            scan += a * 1e-3;
+            conn += r2 * 1e-3;
+            launches += 1;
             uint64_t nbq = std::min<uint64_t>(K, (it < n_iter_min ? n_iter_min : n_iter_max) - it);
             it += nbq;
+            // what the two searches of the step answer: every (sample, node) pair of the NN and of the radius query
             pairs += 2.0 * (double)nbq * (double)nat[s];
-            bytes += 2.0 * (16.0 * (double)nat[s] + 28.0 * (double)nbq);
+            // algorithmic bytes of the searches: node x,y once per query kind, the samples, nn / state writes
+            bytes += 2.0 * 16.0 * (double)nat[s] + (16.0 + 20.0) * (double)nbq;
         }
         metrics.scan_s = scan;
+        metrics.connect_s = conn;
         metrics.scan_launches = launches;
         metrics.scan_pairs = pairs;
         metrics.scan_bytes = bytes;

@@ -36,7 +36,7 @@ class Metrics(C.Structure):
     _fields_ = [("n_iter", C.c_uint64), ("n_nodes", C.c_uint64), ("n_steps", C.c_uint64),
                 ("n_tie_fallbacks", C.c_uint64), ("total_s", C.c_double), ("setup_s", C.c_double),
                 ("device_s", C.c_double), ("scan_s", C.c_double), ("scan_launches", C.c_uint64),
-                ("scan_pairs", C.c_double), ("scan_bytes", C.c_double)]
+                ("scan_pairs", C.c_double), ("scan_bytes", C.c_double), ("connect_s", C.c_double)]
 
 
 class PorrtError(RuntimeError):
