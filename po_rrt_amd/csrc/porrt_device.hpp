@@ -46,6 +46,10 @@ struct __attribute__((aligned(8))) KdRec {
     int child[2];
 };
 
+struct __attribute__((aligned(32))) KdBox {
+    double lox, hix, loy, hiy;      // [lo, hi) per axis (nearest_neighbor.rs:32: `<` goes left, equal goes right)
+};
+
 struct Counters {
     uint32_t n_final;
     uint32_t n_edges;
@@ -57,6 +61,7 @@ struct Counters {
     uint32_t g_nd_len;          // non-duplicate levels of G
     uint32_t g_first_dup[2];    // first level of even / odd depth held by a duplicate of the goal point
     uint32_t n_pages;           // pool pages handed out (region pages)
+    uint32_t kd_long, kd_lev_max, kd_lev_sum, kd_long_lev_max, kd_none;   // diagnostics of k_kd_locate
 };
 
 struct RunConst {
@@ -88,15 +93,14 @@ struct RunConst {
     // per-sample step scratch
     double *q_x, *q_y;          // steered state
     double *kq_x, *kq_y;        // copy for the kd insertion (two step parities)
-    int *kq_vid;
+    int *kq_vid, *kq_nn;
     int *q_nn;
     int *q_vid;
-    unsigned long long *dbg;    // optional per-step phase stamps (diagnostic builds of the host only)
-    uint32_t *heavy_list;       // samples routed to the team connect kernel this step
-    uint32_t *cand_cnt;
-    int *cand_id;
+    uint32_t *cand_cnt;         // neighbour lists of the step: counts and ids are double-buffered by step parity
+    int *cand_id;               // (k_kd_locate reads them beside the next step's search), written by k_near only
     double *cand_val;
     uint32_t cand_cap;
+    uint32_t cand_K;            // samples per parity buffer
     // radius tables: T2[n] = largest d^2 whose sqrt rounds to <= heuristic_radius(n)
     const double *rad_T2;
     // edges (PTO)
@@ -105,6 +109,9 @@ struct RunConst {
     // kd-tree structure of the reference (RRT* tie order, see k_kd_insert): child ids (kEmpty = none),
     // parent id, depth, and where the node's root path leaves the goal path G (bit 31: the node is ON G)
     KdRec *kd_rec;              // packed {x, y, child[2]}: one load per level of a descent
+    KdBox *kd_box;              // the cell a node was inserted into: a point's root path passes the node iff it lies inside
+    KdBox *loc_box;             // per new node of the step: cell of the empty slot k_kd_locate stopped at
+    unsigned long long *kd_hint; // [kHG * kHG] (depth << 32 | id) of the deepest node whose cell covers the square
     int *kd_up;
     uint32_t *kd_depth;
     uint32_t *kd_gexit;
@@ -153,6 +160,13 @@ template <class T>
 __device__ __forceinline__ T g_atomic_min(GPTR(T) p, T v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ------------------------------------------------------------------ small helpers
+
+// neighbour list of sample k in step b (parity buffers)
+__device__ __forceinline__ size_t cand_off(const RunConst &rc, uint32_t b, uint32_t k) { return ((size_t)(b & 1u) * rc.cand_K + k) * rc.cand_cap; }
+__device__ __forceinline__ uint32_t cand_count(const RunConst &rc, uint32_t b, uint32_t k) {
+    const uint32_t c = rc.cand_cnt[(b & 1u) * rc.cand_K + k];
+    return c < rc.cand_cap ? c : rc.cand_cap;
+}
 __device__ __forceinline__ unsigned long long f64_bits(double d) { return (unsigned long long)__double_as_longlong(d); }
 
 // Rust `f64 as u32`: truncate toward zero, saturate, NaN -> 0
@@ -492,15 +506,35 @@ __device__ __forceinline__ double disc_radius(double bound_d2, double qx, double
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-// visit(x, y, id, ok): called by all 64 lanes for every page of every region meeting the box of the disc;
-// ok = this lane's slot holds a node.  q and rho are wave-uniform.
+// visit(x, y, id, ok): called by all 64 lanes together; ok = this lane holds a node.  Every node whose region
+// meets the box of the disc (q, rho) is visited exactly once.  q, rho and N (tree size) are wave-uniform.
+// Three ways to walk, chosen per query / per group of 64 regions by what costs fewer round trips:
+//   flat     the box covers so many regions that streaming the id-ordered arrays nx/ny is cheaper
+//   sparse   few nodes per region (young tree): lane <-> region, slot by slot
+//   pages    lane <-> slot, region after region (four pages in flight)
 template <class Visit>
-__device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double qy, double rho, uint32_t lane, Visit visit) {
+__device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double qy, double rho, uint32_t N, uint32_t lane, Visit visit) {
     int cx0, cy0, cx1, cy1;
     rep_cell(rc, qx - rho, qy - rho, kRG, cx0, cy0);
     rep_cell(rc, qx + rho, qy + rho, kRG, cx1, cy1);
     const uint32_t x0 = uni((uint32_t)cx0), y0 = uni((uint32_t)cy0);
     const uint32_t w = uni((uint32_t)(cx1 - cx0 + 1)), nreg = w * uni((uint32_t)(cy1 - cy0 + 1));
+    if (nreg * 16u > N) {
+        auto gx = as_global(rc.nx), gy = as_global(rc.ny);
+        for (uint32_t j0 = 0; j0 < N; j0 += 256u) {
+            double x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t j = j0 + 64u * u + lane;
+                x[u] = gx[j < N ? j : 0u];
+                y[u] = gy[j < N ? j : 0u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + 64u * u < N) visit(x[u], y[u], (int)(j0 + 64u * u + lane), j0 + 64u * u + lane < N);
+        }
+        return;
+    }
     auto gcnt = as_global(rc.rg_cnt);
     auto gdir = as_global(rc.rg_dir);
     auto gxy = as_global(reinterpret_cast<const dbl2 *>(rc.pg_xy));
@@ -512,6 +546,29 @@ __device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double 
             const uint32_t ry = r / w;
             reg = (y0 + ry) * kRG + x0 + (r - ry * w);
             cnt = gcnt[reg];
+        }
+        uint32_t cmax = cnt, npg = (cnt + kPage - 1) / kPage;
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = __shfl_xor(cmax, off);
+            cmax = o > cmax ? o : cmax;
+            npg += __shfl_xor(npg, off);
+        }
+        cmax = uni(cmax); npg = uni(npg);
+        if (cmax <= kPage && cmax < npg) {                   // sparse: own region, slots s .. s+3
+            for (uint32_t s0 = 0; s0 < cmax; s0 += 4) {
+                dbl2 v[4];
+                int id[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t sl = s0 + u < cnt ? s0 + u : 0u;
+                    v[u] = gxy[(size_t)reg * kPage + sl];
+                    id[u] = gid[(size_t)reg * kPage + sl];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (s0 + u < cmax) visit(v[u].x, v[u].y, id[u], s0 + u < cnt);
+            }
+            continue;
         }
         uint32_t page = reg;                                 // the first page of a region is static
         for (uint32_t j = 0;; ++j) {
@@ -566,7 +623,7 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
     {
         const double m = rc.q_bound[(b & 1u) * rc.part_stride + k];
         auto reach = as_global(rc.reachA);
-        scan_disc(rc, sqx, sqy, disc_radius(m, sqx, sqy), lane, [&](double x, double y, int id, bool ok) {
+        scan_disc(rc, sqx, sqy, disc_radius(m, sqx, sqy), N, lane, [&](double x, double y, int id, bool ok) {
             if (!ok) return;
             const double D = sqrt(dist2(x, y, sqx, sqy));        // the reference compares rounded distances
             bool pass = true;
@@ -605,7 +662,7 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
         rc.q_y[k] = ty;
         // copy for the kd insertion, which runs beside the next steps (double-buffered by step parity)
         const uint32_t o2 = (b & 1u) * rc.part_stride + k;
-        rc.kq_x[o2] = tx; rc.kq_y[o2] = ty; rc.kq_vid[o2] = valid ? vid : -1;
+        rc.kq_x[o2] = tx; rc.kq_y[o2] = ty; rc.kq_vid[o2] = valid ? vid : -1; rc.kq_nn[o2] = nn;
         rc.q_nn[k] = nn;
         rc.q_vid[k] = valid ? vid : -1;
         if (valid) atomicOr(&rc.valid_mask[(size_t)b * vwords + (k >> 6)], 1ull << (k & 63u));
@@ -614,11 +671,11 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
     if (!valid) return;
     // rrt.rs:121 uses the size before insertion, pto.rs:88 after it
     const double T2 = rc.rad_T2[N + (rc.mode == 1 ? 1u : 0u)];
-    auto cid = as_global(rc.cand_id) + (size_t)k * rc.cand_cap;
+    auto cid = as_global(rc.cand_id) + cand_off(rc, b, k);
     const uint32_t cap = rc.cand_cap;
     uint32_t tot = 0;
     bool over = false;
-    scan_disc(rc, tx, ty, disc_radius(T2, tx, ty), lane, [&](double x, double y, int id, bool ok) {
+    scan_disc(rc, tx, ty, disc_radius(T2, tx, ty), N, lane, [&](double x, double y, int id, bool ok) {
         const bool in = ok && dist2(x, y, tx, ty) <= T2;
         const unsigned long long hm = __ballot(in);
         const uint32_t pos = tot + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
@@ -628,7 +685,7 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
         }
         tot += (uint32_t)__popcll(hm);
     });
-    if (lane == 0) rc.cand_cnt[k] = tot;
+    if (lane == 0) rc.cand_cnt[(b & 1u) * rc.cand_K + k] = tot;
     if (over) atomicOr(&rc.cnt->err, (uint32_t)ERR_CAND_OVERFLOW);
 }
 
@@ -842,7 +899,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     const uint32_t N = rc.n_at[b];
     const uint32_t id = N + rank_before(rc, b, vwords, k);
     const double px = rc.q_x[k], py = rc.q_y[k];
-    auto cid = as_global(rc.cand_id) + (size_t)k * rc.cand_cap;
+    auto cid = as_global(rc.cand_id) + cand_off(rc, b, k);            // read-only here
     auto cval = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
     auto gnx = as_global(rc.nx), gny = as_global(rc.ny), gdA = as_global(rc.distA);
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
@@ -926,30 +983,28 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     // rewire phase 1 (rrt.rs:152-161): dist_root candidates, min wins
     auto gdB = as_global(reinterpret_cast<unsigned long long *>(rc.distB));
     if (j0 >= 0) {
-        int keep = -1;
+        double out = -1.0;                  // cand_val after this pass: the candidate dist_root of a rewire, or < 0
         if (nvalid != 0 && cost0 >= 0.0 && j0 != best) {
             const double via = dnew + cost0;
             if (via < dA0) {
                 g_atomic_min(gdB + j0, f64_bits(via));
-                cval[tl] = via;
-                keep = j0;
+                out = via;
             }
         }
-        cid[tl] = keep;
+        cval[tl] = out;
     }
     for (uint32_t a = tl + TS; a < cnt; a += TS) {
         const double cost = cval[a];
         const int j = cid[a];
-        int keep = -1;
+        double out = -1.0;
         if (nvalid != 0 && cost >= 0.0 && j != best) {
             const double via = dnew + cost;
             if (via < gdA[j]) {
                 g_atomic_min(gdB + j, f64_bits(via));
-                cval[a] = via;
-                keep = j;
+                out = via;
             }
         }
-        cid[a] = keep;
+        cval[a] = out;
     }
 }
 
@@ -970,7 +1025,7 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunCon
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t k = blockIdx.x * kConnectWaves + wv;
     const bool active = k < nb && rc.q_vid[k < nb ? k : 0] >= 0;
-    const uint32_t cnt = active ? (rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap) : 0u;
+    const uint32_t cnt = active ? cand_count(rc, b, k) : 0u;
     const bool heavy = active && cnt > kHeavyCand;
     if (lane == 0) s_heavy[wv] = heavy ? cnt : 0u;
     const uint32_t TW = 2u * rc.tile_R + 1u;
@@ -1030,13 +1085,13 @@ __global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__
     }
     if (k >= nb || rc.q_vid[k] < 0) return;
     const int id = (int)(N + rank_before(rc, b, vwords, k));
-    const uint32_t cnt = rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap;
-    const int *cid = rc.cand_id + (size_t)k * rc.cand_cap;
+    const uint32_t cnt = cand_count(rc, b, k);
+    const int *cid = rc.cand_id + cand_off(rc, b, k);
     const double *cval = rc.cand_val + (size_t)k * rc.cand_cap;
     for (uint32_t a = lane; a < cnt; a += 64) {
-        const int j = cid[a];
-        if (j < 0) continue;
         const double via = cval[a];
+        if (!(via >= 0.0)) continue;
+        const int j = cid[a];
         if (f64_bits(via) != f64_bits(rc.distB[j])) continue;
         int old = rc.parent[j];
         while (old < (int)N || id < old) {      // parents from before this step are always < N
@@ -1049,33 +1104,43 @@ __global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__
 }
 
 // Insert this step's nodes into the reference's kd-tree in id order (KdTree::add, nearest_neighbor.rs:29-46;
-// rrt.rs:163) -- only the STRUCTURE is kept (child / parent / depth), searches stay brute force.  It exists to
+// rrt.rs:163) -- only the STRUCTURE is kept (child / parent / depth / cell), searches never use it.  It exists to
 // reproduce the order in which the reference resolves equal-cost parents (kd pre-order).  Two kernels:
-//   k_kd_locate  one thread per new node, spread over many CUs: descend the tree as it stood before the step
-//                down to an empty slot.  The part of the descent that runs along the goal path G (the path of
-//                the point every 100th iteration re-adds: one exact duplicate deeper each time, thousands of
-//                levels late in a run) is not walked: duplicate levels collapse to two comparisons and only the
-//                few non-duplicate levels are tested (see the kernel).
+//   k_kd_locate  one wave per new node: find the empty slot of the tree as it stood before the step.  The descent
+//                does not start at the root: a point's root path passes a node iff the point lies in the cell the
+//                node was inserted into (kd_box), so it starts at the deepest node whose cell covers the whole
+//                square of a 128 x 128 hint grid the point falls into (kd_hint) -- a few levels above the slot
+//                however deep and lopsided the tree is (RRT insertion order gives depths of 100+).  Only when that node lies
+//                on the goal path G (the path of the point every 100th iteration re-adds: one exact duplicate deeper
+//                each time, thousands of levels late in a run) is the exit from G computed the long way: duplicate
+//                levels collapse to two comparisons, only the non-duplicate levels are tested.
+//   k_kd_hint    one wave per new node: raise the hint of every grid square its cell covers completely
 //   k_kd_claim   one workgroup: nodes that reached the same empty slot are ordered by rounds -- the lowest id
 //                takes the slot (atomicMin), the others step below it.  Contenders of one slot always arrive in
 //                the same round because they share the whole path above it, so this equals sequential insertion.
 enum : uint32_t { LOC_SIDE = 1u, LOC_ONPATH = 2u };
+constexpr int kHG = 128;             // hint grid squares per axis
 
-constexpr int kKdTop = 2048;         // oldest nodes = top of the tree (ids grow downwards): staged in LDS by k_kd_locate
+__device__ __forceinline__ bool box_holds(const KdBox &bx, double x, double y) {
+    return bx.lox <= x && x < bx.hix && bx.loy <= y && y < bx.hiy;
+}
+// cell of the child slot `side` of a node at (wx, wy), depth d, whose own cell is bx
+__device__ __forceinline__ void box_cut(KdBox &bx, double wx, double wy, uint32_t depth, uint32_t side) {
+    if (depth & 1u) { if (side) bx.loy = wy; else bx.hiy = wy; }
+    else { if (side) bx.lox = wx; else bx.hix = wx; }
+}
 
-// descend from node `cur` (depth dcur, taking `side`) to an empty slot of the old tree.  Records of the kKdTop
-// oldest nodes come from the LDS copy `top` (a descent spends ~2 ln(kKdTop) of its ~2 ln(N) levels there).
-__device__ __forceinline__ void kd_descend(const RunConst &rc, const KdRec *top, uint32_t n_top, double vx, double vy, int &cur,
-                                           uint32_t &dcur, uint32_t &side) {
+// descend from node `cur` (depth dcur, cell bx, taking `side`) to an empty slot of the old tree; on return bx is
+// the cell of that slot.  One dependent 24-byte load per level.
+__device__ __forceinline__ void kd_descend(const RunConst &rc, double vx, double vy, int &cur, uint32_t &dcur, uint32_t &side, KdBox &bx) {
     auto grec = as_global(rc.kd_rec);
     KdRec rec;
-    if ((uint32_t)cur < n_top) rec = top[cur];
-    else { rec.x = grec[cur].x; rec.y = grec[cur].y; rec.child[0] = grec[cur].child[0]; rec.child[1] = grec[cur].child[1]; }
-    for (;;) {                          // one dependent 24-byte load per level
+    rec.x = grec[cur].x; rec.y = grec[cur].y; rec.child[0] = grec[cur].child[0]; rec.child[1] = grec[cur].child[1];
+    for (;;) {
+        box_cut(bx, rec.x, rec.y, dcur, side);
         const int c = side ? rec.child[1] : rec.child[0];
         if (c == kEmpty) break;
-        if ((uint32_t)c < n_top) rec = top[c];
-        else { rec.x = grec[c].x; rec.y = grec[c].y; rec.child[0] = grec[c].child[0]; rec.child[1] = grec[c].child[1]; }
+        rec.x = grec[c].x; rec.y = grec[c].y; rec.child[0] = grec[c].child[0]; rec.child[1] = grec[c].child[1];
         cur = c;
         dcur += 1;
         side = kd_left(vx, vy, rec.x, rec.y, dcur) ? 0u : 1u;
@@ -1084,85 +1149,96 @@ __device__ __forceinline__ void kd_descend(const RunConst &rc, const KdRec *top,
 
 __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
     const RunConst &rc = *rcp;
-    const uint32_t N = rc.n_at[b];
-    const uint32_t glen0 = __builtin_amdgcn_readfirstlane(rc.cnt->g_len);
-    const uint32_t n_nd = __builtin_amdgcn_readfirstlane(rc.cnt->g_nd_len);
-    const bool dbgt = rc.dbg && blockIdx.x == 0 && threadIdx.x == 0;
-    if (dbgt) rc.dbg[b * 8 + 1] = wall_clock64();
-    __shared__ __attribute__((aligned(16))) KdRec s_top[kKdTop];
-    const uint32_t n_top = N < (uint32_t)kKdTop ? N : (uint32_t)kKdTop;
-    constexpr uint32_t kNdLds = 1024;
-    __shared__ double s_ndx[kNdLds], s_ndy[kNdLds];
-    __shared__ uint32_t s_ndi[kNdLds];
-    {
-        // 24-byte records as 16-byte words, eight loads in flight per lane; then the non-duplicate G levels
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        auto src = reinterpret_cast<GPTR(const u32x4)>(as_global(rc.kd_rec));
-        u32x4 *dst = reinterpret_cast<u32x4 *>(s_top);
-        const uint32_t nw = (n_top * 24u + 15u) / 16u;
-        for (uint32_t w0 = threadIdx.x; w0 < nw; w0 += 8u * 256u) {
-            u32x4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const uint32_t w = w0 + u * 256u; v[u] = src[w < nw ? w : 0u]; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const uint32_t w = w0 + u * 256u; if (w < nw) dst[w] = v[u]; }
-        }
-        for (uint32_t t2 = threadIdx.x; t2 < n_nd && t2 < kNdLds; t2 += 256u) {
-            s_ndi[t2] = rc.g_nd[t2]; s_ndx[t2] = rc.g_nd_x[t2]; s_ndy[t2] = rc.g_nd_y[t2];
-        }
-    }
-    __syncthreads();
-    if (dbgt) rc.dbg[b * 8 + 7] = wall_clock64();
-    // The step's new nodes are the valid samples (positions known since k_nn_reduce_steer), id = N + rank: this
-    // kernel runs beside the step's radius scan and connect.
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t o2 = (b & 1u) * rc.part_stride + (k < nb ? k : 0u);
-    if (k >= nb || rc.kq_vid[o2] < 0) return;
-    const uint32_t t = rank_before(rc, b, vwords, k);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (k >= nb) return;
+    // The step's new nodes are the valid samples (positions known since k_near), id = N + rank: this kernel runs
+    // beside the step's connect and commit.
+    const uint32_t o2 = (b & 1u) * rc.part_stride + k;
+    if (rc.kq_vid[o2] < 0) return;
+    const uint32_t N = uni(rc.n_at[b]);
+    const uint32_t t = uni(rank_before(rc, b, vwords, k));
     const double px = rc.gp_x, py = rc.gp_y;
     const double vx = rc.kq_x[o2], vy = rc.kq_y[o2];
-    {   // the node's kd record exists from here on (k_kd_claim only links it)
+    if (lane == 0) {   // the node's kd record exists from here on (k_kd_claim only links it)
         KdRec rec;
         rec.x = vx; rec.y = vy; rec.child[0] = kEmpty; rec.child[1] = kEmpty;
         rc.kd_rec[N + t] = rec;
     }
-    // Where does this node's descent leave the goal path G?  At the first level whose test it fails.  A level
-    // held by an exact duplicate of the goal point tests `x < p.x` (even depth) or `y < p.y` (odd depth), and
-    // the goal point itself always goes right there, so all duplicate levels reduce to two comparisons against
-    // the first duplicate of each parity; only the few non-duplicate levels (g_nd*) are real tests.
-    uint32_t E = 0xFFFFFFFFu;
-    bool leftE = false;
-    for (uint32_t s0 = 0; s0 < n_nd; ++s0) {
-        uint32_t ii;
-        double wx, wy;
-        if (s0 < kNdLds) { ii = s_ndi[s0]; wx = s_ndx[s0]; wy = s_ndy[s0]; }
-        else { ii = rc.g_nd[s0]; wx = rc.g_nd_x[s0]; wy = rc.g_nd_y[s0]; }
-        const bool gl = kd_left(px, py, wx, wy, ii), vl = kd_left(vx, vy, wx, wy, ii);
-        if (vl != gl && ii < E) { E = ii; leftE = vl; }
+    // start of the descent: the deepest node whose cell covers the point's whole hint-grid square (k_kd_hint)
+    int bd = -1, bu = -1;
+    {
+        int hx, hy;
+        rep_cell(rc, vx, vy, kHG, hx, hy);
+        const unsigned long long hv = rc.kd_hint[hy * kHG + hx];
+        bu = (int)(uint32_t)hv;
+        bd = (int)(uint32_t)(hv >> 32);
+        if (!box_holds(rc.kd_box[bu], vx, vy)) bu = -1;     // cannot happen (see k_kd_hint); the long way is always right
     }
-    if (dbgt) rc.dbg[b * 8 + 5] = wall_clock64();
-    const uint32_t d0 = rc.cnt->g_first_dup[0], d1 = rc.cnt->g_first_dup[1];
-    if (vx < px && d0 < E) { E = d0; leftE = true; }
-    if (vy < py && d1 < E) { E = d1; leftE = true; }
     int cur;
     uint32_t dcur, side, gex = 0, flags = 0;
-    if (E == 0xFFFFFFFFu) {             // on G to its end: below the last node, on the goal point's side
-        dcur = glen0 - 1;
-        cur = rc.g_id[dcur];
-        side = kd_left(px, py, rc.g_x[dcur], rc.g_y[dcur], dcur) ? 0u : 1u;
-        flags = LOC_ONPATH;
-    } else {
-        dcur = E;
-        gex = E;
-        cur = rc.g_id[E];
-        side = leftE ? 0u : 1u;
-        kd_descend(rc, s_top, n_top, vx, vy, cur, dcur, side);
+    KdBox bx;
+    bool long_way = bu < 0;
+    if (!long_way) {
+        const uint32_t ge = rc.kd_gexit[bu];
+        if (ge & kOnG) long_way = true;
+        else {
+            cur = bu; dcur = (uint32_t)bd; gex = ge;
+            bx = rc.kd_box[bu];
+            side = kd_left(vx, vy, rc.kd_rec[bu].x, rc.kd_rec[bu].y, dcur) ? 0u : 1u;
+            kd_descend(rc, vx, vy, cur, dcur, side, bx);
+        }
     }
-    rc.loc_cur[t] = cur;
-    rc.loc_dcur[t] = dcur;
-    rc.loc_gex[t] = gex;
-    rc.loc_flags[t] = flags | (side ? LOC_SIDE : 0u);
-    if (dbgt) { rc.dbg[b * 8 + 4] = wall_clock64(); rc.dbg[b * 8 + 6] = dcur; }
+    if (long_way) {
+        // Where does this node's descent leave the goal path G?  At the first level whose test it fails.  A level
+        // held by an exact duplicate of the goal point tests `x < p.x` (even depth) or `y < p.y` (odd depth), and
+        // the goal point itself always goes right there, so all duplicate levels reduce to two comparisons against
+        // the first duplicate of each parity; only the few non-duplicate levels (g_nd*) are real tests.
+        const uint32_t glen0 = uni(rc.cnt->g_len), n_nd = uni(rc.cnt->g_nd_len);
+        uint32_t E = 0xFFFFFFFFu, leftE = 0;
+        for (uint32_t s0 = lane; s0 < n_nd; s0 += 64u) {
+            const uint32_t ii = rc.g_nd[s0];
+            const double wx = rc.g_nd_x[s0], wy = rc.g_nd_y[s0];
+            const bool gl = kd_left(px, py, wx, wy, ii), vl = kd_left(vx, vy, wx, wy, ii);
+            if (vl != gl && ii < E) { E = ii; leftE = vl ? 1u : 0u; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t oe = __shfl_xor(E, off), ol = __shfl_xor(leftE, off);
+            if (oe < E) { E = oe; leftE = ol; }
+        }
+        const uint32_t d0 = rc.cnt->g_first_dup[0], d1 = rc.cnt->g_first_dup[1];
+        if (vx < px && d0 < E) { E = d0; leftE = 1u; }
+        if (vy < py && d1 < E) { E = d1; leftE = 1u; }
+        if (E == 0xFFFFFFFFu) {             // on G to its end: below the last node, on the goal point's side
+            dcur = glen0 - 1;
+            cur = rc.g_id[dcur];
+            side = kd_left(px, py, rc.g_x[dcur], rc.g_y[dcur], dcur) ? 0u : 1u;
+            flags = LOC_ONPATH;
+            bx = rc.kd_box[cur];
+            box_cut(bx, rc.g_x[dcur], rc.g_y[dcur], dcur, side);
+        } else {
+            dcur = E;
+            gex = E;
+            cur = rc.g_id[E];
+            side = leftE ? 0u : 1u;
+            bx = rc.kd_box[cur];
+            kd_descend(rc, vx, vy, cur, dcur, side, bx);
+        }
+    }
+    if (lane == 0) {
+        {   // diagnostics
+            const uint32_t start_d = long_way ? (gex ? gex : 0u) : (uint32_t)bd;
+            const uint32_t lev = dcur - (flags ? dcur : start_d);
+            atomicAdd(&rc.cnt->kd_lev_sum, lev);
+            atomicMax(&rc.cnt->kd_lev_max, lev);
+            if (long_way) { atomicAdd(&rc.cnt->kd_long, 1u); atomicMax(&rc.cnt->kd_long_lev_max, lev); if (bu < 0) atomicAdd(&rc.cnt->kd_none, 1u); }
+        }
+        rc.loc_cur[t] = cur;
+        rc.loc_dcur[t] = dcur;
+        rc.loc_gex[t] = gex;
+        rc.loc_flags[t] = flags | (side ? LOC_SIDE : 0u);
+        rc.loc_box[t] = bx;
+    }
 }
 
 // One workgroup; a thread owns up to kPer nodes (batch_K <= 4096).
@@ -1171,15 +1247,13 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
     const uint32_t N = rc.n_at[b];
     uint32_t n_new = 0;
     for (uint32_t w = 0; w < vwords; ++w) n_new += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
-    const uint32_t glen0 = __builtin_amdgcn_readfirstlane(rc.cnt->g_len);
     const double px = rc.gp_x, py = rc.gp_y;
-    if (rc.dbg && threadIdx.x == 0) rc.dbg[b * 8 + 0] = wall_clock64();
-    if (rc.dbg && threadIdx.x == 0) rc.dbg[b * 8 + 2] = wall_clock64();
     constexpr int kPer = 4;
     bool todo[kPer], onpath[kPer];
     double vx[kPer], vy[kPer];
     int vidn[kPer], cur[kPer];
     uint32_t side[kPer], dcur[kPer], gex[kPer];
+    KdBox box[kPer];
 #pragma unroll
     for (int r = 0; r < kPer; ++r) {
         const uint32_t t = threadIdx.x + r * 1024u;
@@ -1191,14 +1265,13 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
         cur[r] = rc.loc_cur[tt];
         dcur[r] = rc.loc_dcur[tt];
         gex[r] = rc.loc_gex[tt];
+        box[r] = rc.loc_box[tt];
         vidn[r] = todo[r] ? (int)(N + t) : kEmpty;
         vx[r] = todo[r] ? rc.kd_rec[N + tt].x : 0.0;
         vy[r] = todo[r] ? rc.kd_rec[N + tt].y : 0.0;
     }
-    uint32_t rounds = 0;
     // claim rounds
     for (;;) {
-        ++rounds;
         bool any = false;
 #pragma unroll
         for (int r = 0; r < kPer; ++r) {
@@ -1213,6 +1286,7 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
             if (w == vidn[r]) {
                 rc.kd_up[w] = cur[r];
                 rc.kd_depth[w] = dw;
+                rc.kd_box[w] = box[r];
                 if (onpath[r]) {
                     if (dw + 8 < rc.g_cap) { rc.g_id[dw] = w; rc.g_x[dw] = vx[r]; rc.g_y[dw] = vy[r]; }
                     else atomicOr(&rc.cnt->err, ERR_GPATH_OVERFLOW);
@@ -1233,11 +1307,40 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
                 const bool vl = kd_left(vx[r], vy[r], wx, wy, dw);
                 if (onpath[r] && vl != kd_left(px, py, wx, wy, dw)) { onpath[r] = false; gex[r] = dw; }
                 cur[r] = w; dcur[r] = dw; side[r] = vl ? 0u : 1u;
+                box_cut(box[r], wx, wy, dw, side[r]);
             }
         }
         __syncthreads();
     }
-    if (rc.dbg && threadIdx.x == 0) rc.dbg[b * 8 + 3] = wall_clock64() | ((unsigned long long)rounds << 56);
+}
+
+// After k_kd_claim: a new node whose cell covers a hint-grid square completely is an ancestor of every point that
+// will ever fall into that square; the deepest such node is the best place to start a descent.  The squares between
+// cell(lo) and cell(hi), both excluded, lie inside [lo, hi) because the cell function is monotone; an infinite
+// bound includes the clamped border square.  hint = max over (depth, id), a commutative update.
+__global__ __launch_bounds__(256) void k_kd_hint(const RunConst *__restrict__ rcp, uint32_t b, uint32_t vwords) {
+    const RunConst &rc = *rcp;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t n_new = 0;
+    for (uint32_t w = 0; w < vwords; ++w) n_new += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
+    if (t >= n_new) return;
+    const uint32_t id = rc.n_at[b] + t;
+    const KdBox bx = rc.kd_box[id];
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    int lx, ly, ux, uy;
+    rep_cell(rc, bx.lox, bx.loy, kHG, lx, ly);
+    rep_cell(rc, bx.hix, bx.hiy, kHG, ux, uy);
+    const int ix0 = bx.lox == -INF ? 0 : lx + 1, ix1 = bx.hix == INF ? kHG - 1 : ux - 1;
+    const int iy0 = bx.loy == -INF ? 0 : ly + 1, iy1 = bx.hiy == INF ? kHG - 1 : uy - 1;
+    if (ix0 > ix1 || iy0 > iy1) return;
+    const uint32_t w = (uint32_t)(ix1 - ix0 + 1), n = w * (uint32_t)(iy1 - iy0 + 1);
+    const unsigned long long val = ((unsigned long long)rc.kd_depth[id] << 32) | id;
+    auto gh = as_global(rc.kd_hint);
+    for (uint32_t i = lane; i < n; i += 64u) {
+        const uint32_t ry = i / w;
+        __hip_atomic_fetch_max(gh + (size_t)(iy0 + (int)ry) * kHG + ix0 + (int)(i - ry * w), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // PTO: edges to every neighbour with a valid transition, reachability phase 1 and 2 (pto.rs:95-124)
@@ -1263,11 +1366,11 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
     }
     const uint32_t N = rc.n_at[b];
     const uint32_t id = N + rank_before(rc, b, vwords, k);
-    uint32_t cnt = rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap;
-    int *cid = rc.cand_id + (size_t)k * rc.cand_cap;
+    uint32_t cnt = cand_count(rc, b, k);
+    int *cid = rc.cand_id + cand_off(rc, b, k);
     double *cval = rc.cand_val + (size_t)k * rc.cand_cap;
     if (cnt == 0) {                       // pto.rs:99: nobody in range -> the nearest node
-        if (lane == 0) { cid[0] = rc.q_nn[k]; rc.cand_cnt[k] = 1; }   // lane 0 is also the only reader of slot 0
+        if (lane == 0) { cid[0] = rc.q_nn[k]; rc.cand_cnt[(b & 1u) * rc.cand_K + k] = 1; }   // lane 0 is also the only reader of slot 0
         cnt = 1;
     }
     uint32_t err = 0;
@@ -1344,8 +1447,8 @@ __global__ __launch_bounds__(256) void k_commit_pto(const RunConst *__restrict__
         rc.n_at[b + 1] = N + add;
     }
     if (k >= nb || rc.q_vid[k] < 0) return;
-    const uint32_t cnt = rc.cand_cnt[k] < rc.cand_cap ? rc.cand_cnt[k] : rc.cand_cap;
-    const int *cid = rc.cand_id + (size_t)k * rc.cand_cap;
+    const uint32_t cnt = cand_count(rc, b, k);
+    const int *cid = rc.cand_id + cand_off(rc, b, k);
     const double *cval = rc.cand_val + (size_t)k * rc.cand_cap;
     for (uint32_t a = lane; a < cnt; a += 64) {
         if ((int)cval[a] < 0) continue;

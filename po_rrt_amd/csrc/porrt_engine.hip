@@ -162,17 +162,17 @@ struct porrt_ctx {
     DevBuf<double> d_nx, d_ny, d_distA, d_distB, d_sx, d_sy, d_qx, d_qy, d_qbound, d_pgxy, d_candval, d_radT2, d_inj;
     DevBuf<int> d_parent, d_qnn, d_qvid, d_pgid, d_candid, d_gid, d_kdup;
     DevBuf<KdRec> d_kdrec;
+    DevBuf<KdBox> d_kdbox, d_locbox;
     DevBuf<int> d_loccur;
     DevBuf<uint32_t> d_locdcur, d_locgex, d_locflags, d_kdsurv;
     DevBuf<double> d_gx, d_gy, d_gndx, d_gndy, d_kqx, d_kqy;
-    DevBuf<int> d_kqvid;
+    DevBuf<int> d_kqvid, d_kqnn;
     DevBuf<uint32_t> d_rgcnt, d_rgdir;
     DevBuf<int> d_rep;
-    DevBuf<unsigned long long> d_dbg;
     DevBuf<uint32_t> d_kddepth, d_kdgexit;
-    DevBuf<unsigned long long> d_reachA, d_reachB, d_finalmask, d_validmask;
+    DevBuf<unsigned long long> d_reachA, d_reachB, d_finalmask, d_validmask, d_kdhint;
     DevBuf<uint8_t> d_vid, d_finalflag, d_cls;
-    DevBuf<uint32_t> d_nat, d_sworld, d_candcnt, d_efrom, d_eto, d_etv, d_heavy;
+    DevBuf<uint32_t> d_nat, d_sworld, d_candcnt, d_efrom, d_eto, d_etv;
     DevBuf<Counters> d_cnt;
     DevBuf<RunConst> d_rc;
     DevBuf<PcgJump> d_jump;
@@ -231,9 +231,9 @@ int porrt_ctx::layout_buffers() {
     if (all_bufs.empty()) {
         DevBufBase *list[] = {&d_nx, &d_ny, &d_distA, &d_distB, &d_sx, &d_sy, &d_qx, &d_qy, &d_qbound, &d_pgxy, &d_candval, &d_radT2, &d_inj,
                               &d_parent, &d_qnn, &d_qvid, &d_pgid, &d_candid, &d_gid, &d_kdup, &d_kdrec, &d_gx, &d_gy, &d_rgcnt,
-                              &d_rgdir, &d_rep, &d_dbg, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB,
+                              &d_rgdir, &d_rep, &d_kdbox, &d_locbox, &d_kqnn, &d_kdhint, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB,
                               &d_finalmask, &d_validmask, &d_vid, &d_finalflag, &d_cls, &d_nat, &d_sworld, &d_candcnt, &d_efrom,
-                              &d_eto, &d_etv, &d_heavy, &d_cnt, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags, &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid};
+                              &d_eto, &d_etv, &d_cnt, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags, &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid};
         for (DevBufBase *b2 : list) all_bufs.push_back(b2);
     }
     bool grow_needed = false;
@@ -261,12 +261,12 @@ int porrt_ctx::layout_buffers() {
     d_candid.p = (int *)d_candid.vp; d_gid.p = (int *)d_gid.vp; d_kdup.p = (int *)d_kdup.vp; d_kdrec.p = (KdRec *)d_kdrec.vp;
     d_gx.p = (double *)d_gx.vp; d_gy.p = (double *)d_gy.vp; d_rgcnt.p = (uint32_t *)d_rgcnt.vp; d_rgdir.p = (uint32_t *)d_rgdir.vp;
     d_rep.p = (int *)d_rep.vp;
-    d_dbg.p = (unsigned long long *)d_dbg.vp; d_kddepth.p = (uint32_t *)d_kddepth.vp; d_kdgexit.p = (uint32_t *)d_kdgexit.vp;
+    d_kdbox.p = (KdBox *)d_kdbox.vp; d_locbox.p = (KdBox *)d_locbox.vp; d_kqnn.p = (int *)d_kqnn.vp; d_kdhint.p = (unsigned long long *)d_kdhint.vp; d_kddepth.p = (uint32_t *)d_kddepth.vp; d_kdgexit.p = (uint32_t *)d_kdgexit.vp;
     d_reachA.p = (unsigned long long *)d_reachA.vp; d_reachB.p = (unsigned long long *)d_reachB.vp;
     d_finalmask.p = (unsigned long long *)d_finalmask.vp; d_validmask.p = (unsigned long long *)d_validmask.vp;
     d_vid.p = (uint8_t *)d_vid.vp; d_finalflag.p = (uint8_t *)d_finalflag.vp; d_cls.p = (uint8_t *)d_cls.vp;
     d_nat.p = (uint32_t *)d_nat.vp; d_sworld.p = (uint32_t *)d_sworld.vp; d_candcnt.p = (uint32_t *)d_candcnt.vp;
-    d_efrom.p = (uint32_t *)d_efrom.vp; d_eto.p = (uint32_t *)d_eto.vp; d_etv.p = (uint32_t *)d_etv.vp; d_heavy.p = (uint32_t *)d_heavy.vp;
+    d_efrom.p = (uint32_t *)d_efrom.vp; d_eto.p = (uint32_t *)d_eto.vp; d_etv.p = (uint32_t *)d_etv.vp;
     d_loccur.p = (int *)d_loccur.vp; d_locdcur.p = (uint32_t *)d_locdcur.vp; d_locgex.p = (uint32_t *)d_locgex.vp;
     d_locflags.p = (uint32_t *)d_locflags.vp; d_kdsurv.p = (uint32_t *)d_kdsurv.vp;
     d_gndx.p = (double *)d_gndx.vp; d_gndy.p = (double *)d_gndy.vp;
@@ -380,6 +380,12 @@ __global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y
     rc.g_x[0] = x;
     rc.g_y[0] = y;
     rc.kd_up[0] = -1;
+    {
+        const double INF = __longlong_as_double(0x7FF0000000000000ll);
+        KdBox bx;
+        bx.lox = -INF; bx.hix = INF; bx.loy = -INF; bx.hiy = INF;
+        rc.kd_box[0] = bx;
+    }
     rc.kd_depth[0] = 0;
     rc.kd_gexit[0] = kOnG;
 }
@@ -422,8 +428,9 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     // connect, commit and the next step's search) and join the previous step's.
     (void)hipEventRecord(ev_steered, stream);
     (void)hipStreamWaitEvent(stream2, ev_steered, 0);
-    hipLaunchKernelGGL(k_kd_locate, dim3((nb + 255) / 256), dim3(256), 0, stream2, rcp, b, nb, vwords);
+    hipLaunchKernelGGL(k_kd_locate, dim3(wave_blocks), dim3(256), 0, stream2, rcp, b, nb, vwords);
     hipLaunchKernelGGL(k_kd_claim, dim3(1), dim3(1024), 0, stream2, rcp, b, vwords);
+    hipLaunchKernelGGL(k_kd_hint, dim3(wave_blocks), dim3(256), 0, stream2, rcp, b, vwords);
     (void)hipEventRecord(ev_kd[b & 1u], stream2);
     kd_pend[b & 1u] = true;
     if (kd_pend[(b + 1u) & 1u]) { (void)hipStreamWaitEvent(stream, ev_kd[(b + 1u) & 1u], 0); kd_pend[(b + 1u) & 1u] = false; }
@@ -495,9 +502,9 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         const uint64_t rg_maxp = Nmax / kPage + 2, pg_cap = 2ull * kRegions + Nmax / kPage + 8;
         HIPCHK(d_rgcnt.reserve(kRegions)); HIPCHK(d_rgdir.reserve((size_t)kRegions * rg_maxp));
         HIPCHK(d_pgxy.reserve(2 * (size_t)pg_cap * kPage)); HIPCHK(d_pgid.reserve((size_t)pg_cap * kPage)); HIPCHK(d_qbound.reserve(2 * (size_t)Kpad));
-        HIPCHK(d_candcnt.reserve(K)); HIPCHK(d_heavy.reserve(K));
+        HIPCHK(d_candcnt.reserve(2 * (size_t)K)); HIPCHK(d_kdbox.reserve(Nmax)); HIPCHK(d_locbox.reserve(K)); HIPCHK(d_kqnn.reserve(2 * (size_t)Kpad)); HIPCHK(d_kdhint.reserve((size_t)kHG * kHG));
         HIPCHK(d_loccur.reserve(K)); HIPCHK(d_locdcur.reserve(K)); HIPCHK(d_locgex.reserve(K)); HIPCHK(d_locflags.reserve(K)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_gndx.reserve(Nmax)); HIPCHK(d_gndy.reserve(Nmax));
-        HIPCHK(d_kqx.reserve(2 * (size_t)Kpad)); HIPCHK(d_kqy.reserve(2 * (size_t)Kpad)); HIPCHK(d_kqvid.reserve(2 * (size_t)Kpad)); HIPCHK(d_candid.reserve((size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
+        HIPCHK(d_kqx.reserve(2 * (size_t)Kpad)); HIPCHK(d_kqy.reserve(2 * (size_t)Kpad)); HIPCHK(d_kqvid.reserve(2 * (size_t)Kpad)); HIPCHK(d_candid.reserve(2 * (size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
         HIPCHK(d_gid.reserve(Nmax));
         HIPCHK(d_rep.reserve(kRepTotal));
         HIPCHK(d_kdrec.reserve(Nmax)); HIPCHK(d_gx.reserve(Nmax + 16)); HIPCHK(d_gy.reserve(Nmax + 16)); HIPCHK(d_kdup.reserve(Nmax)); HIPCHK(d_kddepth.reserve(Nmax)); HIPCHK(d_kdgexit.reserve(Nmax));
@@ -509,7 +516,6 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         }
         if (has_grid) HIPCHK(d_cls.reserve((size_t)W * H + 16));
         if (has_inj) HIPCHK(d_inj.reserve(inj_xy.size() + 2));
-        HIPCHK(d_dbg.reserve((steps_max + 2) * 8));
         int r = layout_buffers();
         if (r) return r;
         r = build_cls();
@@ -533,8 +539,8 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.q_x = d_qx.p; c.q_y = d_qy.p; c.q_nn = d_qnn.p; c.q_vid = d_qvid.p;
     c.q_bound = d_qbound.p; c.rg_cnt = d_rgcnt.p; c.rg_dir = d_rgdir.p; c.pg_xy = d_pgxy.p; c.pg_id = d_pgid.p;
     c.rg_maxp = (uint32_t)(Nmax / kPage + 2); c.pg_cap = (uint32_t)(2ull * kRegions + Nmax / kPage + 8);
-    c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p;
-    c.heavy_list = d_heavy.p; c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
+    c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p; c.kq_nn = d_kqnn.p; c.kd_box = d_kdbox.p; c.loc_box = d_locbox.p; c.kd_hint = d_kdhint.p;
+    c.cand_K = K; c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
     c.rad_T2 = d_radT2.p;
     c.e_from = d_efrom.p; c.e_to = d_eto.p; c.e_tv = d_etv.p; c.e_cap = (uint32_t)d_efrom.n;
     c.rep = d_rep.p;
@@ -547,7 +553,6 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         for (int z = 0; z < n_zones; ++z) { x0 = std::min(x0, zone_pos[z][0]); x1 = std::max(x1, zone_pos[z][0]); y0 = std::min(y0, zone_pos[z][1]); y1 = std::max(y1, zone_pos[z][1]); }
         c.bx0 = x0; c.by0 = y0; c.binv_w = 1.0 / (x1 - x0); c.binv_h = 1.0 / (y1 - y0);
     }
-    if (getenv("PORRT_DEBUG")) { (void)hipMemsetAsync(d_dbg.p, 0, (steps_max + 2) * 64, stream); c.dbg = d_dbg.p; }
     c.kd_rec = d_kdrec.p; c.g_x = d_gx.p; c.g_y = d_gy.p; c.kd_up = d_kdup.p; c.kd_depth = d_kddepth.p; c.kd_gexit = d_kdgexit.p;
     c.g_id = d_gid.p; c.g_cap = (uint32_t)std::min<uint64_t>(d_gid.n, 0xFFFFFFFFull);
     c.cls = d_cls.p; c.W = W; c.H = H; c.low0 = low[0]; c.low1 = low[1]; c.ppm = ppm; c.domain = domain; c.has_grid = has_grid;
@@ -604,6 +609,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(hipMemsetAsync(d_cnt.p, 0, sizeof(Counters), stream));
         HIPCHK(hipMemsetAsync(d_rep.p, 0xFF, kRepTotal * sizeof(int), stream));
         HIPCHK(hipMemsetAsync(d_rgcnt.p, 0, kRegions * sizeof(uint32_t), stream));
+        HIPCHK(hipMemsetAsync(d_kdhint.p, 0, (size_t)kHG * kHG * sizeof(unsigned long long), stream));   // the root: depth 0, id 0
         HIPCHK(hipMemsetAsync(d_validmask.p, 0, (steps_max + 2) * vwords * sizeof(unsigned long long), stream));
         t_setup += now_s() - t0;
     }
@@ -792,15 +798,8 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     }
     counters = hc;
     if (getenv("PORRT_DEBUG")) {
-        fprintf(stderr, "[porrt] tie fallbacks %u g_len %u\n", hc.tie_fallbacks, hc.g_len);
-        if (c.dbg) {
-            std::vector<unsigned long long> d((size_t)b * 8);
-            (void)hipMemcpy(d.data(), d_dbg.p, d.size() * 8, hipMemcpyDeviceToHost);
-            for (uint32_t s2 = 0; s2 < b; s2 += std::max(1u, b / 12))
-                fprintf(stderr, "[porrt] step %3u locate: stage %5.1f  nd %5.1f  descent+store %5.1f us (depth %llu) | claim: %5.1f us rounds %llu\n", s2,
-                        (d[s2 * 8 + 7] - d[s2 * 8 + 1]) * 0.01, (d[s2 * 8 + 5] - d[s2 * 8 + 7]) * 0.01, (d[s2 * 8 + 4] - d[s2 * 8 + 5]) * 0.01,
-                        d[s2 * 8 + 6], ((d[s2 * 8 + 3] & 0xFFFFFFFFFFFFFFull) - d[s2 * 8 + 0]) * 0.01, d[s2 * 8 + 3] >> 56);
-        }
+        fprintf(stderr, "[porrt] tie fallbacks %u g_len %u | kd locate: long-way %u (no start %u), levels sum %u max %u, long-way max %u\n", hc.tie_fallbacks, hc.g_len,
+                hc.kd_long, hc.kd_none, hc.kd_lev_sum, hc.kd_lev_max, hc.kd_long_lev_max);
     }
     n_iter = i;
     n_steps = b;
