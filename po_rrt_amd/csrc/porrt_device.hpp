@@ -28,6 +28,7 @@ constexpr int kConnectWaves = 4;     // samples per connect workgroup (one wave 
 constexpr uint32_t kTileRMax = 31;             // LDS tile half-width limit (pixels); above it rays read global
 constexpr int kEmpty = 0x7FFFFFFF;       // empty kd child slot (atomicMin claims it)
 constexpr uint32_t kOnG = 0x80000000u;
+constexpr int kParentPending = -2;       // parent of a new node whose equal-cost parents await the kd structure (k_tie_fix)
 
 enum : uint32_t {
     ERR_RASTER = 1u,        // pixel outside the raster / door pixel without zone / two zones on one segment
@@ -35,7 +36,8 @@ enum : uint32_t {
     ERR_RNG_RETRY = 4u,     // gen_range would have redrawn (host regenerates the stream exactly)
     ERR_EDGE_OVERFLOW = 8u,
     ERR_GPATH_OVERFLOW = 16u,
-    ERR_PAGE_OVERFLOW = 32u
+    ERR_PAGE_OVERFLOW = 32u,
+    ERR_TIE_POOL = 64u       // deferred-tie records
 };
 
 // pixel classes of the pre-classified raster (host builds it in set_grid/set_zones)
@@ -61,7 +63,11 @@ struct Counters {
     uint32_t g_nd_len;          // non-duplicate levels of G
     uint32_t g_first_dup[2];    // first level of even / odd depth held by a duplicate of the goal point
     uint32_t n_pages;           // pool pages handed out (region pages)
-    uint32_t kd_long, kd_lev_max, kd_lev_sum, kd_long_lev_max, kd_none;   // diagnostics of k_kd_locate
+    uint32_t kd_done;           // nodes with complete kd records (release-stored by k_kd_claim)
+    uint32_t pend_cnt, pool_n;  // deferred ties: records, pooled candidate ids
+    uint32_t n_deferred, pend_lo;
+    unsigned long long dbg[8];
+    uint32_t kd_snap;           // step up to whose start the kd structure is complete (release-stored by k_kd_claim)
 };
 
 struct RunConst {
@@ -92,7 +98,7 @@ struct RunConst {
     unsigned long long inj_base, inj_n;
     // per-sample step scratch
     double *q_x, *q_y;          // steered state
-    double *kq_x, *kq_y;        // copy for the kd insertion (two step parities)
+    double *kq_x, *kq_y;        // copy for the kd insertion ([step][sample])
     int *kq_vid, *kq_nn;
     int *q_nn;
     int *q_vid;
@@ -111,6 +117,11 @@ struct RunConst {
     KdRec *kd_rec;              // packed {x, y, child[2]}: one load per level of a descent
     KdBox *kd_box;              // the cell a node was inserted into: a point's root path passes the node iff it lies inside
     KdBox *loc_box;             // per new node of the step: cell of the empty slot k_kd_locate stopped at
+    uint32_t loc_stride;        // loc_* are double-buffered by group parity
+    // deferred equal-cost parents (see connect_rrt_sample / k_tie_fix)
+    int *pend_new, *pend_pool;
+    uint32_t *pend_off, *pend_n, *pend_cur, *pend_state;
+    uint32_t pend_cap, pool_cap;
     unsigned long long *kd_hint; // [kHG * kHG] (depth << 32 | id) of the deepest node whose cell covers the square
     int *kd_up;
     uint32_t *kd_depth;
@@ -121,6 +132,7 @@ struct RunConst {
     int *g_id;                  // G[i] = node at depth i on the kd descent path of the goal point
     double *g_x, *g_y;          // its coordinates, contiguous (the path is scanned, not chased)
     uint32_t g_cap;
+    uint32_t *g_snap;           // [step][4]: g_len, g_nd_len, g_first_dup[0..1] at the start of the step's kd insertion
     double gp_x, gp_y;
     // grid
     const uint8_t *cls;
@@ -660,8 +672,8 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
     if (lane == 0) {
         rc.q_x[k] = tx;
         rc.q_y[k] = ty;
-        // copy for the kd insertion, which runs beside the next steps (double-buffered by step parity)
-        const uint32_t o2 = (b & 1u) * rc.part_stride + k;
+        // copy for the kd insertion, which runs beside the following steps (one slice per step)
+        const size_t o2 = (size_t)b * rc.part_stride + k;
         rc.kq_x[o2] = tx; rc.kq_y[o2] = ty; rc.kq_vid[o2] = valid ? vid : -1; rc.kq_nn[o2] = nn;
         rc.q_nn[k] = nn;
         rc.q_vid[k] = valid ? vid : -1;
@@ -853,6 +865,18 @@ struct Team {
         for (int w = 1; w < W; ++w) t = scr_i[w] < t ? scr_i[w] : t;
         return t;
     }
+    __device__ __forceinline__ int max_i(int v) const { return -min_i(-v); }
+    // values of the team's first lane
+    __device__ __forceinline__ void bcast2(uint32_t &a, uint32_t &b) const {
+        a = (uint32_t)__shfl((int)a, 0);
+        b = (uint32_t)__shfl((int)b, 0);
+        if (W == 1) return;
+        sync();
+        if (wave == 0 && lane == 0) { scr_i[0] = (int)a; scr_i[1] = (int)b; }
+        sync();
+        a = (uint32_t)scr_i[0]; b = (uint32_t)scr_i[1];
+        sync();
+    }
     // lexicographic min of (t, j)
     __device__ __forceinline__ void argmin(double &t, int &j) const {
         for (int off = 32; off > 0; off >>= 1) {
@@ -930,37 +954,84 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     tm.argmin(bt, bj);
     int best;
     double best_cost, dnew;
+    bool deferred = false;
     if (nvalid == 0) {
         // rrt.rs:132-134: fall back to the nearest node, not collision-checked
         best = rc.q_nn[k];
         best_cost = sqrt(dist2(gnx[best], gny[best], px, py));
         dnew = gdA[best] + best_cost;
     } else {
-        // equal totals: the reference keeps the first in kd-tree pre-order (rrt.rs:143-145)
+        // equal totals: the reference keeps the first in kd-tree pre-order (rrt.rs:143-145).  The kd structure is
+        // built beside the steps and may lag: if a tied node is not in it yet, the choice is deferred (k_tie_fix) --
+        // every tied parent gives the same dist_root, so nothing but parent[id] depends on it.
         uint32_t n_tie = 0;
-        int on_min = kEmpty;        // tied nodes ON the goal path: an ancestor chain, the lowest id is first
-        int off_best = kEmpty;      // pre-order-first tied node off the goal path
-        auto tie_visit = [&](int j) {
-            ++n_tie;
-            if (rc.kd_gexit[j] & kOnG) on_min = j < on_min ? j : on_min;
-            else if (off_best == kEmpty || kd_preorder_less(rc, j, off_best)) off_best = j;
-        };
-        if (j0 >= 0 && cost0 >= 0.0 && tot0 == bt) tie_visit(j0);
-        for (uint32_t a = tl + TS; a < cnt; a += TS) {
-            const double cost = cval[a];
-            if (cost >= 0.0) {
-                const int j = cid[a];
-                if (gdA[j] + cost == bt) tie_visit(j);
+        int tie_max = -1;
+        auto each_tie = [&](auto &&f) {
+            if (j0 >= 0 && cost0 >= 0.0 && tot0 == bt) f(j0);
+            for (uint32_t a = tl + TS; a < cnt; a += TS) {
+                const double cost = cval[a];
+                if (cost >= 0.0) {
+                    const int j = cid[a];
+                    if (gdA[j] + cost == bt) f(j);
+                }
             }
-        }
+        };
+        each_tie([&](int j) { ++n_tie; tie_max = j > tie_max ? j : tie_max; });
         n_tie = tm.sum(n_tie);
         best = bj;
         if (n_tie > 1) {
+            tie_max = tm.max_i(tie_max);
+            uint32_t kd_done = 0, unused = 0;
+            if (tl == 0) kd_done = __hip_atomic_load(&rc.cnt->kd_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            tm.bcast2(kd_done, unused);       // one answer for the whole team
+            // first in pre-order among the tied nodes the kd structure already holds
+            int on_min = kEmpty;        // tied nodes ON the goal path: an ancestor chain, the lowest id is first
+            int off_best = kEmpty;      // pre-order-first tied node off the goal path
+            uint32_t n_fresh = 0;
+            each_tie([&](int j) {
+                if ((uint32_t)j >= kd_done) { ++n_fresh; return; }
+                if (rc.kd_gexit[j] & kOnG) on_min = j < on_min ? j : on_min;
+                else if (off_best == kEmpty || kd_preorder_less(rc, j, off_best)) off_best = j;
+            });
             on_min = tm.min_i(on_min);
             off_best = tm.first_preorder(rc, off_best);
-            if (off_best == kEmpty) best = on_min;
-            else if (on_min == kEmpty) best = off_best;
-            else best = kd_preorder_less(rc, on_min, off_best) ? on_min : off_best;
+            int known;
+            if (off_best == kEmpty) known = on_min;
+            else if (on_min == kEmpty) known = off_best;
+            else known = kd_preorder_less(rc, on_min, off_best) ? on_min : off_best;
+            const uint32_t my_fresh = n_fresh;
+            n_fresh = (uint32_t)tie_max < kd_done ? 0u : tm.sum(n_fresh);
+            if (n_fresh == 0) {
+                best = known;
+            } else {
+                // record: the fresh tied ids (+ the best of the known ones) for k_tie_fix
+                deferred = true;
+                const uint32_t m = n_fresh + (known != kEmpty ? 1u : 0u);
+                uint32_t rec = 0, base = 0;
+                if (tl == 0) {
+                    rec = atomicAdd(&rc.cnt->pend_cnt, 1u);
+                    base = atomicAdd(&rc.cnt->pool_n, m);
+                    if (rec < rc.pend_cap && base + m <= rc.pool_cap) {
+                        rc.pend_new[rec] = (int)id; rc.pend_off[rec] = base; rc.pend_n[rec] = m;
+                        rc.pend_cur[rec] = known != kEmpty ? 1u : 0u;
+                        if (known != kEmpty) rc.pend_pool[base] = known;
+                    } else {
+                        err |= ERR_TIE_POOL;
+                    }
+                }
+                tm.bcast2(rec, base);
+                if (rec < rc.pend_cap && base + m <= rc.pool_cap) {
+                    if (my_fresh) {
+                        each_tie([&](int j) { if ((uint32_t)j >= kd_done) rc.pend_pool[base + atomicAdd(&rc.pend_cur[rec], 1u)] = j; });
+                        __threadfence();
+                    }
+                    tm.sync();
+                    if (tl == 0) {
+                        __threadfence();
+                        __hip_atomic_store(&rc.pend_state[rec], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
         }
         best_cost = sqrt(dist2(gnx[best], gny[best], px, py));
         dnew = gdA[best] + best_cost;
@@ -971,7 +1042,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
         rc.nx[id] = px;
         rc.ny[id] = py;
         rep_insert(rc, px, py, (int)id);
-        rc.parent[id] = best;
+        rc.parent[id] = deferred ? kParentPending : best;
         rc.distA[id] = dnew;
         rc.distB[id] = dnew;
         unsigned long long mask = 0;
@@ -1132,14 +1203,15 @@ __device__ __forceinline__ void box_cut(KdBox &bx, double wx, double wy, uint32_
 
 // descend from node `cur` (depth dcur, cell bx, taking `side`) to an empty slot of the old tree; on return bx is
 // the cell of that slot.  One dependent 24-byte load per level.
-__device__ __forceinline__ void kd_descend(const RunConst &rc, double vx, double vy, int &cur, uint32_t &dcur, uint32_t &side, KdBox &bx) {
+__device__ __forceinline__ void kd_descend(const RunConst &rc, uint32_t Nsnap, double vx, double vy, int &cur, uint32_t &dcur, uint32_t &side,
+                                           KdBox &bx) {
     auto grec = as_global(rc.kd_rec);
     KdRec rec;
     rec.x = grec[cur].x; rec.y = grec[cur].y; rec.child[0] = grec[cur].child[0]; rec.child[1] = grec[cur].child[1];
     for (;;) {
         box_cut(bx, rec.x, rec.y, dcur, side);
         const int c = side ? rec.child[1] : rec.child[0];
-        if (c == kEmpty) break;
+        if ((uint32_t)c >= Nsnap) break;              // empty (kEmpty) or newer than the snapshot
         rec.x = grec[c].x; rec.y = grec[c].y; rec.child[0] = grec[c].child[0]; rec.child[1] = grec[c].child[1];
         cur = c;
         dcur += 1;
@@ -1147,17 +1219,28 @@ __device__ __forceinline__ void kd_descend(const RunConst &rc, double vx, double
     }
 }
 
-__global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
+// `bsnap`: the descent sees the tree as it stood at the start of step bsnap <= b (nodes below n_at[bsnap], G as
+// recorded in g_snap[bsnap]); newer nodes are treated as absent and k_kd_claim's rounds finish the descent through
+// them.  That lets this kernel run beside the previous step's k_kd_claim.
+// One launch serves the new nodes of `nsteps` consecutive steps starting at step b0 (the structure is built beside the
+// steps and may lag them, so several steps' nodes are inserted together): wave -> (step, sample).
+// The descent sees the tree as far as k_kd_claim has published it when the wave starts (cnt->kd_snap: nodes below
+// n_at[kd_snap], G as recorded in g_snap[kd_snap]); newer nodes are treated as absent and the claim rounds finish the
+// descent through them.  So this kernel depends on nothing but the steps' k_near and overlaps earlier groups' claims.
+__global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t K, uint32_t nb_last,
+                                                    uint32_t vwords, uint32_t lpar) {
     const RunConst &rc = *rcp;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (k >= nb) return;
-    // The step's new nodes are the valid samples (positions known since k_near), id = N + rank: this kernel runs
-    // beside the step's connect and commit.
-    const uint32_t o2 = (b & 1u) * rc.part_stride + k;
+    const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t st = wid / K, k = wid - st * K;
+    if (st >= nsteps || k >= (st + 1 == nsteps ? nb_last : K)) return;
+    const uint32_t b = b0 + st;
+    // The new nodes are the valid samples (positions known since k_near), id = n_at[b] + rank in their step.
+    const size_t o2 = (size_t)b * rc.part_stride + k;
     if (rc.kq_vid[o2] < 0) return;
-    const uint32_t N = uni(rc.n_at[b]);
-    const uint32_t t = uni(rank_before(rc, b, vwords, k));
+    const uint32_t bsnap = uni(__hip_atomic_load(&rc.cnt->kd_snap, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+    const uint32_t Nsnap = uni(rc.n_at[bsnap]), N = uni(rc.n_at[b0]);
+    const uint32_t t = uni(rc.n_at[b] - N + rank_before(rc, b, vwords, k));
     const double px = rc.gp_x, py = rc.gp_y;
     const double vx = rc.kq_x[o2], vy = rc.kq_y[o2];
     if (lane == 0) {   // the node's kd record exists from here on (k_kd_claim only links it)
@@ -1170,9 +1253,10 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
     {
         int hx, hy;
         rep_cell(rc, vx, vy, kHG, hx, hy);
-        const unsigned long long hv = rc.kd_hint[hy * kHG + hx];
+        const unsigned long long hv = __hip_atomic_load(&rc.kd_hint[hy * kHG + hx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bu = (int)(uint32_t)hv;
-        bd = (int)(uint32_t)(hv >> 32);
+        while ((uint32_t)bu >= Nsnap) bu = __hip_atomic_load(&rc.kd_up[bu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // newer than the snapshot
+        bd = (int)rc.kd_depth[bu];
         if (!box_holds(rc.kd_box[bu], vx, vy)) bu = -1;     // cannot happen (see k_kd_hint); the long way is always right
     }
     int cur;
@@ -1186,7 +1270,7 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
             cur = bu; dcur = (uint32_t)bd; gex = ge;
             bx = rc.kd_box[bu];
             side = kd_left(vx, vy, rc.kd_rec[bu].x, rc.kd_rec[bu].y, dcur) ? 0u : 1u;
-            kd_descend(rc, vx, vy, cur, dcur, side, bx);
+            kd_descend(rc, Nsnap, vx, vy, cur, dcur, side, bx);
         }
     }
     if (long_way) {
@@ -1194,7 +1278,7 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
         // held by an exact duplicate of the goal point tests `x < p.x` (even depth) or `y < p.y` (odd depth), and
         // the goal point itself always goes right there, so all duplicate levels reduce to two comparisons against
         // the first duplicate of each parity; only the few non-duplicate levels (g_nd*) are real tests.
-        const uint32_t glen0 = uni(rc.cnt->g_len), n_nd = uni(rc.cnt->g_nd_len);
+        const uint32_t glen0 = uni(rc.g_snap[4 * bsnap + 0]), n_nd = uni(rc.g_snap[4 * bsnap + 1]);
         uint32_t E = 0xFFFFFFFFu, leftE = 0;
         for (uint32_t s0 = lane; s0 < n_nd; s0 += 64u) {
             const uint32_t ii = rc.g_nd[s0];
@@ -1206,7 +1290,7 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
             const uint32_t oe = __shfl_xor(E, off), ol = __shfl_xor(leftE, off);
             if (oe < E) { E = oe; leftE = ol; }
         }
-        const uint32_t d0 = rc.cnt->g_first_dup[0], d1 = rc.cnt->g_first_dup[1];
+        const uint32_t d0 = rc.g_snap[4 * bsnap + 2], d1 = rc.g_snap[4 * bsnap + 3];
         if (vx < px && d0 < E) { E = d0; leftE = 1u; }
         if (vy < py && d1 < E) { E = d1; leftE = 1u; }
         if (E == 0xFFFFFFFFu) {             // on G to its end: below the last node, on the goal point's side
@@ -1222,95 +1306,181 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
             cur = rc.g_id[E];
             side = leftE ? 0u : 1u;
             bx = rc.kd_box[cur];
-            kd_descend(rc, vx, vy, cur, dcur, side, bx);
+            kd_descend(rc, Nsnap, vx, vy, cur, dcur, side, bx);
         }
     }
     if (lane == 0) {
-        {   // diagnostics
-            const uint32_t start_d = long_way ? (gex ? gex : 0u) : (uint32_t)bd;
-            const uint32_t lev = dcur - (flags ? dcur : start_d);
-            atomicAdd(&rc.cnt->kd_lev_sum, lev);
-            atomicMax(&rc.cnt->kd_lev_max, lev);
-            if (long_way) { atomicAdd(&rc.cnt->kd_long, 1u); atomicMax(&rc.cnt->kd_long_lev_max, lev); if (bu < 0) atomicAdd(&rc.cnt->kd_none, 1u); }
-        }
-        rc.loc_cur[t] = cur;
-        rc.loc_dcur[t] = dcur;
-        rc.loc_gex[t] = gex;
-        rc.loc_flags[t] = flags | (side ? LOC_SIDE : 0u);
-        rc.loc_box[t] = bx;
+        const uint32_t lo = lpar * rc.loc_stride + t;       // two groups may be in flight
+        rc.loc_cur[lo] = cur;
+        rc.loc_dcur[lo] = dcur;
+        rc.loc_gex[lo] = gex;
+        rc.loc_flags[lo] = flags | (side ? LOC_SIDE : 0u);
+        rc.loc_box[lo] = bx;
     }
 }
 
-// One workgroup; a thread owns up to kPer nodes (batch_K <= 4096).
-__global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ rcp, uint32_t b, uint32_t vwords) {
+// One workgroup links the located nodes (at most kClaimMax of them) into the tree.  Nodes that stopped at the same
+// empty slot are ordered by rounds: the lowest id takes the slot (atomicMin), the others step below it and contend
+// for its child slots in the next round.  Contenders of one slot always arrive in the same round because they
+// share the whole path above it, so this equals sequential insertion in id order.  Only the first round touches
+// the slots of old nodes in memory; every later slot belongs to a node of this launch and lives in LDS, next to
+// copies of the coordinates, so a round costs two barriers.
+constexpr uint32_t kClaimMax = 4096;
+__global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords, uint32_t lpar) {
     const RunConst &rc = *rcp;
-    const uint32_t N = rc.n_at[b];
+    __shared__ double s_x[kClaimMax], s_y[kClaimMax];
+    __shared__ int s_ch[kClaimMax][2];
+    const unsigned long long T0 = wall_clock64();
+    const uint32_t N = rc.n_at[b0], b = b0 + nsteps - 1u;
     uint32_t n_new = 0;
-    for (uint32_t w = 0; w < vwords; ++w) n_new += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
+    for (uint32_t w = 0; w < vwords * nsteps; ++w) n_new += __popcll(rc.valid_mask[(size_t)b0 * vwords + w]);
+    if (n_new > kClaimMax) { if (threadIdx.x == 0) atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW); return; }
     const double px = rc.gp_x, py = rc.gp_y;
-    constexpr int kPer = 4;
+    constexpr int kPer = kClaimMax / 1024;
     bool todo[kPer], onpath[kPer];
     double vx[kPer], vy[kPer];
-    int vidn[kPer], cur[kPer];
+    int cur[kPer];              // parent: node id (first round) or index into this launch's nodes (later rounds)
     uint32_t side[kPer], dcur[kPer], gex[kPer];
     KdBox box[kPer];
 #pragma unroll
     for (int r = 0; r < kPer; ++r) {
         const uint32_t t = threadIdx.x + r * 1024u;
         todo[r] = t < n_new;
-        const uint32_t tt = todo[r] ? t : 0u;
-        const uint32_t fl = rc.loc_flags[tt];
+        const uint32_t tt = todo[r] ? t : 0u, lo = lpar * rc.loc_stride + tt;
+        const uint32_t fl = rc.loc_flags[lo];
         onpath[r] = todo[r] && (fl & LOC_ONPATH);
         side[r] = (fl & LOC_SIDE) ? 1u : 0u;
-        cur[r] = rc.loc_cur[tt];
-        dcur[r] = rc.loc_dcur[tt];
-        gex[r] = rc.loc_gex[tt];
-        box[r] = rc.loc_box[tt];
-        vidn[r] = todo[r] ? (int)(N + t) : kEmpty;
+        cur[r] = rc.loc_cur[lo];
+        dcur[r] = rc.loc_dcur[lo];
+        gex[r] = rc.loc_gex[lo];
+        box[r] = rc.loc_box[lo];
         vx[r] = todo[r] ? rc.kd_rec[N + tt].x : 0.0;
         vy[r] = todo[r] ? rc.kd_rec[N + tt].y : 0.0;
+        if (todo[r]) { s_x[t] = vx[r]; s_y[t] = vy[r]; s_ch[t][0] = kEmpty; s_ch[t][1] = kEmpty; }
     }
-    // claim rounds
-    for (;;) {
-        bool any = false;
-#pragma unroll
-        for (int r = 0; r < kPer; ++r) {
-            if (todo[r]) { atomicMin(&rc.kd_rec[cur[r]].child[side[r]], vidn[r]); any = true; }
+    // publish one node: parent link, depth, cell, and the goal path bookkeeping
+    auto finish = [&](int r, uint32_t t, int parent_id) {
+        const int w = (int)(N + t);
+        const uint32_t dw = dcur[r] + 1u;
+        rc.kd_rec[parent_id].child[side[r]] = w;
+        rc.kd_up[w] = parent_id;
+        rc.kd_depth[w] = dw;
+        rc.kd_box[w] = box[r];
+        if (onpath[r]) {
+            if (dw + 8 < rc.g_cap) { rc.g_id[dw] = w; rc.g_x[dw] = vx[r]; rc.g_y[dw] = vy[r]; }
+            else atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW);
+            rc.kd_gexit[w] = dw | kOnG;
+            atomicMax(&rc.cnt->g_len, dw + 1);
+            if (vx[r] == px && vy[r] == py) atomicMin(&rc.cnt->g_first_dup[dw & 1u], dw);
+            else {
+                const uint32_t sl = atomicAdd(&rc.cnt->g_nd_len, 1u);
+                rc.g_nd[sl] = dw; rc.g_nd_x[sl] = vx[r]; rc.g_nd_y[sl] = vy[r];
+            }
+        } else {
+            rc.kd_gexit[w] = gex[r];
         }
-        if (!__syncthreads_or(any)) break;
+    };
+    // step below the winner w (a node of this launch, index tw)
+    auto step_below = [&](int r, uint32_t tw) {
+        const double wx = s_x[tw], wy = s_y[tw];
+        const uint32_t dw = dcur[r] + 1u;
+        const bool vl = kd_left(vx[r], vy[r], wx, wy, dw);
+        if (onpath[r] && vl != kd_left(px, py, wx, wy, dw)) { onpath[r] = false; gex[r] = dw; }
+        cur[r] = (int)tw; dcur[r] = dw; side[r] = vl ? 0u : 1u;
+        box_cut(box[r], wx, wy, dw, side[r]);
+    };
+    const unsigned long long T1 = wall_clock64();
+    // first round: slots of old nodes
+#pragma unroll
+    for (int r = 0; r < kPer; ++r)
+        if (todo[r]) atomicMin(&rc.kd_rec[cur[r]].child[side[r]], (int)(N + threadIdx.x + r * 1024u));
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+        if (!todo[r]) continue;
+        const uint32_t t = threadIdx.x + r * 1024u;
+        const int w = atomicMin(&rc.kd_rec[cur[r]].child[side[r]], kEmpty);   // read the winner at L2
+        if (w == (int)(N + t)) { finish(r, t, cur[r]); todo[r] = false; }
+        else step_below(r, (uint32_t)w - N);
+    }
+    const unsigned long long T2 = wall_clock64();
+    // later rounds: slots of this launch's nodes, in LDS.  While many nodes are still moving, the whole workgroup
+    // plays a round (two barriers); the last few (the step's copies of the goal point, one below the other) are
+    // handed to ONE wave, whose rounds need no barrier at all.
+    __shared__ uint32_t s_nact, s_tail_t[64], s_tail_cur[64], s_tail_fl[64], s_tail_d[64], s_tail_gex[64];
+    __shared__ KdBox s_tail_box[64];
+    for (;;) {
+        uint32_t mine = 0;
+#pragma unroll
+        for (int r = 0; r < kPer; ++r) mine += todo[r] ? 1u : 0u;
+        if (threadIdx.x == 0) s_nact = 0;
+        __syncthreads();
+        if (mine) atomicAdd(&s_nact, mine);
+        __syncthreads();
+        const uint32_t n_act = s_nact;
+        if (n_act <= 64u) break;
+#pragma unroll
+        for (int r = 0; r < kPer; ++r)
+            if (todo[r]) atomicMin(&s_ch[cur[r]][side[r]], (int)(threadIdx.x + r * 1024u));
+        __syncthreads();
 #pragma unroll
         for (int r = 0; r < kPer; ++r) {
             if (!todo[r]) continue;
-            const int w = atomicMin(&rc.kd_rec[cur[r]].child[side[r]], kEmpty);   // read the winner at L2
-            const uint32_t dw = dcur[r] + 1;
-            if (w == vidn[r]) {
-                rc.kd_up[w] = cur[r];
-                rc.kd_depth[w] = dw;
-                rc.kd_box[w] = box[r];
-                if (onpath[r]) {
-                    if (dw + 8 < rc.g_cap) { rc.g_id[dw] = w; rc.g_x[dw] = vx[r]; rc.g_y[dw] = vy[r]; }
-                    else atomicOr(&rc.cnt->err, ERR_GPATH_OVERFLOW);
-                    rc.kd_gexit[w] = dw | kOnG;
-                    atomicMax(&rc.cnt->g_len, dw + 1);
-                    if (vx[r] == px && vy[r] == py) atomicMin(&rc.cnt->g_first_dup[dw & 1u], dw);
-                    else {
-                        const uint32_t sl = atomicAdd(&rc.cnt->g_nd_len, 1u);
-                        rc.g_nd[sl] = dw; rc.g_nd_x[sl] = vx[r]; rc.g_nd_y[sl] = vy[r];
-                    }
-                } else {
-                    rc.kd_gexit[w] = gex[r];
-                }
-                todo[r] = false;
-            } else {
-                // step below the winner (k_kd_locate wrote its record)
-                const double wx = rc.kd_rec[w].x, wy = rc.kd_rec[w].y;
-                const bool vl = kd_left(vx[r], vy[r], wx, wy, dw);
-                if (onpath[r] && vl != kd_left(px, py, wx, wy, dw)) { onpath[r] = false; gex[r] = dw; }
-                cur[r] = w; dcur[r] = dw; side[r] = vl ? 0u : 1u;
-                box_cut(box[r], wx, wy, dw, side[r]);
-            }
+            const uint32_t t = threadIdx.x + r * 1024u;
+            const int w = s_ch[cur[r]][side[r]];
+            if (w == (int)t) { finish(r, t, (int)(N + (uint32_t)cur[r])); todo[r] = false; }
+            else step_below(r, (uint32_t)w);
+        }
+    }
+    const unsigned long long T3 = wall_clock64();
+    if (s_nact) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_nact = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kPer; ++r) {
+            if (!todo[r]) continue;
+            const uint32_t q = atomicAdd(&s_nact, 1u);
+            s_tail_t[q] = threadIdx.x + r * 1024u; s_tail_cur[q] = (uint32_t)cur[r]; s_tail_fl[q] = side[r] | (onpath[r] ? 2u : 0u);
+            s_tail_d[q] = dcur[r]; s_tail_gex[q] = gex[r]; s_tail_box[q] = box[r];
         }
         __syncthreads();
+        if (threadIdx.x < 64u) {
+            const uint32_t q = threadIdx.x;
+            todo[0] = q < s_nact;
+            uint32_t t = 0;
+            if (todo[0]) {
+                t = s_tail_t[q]; cur[0] = (int)s_tail_cur[q]; side[0] = s_tail_fl[q] & 1u; onpath[0] = s_tail_fl[q] & 2u;
+                dcur[0] = s_tail_d[q]; gex[0] = s_tail_gex[q]; box[0] = s_tail_box[q]; vx[0] = s_x[t]; vy[0] = s_y[t];
+            }
+            while (__ballot(todo[0])) {
+                if (todo[0]) atomicMin(&s_ch[cur[0]][side[0]], (int)t);
+                __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0) only: the LDS atomics, not the stores of finish()
+                __builtin_amdgcn_wave_barrier();
+                if (todo[0]) {
+                    const int w = s_ch[cur[0]][side[0]];
+                    if (w == (int)t) { finish(0, t, (int)(N + (uint32_t)cur[0])); todo[0] = false; }
+                    else step_below(0, (uint32_t)w);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    const unsigned long long T4 = wall_clock64();
+    // every record of the group is written: connect kernels running beside us may now trust ids < N + n_new
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long T5 = wall_clock64();
+        rc.cnt->dbg[0] += T1 - T0; rc.cnt->dbg[1] += T2 - T1; rc.cnt->dbg[2] += T3 - T2; rc.cnt->dbg[3] += T4 - T3; rc.cnt->dbg[4] += T5 - T4; rc.cnt->dbg[5] += 1;
+        // G as the next k_kd_locate may see it
+        rc.g_snap[4 * (b + 1) + 0] = __hip_atomic_load(&rc.cnt->g_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rc.g_snap[4 * (b + 1) + 1] = __hip_atomic_load(&rc.cnt->g_nd_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rc.g_snap[4 * (b + 1) + 2] = __hip_atomic_load(&rc.cnt->g_first_dup[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rc.g_snap[4 * (b + 1) + 3] = __hip_atomic_load(&rc.cnt->g_first_dup[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        __hip_atomic_store(&rc.cnt->kd_snap, b + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&rc.cnt->kd_done, N + n_new, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1318,14 +1488,14 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
 // will ever fall into that square; the deepest such node is the best place to start a descent.  The squares between
 // cell(lo) and cell(hi), both excluded, lie inside [lo, hi) because the cell function is monotone; an infinite
 // bound includes the clamped border square.  hint = max over (depth, id), a commutative update.
-__global__ __launch_bounds__(256) void k_kd_hint(const RunConst *__restrict__ rcp, uint32_t b, uint32_t vwords) {
+__global__ __launch_bounds__(256) void k_kd_hint(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords) {
     const RunConst &rc = *rcp;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);
     uint32_t n_new = 0;
-    for (uint32_t w = 0; w < vwords; ++w) n_new += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
+    for (uint32_t w = 0; w < vwords * nsteps; ++w) n_new += __popcll(rc.valid_mask[(size_t)b0 * vwords + w]);
     if (t >= n_new) return;
-    const uint32_t id = rc.n_at[b] + t;
+    const uint32_t id = rc.n_at[b0] + t;
     const KdBox bx = rc.kd_box[id];
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
     int lx, ly, ux, uy;
@@ -1340,6 +1510,52 @@ __global__ __launch_bounds__(256) void k_kd_hint(const RunConst *__restrict__ rc
     for (uint32_t i = lane; i < n; i += 64u) {
         const uint32_t ry = i / w;
         __hip_atomic_fetch_max(gh + (size_t)(iy0 + (int)ry) * kHG + ix0 + (int)(i - ry * w), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Resolve deferred equal-cost parents whose tied nodes are all in the kd structure by now.  One workgroup, one
+// wave per record, starting at the first record not yet settled; runs on the kd stream after each k_kd_claim and
+// once more at the end of a run.  The parent is only installed if no rewire replaced the placeholder in the
+// meantime (a rewire is final, rrt.rs:152-161).
+__global__ __launch_bounds__(1024) void k_tie_fix(const RunConst *__restrict__ rcp) {
+    const RunConst &rc = *rcp;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t n = __hip_atomic_load(&rc.cnt->pend_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    n = n < rc.pend_cap ? n : rc.pend_cap;
+    const uint32_t lo = rc.cnt->pend_lo;
+    const uint32_t kd_done = __hip_atomic_load(&rc.cnt->kd_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    Team<1> tm;
+    tm.scr_d = nullptr; tm.scr_i = nullptr; tm.wave = 0; tm.lane = lane;
+    for (uint32_t p = lo + wv; p < n; p += 16u) {
+        if (__hip_atomic_load(&rc.pend_state[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1u) continue;
+        const uint32_t base = rc.pend_off[p], m = rc.pend_n[p];
+        int mx = -1;
+        for (uint32_t a = lane; a < m; a += 64u) { const int j = rc.pend_pool[base + a]; mx = j > mx ? j : mx; }
+        mx = tm.max_i(mx);
+        if ((uint32_t)mx >= kd_done) continue;
+        int on_min = kEmpty, off_best = kEmpty;
+        for (uint32_t a = lane; a < m; a += 64u) {
+            const int j = rc.pend_pool[base + a];
+            if (rc.kd_gexit[j] & kOnG) on_min = j < on_min ? j : on_min;
+            else if (off_best == kEmpty || kd_preorder_less(rc, j, off_best)) off_best = j;
+        }
+        on_min = tm.min_i(on_min);
+        off_best = tm.first_preorder(rc, off_best);
+        int best;
+        if (off_best == kEmpty) best = on_min;
+        else if (on_min == kEmpty) best = off_best;
+        else best = kd_preorder_less(rc, on_min, off_best) ? on_min : off_best;
+        if (lane == 0) {
+            atomicCAS(&rc.parent[rc.pend_new[p]], kParentPending, best);
+            rc.pend_state[p] = 2u;
+            atomicAdd(&rc.cnt->n_deferred, 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {       // records settle roughly in order: skip the settled prefix next time
+        uint32_t l = lo;
+        while (l < n && __hip_atomic_load(&rc.pend_state[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u) ++l;
+        rc.cnt->pend_lo = l;
     }
 }
 

@@ -167,7 +167,8 @@ struct porrt_ctx {
     DevBuf<uint32_t> d_locdcur, d_locgex, d_locflags, d_kdsurv;
     DevBuf<double> d_gx, d_gy, d_gndx, d_gndy, d_kqx, d_kqy;
     DevBuf<int> d_kqvid, d_kqnn;
-    DevBuf<uint32_t> d_rgcnt, d_rgdir;
+    DevBuf<uint32_t> d_rgcnt, d_rgdir, d_gsnap, d_pendoff, d_pendn, d_pendcur, d_pendstate;
+    DevBuf<int> d_pendnew, d_pendpool;
     DevBuf<int> d_rep;
     DevBuf<uint32_t> d_kddepth, d_kdgexit;
     DevBuf<unsigned long long> d_reachA, d_reachB, d_finalmask, d_validmask, d_kdhint;
@@ -214,9 +215,11 @@ struct porrt_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bound[2] = {nullptr, nullptr};
     bool bound_pending[2] = {false, false};
     void join_side();
+    void launch_kd_group();
+    uint32_t kd_b0 = 0, kd_last_b = 0, kd_last_nb = 0, kd_group = 1, kd_gidx = 0;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_step_done = nullptr, ev_kd[2] = {nullptr, nullptr}, ev_steered = nullptr, ev_located = nullptr;
-    bool kd_pend[2] = {false, false}, loc_pending = false;
+    bool kd_pend[2] = {false, false}, loc_pending = false, side_active = false;
     // cached hipGraph of the steps up to n_iter_min
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_key[6] = {0, 0, 0, 0, 0, 0};
@@ -231,7 +234,7 @@ int porrt_ctx::layout_buffers() {
     if (all_bufs.empty()) {
         DevBufBase *list[] = {&d_nx, &d_ny, &d_distA, &d_distB, &d_sx, &d_sy, &d_qx, &d_qy, &d_qbound, &d_pgxy, &d_candval, &d_radT2, &d_inj,
                               &d_parent, &d_qnn, &d_qvid, &d_pgid, &d_candid, &d_gid, &d_kdup, &d_kdrec, &d_gx, &d_gy, &d_rgcnt,
-                              &d_rgdir, &d_rep, &d_kdbox, &d_locbox, &d_kqnn, &d_kdhint, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB,
+                              &d_rgdir, &d_rep, &d_kdbox, &d_locbox, &d_kqnn, &d_kdhint, &d_gsnap, &d_pendoff, &d_pendn, &d_pendcur, &d_pendstate, &d_pendnew, &d_pendpool, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB,
                               &d_finalmask, &d_validmask, &d_vid, &d_finalflag, &d_cls, &d_nat, &d_sworld, &d_candcnt, &d_efrom,
                               &d_eto, &d_etv, &d_cnt, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags, &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid};
         for (DevBufBase *b2 : list) all_bufs.push_back(b2);
@@ -261,7 +264,9 @@ int porrt_ctx::layout_buffers() {
     d_candid.p = (int *)d_candid.vp; d_gid.p = (int *)d_gid.vp; d_kdup.p = (int *)d_kdup.vp; d_kdrec.p = (KdRec *)d_kdrec.vp;
     d_gx.p = (double *)d_gx.vp; d_gy.p = (double *)d_gy.vp; d_rgcnt.p = (uint32_t *)d_rgcnt.vp; d_rgdir.p = (uint32_t *)d_rgdir.vp;
     d_rep.p = (int *)d_rep.vp;
-    d_kdbox.p = (KdBox *)d_kdbox.vp; d_locbox.p = (KdBox *)d_locbox.vp; d_kqnn.p = (int *)d_kqnn.vp; d_kdhint.p = (unsigned long long *)d_kdhint.vp; d_kddepth.p = (uint32_t *)d_kddepth.vp; d_kdgexit.p = (uint32_t *)d_kdgexit.vp;
+    d_kdbox.p = (KdBox *)d_kdbox.vp; d_locbox.p = (KdBox *)d_locbox.vp; d_kqnn.p = (int *)d_kqnn.vp; d_kdhint.p = (unsigned long long *)d_kdhint.vp;
+    d_gsnap.p = (uint32_t *)d_gsnap.vp; d_pendoff.p = (uint32_t *)d_pendoff.vp; d_pendn.p = (uint32_t *)d_pendn.vp; d_pendcur.p = (uint32_t *)d_pendcur.vp;
+    d_pendstate.p = (uint32_t *)d_pendstate.vp; d_pendnew.p = (int *)d_pendnew.vp; d_pendpool.p = (int *)d_pendpool.vp; d_kddepth.p = (uint32_t *)d_kddepth.vp; d_kdgexit.p = (uint32_t *)d_kdgexit.vp;
     d_reachA.p = (unsigned long long *)d_reachA.vp; d_reachB.p = (unsigned long long *)d_reachB.vp;
     d_finalmask.p = (unsigned long long *)d_finalmask.vp; d_validmask.p = (unsigned long long *)d_validmask.vp;
     d_vid.p = (uint8_t *)d_vid.vp; d_finalflag.p = (uint8_t *)d_finalflag.vp; d_cls.p = (uint8_t *)d_cls.vp;
@@ -388,6 +393,9 @@ __global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y
     }
     rc.kd_depth[0] = 0;
     rc.kd_gexit[0] = kOnG;
+    rc.cnt->kd_done = 1;
+    rc.cnt->kd_snap = 0;
+    rc.g_snap[0] = 1; rc.g_snap[1] = rc.cnt->g_nd_len; rc.g_snap[2] = rc.cnt->g_first_dup[0]; rc.g_snap[3] = rc.cnt->g_first_dup[1];
 }
 
 void porrt_ctx::launch_bound(hipStream_t st, uint32_t b, uint32_t bsnap, uint32_t i0, uint32_t nb) {
@@ -422,29 +430,60 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
         hipLaunchKernelGGL(k_commit_pto, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, nb, vwords);
         return;
     }
-    // this step's connect orders tied parents by the kd structure of the tree before the step: the previous step's
-    // insertion must be complete (this step's own insertion may run concurrently)
-    // One sync point per step: fork this step's kd insertion (positions are final since k_near; it runs beside
-    // connect, commit and the next step's search) and join the previous step's.
+    // RRT*: the kd structure that orders equal-cost parents is built beside the steps on a second stream, several
+    // steps' nodes at a time, and is never waited for -- a tie that needs nodes it does not hold yet is deferred
+    // (k_tie_fix).
     (void)hipEventRecord(ev_steered, stream);
-    (void)hipStreamWaitEvent(stream2, ev_steered, 0);
-    hipLaunchKernelGGL(k_kd_locate, dim3(wave_blocks), dim3(256), 0, stream2, rcp, b, nb, vwords);
-    hipLaunchKernelGGL(k_kd_claim, dim3(1), dim3(1024), 0, stream2, rcp, b, vwords);
-    hipLaunchKernelGGL(k_kd_hint, dim3(wave_blocks), dim3(256), 0, stream2, rcp, b, vwords);
-    (void)hipEventRecord(ev_kd[b & 1u], stream2);
-    kd_pend[b & 1u] = true;
-    if (kd_pend[(b + 1u) & 1u]) { (void)hipStreamWaitEvent(stream, ev_kd[(b + 1u) & 1u], 0); kd_pend[(b + 1u) & 1u] = false; }
     ev();
     if (lds_bytes) hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
     else hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
     ev();
     hipLaunchKernelGGL(k_commit_rrt, dim3(std::max(wave_blocks, (nxt_nb + 255) / 256)), dim3(256), 0, stream, rcp, b, nb, vwords, nxt_i0, nxt_nb);
+    kd_last_b = b; kd_last_nb = nb;
+    side_active = true;
+    if (b + 1 - kd_b0 >= kd_group) launch_kd_group();
 }
 
-// join the side stream back into the main stream (end of a launch sequence / of a capture)
+// kd insertion of steps [kd_b0, kd_last_b] on the side stream (positions are final since the last k_near; the
+// deferred ties are looked at again once the last commit is through)
+void porrt_ctx::launch_kd_group() {
+    if (kd_b0 > kd_last_b) return;
+    const RunConst *rcp = d_rc.p;
+    const uint32_t nsteps = kd_last_b - kd_b0 + 1, K = rc.cand_K, vwords = (K + 63) / 64;
+    (void)hipStreamWaitEvent(stream2, ev_steered, 0);
+    hipLaunchKernelGGL(k_kd_locate, dim3((nsteps * K * 64 + 255) / 256), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u);
+    hipLaunchKernelGGL(k_kd_claim, dim3(1), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords, 0u);
+    hipLaunchKernelGGL(k_kd_hint, dim3((nsteps * K * 64 + 255) / 256), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords);
+    (void)hipEventRecord(ev_step_done, stream);
+    (void)hipStreamWaitEvent(stream2, ev_step_done, 0);
+    hipLaunchKernelGGL(k_tie_fix, dim3(1), dim3(1024), 0, stream2, rcp);
+    // A lagging join: the main stream waits for the group BEFORE this one, which had a whole group of steps to finish.
+    // It bounds how far the kd structure may fall behind and keeps a replayed hipGraph from running the side branch last.
+    const uint32_t par = kd_gidx & 1u;
+    (void)hipEventRecord(ev_kd[par], stream2);
+    kd_pend[par] = true;
+    if (kd_pend[par ^ 1u]) { (void)hipStreamWaitEvent(stream, ev_kd[par ^ 1u], 0); kd_pend[par ^ 1u] = false; }
+    ++kd_gidx;
+    kd_b0 = kd_last_b + 1;
+}
+
+// steps whose new nodes are inserted into the kd structure together (at most 4096 nodes, the claim kernel's capacity)
+static uint32_t kd_group_for(uint32_t K) {
+    uint32_t g = std::max<uint32_t>(1u, std::min<uint32_t>(8u, 4096u / K));
+    if (const char *s = getenv("PORRT_KD_GROUP")) g = std::max<uint32_t>(1u, std::min<uint32_t>(g, (uint32_t)atoi(s)));
+    return g;
+}
+
+// join the kd streams back into the main stream (end of a launch sequence / of a capture) and settle what is
+// left of the deferred ties
 void porrt_ctx::join_side() {
-    for (int p2 = 0; p2 < 2; ++p2)
-        if (kd_pend[p2]) { (void)hipStreamWaitEvent(stream, ev_kd[p2], 0); kd_pend[p2] = false; }
+    if (!side_active) return;
+    launch_kd_group();
+    (void)hipEventRecord(ev_join, stream2);
+    (void)hipStreamWaitEvent(stream, ev_join, 0);
+    kd_pend[0] = kd_pend[1] = false;
+    hipLaunchKernelGGL(k_tie_fix, dim3(1), dim3(1024), 0, stream, (const RunConst *)d_rc.p);
+    side_active = false;
 }
 
 int porrt_ctx::grow(const double start[2], double max_step, double search_radius, uint64_t n_iter_min, uint64_t n_iter_max,
@@ -490,6 +529,8 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     const uint32_t vwords = (K + 63) / 64;
     const uint32_t Kpad = vwords * 64;       // sample stride of the per-chunk arrays (multiple of the wave size)
     const uint32_t cand_cap = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(opt_cand_cap, 64), Nmax);
+    // deferred equal-cost parents: at most one record per iteration; the pooled ids are bounded by experience
+    const uint64_t pend_cap = n_iter_max + 2, pool_cap = std::max<uint64_t>(1u << 20, 16 * n_iter_max);
     {
         double t0 = now_s();
         HIPCHK(d_nx.reserve(Nmax)); HIPCHK(d_ny.reserve(Nmax)); HIPCHK(d_distA.reserve(Nmax)); HIPCHK(d_distB.reserve(Nmax));
@@ -502,9 +543,11 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         const uint64_t rg_maxp = Nmax / kPage + 2, pg_cap = 2ull * kRegions + Nmax / kPage + 8;
         HIPCHK(d_rgcnt.reserve(kRegions)); HIPCHK(d_rgdir.reserve((size_t)kRegions * rg_maxp));
         HIPCHK(d_pgxy.reserve(2 * (size_t)pg_cap * kPage)); HIPCHK(d_pgid.reserve((size_t)pg_cap * kPage)); HIPCHK(d_qbound.reserve(2 * (size_t)Kpad));
-        HIPCHK(d_candcnt.reserve(2 * (size_t)K)); HIPCHK(d_kdbox.reserve(Nmax)); HIPCHK(d_locbox.reserve(K)); HIPCHK(d_kqnn.reserve(2 * (size_t)Kpad)); HIPCHK(d_kdhint.reserve((size_t)kHG * kHG));
-        HIPCHK(d_loccur.reserve(K)); HIPCHK(d_locdcur.reserve(K)); HIPCHK(d_locgex.reserve(K)); HIPCHK(d_locflags.reserve(K)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_gndx.reserve(Nmax)); HIPCHK(d_gndy.reserve(Nmax));
-        HIPCHK(d_kqx.reserve(2 * (size_t)Kpad)); HIPCHK(d_kqy.reserve(2 * (size_t)Kpad)); HIPCHK(d_kqvid.reserve(2 * (size_t)Kpad)); HIPCHK(d_candid.reserve(2 * (size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
+        HIPCHK(d_candcnt.reserve(2 * (size_t)K)); HIPCHK(d_kdbox.reserve(Nmax)); HIPCHK(d_locbox.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_kqnn.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kdhint.reserve((size_t)kHG * kHG));
+        HIPCHK(d_loccur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locdcur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locgex.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locflags.reserve(2 * (8 * (size_t)K + 4096)));
+        HIPCHK(d_gsnap.reserve((steps_max + 4) * 4)); HIPCHK(d_pendoff.reserve(pend_cap)); HIPCHK(d_pendn.reserve(pend_cap)); HIPCHK(d_pendcur.reserve(pend_cap));
+        HIPCHK(d_pendstate.reserve(pend_cap)); HIPCHK(d_pendnew.reserve(pend_cap)); HIPCHK(d_pendpool.reserve(pool_cap)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_gndx.reserve(Nmax)); HIPCHK(d_gndy.reserve(Nmax));
+        HIPCHK(d_kqx.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kqy.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kqvid.reserve((steps_max + 2) * Kpad)); HIPCHK(d_candid.reserve(2 * (size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
         HIPCHK(d_gid.reserve(Nmax));
         HIPCHK(d_rep.reserve(kRepTotal));
         HIPCHK(d_kdrec.reserve(Nmax)); HIPCHK(d_gx.reserve(Nmax + 16)); HIPCHK(d_gy.reserve(Nmax + 16)); HIPCHK(d_kdup.reserve(Nmax)); HIPCHK(d_kddepth.reserve(Nmax)); HIPCHK(d_kdgexit.reserve(Nmax));
@@ -539,7 +582,9 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.q_x = d_qx.p; c.q_y = d_qy.p; c.q_nn = d_qnn.p; c.q_vid = d_qvid.p;
     c.q_bound = d_qbound.p; c.rg_cnt = d_rgcnt.p; c.rg_dir = d_rgdir.p; c.pg_xy = d_pgxy.p; c.pg_id = d_pgid.p;
     c.rg_maxp = (uint32_t)(Nmax / kPage + 2); c.pg_cap = (uint32_t)(2ull * kRegions + Nmax / kPage + 8);
-    c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p; c.kq_nn = d_kqnn.p; c.kd_box = d_kdbox.p; c.loc_box = d_locbox.p; c.kd_hint = d_kdhint.p;
+    c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p; c.kq_nn = d_kqnn.p; c.kd_box = d_kdbox.p; c.loc_box = d_locbox.p; c.kd_hint = d_kdhint.p; c.g_snap = d_gsnap.p; c.loc_stride = 8 * K + 4096;
+    c.pend_new = d_pendnew.p; c.pend_pool = d_pendpool.p; c.pend_off = d_pendoff.p; c.pend_n = d_pendn.p; c.pend_cur = d_pendcur.p; c.pend_state = d_pendstate.p;
+    c.pend_cap = (uint32_t)std::min<uint64_t>(pend_cap, 0xFFFFFFFFull); c.pool_cap = (uint32_t)std::min<uint64_t>(pool_cap, 0xFFFFFFFFull);
     c.cand_K = K; c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
     c.rad_T2 = d_radT2.p;
     c.e_from = d_efrom.p; c.e_to = d_eto.p; c.e_tv = d_etv.p; c.e_cap = (uint32_t)d_efrom.n;
@@ -609,6 +654,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(hipMemsetAsync(d_cnt.p, 0, sizeof(Counters), stream));
         HIPCHK(hipMemsetAsync(d_rep.p, 0xFF, kRepTotal * sizeof(int), stream));
         HIPCHK(hipMemsetAsync(d_rgcnt.p, 0, kRegions * sizeof(uint32_t), stream));
+        HIPCHK(hipMemsetAsync(d_pendstate.p, 0, pend_cap * sizeof(uint32_t), stream));
         HIPCHK(hipMemsetAsync(d_kdhint.p, 0, (size_t)kHG * kHG * sizeof(unsigned long long), stream));   // the root: depth 0, id 0
         HIPCHK(hipMemsetAsync(d_validmask.p, 0, (steps_max + 2) * vwords * sizeof(unsigned long long), stream));
         t_setup += now_s() - t0;
@@ -706,8 +752,11 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         if (r) return r;
     }
     HIPCHK(hipEventRecord(ev_first, stream));
+    side_active = false;
+    kd_b0 = 0; kd_last_b = 0; kd_last_nb = 0; kd_gidx = 0;
     kd_pend[0] = kd_pend[1] = false;
-    if (opt_graph && !prof && n_iter_min > 0) {
+    kd_group = kd_group_for(K);
+    if (opt_graph && !prof && n_iter_min > 0 && !getenv("PORRT_NO_GRAPH")) {
         // all steps up to n_iter_min as one hipGraph (two branches: main pipeline + kd insertion); the graph
         // only depends on the launch geometry, so it is instantiated once and replayed by later grows
         const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)d_rc.p, 1};
@@ -715,6 +764,8 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
             double t0 = now_s();
             if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
             hipGraph_t g = nullptr;
+            // stream capture: the side stream only ever waits on events of the capturing stream, and the capturing
+            // stream joins it once at the end (HIP's capture bookkeeping does not take side streams that wait on each other)
             HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
             uint64_t ci = 0;
             uint32_t cb = 0;
@@ -736,6 +787,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         }
         HIPCHK(hipGraphLaunch(graph_exec, stream));
         while (i < n_iter_min) { i += std::min<uint64_t>(K, n_iter_min - i); ++b; }
+        kd_b0 = b; kd_last_b = b ? b - 1 : 0;      // the graph inserted every step it ran into the kd structure and joined
     } else {
         if (mode == PORRT_MODE_RRT && n_iter_min > 0) launch_bound(stream, 0, 0, 0, (uint32_t)std::min<uint64_t>(K, n_iter_min));
         while (i < n_iter_min) {
@@ -798,8 +850,9 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     }
     counters = hc;
     if (getenv("PORRT_DEBUG")) {
-        fprintf(stderr, "[porrt] tie fallbacks %u g_len %u | kd locate: long-way %u (no start %u), levels sum %u max %u, long-way max %u\n", hc.tie_fallbacks, hc.g_len,
-                hc.kd_long, hc.kd_none, hc.kd_lev_sum, hc.kd_lev_max, hc.kd_long_lev_max);
+        fprintf(stderr, "[porrt] tie fallbacks %u g_len %u\n", hc.tie_fallbacks, hc.g_len);
+        fprintf(stderr, "[porrt] claim phases (us avg): load %.1f round1 %.1f block-rounds %.1f tail %.1f fence %.1f over %llu launches\n", hc.dbg[0] * 0.01 / (hc.dbg[5] + 1e-9), hc.dbg[1] * 0.01 / (hc.dbg[5] + 1e-9), hc.dbg[2] * 0.01 / (hc.dbg[5] + 1e-9), hc.dbg[3] * 0.01 / (hc.dbg[5] + 1e-9), hc.dbg[4] * 0.01 / (hc.dbg[5] + 1e-9), hc.dbg[5]);
+        fprintf(stderr, "[porrt] deferred ties: records %u pooled ids %u settled %u\n", hc.pend_cnt, hc.pool_n, hc.n_deferred);
     }
     n_iter = i;
     n_steps = b;
@@ -851,6 +904,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
 
     if (hc.err & ERR_RASTER) { set_err("raster access outside the map, door pixel without zone id, or two zones on one segment (the reference panics here)"); return PORRT_ERR_RASTER; }
     if (hc.err & ERR_EDGE_OVERFLOW) { set_err("edge pool overflow"); return PORRT_ERR_CAPACITY; }
+    if (hc.err & (ERR_TIE_POOL | ERR_PAGE_OVERFLOW)) { set_err("deferred-tie pool / region page pool overflow"); return PORRT_ERR_CAPACITY; }
     if (mode == PORRT_MODE_PTO && !complete) { set_err("final nodes are not reached for each world"); rcode = PORRT_INCOMPLETE; }
     return rcode;
 }
