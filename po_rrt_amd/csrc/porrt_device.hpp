@@ -75,7 +75,6 @@ struct RunConst {
     double *nx, *ny;
     int *rep;                   // cell -> some node in that cell (3-level pyramid), only ever used for bounds
     double bx0, by0, binv_w, binv_h;   // box the pyramid covers
-    double *q_bound;            // per sample (two step parities): upper bound of its squared NN distance
     // region pages (see scan_disc)
     uint32_t *rg_cnt;           // nodes per region
     uint32_t *rg_dir;           // [region][j]: j-th page of the region, j >= 1
@@ -435,57 +434,37 @@ __device__ __forceinline__ void rep_insert(const RunConst &rc, double x, double 
     }
 }
 
-// One thread per sample: upper bound of its nearest-neighbour distance from the pyramid (finest level whose
-// 3x3 neighbourhood holds a node that passes the world filter), turned into the scan's key threshold.
-// Upper bound of sample k's nearest-neighbour distance from the pyramid (finest level whose 3x3 neighbourhood
-// holds a node with id < N that passes the world filter), turned into the scan's key threshold for step b.
+// Upper bound of a sample's squared nearest-neighbour distance from the pyramid: the finest level whose 3x3
+// neighbourhood of the sample's cell holds a node with id < N that passes the world filter (lanes 0..8 take one
+// cell each).  The sample is wave-uniform.
 template <bool PTO>
-__device__ __forceinline__ void nn_bound_sample(const RunConst &rc, uint32_t b, uint32_t N, uint32_t i0, uint32_t k) {
-    const double qx = rc.sx[i0 + k], qy = rc.sy[i0 + k];
-    uint32_t world = 0;
-    if (PTO) world = rc.sworld[i0 + k];
+__device__ __forceinline__ double nn_bound_wave(const RunConst &rc, uint32_t N, double qx, double qy, uint32_t world, uint32_t lane) {
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
     double m = INF;
-    for (int l = 0; l < kRepLevels && m == INF; ++l) {
+    for (int l = 0; l < kRepLevels; ++l) {
         const int G = rep_dim(l);
         int cx, cy;
         rep_cell(rc, qx, qy, G, cx, cy);
-        int r9[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {                    // nine independent loads
-            const int x = cx + (t % 3) - 1, y = cy + (t / 3) - 1;
-            const bool ok = x >= 0 && y >= 0 && x < G && y < G;
-            r9[t] = ok ? rc.rep[rep_off(l) + y * G + x] : -1;
+        int r = -1;
+        if (lane < 9u) {
+            const int x = cx + (int)(lane % 3u) - 1, y = cy + (int)(lane / 3u) - 1;
+            if (x >= 0 && y >= 0 && x < G && y < G) r = rc.rep[rep_off(l) + y * G + x];
         }
-        double x9[9], y9[9];
-        unsigned long long m9[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const bool ok = r9[t] >= 0 && (uint32_t)r9[t] < N;
-            const int r = ok ? r9[t] : 0;
-            x9[t] = rc.nx[r]; y9[t] = rc.ny[r];
-            m9[t] = PTO ? rc.reachA[r] : ~0ull;
-            if (!ok) m9[t] = 0;
+        double d2 = INF;
+        if (r >= 0 && (uint32_t)r < N) {
+            bool pass = true;
+            if (PTO) pass = (rc.reachA[r] >> world) & 1ull;
+            if (pass) d2 = dist2(rc.nx[r], rc.ny[r], qx, qy);
         }
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            if ((m9[t] >> world) & 1ull) {
-                const double d2 = dist2(x9[t], y9[t], qx, qy);
-                m = d2 < m ? d2 : m;
-            }
+        for (int off = 8; off > 0; off >>= 1) {           // lanes 0..15 hold everything
+            const double o = __shfl_xor(d2, off);
+            d2 = o < d2 ? o : d2;
         }
+        m = __shfl(d2, 0);
+        if (m < INF) break;
     }
     if (m == INF && !PTO) m = dist2(rc.nx[0], rc.ny[0], qx, qy);      // the root always exists
-    rc.q_bound[(b & 1u) * rc.part_stride + k] = m;         // double-buffered by step parity
-}
-
-// stand-alone form: first step of a run, PTO steps (fresh reach masks), steps beyond n_iter_min
-template <bool PTO>
-__global__ __launch_bounds__(256) void k_nn_bound(const RunConst *__restrict__ rcp, uint32_t b, uint32_t bsnap, uint32_t i0, uint32_t nb) {
-    const RunConst &rc = *rcp;
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= nb) return;
-    nn_bound_sample<PTO>(rc, b, rc.n_at[bsnap], i0, k);
+    return m;
 }
 
 // ------------------------------------------------------------------ region pages + near search
@@ -499,6 +478,7 @@ __global__ __launch_bounds__(256) void k_nn_bound(const RunConst *__restrict__ r
 // One WAVE serves one sample: lanes <-> the 64 slots of a page (coalesced 1 KiB + 256 B loads, four pages in
 // flight), hits are compacted with a ballot.
 __device__ __forceinline__ uint32_t rank_before(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k);
+__device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k, uint32_t lane);
 constexpr int kRG = 64;
 constexpr uint32_t kRegions = kRG * kRG;
 constexpr uint32_t kPage = 64;
@@ -619,10 +599,19 @@ __device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double 
 // after the distance test), steer + point validity (common.rs:215-225, map_shelves_io.rs:158-170,
 // map_io.rs:165-181), then the radius search around the steered state (nearest_neighbor.rs:94-126:
 // norm2 <= radius  <=>  d2 <= T2 with T2 from the host table) into the sample's neighbour list.
+// The launch may carry the PREVIOUS step's rewire phase 2 in extra workgroups (cb = that step, cnb its samples):
+// the two touch disjoint data, and the step chain loses a kernel.
 template <bool PTO>
-__global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords) {
+__global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, uint32_t cb,
+                                              uint32_t cnb) {
     const RunConst &rc = *rcp;
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t near_blocks = (nb + 3u) / 4u;
+    if (blockIdx.x >= near_blocks) {
+        const uint32_t ck = (blockIdx.x - near_blocks) * 4u + (threadIdx.x >> 6);
+        if (!PTO && ck < cnb) commit_rrt_sample(rc, cb, vwords, ck, lane);
+        return;
+    }
     const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (k >= nb) return;
     const uint32_t N = uni(rc.n_at[b]);
@@ -633,7 +622,7 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
     double bestD = INF;
     int best = 0x7FFFFFFF;
     {
-        const double m = rc.q_bound[(b & 1u) * rc.part_stride + k];
+        const double m = nn_bound_wave<PTO>(rc, N, sqx, sqy, world, lane);
         auto reach = as_global(rc.reachA);
         scan_disc(rc, sqx, sqy, disc_radius(m, sqx, sqy), N, lane, [&](double x, double y, int id, bool ok) {
             if (!ok) return;
@@ -710,7 +699,12 @@ __device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, u
     __shared__ uint32_t s_np, s_base;
     const uint32_t T = blockDim.x;
     for (uint32_t r = threadIdx.x; r < kRegions; r += T) s_add[r] = 0;
-    if (threadIdx.x == 0) { s_np = 0; s_base = kRegions + rc.cnt->n_pages; }
+    if (threadIdx.x == 0) {
+        s_np = 0; s_base = kRegions + rc.cnt->n_pages;
+        uint32_t add = 0;
+        for (uint32_t w = 0; w < vwords; ++w) add += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
+        rc.n_at[b + 1] = rc.n_at[b] + add;        // tree size at the start of the next step
+    }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < nb; k += T)
         if (rc.q_vid[k] >= 0) s_off[k] = (uint16_t)atomicAdd(&s_add[region_of(rc, rc.q_x[k], rc.q_y[k])], 1u);
@@ -1131,30 +1125,11 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunCon
     if (err) atomicOr(&rc.cnt->err, err);
 }
 
-// RRT*: rewire phase 2.  A pair wins iff its candidate equals the accumulated minimum; among equal
-// candidates the lowest new id wins (sequential order of the reference, strict `<`, rrt.rs:157).
-__global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords,
-                                                     uint32_t nxt_i0, uint32_t nxt_nb) {
-    const RunConst &rc = *rcp;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t k = (blockIdx.x * 256u + threadIdx.x) >> 6;
+// RRT*: rewire phase 2 for sample k of step b (one wave).  A pair wins iff its candidate equals the accumulated
+// minimum; among equal candidates the lowest new id wins (sequential order of the reference, strict `<`, rrt.rs:157).
+__device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k, uint32_t lane) {
+    if (!((rc.valid_mask[(size_t)b * vwords + (k >> 6)] >> (k & 63u)) & 1ull)) return;
     const uint32_t N = rc.n_at[b];
-    {
-        // NN bounds of the NEXT step (its samples are known since the start of the run; every node written by
-        // this step's connect kernel may serve as a bound)
-        const uint32_t kb = blockIdx.x * 256u + threadIdx.x;
-        if (kb < nxt_nb) {
-            uint32_t add = 0;
-            for (uint32_t w = 0; w < vwords; ++w) add += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
-            nn_bound_sample<false>(rc, b + 1, N + add, nxt_i0, kb);
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        uint32_t add = 0;
-        for (uint32_t w = 0; w < vwords; ++w) add += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
-        rc.n_at[b + 1] = N + add;
-    }
-    if (k >= nb || rc.q_vid[k] < 0) return;
     const int id = (int)(N + rank_before(rc, b, vwords, k));
     const uint32_t cnt = cand_count(rc, b, k);
     const int *cid = rc.cand_id + cand_off(rc, b, k);
@@ -1172,6 +1147,12 @@ __global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__
         }
         rc.distA[j] = via;
     }
+}
+
+// stand-alone form (last step of a launch sequence)
+__global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
+    const uint32_t k = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    if (k < nb) commit_rrt_sample(*rcp, b, vwords, k, threadIdx.x & 63u);
 }
 
 // Insert this step's nodes into the reference's kd-tree in id order (KdTree::add, nearest_neighbor.rs:29-46;

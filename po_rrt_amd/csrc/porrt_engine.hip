@@ -210,7 +210,8 @@ struct porrt_ctx {
     int download();
     void launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, size_t lds_bytes, bool prof, size_t &ev_used,
                      uint32_t nxt2_i0, uint32_t nxt2_nb);
-    void launch_bound(hipStream_t st, uint32_t b, uint32_t bsnap, uint32_t i0, uint32_t nb);
+    void flush_commit();
+    uint32_t commit_pend_b = 0xFFFFFFFFu, commit_pend_nb = 0;     // RRT*: step whose rewire phase 2 rides in the next k_near
     hipStream_t stream3 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bound[2] = {nullptr, nullptr};
     bool bound_pending[2] = {false, false};
@@ -398,12 +399,6 @@ __global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y
     rc.g_snap[0] = 1; rc.g_snap[1] = rc.cnt->g_nd_len; rc.g_snap[2] = rc.cnt->g_first_dup[0]; rc.g_snap[3] = rc.cnt->g_first_dup[1];
 }
 
-void porrt_ctx::launch_bound(hipStream_t st, uint32_t b, uint32_t bsnap, uint32_t i0, uint32_t nb) {
-    const dim3 kgrid((nb + 255) / 256);
-    if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_nn_bound<true>, kgrid, dim3(256), 0, st, (const RunConst *)d_rc.p, b, bsnap, i0, nb);
-    else hipLaunchKernelGGL(k_nn_bound<false>, kgrid, dim3(256), 0, st, (const RunConst *)d_rc.p, b, bsnap, i0, nb);
-}
-
 // One step.  Main stream: near (NN + steer + radius search), connect, commit (which also bounds the next step's
 // samples).  Side stream (RRT*): order-exact kd insertion of this step's nodes, started as soon as their positions
 // are final and needed only by the NEXT step's connect -- two cross-stream edges per step.
@@ -415,10 +410,14 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
         if (prof && ev_used < ev_pool.size()) (void)hipEventRecord(ev_pool[ev_used++], stream);
     };
     const bool rrt = mode == PORRT_MODE_RRT;
-    if (!rrt) launch_bound(stream, b, b, i0, nb);      // PTO: bounds in-stream (the world filter wants fresh reach masks)
     ev();
-    if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_near<true>, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, i0, nb, vwords);
-    else hipLaunchKernelGGL(k_near<false>, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, i0, nb, vwords);
+    if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_near<true>, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, i0, nb, vwords, 0xFFFFFFFFu, 0u);
+    else {
+        // the previous step's rewire phase 2 rides along in extra workgroups
+        const uint32_t cblocks = commit_pend_b != 0xFFFFFFFFu ? (commit_pend_nb + 3) / 4 : 0;
+        hipLaunchKernelGGL(k_near<false>, dim3(wave_blocks + cblocks), dim3(256), 0, stream, rcp, b, i0, nb, vwords, commit_pend_b, cblocks ? commit_pend_nb : 0u);
+        commit_pend_b = 0xFFFFFFFFu;
+    }
     ev();
     // + 1: the workgroup that files the new nodes into the region pages
     const dim3 cgrid((nb + kConnectWaves - 1) / kConnectWaves + 1), cblock(kConnectWaves * 64);
@@ -438,7 +437,8 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     if (lds_bytes) hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
     else hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
     ev();
-    hipLaunchKernelGGL(k_commit_rrt, dim3(std::max(wave_blocks, (nxt_nb + 255) / 256)), dim3(256), 0, stream, rcp, b, nb, vwords, nxt_i0, nxt_nb);
+    (void)nxt_i0; (void)nxt_nb;
+    commit_pend_b = b; commit_pend_nb = nb;
     kd_last_b = b; kd_last_nb = nb;
     side_active = true;
     if (b + 1 - kd_b0 >= kd_group) launch_kd_group();
@@ -476,7 +476,16 @@ static uint32_t kd_group_for(uint32_t K) {
 
 // join the kd streams back into the main stream (end of a launch sequence / of a capture) and settle what is
 // left of the deferred ties
+// the last launched step's rewire phase 2, stand-alone
+void porrt_ctx::flush_commit() {
+    if (commit_pend_b == 0xFFFFFFFFu) return;
+    const uint32_t vwords = (rc.cand_K + 63) / 64;
+    hipLaunchKernelGGL(k_commit_rrt, dim3((commit_pend_nb * 64 + 255) / 256), dim3(256), 0, stream, (const RunConst *)d_rc.p, commit_pend_b, commit_pend_nb, vwords);
+    commit_pend_b = 0xFFFFFFFFu;
+}
+
 void porrt_ctx::join_side() {
+    flush_commit();
     if (!side_active) return;
     launch_kd_group();
     (void)hipEventRecord(ev_join, stream2);
@@ -542,7 +551,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         // region pages: one static page per region + a pool that cannot run out (sum of ceil(n_r / 64) <= N / 64 + regions)
         const uint64_t rg_maxp = Nmax / kPage + 2, pg_cap = 2ull * kRegions + Nmax / kPage + 8;
         HIPCHK(d_rgcnt.reserve(kRegions)); HIPCHK(d_rgdir.reserve((size_t)kRegions * rg_maxp));
-        HIPCHK(d_pgxy.reserve(2 * (size_t)pg_cap * kPage)); HIPCHK(d_pgid.reserve((size_t)pg_cap * kPage)); HIPCHK(d_qbound.reserve(2 * (size_t)Kpad));
+        HIPCHK(d_pgxy.reserve(2 * (size_t)pg_cap * kPage)); HIPCHK(d_pgid.reserve((size_t)pg_cap * kPage)); 
         HIPCHK(d_candcnt.reserve(2 * (size_t)K)); HIPCHK(d_kdbox.reserve(Nmax)); HIPCHK(d_locbox.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_kqnn.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kdhint.reserve((size_t)kHG * kHG));
         HIPCHK(d_loccur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locdcur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locgex.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locflags.reserve(2 * (8 * (size_t)K + 4096)));
         HIPCHK(d_gsnap.reserve((steps_max + 4) * 4)); HIPCHK(d_pendoff.reserve(pend_cap)); HIPCHK(d_pendn.reserve(pend_cap)); HIPCHK(d_pendcur.reserve(pend_cap));
@@ -580,7 +589,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.inj_xy = (has_inj && !host_samples) ? d_inj.p : nullptr;
     c.inj_base = inj_pos; c.inj_n = inj_xy.size() / 2;
     c.q_x = d_qx.p; c.q_y = d_qy.p; c.q_nn = d_qnn.p; c.q_vid = d_qvid.p;
-    c.q_bound = d_qbound.p; c.rg_cnt = d_rgcnt.p; c.rg_dir = d_rgdir.p; c.pg_xy = d_pgxy.p; c.pg_id = d_pgid.p;
+    c.rg_cnt = d_rgcnt.p; c.rg_dir = d_rgdir.p; c.pg_xy = d_pgxy.p; c.pg_id = d_pgid.p;
     c.rg_maxp = (uint32_t)(Nmax / kPage + 2); c.pg_cap = (uint32_t)(2ull * kRegions + Nmax / kPage + 8);
     c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p; c.kq_nn = d_kqnn.p; c.kd_box = d_kdbox.p; c.loc_box = d_locbox.p; c.kd_hint = d_kdhint.p; c.g_snap = d_gsnap.p; c.loc_stride = 8 * K + 4096;
     c.pend_new = d_pendnew.p; c.pend_pool = d_pendpool.p; c.pend_off = d_pendoff.p; c.pend_n = d_pendn.p; c.pend_cur = d_pendcur.p; c.pend_state = d_pendstate.p;
@@ -753,6 +762,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     }
     HIPCHK(hipEventRecord(ev_first, stream));
     side_active = false;
+    commit_pend_b = 0xFFFFFFFFu;
     kd_b0 = 0; kd_last_b = 0; kd_last_nb = 0; kd_gidx = 0;
     kd_pend[0] = kd_pend[1] = false;
     kd_group = kd_group_for(K);
@@ -769,7 +779,6 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
             HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
             uint64_t ci = 0;
             uint32_t cb = 0;
-            if (mode == PORRT_MODE_RRT) launch_bound(stream, 0, 0, 0, (uint32_t)std::min<uint64_t>(K, n_iter_min));
             while (ci < n_iter_min) {
                 uint32_t nb = (uint32_t)std::min<uint64_t>(K, n_iter_min - ci);
                 uint64_t i2 = ci + nb;                                                       // start of step cb+1
@@ -789,7 +798,6 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         while (i < n_iter_min) { i += std::min<uint64_t>(K, n_iter_min - i); ++b; }
         kd_b0 = b; kd_last_b = b ? b - 1 : 0;      // the graph inserted every step it ran into the kd structure and joined
     } else {
-        if (mode == PORRT_MODE_RRT && n_iter_min > 0) launch_bound(stream, 0, 0, 0, (uint32_t)std::min<uint64_t>(K, n_iter_min));
         while (i < n_iter_min) {
             uint32_t nb = (uint32_t)std::min<uint64_t>(K, n_iter_min - i);
             uint64_t i2 = i + nb;
@@ -822,7 +830,6 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         t_setup += now_s() - t0;
         r = make_samples(i, nb);
         if (r) return r;
-        if (mode == PORRT_MODE_RRT) launch_bound(stream, b, b, (uint32_t)i, nb);     // beyond n_iter_min: in-stream
         launch_step(b, (uint32_t)i, nb, vwords, lds_bytes, prof, ev_used, 0, 0);
         join_side();
         i += nb;
