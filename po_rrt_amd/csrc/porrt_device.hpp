@@ -52,6 +52,15 @@ struct __attribute__((aligned(32))) KdBox {
     double lox, hix, loy, hiy;      // [lo, hi) per axis (nearest_neighbor.rs:32: `<` goes left, equal goes right)
 };
 
+struct KdMove {                 // a node on its way down
+    uint32_t t;                 // index among the launch's new nodes (id = N + t)
+    int cur;                    // parent: node id, or index of a new node once below one
+    uint32_t side, dcur, gex;
+    bool onpath;
+    double vx, vy;
+    KdBox box;
+};
+
 struct Counters {
     uint32_t n_final;
     uint32_t n_edges;
@@ -66,7 +75,7 @@ struct Counters {
     uint32_t kd_done;           // nodes with complete kd records (release-stored by k_kd_claim)
     uint32_t pend_cnt, pool_n;  // deferred ties: records, pooled candidate ids
     uint32_t n_deferred, pend_lo;
-    unsigned long long dbg[8];
+    uint32_t n_losers;          // k_kd_link -> k_kd_claim
     uint32_t kd_snap;           // step up to whose start the kd structure is complete (release-stored by k_kd_claim)
 };
 
@@ -117,6 +126,7 @@ struct RunConst {
     KdBox *kd_box;              // the cell a node was inserted into: a point's root path passes the node iff it lies inside
     KdBox *loc_box;             // per new node of the step: cell of the empty slot k_kd_locate stopped at
     uint32_t loc_stride;        // loc_* are double-buffered by group parity
+    KdMove *kd_losers;          // nodes that lost the bid for their slot ([kClaimMax])
     // deferred equal-cost parents (see connect_rrt_sample / k_tie_fix)
     int *pend_new, *pend_pool;
     uint32_t *pend_off, *pend_n, *pend_cur, *pend_state;
@@ -1297,163 +1307,189 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
         rc.loc_gex[lo] = gex;
         rc.loc_flags[lo] = flags | (side ? LOC_SIDE : 0u);
         rc.loc_box[lo] = bx;
+        atomicMin(&rc.kd_rec[cur].child[side], (int)(N + t));     // first round's bid for the slot (k_kd_link)
     }
 }
 
-// One workgroup links the located nodes (at most kClaimMax of them) into the tree.  Nodes that stopped at the same
-// empty slot are ordered by rounds: the lowest id takes the slot (atomicMin), the others step below it and contend
-// for its child slots in the next round.  Contenders of one slot always arrive in the same round because they
-// share the whole path above it, so this equals sequential insertion in id order.  Only the first round touches
-// the slots of old nodes in memory; every later slot belongs to a node of this launch and lives in LDS, next to
-// copies of the coordinates, so a round costs two barriers.
+// Linking the located nodes into the tree.  Nodes that stopped at the same empty slot must be ordered as sequential
+// insertion in id order would order them: the lowest id takes the slot, the others step below it and contend for its
+// child slots, and so on ("rounds"; contenders of one slot always arrive in the same round because they share the
+// whole path above it).
+//   k_kd_locate  ends with the first round's bid: atomicMin of the id on the slot it found.
+//   k_kd_link    one thread per node, whole GPU: a node that holds its slot is published (parent, depth, cell, goal
+//                path bookkeeping); a loser steps below the winner and is parked in the loser list.
+//   k_kd_claim   one workgroup: plays the remaining rounds for the (few) losers -- every slot they can still reach
+//                belongs to a node of this launch, so the slots live in LDS.  While many nodes are still moving the
+//                whole workgroup plays a round; the last <= 64 are handed to ONE wave, whose rounds need no barrier,
+//                and contenders that are all the same point (the step's copies of the goal point, re-added every
+//                100th iteration) are settled as a chain at once.  Then it publishes how far the structure is complete.
 constexpr uint32_t kClaimMax = 4096;
-__global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords, uint32_t lpar) {
-    const RunConst &rc = *rcp;
-    __shared__ double s_x[kClaimMax], s_y[kClaimMax];
-    __shared__ int s_ch[kClaimMax][2];
-    const unsigned long long T0 = wall_clock64();
-    const uint32_t N = rc.n_at[b0], b = b0 + nsteps - 1u;
+
+// publish one node: parent link, depth, cell, and the goal path bookkeeping
+__device__ __forceinline__ void kd_publish(const RunConst &rc, uint32_t N, const KdMove &m, int parent_id) {
+    const int w = (int)(N + m.t);
+    const uint32_t dw = m.dcur + 1u;
+    rc.kd_rec[parent_id].child[m.side] = w;
+    rc.kd_up[w] = parent_id;
+    rc.kd_depth[w] = dw;
+    rc.kd_box[w] = m.box;
+    if (m.onpath) {
+        if (dw + 8 < rc.g_cap) { rc.g_id[dw] = w; rc.g_x[dw] = m.vx; rc.g_y[dw] = m.vy; }
+        else atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW);
+        rc.kd_gexit[w] = dw | kOnG;
+        atomicMax(&rc.cnt->g_len, dw + 1);
+        if (m.vx == rc.gp_x && m.vy == rc.gp_y) atomicMin(&rc.cnt->g_first_dup[dw & 1u], dw);
+        else {
+            const uint32_t sl = atomicAdd(&rc.cnt->g_nd_len, 1u);
+            rc.g_nd[sl] = dw; rc.g_nd_x[sl] = m.vx; rc.g_nd_y[sl] = m.vy;
+        }
+    } else {
+        rc.kd_gexit[w] = m.gex;
+    }
+}
+
+// step below the winner, a node of this launch with index tw at (wx, wy)
+__device__ __forceinline__ void kd_step_below(const RunConst &rc, KdMove &m, uint32_t tw, double wx, double wy) {
+    const uint32_t dw = m.dcur + 1u;
+    const bool vl = kd_left(m.vx, m.vy, wx, wy, dw);
+    if (m.onpath && vl != kd_left(rc.gp_x, rc.gp_y, wx, wy, dw)) { m.onpath = false; m.gex = dw; }
+    m.cur = (int)tw; m.dcur = dw; m.side = vl ? 0u : 1u;
+    box_cut(m.box, wx, wy, dw, m.side);
+}
+
+__device__ __forceinline__ uint32_t kd_group_size(const RunConst &rc, uint32_t b0, uint32_t nsteps, uint32_t vwords) {
     uint32_t n_new = 0;
     for (uint32_t w = 0; w < vwords * nsteps; ++w) n_new += __popcll(rc.valid_mask[(size_t)b0 * vwords + w]);
+    return n_new;
+}
+
+__global__ __launch_bounds__(256) void k_kd_link(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords, uint32_t lpar) {
+    const RunConst &rc = *rcp;
+    const uint32_t N = rc.n_at[b0];
+    const uint32_t n_new = kd_group_size(rc, b0, nsteps, vwords);
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_new || n_new > kClaimMax) return;
+    const uint32_t lo = lpar * rc.loc_stride + t;
+    KdMove m;
+    m.t = t;
+    const uint32_t fl = rc.loc_flags[lo];
+    m.onpath = fl & LOC_ONPATH;
+    m.side = (fl & LOC_SIDE) ? 1u : 0u;
+    m.cur = rc.loc_cur[lo];
+    m.dcur = rc.loc_dcur[lo];
+    m.gex = rc.loc_gex[lo];
+    m.box = rc.loc_box[lo];
+    m.vx = rc.kd_rec[N + t].x;
+    m.vy = rc.kd_rec[N + t].y;
+    const int w = rc.kd_rec[m.cur].child[m.side];           // the bids were placed by k_kd_locate
+    if (w == (int)(N + t)) { kd_publish(rc, N, m, m.cur); return; }
+    if ((uint32_t)w < N) { atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW); return; }    // cannot happen: the slot was empty in the old tree
+    kd_step_below(rc, m, (uint32_t)w - N, rc.kd_rec[w].x, rc.kd_rec[w].y);
+    rc.kd_losers[atomicAdd(&rc.cnt->n_losers, 1u)] = m;
+}
+
+__global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords) {
+    const RunConst &rc = *rcp;
+    __shared__ int s_ch[kClaimMax][2];
+    __shared__ uint32_t s_nact;
+    __shared__ KdMove s_tail[64];
+    const uint32_t N = rc.n_at[b0], b = b0 + nsteps - 1u;
+    const uint32_t n_new = kd_group_size(rc, b0, nsteps, vwords);
     if (n_new > kClaimMax) { if (threadIdx.x == 0) atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW); return; }
-    const double px = rc.gp_x, py = rc.gp_y;
-    constexpr int kPer = kClaimMax / 1024;
-    bool todo[kPer], onpath[kPer];
-    double vx[kPer], vy[kPer];
-    int cur[kPer];              // parent: node id (first round) or index into this launch's nodes (later rounds)
-    uint32_t side[kPer], dcur[kPer], gex[kPer];
-    KdBox box[kPer];
-#pragma unroll
-    for (int r = 0; r < kPer; ++r) {
-        const uint32_t t = threadIdx.x + r * 1024u;
-        todo[r] = t < n_new;
-        const uint32_t tt = todo[r] ? t : 0u, lo = lpar * rc.loc_stride + tt;
-        const uint32_t fl = rc.loc_flags[lo];
-        onpath[r] = todo[r] && (fl & LOC_ONPATH);
-        side[r] = (fl & LOC_SIDE) ? 1u : 0u;
-        cur[r] = rc.loc_cur[lo];
-        dcur[r] = rc.loc_dcur[lo];
-        gex[r] = rc.loc_gex[lo];
-        box[r] = rc.loc_box[lo];
-        vx[r] = todo[r] ? rc.kd_rec[N + tt].x : 0.0;
-        vy[r] = todo[r] ? rc.kd_rec[N + tt].y : 0.0;
-        if (todo[r]) { s_x[t] = vx[r]; s_y[t] = vy[r]; s_ch[t][0] = kEmpty; s_ch[t][1] = kEmpty; }
-    }
-    // publish one node: parent link, depth, cell, and the goal path bookkeeping
-    auto finish = [&](int r, uint32_t t, int parent_id) {
-        const int w = (int)(N + t);
-        const uint32_t dw = dcur[r] + 1u;
-        rc.kd_rec[parent_id].child[side[r]] = w;
-        rc.kd_up[w] = parent_id;
-        rc.kd_depth[w] = dw;
-        rc.kd_box[w] = box[r];
-        if (onpath[r]) {
-            if (dw + 8 < rc.g_cap) { rc.g_id[dw] = w; rc.g_x[dw] = vx[r]; rc.g_y[dw] = vy[r]; }
-            else atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW);
-            rc.kd_gexit[w] = dw | kOnG;
-            atomicMax(&rc.cnt->g_len, dw + 1);
-            if (vx[r] == px && vy[r] == py) atomicMin(&rc.cnt->g_first_dup[dw & 1u], dw);
-            else {
-                const uint32_t sl = atomicAdd(&rc.cnt->g_nd_len, 1u);
-                rc.g_nd[sl] = dw; rc.g_nd_x[sl] = vx[r]; rc.g_nd_y[sl] = vy[r];
-            }
-        } else {
-            rc.kd_gexit[w] = gex[r];
-        }
-    };
-    // step below the winner w (a node of this launch, index tw)
-    auto step_below = [&](int r, uint32_t tw) {
-        const double wx = s_x[tw], wy = s_y[tw];
-        const uint32_t dw = dcur[r] + 1u;
-        const bool vl = kd_left(vx[r], vy[r], wx, wy, dw);
-        if (onpath[r] && vl != kd_left(px, py, wx, wy, dw)) { onpath[r] = false; gex[r] = dw; }
-        cur[r] = (int)tw; dcur[r] = dw; side[r] = vl ? 0u : 1u;
-        box_cut(box[r], wx, wy, dw, side[r]);
-    };
-    const unsigned long long T1 = wall_clock64();
-    // first round: slots of old nodes
-#pragma unroll
-    for (int r = 0; r < kPer; ++r)
-        if (todo[r]) atomicMin(&rc.kd_rec[cur[r]].child[side[r]], (int)(N + threadIdx.x + r * 1024u));
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < kPer; ++r) {
-        if (!todo[r]) continue;
-        const uint32_t t = threadIdx.x + r * 1024u;
-        const int w = atomicMin(&rc.kd_rec[cur[r]].child[side[r]], kEmpty);   // read the winner at L2
-        if (w == (int)(N + t)) { finish(r, t, cur[r]); todo[r] = false; }
-        else step_below(r, (uint32_t)w - N);
-    }
-    const unsigned long long T2 = wall_clock64();
-    // later rounds: slots of this launch's nodes, in LDS.  While many nodes are still moving, the whole workgroup
-    // plays a round (two barriers); the last few (the step's copies of the goal point, one below the other) are
-    // handed to ONE wave, whose rounds need no barrier at all.
-    __shared__ uint32_t s_nact, s_tail_t[64], s_tail_cur[64], s_tail_fl[64], s_tail_d[64], s_tail_gex[64];
-    __shared__ KdBox s_tail_box[64];
-    for (;;) {
-        uint32_t mine = 0;
-#pragma unroll
-        for (int r = 0; r < kPer; ++r) mine += todo[r] ? 1u : 0u;
-        if (threadIdx.x == 0) s_nact = 0;
-        __syncthreads();
-        if (mine) atomicAdd(&s_nact, mine);
-        __syncthreads();
-        const uint32_t n_act = s_nact;
-        if (n_act <= 64u) break;
-#pragma unroll
-        for (int r = 0; r < kPer; ++r)
-            if (todo[r]) atomicMin(&s_ch[cur[r]][side[r]], (int)(threadIdx.x + r * 1024u));
-        __syncthreads();
+    const uint32_t n_l = rc.cnt->n_losers;
+    auto grec = as_global(rc.kd_rec);
+    if (n_l) {
+        for (uint32_t t = threadIdx.x; t < n_new; t += 1024u) { s_ch[t][0] = kEmpty; s_ch[t][1] = kEmpty; }
+        constexpr int kPer = kClaimMax / 1024;
+        bool todo[kPer];
+        KdMove mv[kPer];
 #pragma unroll
         for (int r = 0; r < kPer; ++r) {
-            if (!todo[r]) continue;
-            const uint32_t t = threadIdx.x + r * 1024u;
-            const int w = s_ch[cur[r]][side[r]];
-            if (w == (int)t) { finish(r, t, (int)(N + (uint32_t)cur[r])); todo[r] = false; }
-            else step_below(r, (uint32_t)w);
+            const uint32_t q = threadIdx.x + r * 1024u;
+            todo[r] = q < n_l;
+            mv[r] = rc.kd_losers[todo[r] ? q : 0u];
         }
-    }
-    const unsigned long long T3 = wall_clock64();
-    if (s_nact) {
         __syncthreads();
-        if (threadIdx.x == 0) s_nact = 0;
-        __syncthreads();
+        auto settle = [&](KdMove &m, bool &td) {            // after the bids of a round
+            const int w = s_ch[m.cur][m.side];
+            if (w == (int)m.t) { kd_publish(rc, N, m, (int)(N + (uint32_t)m.cur)); td = false; }
+            else kd_step_below(rc, m, (uint32_t)w, grec[N + (uint32_t)w].x, grec[N + (uint32_t)w].y);
+        };
+        for (;;) {
+            uint32_t mine = 0;
 #pragma unroll
-        for (int r = 0; r < kPer; ++r) {
-            if (!todo[r]) continue;
-            const uint32_t q = atomicAdd(&s_nact, 1u);
-            s_tail_t[q] = threadIdx.x + r * 1024u; s_tail_cur[q] = (uint32_t)cur[r]; s_tail_fl[q] = side[r] | (onpath[r] ? 2u : 0u);
-            s_tail_d[q] = dcur[r]; s_tail_gex[q] = gex[r]; s_tail_box[q] = box[r];
+            for (int r = 0; r < kPer; ++r) mine += todo[r] ? 1u : 0u;
+            if (threadIdx.x == 0) s_nact = 0;
+            __syncthreads();
+            if (mine) atomicAdd(&s_nact, mine);
+            __syncthreads();
+            if (s_nact <= 64u) break;
+#pragma unroll
+            for (int r = 0; r < kPer; ++r)
+                if (todo[r]) atomicMin(&s_ch[mv[r].cur][mv[r].side], (int)mv[r].t);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kPer; ++r)
+                if (todo[r]) settle(mv[r], todo[r]);
         }
-        __syncthreads();
-        if (threadIdx.x < 64u) {
-            const uint32_t q = threadIdx.x;
-            todo[0] = q < s_nact;
-            uint32_t t = 0;
-            if (todo[0]) {
-                t = s_tail_t[q]; cur[0] = (int)s_tail_cur[q]; side[0] = s_tail_fl[q] & 1u; onpath[0] = s_tail_fl[q] & 2u;
-                dcur[0] = s_tail_d[q]; gex[0] = s_tail_gex[q]; box[0] = s_tail_box[q]; vx[0] = s_x[t]; vy[0] = s_y[t];
-            }
-            while (__ballot(todo[0])) {
-                if (todo[0]) atomicMin(&s_ch[cur[0]][side[0]], (int)t);
-                __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0) only: the LDS atomics, not the stores of finish()
-                __builtin_amdgcn_wave_barrier();
-                if (todo[0]) {
-                    const int w = s_ch[cur[0]][side[0]];
-                    if (w == (int)t) { finish(0, t, (int)(N + (uint32_t)cur[0])); todo[0] = false; }
-                    else step_below(0, (uint32_t)w);
+        if (s_nact) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_nact = 0;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kPer; ++r)
+                if (todo[r]) s_tail[atomicAdd(&s_nact, 1u)] = mv[r];
+            __syncthreads();
+            if (threadIdx.x < 64u) {
+                bool td = threadIdx.x < s_nact;
+                KdMove m = s_tail[td ? threadIdx.x : 0u];
+                while (__ballot(td)) {
+                    {   // contenders of one slot that are all the same point form a chain in id order: settle it at once
+                        const uint32_t slot = ((uint32_t)m.cur << 1) | m.side;
+                        unsigned long long rem = __ballot(td);
+                        while (rem) {
+                            const int l0 = (int)__builtin_ctzll(rem);
+                            const uint32_t slot0 = (uint32_t)__builtin_amdgcn_readlane((int)slot, l0);
+                            const double x0 = __shfl(m.vx, l0), y0 = __shfl(m.vy, l0);
+                            const unsigned long long grp = __ballot(td && slot == slot0);
+                            const unsigned long long same = __ballot(td && slot == slot0 && m.vx == x0 && m.vy == y0);
+                            rem &= ~grp;
+                            if (same != grp || __popcll(grp) < 2) continue;
+                            const bool in = (grp >> threadIdx.x) & 1ull;
+                            uint32_t rank = 0, par = 0;
+                            for (unsigned long long mm = grp; mm;) {
+                                const int l = (int)__builtin_ctzll(mm);
+                                mm &= mm - 1;
+                                const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)m.t, l);
+                                if (in && tl < m.t) { ++rank; par = (rank == 1 || tl > par) ? tl : par; }
+                            }
+                            if (in) {
+                                if (rank == 0) {
+                                    s_ch[m.cur][m.side] = (int)m.t;
+                                    kd_publish(rc, N, m, (int)(N + (uint32_t)m.cur));
+                                } else {
+                                    for (uint32_t i = 0; i < rank; ++i) kd_step_below(rc, m, par, m.vx, m.vy);   // same point at every level
+                                    s_ch[par][m.side] = (int)m.t;
+                                    kd_publish(rc, N, m, (int)(N + par));
+                                }
+                                td = false;
+                            }
+                        }
+                    }
+                    if (td) atomicMin(&s_ch[m.cur][m.side], (int)m.t);
+                    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0) only: the LDS atomics, not the stores of kd_publish
+                    __builtin_amdgcn_wave_barrier();
+                    if (td) settle(m, td);
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_wave_barrier();
             }
         }
     }
-    const unsigned long long T4 = wall_clock64();
     // every record of the group is written: connect kernels running beside us may now trust ids < N + n_new
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long T5 = wall_clock64();
-        rc.cnt->dbg[0] += T1 - T0; rc.cnt->dbg[1] += T2 - T1; rc.cnt->dbg[2] += T3 - T2; rc.cnt->dbg[3] += T4 - T3; rc.cnt->dbg[4] += T5 - T4; rc.cnt->dbg[5] += 1;
+        rc.cnt->n_losers = 0;
         // G as the next k_kd_locate may see it
         rc.g_snap[4 * (b + 1) + 0] = __hip_atomic_load(&rc.cnt->g_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         rc.g_snap[4 * (b + 1) + 1] = __hip_atomic_load(&rc.cnt->g_nd_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

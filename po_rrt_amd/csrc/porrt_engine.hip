@@ -163,6 +163,7 @@ struct porrt_ctx {
     DevBuf<int> d_parent, d_qnn, d_qvid, d_pgid, d_candid, d_gid, d_kdup;
     DevBuf<KdRec> d_kdrec;
     DevBuf<KdBox> d_kdbox, d_locbox;
+    DevBuf<KdMove> d_kdlosers;
     DevBuf<int> d_loccur;
     DevBuf<uint32_t> d_locdcur, d_locgex, d_locflags, d_kdsurv;
     DevBuf<double> d_gx, d_gy, d_gndx, d_gndy, d_kqx, d_kqy;
@@ -235,7 +236,7 @@ int porrt_ctx::layout_buffers() {
     if (all_bufs.empty()) {
         DevBufBase *list[] = {&d_nx, &d_ny, &d_distA, &d_distB, &d_sx, &d_sy, &d_qx, &d_qy, &d_qbound, &d_pgxy, &d_candval, &d_radT2, &d_inj,
                               &d_parent, &d_qnn, &d_qvid, &d_pgid, &d_candid, &d_gid, &d_kdup, &d_kdrec, &d_gx, &d_gy, &d_rgcnt,
-                              &d_rgdir, &d_rep, &d_kdbox, &d_locbox, &d_kqnn, &d_kdhint, &d_gsnap, &d_pendoff, &d_pendn, &d_pendcur, &d_pendstate, &d_pendnew, &d_pendpool, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB,
+                              &d_rgdir, &d_rep, &d_kdbox, &d_locbox, &d_kdlosers, &d_kqnn, &d_kdhint, &d_gsnap, &d_pendoff, &d_pendn, &d_pendcur, &d_pendstate, &d_pendnew, &d_pendpool, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB,
                               &d_finalmask, &d_validmask, &d_vid, &d_finalflag, &d_cls, &d_nat, &d_sworld, &d_candcnt, &d_efrom,
                               &d_eto, &d_etv, &d_cnt, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags, &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid};
         for (DevBufBase *b2 : list) all_bufs.push_back(b2);
@@ -265,7 +266,7 @@ int porrt_ctx::layout_buffers() {
     d_candid.p = (int *)d_candid.vp; d_gid.p = (int *)d_gid.vp; d_kdup.p = (int *)d_kdup.vp; d_kdrec.p = (KdRec *)d_kdrec.vp;
     d_gx.p = (double *)d_gx.vp; d_gy.p = (double *)d_gy.vp; d_rgcnt.p = (uint32_t *)d_rgcnt.vp; d_rgdir.p = (uint32_t *)d_rgdir.vp;
     d_rep.p = (int *)d_rep.vp;
-    d_kdbox.p = (KdBox *)d_kdbox.vp; d_locbox.p = (KdBox *)d_locbox.vp; d_kqnn.p = (int *)d_kqnn.vp; d_kdhint.p = (unsigned long long *)d_kdhint.vp;
+    d_kdbox.p = (KdBox *)d_kdbox.vp; d_locbox.p = (KdBox *)d_locbox.vp; d_kdlosers.p = (KdMove *)d_kdlosers.vp; d_kqnn.p = (int *)d_kqnn.vp; d_kdhint.p = (unsigned long long *)d_kdhint.vp;
     d_gsnap.p = (uint32_t *)d_gsnap.vp; d_pendoff.p = (uint32_t *)d_pendoff.vp; d_pendn.p = (uint32_t *)d_pendn.vp; d_pendcur.p = (uint32_t *)d_pendcur.vp;
     d_pendstate.p = (uint32_t *)d_pendstate.vp; d_pendnew.p = (int *)d_pendnew.vp; d_pendpool.p = (int *)d_pendpool.vp; d_kddepth.p = (uint32_t *)d_kddepth.vp; d_kdgexit.p = (uint32_t *)d_kdgexit.vp;
     d_reachA.p = (unsigned long long *)d_reachA.vp; d_reachB.p = (unsigned long long *)d_reachB.vp;
@@ -452,7 +453,8 @@ void porrt_ctx::launch_kd_group() {
     const uint32_t nsteps = kd_last_b - kd_b0 + 1, K = rc.cand_K, vwords = (K + 63) / 64;
     (void)hipStreamWaitEvent(stream2, ev_steered, 0);
     hipLaunchKernelGGL(k_kd_locate, dim3((nsteps * K * 64 + 255) / 256), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u);
-    hipLaunchKernelGGL(k_kd_claim, dim3(1), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords, 0u);
+    hipLaunchKernelGGL(k_kd_link, dim3((nsteps * K + 255) / 256), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords, 0u);
+    hipLaunchKernelGGL(k_kd_claim, dim3(1), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
     hipLaunchKernelGGL(k_kd_hint, dim3((nsteps * K * 64 + 255) / 256), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords);
     (void)hipEventRecord(ev_step_done, stream);
     (void)hipStreamWaitEvent(stream2, ev_step_done, 0);
@@ -467,9 +469,11 @@ void porrt_ctx::launch_kd_group() {
     kd_b0 = kd_last_b + 1;
 }
 
-// steps whose new nodes are inserted into the kd structure together (at most 4096 nodes, the claim kernel's capacity)
+// steps whose new nodes are inserted into the kd structure together (about 2048 nodes: the kd kernels' run time is
+// set by the deepest descent, not by the node count, so two steps of K = 1024 cost little more than one; at most
+// kClaimMax nodes)
 static uint32_t kd_group_for(uint32_t K) {
-    uint32_t g = std::max<uint32_t>(1u, std::min<uint32_t>(8u, 4096u / K));
+    uint32_t g = std::max<uint32_t>(1u, std::min<uint32_t>(8u, 2048u / K));
     if (const char *s = getenv("PORRT_KD_GROUP")) g = std::max<uint32_t>(1u, std::min<uint32_t>(g, (uint32_t)atoi(s)));
     return g;
 }
@@ -552,7 +556,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         const uint64_t rg_maxp = Nmax / kPage + 2, pg_cap = 2ull * kRegions + Nmax / kPage + 8;
         HIPCHK(d_rgcnt.reserve(kRegions)); HIPCHK(d_rgdir.reserve((size_t)kRegions * rg_maxp));
         HIPCHK(d_pgxy.reserve(2 * (size_t)pg_cap * kPage)); HIPCHK(d_pgid.reserve((size_t)pg_cap * kPage)); 
-        HIPCHK(d_candcnt.reserve(2 * (size_t)K)); HIPCHK(d_kdbox.reserve(Nmax)); HIPCHK(d_locbox.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_kqnn.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kdhint.reserve((size_t)kHG * kHG));
+        HIPCHK(d_candcnt.reserve(2 * (size_t)K)); HIPCHK(d_kdbox.reserve(Nmax)); HIPCHK(d_kdlosers.reserve(kClaimMax)); HIPCHK(d_locbox.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_kqnn.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kdhint.reserve((size_t)kHG * kHG));
         HIPCHK(d_loccur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locdcur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locgex.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locflags.reserve(2 * (8 * (size_t)K + 4096)));
         HIPCHK(d_gsnap.reserve((steps_max + 4) * 4)); HIPCHK(d_pendoff.reserve(pend_cap)); HIPCHK(d_pendn.reserve(pend_cap)); HIPCHK(d_pendcur.reserve(pend_cap));
         HIPCHK(d_pendstate.reserve(pend_cap)); HIPCHK(d_pendnew.reserve(pend_cap)); HIPCHK(d_pendpool.reserve(pool_cap)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_gndx.reserve(Nmax)); HIPCHK(d_gndy.reserve(Nmax));
@@ -591,7 +595,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.q_x = d_qx.p; c.q_y = d_qy.p; c.q_nn = d_qnn.p; c.q_vid = d_qvid.p;
     c.rg_cnt = d_rgcnt.p; c.rg_dir = d_rgdir.p; c.pg_xy = d_pgxy.p; c.pg_id = d_pgid.p;
     c.rg_maxp = (uint32_t)(Nmax / kPage + 2); c.pg_cap = (uint32_t)(2ull * kRegions + Nmax / kPage + 8);
-    c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p; c.kq_nn = d_kqnn.p; c.kd_box = d_kdbox.p; c.loc_box = d_locbox.p; c.kd_hint = d_kdhint.p; c.g_snap = d_gsnap.p; c.loc_stride = 8 * K + 4096;
+    c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p; c.kq_nn = d_kqnn.p; c.kd_box = d_kdbox.p; c.loc_box = d_locbox.p; c.kd_losers = d_kdlosers.p; c.kd_hint = d_kdhint.p; c.g_snap = d_gsnap.p; c.loc_stride = 8 * K + 4096;
     c.pend_new = d_pendnew.p; c.pend_pool = d_pendpool.p; c.pend_off = d_pendoff.p; c.pend_n = d_pendn.p; c.pend_cur = d_pendcur.p; c.pend_state = d_pendstate.p;
     c.pend_cap = (uint32_t)std::min<uint64_t>(pend_cap, 0xFFFFFFFFull); c.pool_cap = (uint32_t)std::min<uint64_t>(pool_cap, 0xFFFFFFFFull);
     c.cand_K = K; c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
@@ -858,7 +862,6 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     counters = hc;
     if (getenv("PORRT_DEBUG")) {
         fprintf(stderr, "[porrt] tie fallbacks %u g_len %u\n", hc.tie_fallbacks, hc.g_len);
-        fprintf(stderr, "[porrt] claim phases (us avg): load %.1f round1 %.1f block-rounds %.1f tail %.1f fence %.1f over %llu launches\n", hc.dbg[0] * 0.01 / (hc.dbg[5] + 1e-9), hc.dbg[1] * 0.01 / (hc.dbg[5] + 1e-9), hc.dbg[2] * 0.01 / (hc.dbg[5] + 1e-9), hc.dbg[3] * 0.01 / (hc.dbg[5] + 1e-9), hc.dbg[4] * 0.01 / (hc.dbg[5] + 1e-9), hc.dbg[5]);
         fprintf(stderr, "[porrt] deferred ties: records %u pooled ids %u settled %u\n", hc.pend_cnt, hc.pool_n, hc.n_deferred);
     }
     n_iter = i;

@@ -11,7 +11,7 @@ for r in q:
     if n.startswith('k_near'):
         cur=[];steps.append(cur)
     if cur is not None: cur.append((n,(int(r['Start_Timestamp'])-t0)/1e3,(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3))
-for si in (2,10,30,60,100,107):
+for si in (2,10,30,60,61,62,63,100,101,107):
     if si>=len(steps): continue
     s=steps[si]; b=s[0][1]
     print(si,' '.join('%s@%.0f+%.0f'%(n[2:9],t-b,d) for n,t,d in s))
