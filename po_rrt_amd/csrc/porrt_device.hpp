@@ -927,6 +927,16 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     const uint32_t N = rc.n_at[b];
     const uint32_t id = N + rank_before(rc, b, vwords, k);
     const double px = rc.q_x[k], py = rc.q_y[k];
+    // SquareGoal test (common.rs:336-345), lane g <-> goal g: the loads go out now, the answer is needed at the end
+    double goal_d = __longlong_as_double(0x7FF0000000000000ll);
+    unsigned long long goal_m = 0;
+    const int goal_kind = rc.goal_kind;
+    if (goal_kind == 1 && tm.lane < rc.G) {
+        goal_d = fabs(rc.gcx[tm.lane] - px);
+        goal_d += fabs(rc.gcy[tm.lane] - py);
+        goal_m = rc.gmask[tm.lane];
+    }
+    const double goal_l1 = rc.g_l1;
     auto cid = as_global(rc.cand_id) + cand_off(rc, b, k);            // read-only here
     auto cval = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
     auto gnx = as_global(rc.nx), gny = as_global(rc.ny), gdA = as_global(rc.distA);
@@ -1037,22 +1047,52 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
                 }
             }
         }
-        best_cost = sqrt(dist2(gnx[best], gny[best], px, py));
-        dnew = gdA[best] + best_cost;
+        // cost and dist_root through the chosen parent: the lane that holds it as its first candidate has both
+        const unsigned long long own = W == 1 ? __ballot(j0 == best && cost0 >= 0.0) : 0ull;
+        if (own) {
+            const int src = (int)__builtin_ctzll(own);
+            best_cost = __shfl(cost0, src);
+            dnew = __shfl(tot0, src);
+        } else {
+            best_cost = sqrt(dist2(gnx[best], gny[best], px, py));
+            dnew = gdA[best] + best_cost;
+        }
     }
 
     // new node (rrt.rs:148, 30-37) and goal test (rrt.rs:165-167)
+    bool fin = false;
+    unsigned long long fmask = 0;
+    if (goal_kind == 1) {
+        const unsigned long long hits = __ballot(goal_d < goal_l1);      // first listed goal wins
+        if (hits) { fin = true; fmask = __shfl(goal_m, (int)__builtin_ctzll(hits)); }
+    }
     if (tl == 0) {
-        rc.nx[id] = px;
-        rc.ny[id] = py;
-        rep_insert(rc, px, py, (int)id);
-        rc.parent[id] = deferred ? kParentPending : best;
-        rc.distA[id] = dnew;
-        rc.distB[id] = dnew;
-        unsigned long long mask = 0;
-        const bool fin = goal_hit(rc, ggrid, px, py, mask, &err);
-        rc.final_flag[id] = fin ? 1 : 0;
-        rc.final_mask[id] = fin ? mask : 0ull;
+        // everything that READS memory first (the memory counter is in order: a load's wait behind a store waits for
+        // the store's round trip too), then nothing but stores
+        if (goal_kind == 2) fin = goal_hit(rc, ggrid, px, py, fmask, &err);
+        int rep_at[kRepLevels];
+#pragma unroll
+        for (int l = 0; l < kRepLevels; ++l) {
+            int cx, cy;
+            const int G = rep_dim(l);
+            rep_cell(rc, px, py, G, cx, cy);
+            rep_at[l] = rep_off(l) + cy * G + cx;
+        }
+        auto g_rep = as_global(rc.rep);
+        auto g_par = as_global(rc.parent);
+        auto g_ff = as_global(rc.final_flag);
+        auto g_fm = as_global(rc.final_mask);
+        auto g_dB = as_global(rc.distB);
+        auto g_nx = as_global(rc.nx), g_ny = as_global(rc.ny), g_dA = as_global(rc.distA);
+        g_nx[id] = px;
+        g_ny[id] = py;
+#pragma unroll
+        for (int l = 0; l < kRepLevels; ++l) g_rep[rep_at[l]] = (int)id;
+        g_par[id] = deferred ? kParentPending : best;
+        g_dA[id] = dnew;
+        g_dB[id] = dnew;
+        g_ff[id] = fin ? 1 : 0;
+        g_fm[id] = fin ? fmask : 0ull;
         if (fin) atomicAdd(&rc.cnt->n_final, 1u);
     }
     // rewire phase 1 (rrt.rs:152-161): dist_root candidates, min wins
