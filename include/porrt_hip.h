@@ -138,7 +138,9 @@ typedef struct {
 } porrt_metrics;
 int porrt_get_metrics(const porrt_ctx *ctx, porrt_metrics *out);
 /* options: "profile" (0/1 per-kernel HIP events), "cand_cap" (initial neighbour-list
- * capacity per sample), "graph" (0/1 replay the growth loop as a hipGraph) */
+ * capacity per sample), "graph" (0/1 replay the growth loop as a hipGraph), "kd_group" (steps whose
+ * new nodes enter the tie-order structure together; 0 = chosen from batch_K).  None of them changes
+ * a result. */
 int porrt_set_option(porrt_ctx *ctx, const char *name, int64_t value);
 
 /* Device arithmetic self-test: sqrt and divide of n doubles on the GPU versus the host's correctly

@@ -157,6 +157,7 @@ struct porrt_ctx {
     // ---- options
     bool opt_profile = false;
     bool opt_graph = true;
+    uint32_t opt_kd_group = 0;     // steps per kd insertion (0 = choose by K)
     uint32_t opt_cand_cap = 2048;
     // ---- device buffers
     DevBuf<double> d_nx, d_ny, d_distA, d_distB, d_sx, d_sy, d_qx, d_qy, d_qbound, d_pgxy, d_candval, d_radT2, d_inj;
@@ -472,9 +473,10 @@ void porrt_ctx::launch_kd_group() {
 // steps whose new nodes are inserted into the kd structure together (about 2048 nodes: the kd kernels' run time is
 // set by the deepest descent, not by the node count, so two steps of K = 1024 cost little more than one; at most
 // kClaimMax nodes)
-static uint32_t kd_group_for(uint32_t K) {
+static uint32_t kd_group_for(uint32_t K, uint32_t opt) {
+    const uint32_t cap = std::max<uint32_t>(1u, std::min<uint32_t>(8u, kClaimMax / K));
     uint32_t g = std::max<uint32_t>(1u, std::min<uint32_t>(8u, 2048u / K));
-    if (const char *s = getenv("PORRT_KD_GROUP")) g = std::max<uint32_t>(1u, std::min<uint32_t>(g, (uint32_t)atoi(s)));
+    if (opt) g = std::min(opt, cap);
     return g;
 }
 
@@ -769,11 +771,11 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     commit_pend_b = 0xFFFFFFFFu;
     kd_b0 = 0; kd_last_b = 0; kd_last_nb = 0; kd_gidx = 0;
     kd_pend[0] = kd_pend[1] = false;
-    kd_group = kd_group_for(K);
-    if (opt_graph && !prof && n_iter_min > 0 && !getenv("PORRT_NO_GRAPH")) {
+    kd_group = kd_group_for(K, opt_kd_group);
+    if (opt_graph && !prof && n_iter_min > 0) {
         // all steps up to n_iter_min as one hipGraph (two branches: main pipeline + kd insertion); the graph
         // only depends on the launch geometry, so it is instantiated once and replayed by later grows
-        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)d_rc.p, 1};
+        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)d_rc.p, kd_group};
         if (!graph_exec || memcmp(key, graph_key, sizeof key)) {
             double t0 = now_s();
             if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -1306,6 +1308,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "profile")) c->opt_profile = value != 0;
     else if (!strcmp(name, "cand_cap")) c->opt_cand_cap = (uint32_t)std::max<int64_t>(64, std::min<int64_t>(value, 1 << 26));
     else if (!strcmp(name, "graph")) c->opt_graph = value != 0;
+    else if (!strcmp(name, "kd_group")) c->opt_kd_group = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else { c->set_err(std::string("unknown option ") + name); return PORRT_ERR_INVALID; }
     return PORRT_OK;
 }

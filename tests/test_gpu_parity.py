@@ -123,6 +123,19 @@ def test_headline_config_full_size(eng_mod):
     assert_same(e, o)
 
 
+@pytest.mark.parametrize("opts", [dict(graph=0), dict(kd_group=1), dict(kd_group=4), dict(graph=0, kd_group=3), dict(profile=1)],
+                         ids=lambda o: ",".join("%s=%s" % kv for kv in o.items()))
+def test_launch_modes_do_not_change_results(eng_mod, opts):
+    """hipGraph replay vs eager launches, and how many steps' nodes enter the kd tie-order structure together (the
+    structure lags the steps; equal-cost parents that need it are settled later), must give the same tree."""
+    case = cases.cfg2(30000)
+    e0, _ = run_gpu(eng_mod, case, 1024)
+    e1, _ = run_gpu(eng_mod, case, 1024, **opts)
+    assert_same(e1, e0)
+    o, _ = run_orc(case, 1024)
+    assert_same(e1, o)
+
+
 def test_injected_samples_equal_seeded_stream(eng_mod):
     case = cases.cfg1(2000)
     e1, _ = run_gpu(eng_mod, case, 256)
