@@ -10,7 +10,7 @@ region; the tree stays on the device (results are downloaded lazily, outside the
 For N > 1 it is launched by torch.distributed.run, one rank per GPU: every rank plans its own independent
 queries (different RNG seeds, no data-path collective: weak scaling) and the job ends with ONE RCCL exchange:
 all_gather of the best path costs + broadcast of the winning tree.
-Rank 0 prints one JSON line.  `roofline` is measured live with HIP events around the scan kernels;
+Rank 0 prints one JSON line.  `roofline` is measured live with HIP events around the search and connect kernels;
 `cpu_baseline` times the single-thread C restatement of the reference loop (oracle/) on the host.
 """
 import argparse
@@ -25,7 +25,6 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-FLOP_PER_PAIR = 3.0            # f32 filter key: 2 FMA + 1 compare per (sample, node) pair
 
 
 def main():
@@ -107,15 +106,15 @@ def main():
     else:
         total_nodes = float(agg["nodes"])
 
-    # roofline pass: the same queries again with HIP events around the scan kernels (eager launches on the
-    # engine's own stream; the timed region above replays the steps as a hipGraph, which cannot carry events)
-    prof = dict(scan_s=0.0, scan_pairs=0.0, scan_bytes=0.0, scan_launches=0, device_s=0.0)
+    # roofline pass: the same queries again with HIP events around the search and connect kernels (eager launches
+    # on the engine's own stream; the timed region above replays the steps as a hipGraph, which cannot carry events)
+    prof = dict(scan_s=0.0, scan_pairs=0.0, scan_bytes=0.0, scan_launches=0, device_s=0.0, connect_s=0.0, nodes=0.0)
     if rank == 0 and not args.no_profile:
         eng.set_option("profile", 1)
         for s in range(args.profile_steps):
-            run_query(s * world + rank)
+            prof["nodes"] += run_query(s * world + rank)
             m = eng.metrics()
-            for k in ("scan_s", "scan_pairs", "scan_bytes", "device_s"):
+            for k in ("scan_s", "scan_pairs", "scan_bytes", "device_s", "connect_s"):
                 prof[k] += m[k]
             prof["scan_launches"] += m["scan_launches"]
         eng.set_option("profile", 0)
@@ -146,44 +145,58 @@ def main():
                 "best_path_cost": win_cost,
                 "winner_rank": winner,
                 "loop_s_rank0": t_loop,
-                "launch": "hipGraph replay of all steps (3 streams: pipeline, heavy connect, kd insertion + bounds)",
+                "launch": "hipGraph replay of all steps (main stream: search, connect; side stream: kd tie-order structure, never waited for)",
             },
         }
         if prof["scan_s"] > 0:
-            agg.update(prof)
-            achieved = agg["scan_bytes"] / agg["scan_s"] / 1e9
-            tflops = FLOP_PER_PAIR * agg["scan_pairs"] / agg["scan_s"] / 1e12
-            traffic, traffic_note = None, None
-            try:    # HBM traffic per launch from the committed rocprofv3 --pmc passes (profiles/r1_pmc_traffic.json)
+            L = max(prof["scan_launches"], 1)
+            # SURVEY 8d, per step ("batch"): the searches stream node x,y (16 B/node per query kind) + samples and
+            # nn/state writes (36 B/sample); connect reads dist_root (8 B/node), the 40 kB grid, and writes the
+            # committed nodes (28 B each).  N_b averaged over the run's steps.
+            grid_bytes = 200.0 * 200.0
+            nb_avg = prof["scan_pairs"] / (2.0 * args.batch * L)
+            near_bytes = prof["scan_bytes"] / L
+            conn_bytes = 8.0 * nb_avg + grid_bytes + 28.0 * prof["nodes"] / L
+            near_us, conn_us = 1e6 * prof["scan_s"] / L, 1e6 * prof["connect_s"] / L
+            pm = {}
+            try:    # HBM traffic per launch from the committed rocprofv3 --pmc passes
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-                ks = [pm[k] for k in pm if k.startswith("k_nn_scan") or k.startswith("k_radius_scan")]
-                if ks:
-                    traffic = sum(2.0 * k["fetch_bytes_per_launch_raw"] + k["write_bytes_per_launch"] for k in ks) / len(ks)
-                    traffic_note = ("bytes per scan launch = 2 x FETCH_SIZE (gfx950 under-reports streaming reads) + WRITE_SIZE, "
-                                    "separate --pmc passes of this command; raw fetch %.0f B, write %.0f B"
-                                    % (sum(k["fetch_bytes_per_launch_raw"] for k in ks) / len(ks),
-                                       sum(k["write_bytes_per_launch"] for k in ks) / len(ks)))
             except Exception:
                 pass
+
+            def traffic_of(prefix):
+                ks = [pm[k] for k in pm if k.startswith(prefix)]
+                if not ks:
+                    return None
+                return sum(2.0 * k["fetch_bytes_per_launch_raw"] + k["write_bytes_per_launch"] for k in ks) / len(ks)
+
+            dom = "k_connect_rrt" if conn_us >= near_us else "k_near"
+            dom_bytes, dom_us = (conn_bytes, conn_us) if dom == "k_connect_rrt" else (near_bytes, near_us)
+            achieved = dom_bytes / (dom_us * 1e-6) / 1e9
             out["roofline"] = {
                 "bound": "hbm",
-                "kernel": "k_nn_scan + k_radius_scan (same loop body; K x N_b sample-node pairs per launch)",
+                "kernel": dom,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_note": traffic_note,
-                "avg_launch_us": 1e6 * agg["scan_s"] / max(agg["scan_launches"], 1),
-                "launches": agg["scan_launches"],
-                "algorithmic_bytes_per_launch": agg["scan_bytes"] / max(agg["scan_launches"], 1),
-                "note": "K=1024 samples reuse every node byte, so the scans are VALU-issue bound by design, not HBM bound; "
-                        "the hot loop is an f32 filter key (2 FMA + 1 compare per pair), exact f64 only on the rare hits",
-                "valu": {"pairs_per_s": agg["scan_pairs"] / agg["scan_s"], "instr_per_pair": 3,
-                         "achieved_tinstr_s": 3 * agg["scan_pairs"] / agg["scan_s"] / 1e12,
-                         "peak_tinstr_s": 78.6, "frac": 3 * agg["scan_pairs"] / agg["scan_s"] / 1e12 / 78.6,
-                         "peak_note": "f32 VALU issue peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (measured 66 T lane-instr/s)"},
-                "scan_share_of_device_time": agg["scan_s"] / max(agg["device_s"], 1e-12),
+                "traffic": traffic_of(dom),
+                "traffic_note": "HBM bytes per launch = 2 x FETCH_SIZE (gfx950 under-reports streaming reads; these kernels gather, "
+                                "so the raw figure may be the truer one) + WRITE_SIZE, separate --pmc passes (profiles/r1_pmc_traffic.json)",
+                "avg_launch_us": dom_us,
+                "launches": L,
+                "algorithmic_bytes_per_launch": dom_bytes,
+                "note": "The step chain is latency bound, not bandwidth bound: ~110 dependent steps per query, each a "
+                        "chain of dependent loads (0.5-1 us each).  The searches touch only the region pages a query disc "
+                        "meets, so real traffic is far below the brute-force figure used for `achieved` (SURVEY 8d).",
+                "kernels": {
+                    "k_near": {"avg_launch_us": near_us, "algorithmic_bytes_per_launch": near_bytes,
+                               "achieved_GBs": near_bytes / (near_us * 1e-6) / 1e9, "traffic": traffic_of("k_near"),
+                               "pairs_answered_per_s": prof["scan_pairs"] / prof["scan_s"]},
+                    "k_connect_rrt": {"avg_launch_us": conn_us, "algorithmic_bytes_per_launch": conn_bytes,
+                                      "achieved_GBs": conn_bytes / (conn_us * 1e-6) / 1e9, "traffic": traffic_of("k_connect_rrt")},
+                },
+                "share_of_device_time": (prof["scan_s"] + prof["connect_s"]) / max(prof["device_s"], 1e-12),
             }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(case, args)
