@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
 """Headline benchmark: RRT node-expansions/sec on the map_benchmark-like map (BASELINE.json configs[1]).
 
-A "step" is one whole planning query: porrt_grow() of an RRT* tree with batch K=1024 samples per GPU step
-until n_iter iterations are spent (~100k-node tree), on the synthetic 200x200 map_benchmark stand-in
-(the reference's raster is a Git-LFS pointer).  Inputs (grid, tables) are resident in HBM before the timed
-region; the tree stays on the device (results are downloaded lazily, outside the timed region).
+A "step" is one pass of the hot path over one batch of synthetic input: Q independent planning queries of
+configs[1] per GPU (default Q = 8, --queries), each an RRT* tree grown with batch K=1024 samples per grow step
+until n_iter iterations are spent (~100k-node tree) on the synthetic 200x200 map_benchmark stand-in (the
+reference's raster is a Git-LFS pointer), all Q advanced together by porrt_grow_batch (one launch sequence, one
+grid row per query: their dependent-load chains overlap inside every kernel).  A single query is latency bound
+(8 ms); the TAMP caller issues thousands of independent ones, so throughput is what a GPU is for here.  The
+single-query figure is measured too and reported in `config.single_query`.  Inputs (grid, tables) are resident in
+HBM before the timed region; the trees stay on the device (results are downloaded lazily).
 
   python bench.py --gpus N --steps K --warmup W
 For N > 1 it is launched by torch.distributed.run, one rank per GPU: every rank plans its own independent
@@ -34,6 +38,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n-iter", type=int, default=111500, help="iterations per query (~100k-node tree)")
     ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--queries", type=int, default=8, help="independent queries advanced together per step and GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event roofline pass")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps run with per-kernel HIP events for `roofline`")
@@ -63,31 +68,37 @@ def main():
         torch.cuda.synchronize()
 
     case = cases.cfg2(args.n_iter)
-    eng = po_rrt_amd.Engine(local_rank)
-    cases.configure(eng, case)
-    eng.set_option("profile", 0)
+    Q = max(1, args.queries)
+    engs = [cases.configure(po_rrt_amd.Engine(local_rank), case) for _ in range(Q)]
+    eng = engs[0]
+    for e in engs:
+        e.set_option("profile", 0)
+    starts = [case.start] * Q
 
-    def run_query(q):
-        eng.set_sampler((-1.0, -1.0), (1.0, 1.0), q)          # query q = RNG seed q
-        cases.grow(eng, case, K=args.batch)
-        return eng.num_nodes() - 1
+    def run_step(s):
+        """one step = Q queries; query ids (= RNG seeds) are unique over steps, ranks and slots"""
+        for j, e in enumerate(engs):
+            e.set_sampler((-1.0, -1.0), (1.0, 1.0), (s * world + rank) * Q + j)
+        po_rrt_amd.Engine.grow_batch(engs, starts, case.max_step, case.search_radius, case.n_iter_min, args.batch)
+        return sum(e.num_nodes() - 1 for e in engs)
 
     for w in range(args.warmup):
-        run_query(10_000 + w * world + rank)
+        run_step(10_000 + w)
 
     agg = dict(nodes=0, device_s=0.0, setup_s=0.0)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        agg["nodes"] += run_query(s * world + rank)
-        m = eng.metrics()
-        agg["device_s"] += m["device_s"]
-        agg["setup_s"] += m["setup_s"]
+        agg["nodes"] += run_step(s)
+        agg["device_s"] += eng.metrics()["device_s"]
     t_loop = time.perf_counter() - t0
     # the one exchange of the job: who holds the best tree?  (download happens here, once per rank)
-    sol = eng.best_solution()
-    my_cost = sol[1] if sol is not None else float("inf")
-    xy, parent, dist_root = eng.tree()
+    my_cost, best_e = float("inf"), eng
+    for e in engs:
+        sol = e.best_solution()
+        if sol is not None and sol[1] < my_cost:
+            my_cost, best_e = sol[1], e
+    xy, parent, dist_root = best_e.tree()
     from po_rrt_amd import sharding
     winner, win_cost, _, wparent, _ = sharding.exchange_best_tree(my_cost, xy, parent, dist_root,
                                                                     dist=dist if world > 1 else None, device="cuda")
@@ -106,13 +117,27 @@ def main():
     else:
         total_nodes = float(agg["nodes"])
 
-    # roofline pass: the same queries again with HIP events around the search and connect kernels (eager launches
-    # on the engine's own stream; the timed region above replays the steps as a hipGraph, which cannot carry events)
+    # latency mode for reference: the same query alone (porrt_grow, one context), outside the timed region
+    single = None
+    if rank == 0:
+        eng.set_sampler((-1.0, -1.0), (1.0, 1.0), 777)
+        cases.grow(eng, case, K=args.batch)
+        ts = []
+        for r in range(3):
+            eng.set_sampler((-1.0, -1.0), (1.0, 1.0), 778 + r)
+            t1 = time.perf_counter()
+            cases.grow(eng, case, K=args.batch)
+            ts.append((time.perf_counter() - t1, eng.num_nodes() - 1))
+        ts.sort()
+        single = {"ms_per_query": 1e3 * ts[1][0], "node_expansions_per_s": ts[1][1] / ts[1][0]}
+
+    # roofline pass: the same step again with HIP events around the search and connect kernels (eager launches on the
+    # engine's own stream; the timed region above replays the steps as a hipGraph, which cannot carry events)
     prof = dict(scan_s=0.0, scan_pairs=0.0, scan_bytes=0.0, scan_launches=0, device_s=0.0, connect_s=0.0, nodes=0.0)
     if rank == 0 and not args.no_profile:
         eng.set_option("profile", 1)
         for s in range(args.profile_steps):
-            prof["nodes"] += run_query(s * world + rank)
+            prof["nodes"] += run_step(s)
             m = eng.metrics()
             for k in ("scan_s", "scan_pairs", "scan_bytes", "device_s", "connect_s"):
                 prof[k] += m[k]
@@ -137,11 +162,15 @@ def main():
                 "workload": "map_benchmark-like 200x200 synthetic map (reference raster is a Git-LFS pointer), 2D RRT* "
                             "(rrt.rs grow_tree), batch K=%d samples/step, %d iterations -> ~%d-node tree per query, "
                             "max_step 0.1, search_radius 2.0, start (0,-1), SquareGoal (0.9,0) r=0.05; "
-                            "one query per step per GPU, seeds differ" % (args.batch, args.n_iter, agg["nodes"] // max(args.steps, 1) + 1),
+                            "%d independent queries per step per GPU (porrt_grow_batch), seeds differ"
+                            % (args.batch, args.n_iter, agg["nodes"] // max(args.steps * Q, 1) + 1, Q),
                 "batch_K": args.batch,
                 "n_iter": args.n_iter,
-                "nodes_per_query": agg["nodes"] / max(args.steps, 1),
-                "parallelism": "independent queries per GPU (x%d), one RCCL all_gather+broadcast at the end" % world,
+                "queries_per_step_per_gpu": Q,
+                "nodes_per_query": agg["nodes"] / max(args.steps * Q, 1),
+                "ms_per_query": 1e3 * elapsed / max(args.steps * Q, 1),
+                "single_query": single,
+                "parallelism": "independent queries: %d per GPU advanced together x %d GPU(s), one RCCL all_gather+broadcast at the end" % (Q, world),
                 "best_path_cost": win_cost,
                 "winner_rank": winner,
                 "loop_s_rank0": t_loop,
@@ -154,9 +183,9 @@ def main():
             # nn/state writes (36 B/sample); connect reads dist_root (8 B/node), the 40 kB grid, and writes the
             # committed nodes (28 B each).  N_b averaged over the run's steps.
             grid_bytes = 200.0 * 200.0
-            nb_avg = prof["scan_pairs"] / (2.0 * args.batch * L)
+            nb_avg = prof["scan_pairs"] / (2.0 * args.batch * L)        # summed over the Q queries of a launch
             near_bytes = prof["scan_bytes"] / L
-            conn_bytes = 8.0 * nb_avg + grid_bytes + 28.0 * prof["nodes"] / L
+            conn_bytes = 8.0 * nb_avg + Q * grid_bytes + 28.0 * prof["nodes"] / L
             near_us, conn_us = 1e6 * prof["scan_s"] / L, 1e6 * prof["connect_s"] / L
             pm = {}
             try:    # HBM traffic per launch from the committed rocprofv3 --pmc passes
@@ -186,7 +215,7 @@ def main():
                 "avg_launch_us": dom_us,
                 "launches": L,
                 "algorithmic_bytes_per_launch": dom_bytes,
-                "note": "The step chain is latency bound, not bandwidth bound: ~110 dependent steps per query, each a "
+                "note": "One launch serves the Q queries of the step.  The step chain is latency bound, not bandwidth bound: ~110 dependent steps per query, each a "
                         "chain of dependent loads (0.5-1 us each).  The searches touch only the region pages a query disc "
                         "meets, so real traffic is far below the brute-force figure used for `achieved` (SURVEY 8d).",
                 "kernels": {

@@ -94,6 +94,17 @@ int porrt_grow(porrt_ctx *ctx, const double start[2], double max_step, double se
 /* ---- results, copied into caller-owned buffers (query the sizes first).
  * Replaces: RRTTree{nodes: Vec<RRTNode{state,parent_id,dist_from_root}>} (rrt.rs:14-22)
  * and the final ids returned by grow_tree (rrt.rs:103,165-167). */
+/* The same growth for several contexts of ONE device at once, with a fixed iteration budget
+ * (n_iter_min == n_iter_max == n_iter: the loop condition of rrt.rs:109 / pto.rs:67 is never consulted,
+ * as in the reference's benchmark drivers, main.rs:532).  Independent queries -- the TAMP caller issues
+ * thousands (map_shelves_tamp_rrt.rs:163-291) -- overlap their dependent-load chains inside each kernel
+ * launch (one grid row per context) instead of queueing behind each other.  starts = n_ctx x 2.  Every
+ * context keeps its own map, goal, sampler state and results, exactly as after n_ctx porrt_grow calls;
+ * the getters are per context.  Contexts must not be used concurrently elsewhere during the call.
+ * Returns the worst member code (PORRT_INCOMPLETE if a PTO member's final set is incomplete). */
+int porrt_grow_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, const double *starts, double max_step,
+                     double search_radius, uint64_t n_iter, uint32_t batch_K, int mode);
+
 uint64_t porrt_num_nodes(const porrt_ctx *ctx);
 uint64_t porrt_num_iterations(const porrt_ctx *ctx);
 int      porrt_get_tree(const porrt_ctx *ctx, double *xy /* N*2 */, int64_t *parent /* -1 = root */,

@@ -614,7 +614,7 @@ __device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double 
 template <bool PTO>
 __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, uint32_t cb,
                                               uint32_t cnb) {
-    const RunConst &rc = *rcp;
+    const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t near_blocks = (nb + 3u) / 4u;
     if (blockIdx.x >= near_blocks) {
@@ -1135,7 +1135,7 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunCon
     __shared__ double s_d[kConnectWaves];
     __shared__ int s_i[kConnectWaves];
     __shared__ uint32_t s_heavy[kConnectWaves];
-    const RunConst &rc = *rcp;
+    const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     if (blockIdx.x == gridDim.x - 1) { insert_step_pages(rc, b, nb, vwords); return; }    // the extra block
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t k = blockIdx.x * kConnectWaves + wv;
@@ -1202,7 +1202,7 @@ __device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vword
 // stand-alone form (last step of a launch sequence)
 __global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
     const uint32_t k = (blockIdx.x * 256u + threadIdx.x) >> 6;
-    if (k < nb) commit_rrt_sample(*rcp, b, vwords, k, threadIdx.x & 63u);
+    if (k < nb) commit_rrt_sample(rcp[blockIdx.y], b, vwords, k, threadIdx.x & 63u);
 }
 
 // Insert this step's nodes into the reference's kd-tree in id order (KdTree::add, nearest_neighbor.rs:29-46;
@@ -1260,7 +1260,7 @@ __device__ __forceinline__ void kd_descend(const RunConst &rc, uint32_t Nsnap, d
 // descent through them.  So this kernel depends on nothing but the steps' k_near and overlaps earlier groups' claims.
 __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t K, uint32_t nb_last,
                                                     uint32_t vwords, uint32_t lpar) {
-    const RunConst &rc = *rcp;
+    const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t st = wid / K, k = wid - st * K;
@@ -1404,7 +1404,7 @@ __device__ __forceinline__ uint32_t kd_group_size(const RunConst &rc, uint32_t b
 }
 
 __global__ __launch_bounds__(256) void k_kd_link(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords, uint32_t lpar) {
-    const RunConst &rc = *rcp;
+    const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     const uint32_t N = rc.n_at[b0];
     const uint32_t n_new = kd_group_size(rc, b0, nsteps, vwords);
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -1429,7 +1429,7 @@ __global__ __launch_bounds__(256) void k_kd_link(const RunConst *__restrict__ rc
 }
 
 __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords) {
-    const RunConst &rc = *rcp;
+    const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     __shared__ int s_ch[kClaimMax][2];
     __shared__ uint32_t s_nact;
     __shared__ KdMove s_tail[64];
@@ -1546,7 +1546,7 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
 // cell(lo) and cell(hi), both excluded, lie inside [lo, hi) because the cell function is monotone; an infinite
 // bound includes the clamped border square.  hint = max over (depth, id), a commutative update.
 __global__ __launch_bounds__(256) void k_kd_hint(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords) {
-    const RunConst &rc = *rcp;
+    const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);
     uint32_t n_new = 0;
@@ -1575,7 +1575,7 @@ __global__ __launch_bounds__(256) void k_kd_hint(const RunConst *__restrict__ rc
 // once more at the end of a run.  The parent is only installed if no rewire replaced the placeholder in the
 // meantime (a rewire is final, rrt.rs:152-161).
 __global__ __launch_bounds__(1024) void k_tie_fix(const RunConst *__restrict__ rcp) {
-    const RunConst &rc = *rcp;
+    const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     uint32_t n = __hip_atomic_load(&rc.cnt->pend_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     n = n < rc.pend_cap ? n : rc.pend_cap;
@@ -1621,7 +1621,7 @@ template <bool LDSGRID>
 __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
                                                                      uint32_t vwords) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_tiles[];
-    const RunConst &rc = *rcp;
+    const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     if (blockIdx.x == gridDim.x - 1) { insert_step_pages(rc, b, nb, vwords); return; }    // the extra block
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = blockIdx.x * kConnectWaves + (threadIdx.x >> 6);
@@ -1710,7 +1710,7 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
 
 // PTO: publish the reach masks touched in this step and refresh the finality (pto_reachability.rs:92-101)
 __global__ __launch_bounds__(256) void k_commit_pto(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
-    const RunConst &rc = *rcp;
+    const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t N = rc.n_at[b];

@@ -25,6 +25,15 @@ typedef unsigned __int128 u128;
 
 namespace {
 
+#define HIPCHK_CTX(ctx, expr)                                                                      \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (ctx)->set_err(std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+            return PORRT_ERR_DEVICE;                                                               \
+        }                                                                                          \
+    } while (0)
+
 #define HIPCHK(expr)                                                                               \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -208,11 +217,17 @@ struct porrt_ctx {
     int grow(const double start[2], double max_step, double search_radius, uint64_t n_iter_min, uint64_t n_iter_max,
              uint32_t K, int mode);
     int grow_once(const double start[2], double max_step, double search_radius, uint64_t n_iter_min, uint64_t n_iter_max,
-                  uint32_t K, int mode, bool host_samples);
+                  uint32_t K, int mode, bool host_samples, int stage = 0);
+    int finish_batch_member(uint64_t n_iter_done, uint32_t steps, float device_ms);
+    size_t run_lds_bytes = 0;
+    RunConst *d_rcarr = nullptr;      // leader of a porrt_grow_batch: the members' RunConst, one per grid row
+    size_t rcarr_cap = 0;
     int download();
     void launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, size_t lds_bytes, bool prof, size_t &ev_used,
                      uint32_t nxt2_i0, uint32_t nxt2_nb);
     void flush_commit();
+    const RunConst *launch_rcp = nullptr;     // RunConst array the step kernels read (one row of the grid per entry)
+    uint32_t launch_Q = 1;
     uint32_t commit_pend_b = 0xFFFFFFFFu, commit_pend_nb = 0;     // RRT*: step whose rewire phase 2 rides in the next k_near
     hipStream_t stream3 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bound[2] = {nullptr, nullptr};
@@ -407,28 +422,29 @@ __global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y
 void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, size_t lds_bytes, bool prof, size_t &ev_used,
                             uint32_t nxt_i0, uint32_t nxt_nb) {
     const uint32_t wave_blocks = (nb * 64 + 255) / 256;
-    const RunConst *rcp = d_rc.p;
+    const RunConst *rcp = launch_rcp;
+    const uint32_t Q = launch_Q;
     auto ev = [&](void) {
         if (prof && ev_used < ev_pool.size()) (void)hipEventRecord(ev_pool[ev_used++], stream);
     };
     const bool rrt = mode == PORRT_MODE_RRT;
     ev();
-    if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_near<true>, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, i0, nb, vwords, 0xFFFFFFFFu, 0u);
+    if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_near<true>, dim3(wave_blocks, Q), dim3(256), 0, stream, rcp, b, i0, nb, vwords, 0xFFFFFFFFu, 0u);
     else {
         // the previous step's rewire phase 2 rides along in extra workgroups
         const uint32_t cblocks = commit_pend_b != 0xFFFFFFFFu ? (commit_pend_nb + 3) / 4 : 0;
-        hipLaunchKernelGGL(k_near<false>, dim3(wave_blocks + cblocks), dim3(256), 0, stream, rcp, b, i0, nb, vwords, commit_pend_b, cblocks ? commit_pend_nb : 0u);
+        hipLaunchKernelGGL(k_near<false>, dim3(wave_blocks + cblocks, Q), dim3(256), 0, stream, rcp, b, i0, nb, vwords, commit_pend_b, cblocks ? commit_pend_nb : 0u);
         commit_pend_b = 0xFFFFFFFFu;
     }
     ev();
     // + 1: the workgroup that files the new nodes into the region pages
-    const dim3 cgrid((nb + kConnectWaves - 1) / kConnectWaves + 1), cblock(kConnectWaves * 64);
+    const dim3 cgrid((nb + kConnectWaves - 1) / kConnectWaves + 1, Q), cblock(kConnectWaves * 64);
     if (!rrt) {
         ev();
         if (lds_bytes) hipLaunchKernelGGL(k_connect_pto<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
         else hipLaunchKernelGGL(k_connect_pto<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
         ev();
-        hipLaunchKernelGGL(k_commit_pto, dim3(wave_blocks), dim3(256), 0, stream, rcp, b, nb, vwords);
+        hipLaunchKernelGGL(k_commit_pto, dim3(wave_blocks, Q), dim3(256), 0, stream, rcp, b, nb, vwords);
         return;
     }
     // RRT*: the kd structure that orders equal-cost parents is built beside the steps on a second stream, several
@@ -450,16 +466,17 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
 // deferred ties are looked at again once the last commit is through)
 void porrt_ctx::launch_kd_group() {
     if (kd_b0 > kd_last_b) return;
-    const RunConst *rcp = d_rc.p;
+    const RunConst *rcp = launch_rcp;
+    const uint32_t Q = launch_Q;
     const uint32_t nsteps = kd_last_b - kd_b0 + 1, K = rc.cand_K, vwords = (K + 63) / 64;
     (void)hipStreamWaitEvent(stream2, ev_steered, 0);
-    hipLaunchKernelGGL(k_kd_locate, dim3((nsteps * K * 64 + 255) / 256), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u);
-    hipLaunchKernelGGL(k_kd_link, dim3((nsteps * K + 255) / 256), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords, 0u);
-    hipLaunchKernelGGL(k_kd_claim, dim3(1), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
-    hipLaunchKernelGGL(k_kd_hint, dim3((nsteps * K * 64 + 255) / 256), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords);
+    hipLaunchKernelGGL(k_kd_locate, dim3((nsteps * K * 64 + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u);
+    hipLaunchKernelGGL(k_kd_link, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords, 0u);
+    hipLaunchKernelGGL(k_kd_claim, dim3(1, Q), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
+    hipLaunchKernelGGL(k_kd_hint, dim3((nsteps * K * 64 + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords);
     (void)hipEventRecord(ev_step_done, stream);
     (void)hipStreamWaitEvent(stream2, ev_step_done, 0);
-    hipLaunchKernelGGL(k_tie_fix, dim3(1), dim3(1024), 0, stream2, rcp);
+    hipLaunchKernelGGL(k_tie_fix, dim3(1, Q), dim3(1024), 0, stream2, rcp);
     // A lagging join: the main stream waits for the group BEFORE this one, which had a whole group of steps to finish.
     // It bounds how far the kd structure may fall behind and keeps a replayed hipGraph from running the side branch last.
     const uint32_t par = kd_gidx & 1u;
@@ -486,7 +503,7 @@ static uint32_t kd_group_for(uint32_t K, uint32_t opt) {
 void porrt_ctx::flush_commit() {
     if (commit_pend_b == 0xFFFFFFFFu) return;
     const uint32_t vwords = (rc.cand_K + 63) / 64;
-    hipLaunchKernelGGL(k_commit_rrt, dim3((commit_pend_nb * 64 + 255) / 256), dim3(256), 0, stream, (const RunConst *)d_rc.p, commit_pend_b, commit_pend_nb, vwords);
+    hipLaunchKernelGGL(k_commit_rrt, dim3((commit_pend_nb * 64 + 255) / 256, launch_Q), dim3(256), 0, stream, launch_rcp, commit_pend_b, commit_pend_nb, vwords);
     commit_pend_b = 0xFFFFFFFFu;
 }
 
@@ -497,7 +514,7 @@ void porrt_ctx::join_side() {
     (void)hipEventRecord(ev_join, stream2);
     (void)hipStreamWaitEvent(stream, ev_join, 0);
     kd_pend[0] = kd_pend[1] = false;
-    hipLaunchKernelGGL(k_tie_fix, dim3(1), dim3(1024), 0, stream, (const RunConst *)d_rc.p);
+    hipLaunchKernelGGL(k_tie_fix, dim3(1, launch_Q), dim3(1024), 0, stream, launch_rcp);
     side_active = false;
 }
 
@@ -530,8 +547,10 @@ int porrt_ctx::grow(const double start[2], double max_step, double search_radius
     return PORRT_ERR_CAPACITY;
 }
 
+// stage 0: the whole call.  stage 1 (member of a porrt_grow_batch): everything up to the growth loop -- buffers,
+// run constants, root, sample stream -- and return; the batch leader runs the steps for all members.
 int porrt_ctx::grow_once(const double start[2], double max_step, double search_radius, uint64_t n_iter_min, uint64_t n_iter_max,
-                         uint32_t K, int mode_, bool host_samples) {
+                         uint32_t K, int mode_, bool host_samples, int stage) {
     const double t_begin = now_s();
     double t_setup = 0.0;
     HIPCHK(hipSetDevice(device));
@@ -766,6 +785,14 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         r = make_samples(0, n_iter_min);
         if (r) return r;
     }
+    run_lds_bytes = lds_bytes;
+    if (stage == 1) {
+        (void)hipEventDestroy(ev_first);
+        (void)hipEventDestroy(ev_last);
+        return PORRT_OK;
+    }
+    launch_rcp = d_rc.p;
+    launch_Q = 1;
     HIPCHK(hipEventRecord(ev_first, stream));
     side_active = false;
     commit_pend_b = 0xFFFFFFFFu;
@@ -775,7 +802,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     if (opt_graph && !prof && n_iter_min > 0) {
         // all steps up to n_iter_min as one hipGraph (two branches: main pipeline + kd insertion); the graph
         // only depends on the launch geometry, so it is instantiated once and replayed by later grows
-        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)d_rc.p, kd_group};
+        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)launch_rcp, kd_group | ((uint64_t)launch_Q << 32)};
         if (!graph_exec || memcmp(key, graph_key, sizeof key)) {
             double t0 = now_s();
             if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -962,6 +989,190 @@ int porrt_ctx::download() {
 }
 
 // ========================================================================================== C ABI
+// A member's bookkeeping after the leader of a porrt_grow_batch ran the steps (fixed iteration budget: the loop
+// condition is never consulted, n_iter_min == n_iter_max).
+int porrt_ctx::finish_batch_member(uint64_t n_iter_done, uint32_t steps, float device_ms) {
+    Counters hc;
+    uint32_t n_final_nodes = 0;
+    HIPCHK(hipMemcpy(&hc, d_cnt.p, sizeof hc, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&n_final_nodes, d_nat.p + steps, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (hc.err & ERR_CAND_OVERFLOW) return -100;
+    if (hc.err & ERR_RNG_RETRY) { set_err("a float draw would have been redrawn: grow this context on its own"); return PORRT_ERR_INVALID; }
+    counters = hc;
+    n_iter = n_iter_done;
+    n_steps = steps;
+    n_nodes = n_final_nodes;
+    const unsigned long long all = rc.all_worlds;
+    complete = mode == PORRT_MODE_PTO ? (hc.n_final > 0 && (hc.finality & all) == all) : hc.n_final > 0;
+    have_results = true;
+    downloaded = false;
+    const uint64_t calls = n_iter_done - n_iter_done / 100;
+    if (has_inj) inj_pos += calls;
+    else crng.advance((u128)2 * calls);
+    memset(&metrics, 0, sizeof metrics);
+    metrics.n_iter = n_iter;
+    metrics.n_nodes = n_nodes;
+    metrics.n_steps = n_steps;
+    metrics.n_tie_fallbacks = hc.tie_fallbacks + ((hc.err & ERR_GPATH_OVERFLOW) ? 1 : 0);
+    metrics.device_s = device_ms * 1e-3;
+    metrics.total_s = metrics.device_s;
+    if (hc.err & ERR_RASTER) { set_err("raster access outside the map, door pixel without zone id, or two zones on one segment (the reference panics here)"); return PORRT_ERR_RASTER; }
+    if (hc.err & ERR_EDGE_OVERFLOW) { set_err("edge pool overflow"); return PORRT_ERR_CAPACITY; }
+    if (hc.err & (ERR_TIE_POOL | ERR_PAGE_OVERFLOW)) { set_err("deferred-tie pool / region page pool overflow"); return PORRT_ERR_CAPACITY; }
+    if (mode == PORRT_MODE_PTO && !complete) { set_err("final nodes are not reached for each world"); return PORRT_INCOMPLETE; }
+    return PORRT_OK;
+}
+
+// porrt_grow_batch: the same growth, with a fixed iteration budget, for several contexts of one device at once.
+// Context 0 leads: every step kernel is launched once with one grid row per context, so the contexts' dependent
+// load chains overlap inside each kernel instead of queueing behind each other.
+static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, double max_step, double search_radius, uint64_t n_iter,
+                      uint32_t K, int mode) {
+    porrt_ctx *L = cs[0];
+    if (K == 0 || K > 4096) { L->set_err("batch_K must be in 1..4096"); return PORRT_ERR_INVALID; }
+    if (mode != PORRT_MODE_RRT && mode != PORRT_MODE_PTO) { L->set_err("bad mode"); return PORRT_ERR_INVALID; }
+    if (n_iter == 0 || n_iter + 2 >= 0x7FFFFFF0ull) { L->set_err("n_iter"); return PORRT_ERR_INVALID; }
+    if (!(max_step > 0.0) || !(search_radius >= 0.0)) { L->set_err("max_step / search_radius"); return PORRT_ERR_INVALID; }
+    for (uint32_t q = 0; q < n; ++q) {
+        if (!cs[q] || cs[q]->device != L->device) { L->set_err("porrt_grow_batch: contexts of one device"); return PORRT_ERR_INVALID; }
+        for (uint32_t r = 0; r < q; ++r) if (cs[r] == cs[q]) { L->set_err("porrt_grow_batch: a context appears twice"); return PORRT_ERR_INVALID; }
+        if (mode == PORRT_MODE_PTO && !cs[q]->has_grid) { cs[q]->set_err("PTO mode needs a grid"); return PORRT_ERR_INVALID; }
+        cs[q]->have_results = false;
+        cs[q]->downloaded = false;
+    }
+    HIPCHK_CTX(L, hipSetDevice(L->device));
+    std::vector<Pcg64> c0(n), d0(n);
+    std::vector<size_t> ip0(n), iw0(n);
+    for (uint32_t q = 0; q < n; ++q) { c0[q] = cs[q]->crng; d0[q] = cs[q]->drng; ip0[q] = cs[q]->inj_pos; iw0[q] = cs[q]->inj_wpos; }
+    if (L->rcarr_cap < n) {
+        if (L->d_rcarr) (void)hipFree(L->d_rcarr);
+        L->d_rcarr = nullptr; L->rcarr_cap = 0;
+        HIPCHK_CTX(L, hipMalloc(&L->d_rcarr, (size_t)n * sizeof(RunConst)));
+        L->rcarr_cap = n;
+        if (L->graph_exec) { (void)hipGraphExecDestroy(L->graph_exec); L->graph_exec = nullptr; }
+    }
+    const uint32_t vwords = (K + 63) / 64;
+    for (int attempt = 0; attempt < 12; ++attempt) {
+        // every member: buffers, run constants, root, samples -- on its own stream
+        for (uint32_t q = 0; q < n; ++q) {
+            int r = cs[q]->grow_once(starts + 2 * q, max_step, search_radius, n_iter, n_iter, K, mode, false, 1);
+            if (r) { if (cs[q] != L) L->set_err(cs[q]->err); return r; }
+            if (cs[q]->run_lds_bytes != L->run_lds_bytes) { L->set_err("porrt_grow_batch: the contexts' rasters need different LDS tiles (max_step * ppm differs)"); return PORRT_ERR_INVALID; }
+        }
+        for (uint32_t q = 0; q < n; ++q) {
+            HIPCHK_CTX(L, hipStreamSynchronize(cs[q]->stream));
+            HIPCHK_CTX(L, hipMemcpyAsync(L->d_rcarr + q, &cs[q]->rc, sizeof(RunConst), hipMemcpyHostToDevice, L->stream));
+        }
+        // the leader: all steps, one hipGraph (or eager), grid rows = contexts
+        L->launch_rcp = L->d_rcarr;
+        L->launch_Q = n;
+        L->side_active = false;
+        L->commit_pend_b = 0xFFFFFFFFu;
+        L->kd_b0 = 0; L->kd_last_b = 0; L->kd_last_nb = 0; L->kd_gidx = 0;
+        L->kd_pend[0] = L->kd_pend[1] = false;
+        L->kd_group = kd_group_for(K, L->opt_kd_group);
+        hipEvent_t e0, e1;
+        HIPCHK_CTX(L, hipEventCreate(&e0));
+        HIPCHK_CTX(L, hipEventCreate(&e1));
+        HIPCHK_CTX(L, hipEventRecord(e0, L->stream));
+        size_t ev_used = 0;
+        const bool prof = L->opt_profile;
+        if (prof) {
+            const size_t want = (size_t)(n_iter / K + 6) * 4 + 4;
+            while (L->ev_pool.size() < want) {
+                hipEvent_t ev;
+                HIPCHK_CTX(L, hipEventCreate(&ev));
+                L->ev_pool.push_back(ev);
+            }
+        }
+        auto all_steps = [&]() {
+            uint64_t ci = 0;
+            uint32_t cb = 0;
+            while (ci < n_iter) {
+                const uint32_t nb = (uint32_t)std::min<uint64_t>(K, n_iter - ci);
+                L->launch_step(cb, (uint32_t)ci, nb, vwords, L->run_lds_bytes, prof, ev_used, 0, 0);
+                ci += nb;
+                ++cb;
+            }
+            L->join_side();
+            return cb;
+        };
+        uint32_t steps = 0;
+        if (L->opt_graph && !prof) {
+            const uint64_t key[6] = {(uint64_t)mode, K, n_iter, L->run_lds_bytes, (uint64_t)(uintptr_t)L->launch_rcp, L->kd_group | ((uint64_t)n << 32)};
+            if (!L->graph_exec || memcmp(key, L->graph_key, sizeof key)) {
+                if (L->graph_exec) { (void)hipGraphExecDestroy(L->graph_exec); L->graph_exec = nullptr; }
+                hipGraph_t g = nullptr;
+                HIPCHK_CTX(L, hipStreamBeginCapture(L->stream, hipStreamCaptureModeThreadLocal));
+                (void)all_steps();
+                HIPCHK_CTX(L, hipStreamEndCapture(L->stream, &g));
+                HIPCHK_CTX(L, hipGraphInstantiate(&L->graph_exec, g, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(g);
+                memcpy(L->graph_key, key, sizeof key);
+            }
+            HIPCHK_CTX(L, hipGraphLaunch(L->graph_exec, L->stream));
+            steps = (uint32_t)((n_iter + K - 1) / K);
+        } else {
+            steps = all_steps();
+        }
+        HIPCHK_CTX(L, hipEventRecord(e1, L->stream));
+        HIPCHK_CTX(L, hipStreamSynchronize(L->stream));
+        {
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { L->set_err(std::string("kernel launch: ") + hipGetErrorString(e)); return PORRT_ERR_DEVICE; }
+        }
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        L->launch_rcp = L->d_rc.p;
+        L->launch_Q = 1;
+        bool retry = false;
+        int worst = PORRT_OK;
+        for (uint32_t q = 0; q < n; ++q) {
+            int r = cs[q]->finish_batch_member(n_iter, steps, ms);
+            if (r == -100) retry = true;
+            else if (r < 0) { if (cs[q] != L) L->set_err(cs[q]->err); return r; }
+            else if (r > worst) worst = r;
+        }
+        if (!retry && prof) {
+            // events were recorded around k_near [0,1] and the connect kernel [2,3] of every step (all members at once);
+            // the leader's metrics carry the batch totals
+            double scan = 0, conn = 0, pairs = 0, bytes = 0;
+            uint64_t launches = 0;
+            for (uint32_t s = 0; s < steps && (size_t)(4 * s + 3) < ev_used; ++s) {
+                float a = 0, r2 = 0;
+                (void)hipEventElapsedTime(&a, L->ev_pool[4 * s + 0], L->ev_pool[4 * s + 1]);
+                (void)hipEventElapsedTime(&r2, L->ev_pool[4 * s + 2], L->ev_pool[4 * s + 3]);
+                scan += a * 1e-3;
+                conn += r2 * 1e-3;
+                ++launches;
+            }
+            std::vector<uint32_t> nat(steps + 1);
+            for (uint32_t q = 0; q < n; ++q) {
+                HIPCHK_CTX(L, hipMemcpy(nat.data(), cs[q]->d_nat.p, (steps + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                uint64_t it = 0;
+                for (uint32_t s = 0; s < steps; ++s) {
+                    const uint64_t nbq = std::min<uint64_t>(K, n_iter - it);
+                    it += nbq;
+                    pairs += 2.0 * (double)nbq * (double)nat[s];
+                    bytes += 2.0 * 16.0 * (double)nat[s] + (16.0 + 20.0) * (double)nbq;
+                }
+            }
+            L->metrics.scan_s = scan; L->metrics.connect_s = conn; L->metrics.scan_launches = launches;
+            L->metrics.scan_pairs = pairs; L->metrics.scan_bytes = bytes;
+        }
+        if (!retry) return worst;
+        for (uint32_t q = 0; q < n; ++q) {          // neighbour lists overflowed somewhere: regrow them everywhere and replay
+            cs[q]->opt_cand_cap = (uint32_t)std::min<uint64_t>((uint64_t)cs[q]->opt_cand_cap * 4, n_iter + 2);
+            cs[q]->crng = c0[q]; cs[q]->drng = d0[q]; cs[q]->inj_pos = ip0[q]; cs[q]->inj_wpos = iw0[q];
+            cs[q]->have_results = false;
+        }
+    }
+    L->set_err("neighbour list capacity");
+    return PORRT_ERR_CAPACITY;
+}
+
 extern "C" {
 
 porrt_ctx *porrt_create(int device) {
@@ -1007,6 +1218,7 @@ void porrt_destroy(porrt_ctx *c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (int p2 = 0; p2 < 2; ++p2) if (c->ev_bound[p2]) (void)hipEventDestroy(c->ev_bound[p2]);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
+    if (c->d_rcarr) (void)hipFree(c->d_rcarr);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1140,6 +1352,12 @@ int porrt_grow(porrt_ctx *c, const double start[2], double max_step, double sear
                uint32_t batch_K, int mode) {
     if (!c || !start) return PORRT_ERR_INVALID;
     return c->grow(start, max_step, search_radius, n_iter_min, n_iter_max, batch_K, mode);
+}
+
+int porrt_grow_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, const double *starts, double max_step, double search_radius, uint64_t n_iter,
+                     uint32_t batch_K, int mode) {
+    if (!ctxs || !n_ctx || !starts || !ctxs[0]) return PORRT_ERR_INVALID;
+    return grow_batch(ctxs, n_ctx, starts, max_step, search_radius, n_iter, batch_K, mode);
 }
 
 uint64_t porrt_num_nodes(const porrt_ctx *c) { return c && c->have_results ? c->n_nodes : 0; }

@@ -136,6 +136,41 @@ def test_launch_modes_do_not_change_results(eng_mod, opts):
     assert_same(e1, o)
 
 
+@pytest.mark.parametrize("graph", [1, 0])
+def test_grow_batch_equals_separate_grows(eng_mod, graph):
+    """porrt_grow_batch (one launch sequence, one grid row per context) == the same contexts grown one by one."""
+    cs = [cases.cfg2(20000, seed=s) for s in (0, 1, 2)] + [cases.cfg2(20000, seed=3, grid="map_benchmark_like_c")]
+    single = []
+    for c in cs:
+        e, _ = run_gpu(eng_mod, c, 1024)
+        single.append(e)
+    engs = []
+    for c in cs:
+        e = eng_mod.Engine()
+        e.set_option("graph", graph)
+        engs.append(cases.configure(e, c))
+    for rep in range(2):                    # second round: sampler states moved on, the cached graph is replayed
+        eng_mod.Engine.grow_batch(engs, [c.start for c in cs], cs[0].max_step, cs[0].search_radius, cs[0].n_iter_min, 1024)
+        if rep == 0:
+            for e, s in zip(engs, single):
+                assert_same(e, s)
+        else:
+            for e, c in zip(engs, cs):
+                o = cases.configure(orc.Oracle(), c)
+                cases.grow(o, c, K=1024, algo=orc.ALGO_BATCHED_KD)
+                cases.grow(o, c, K=1024, algo=orc.ALGO_BATCHED_KD)          # the oracle's sampler moves on the same way
+                assert_same(e, o)
+
+
+def test_grow_batch_pto(eng_mod):
+    cs = [cases.cfg3(6000, 6000, seed=s) for s in (0, 1)]
+    engs = [cases.configure(eng_mod.Engine(), c) for c in cs]
+    eng_mod.Engine.grow_batch(engs, [c.start for c in cs], cs[0].max_step, cs[0].search_radius, 6000, 256, mode=cases.PTO)
+    for e, c in zip(engs, cs):
+        o, _ = run_orc(c, 256)
+        assert_same(e, o, pto=True)
+
+
 def test_injected_samples_equal_seeded_stream(eng_mod):
     case = cases.cfg1(2000)
     e1, _ = run_gpu(eng_mod, case, 256)
