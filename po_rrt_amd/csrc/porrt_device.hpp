@@ -113,6 +113,8 @@ struct RunConst {
     uint32_t *cand_cnt;         // neighbour lists of the step: counts and ids are double-buffered by step parity
     int *cand_id;               // (k_kd_locate reads them beside the next step's search), written by k_near only
     double *cand_val;
+    double *cand_xy;            // coordinates of the listed neighbours (same layout and parity as cand_id, 16 B each): the
+                                // search has them in registers, connect would otherwise gather two more cache lines per neighbour
     uint32_t cand_cap;
     uint32_t cand_K;            // samples per parity buffer
     // radius tables: T2[n] = largest d^2 whose sqrt rounds to <= heuristic_radius(n)
@@ -683,6 +685,7 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
     // rrt.rs:121 uses the size before insertion, pto.rs:88 after it
     const double T2 = rc.rad_T2[N + (rc.mode == 1 ? 1u : 0u)];
     auto cid = as_global(rc.cand_id) + cand_off(rc, b, k);
+    auto cxy = as_global(reinterpret_cast<dbl2 *>(rc.cand_xy)) + cand_off(rc, b, k);
     const uint32_t cap = rc.cand_cap;
     uint32_t tot = 0;
     bool over = false;
@@ -691,8 +694,14 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
         const unsigned long long hm = __ballot(in);
         const uint32_t pos = tot + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
         if (in) {
-            if (pos < cap) cid[pos] = id;
-            else over = true;
+            if (pos < cap) {
+                cid[pos] = id;
+                dbl2 v;
+                v.x = x; v.y = y;
+                cxy[pos] = v;
+            } else {
+                over = true;
+            }
         }
         tot += (uint32_t)__popcll(hm);
     });
@@ -939,6 +948,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     const double goal_l1 = rc.g_l1;
     auto cid = as_global(rc.cand_id) + cand_off(rc, b, k);            // read-only here
     auto cval = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
+    auto cxy = as_global(reinterpret_cast<const dbl2 *>(rc.cand_xy)) + cand_off(rc, b, k);
     auto gnx = as_global(rc.nx), gny = as_global(rc.ny), gdA = as_global(rc.distA);
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
     GlobalGrid ggrid;
@@ -952,7 +962,8 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     double cost0 = -1.0, tot0 = INF, dA0 = 0.0;
     for (uint32_t a = tl; a < cnt; a += TS) {
         const int j = cid[a];
-        const double ax = gnx[j], ay = gny[j], dA = gdA[j];
+        const dbl2 axy = cxy[a];
+        const double ax = axy.x, ay = axy.y, dA = gdA[j];
         const double cost = sqrt(dist2(ax, ay, px, py));
         bool ok = true;
         if (rc.has_grid) ok = traversed_class(rc, grid, ax, ay, px, py, &err) == CLS_FREE;
@@ -1642,8 +1653,14 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
     uint32_t cnt = cand_count(rc, b, k);
     int *cid = rc.cand_id + cand_off(rc, b, k);
     double *cval = rc.cand_val + (size_t)k * rc.cand_cap;
+    dbl2 *cxy = reinterpret_cast<dbl2 *>(rc.cand_xy) + cand_off(rc, b, k);
     if (cnt == 0) {                       // pto.rs:99: nobody in range -> the nearest node
-        if (lane == 0) { cid[0] = rc.q_nn[k]; rc.cand_cnt[(b & 1u) * rc.cand_K + k] = 1; }   // lane 0 is also the only reader of slot 0
+        if (lane == 0) {                  // lane 0 is also the only reader of slot 0
+            const int nn = rc.q_nn[k];
+            dbl2 v;
+            v.x = rc.nx[nn]; v.y = rc.ny[nn];
+            cid[0] = nn; cxy[0] = v; rc.cand_cnt[(b & 1u) * rc.cand_K + k] = 1;
+        }
         cnt = 1;
     }
     uint32_t err = 0;
@@ -1651,7 +1668,8 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
     uint32_t n_edges = 0;
     for (uint32_t a = lane; a < cnt; a += 64) {
         const int j = cid[a];
-        const int cls = traversed_class(rc, grid, rc.nx[j], rc.ny[j], px, py, &err);
+        const dbl2 axy = cxy[a];
+        const int cls = traversed_class(rc, grid, axy.x, axy.y, px, py, &err);
         const int tv = class_to_validity(rc, cls);
         cval[a] = (double)tv;
         if (tv >= 0) {

@@ -169,7 +169,7 @@ struct porrt_ctx {
     uint32_t opt_kd_group = 0;     // steps per kd insertion (0 = choose by K)
     uint32_t opt_cand_cap = 2048;
     // ---- device buffers
-    DevBuf<double> d_nx, d_ny, d_distA, d_distB, d_sx, d_sy, d_qx, d_qy, d_qbound, d_pgxy, d_candval, d_radT2, d_inj;
+    DevBuf<double> d_nx, d_ny, d_distA, d_distB, d_sx, d_sy, d_qx, d_qy, d_qbound, d_pgxy, d_candxy, d_candval, d_radT2, d_inj;
     DevBuf<int> d_parent, d_qnn, d_qvid, d_pgid, d_candid, d_gid, d_kdup;
     DevBuf<KdRec> d_kdrec;
     DevBuf<KdBox> d_kdbox, d_locbox;
@@ -250,7 +250,7 @@ struct porrt_ctx {
 // every grow re-initialises what it uses, and the cached uploads are marked stale.
 int porrt_ctx::layout_buffers() {
     if (all_bufs.empty()) {
-        DevBufBase *list[] = {&d_nx, &d_ny, &d_distA, &d_distB, &d_sx, &d_sy, &d_qx, &d_qy, &d_qbound, &d_pgxy, &d_candval, &d_radT2, &d_inj,
+        DevBufBase *list[] = {&d_nx, &d_ny, &d_distA, &d_distB, &d_sx, &d_sy, &d_qx, &d_qy, &d_qbound, &d_pgxy, &d_candxy, &d_candval, &d_radT2, &d_inj,
                               &d_parent, &d_qnn, &d_qvid, &d_pgid, &d_candid, &d_gid, &d_kdup, &d_kdrec, &d_gx, &d_gy, &d_rgcnt,
                               &d_rgdir, &d_rep, &d_kdbox, &d_locbox, &d_kdlosers, &d_kqnn, &d_kdhint, &d_gsnap, &d_pendoff, &d_pendn, &d_pendcur, &d_pendstate, &d_pendnew, &d_pendpool, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB,
                               &d_finalmask, &d_validmask, &d_vid, &d_finalflag, &d_cls, &d_nat, &d_sworld, &d_candcnt, &d_efrom,
@@ -277,7 +277,7 @@ int porrt_ctx::layout_buffers() {
     for (DevBufBase *b2 : all_bufs) { b2->vp = (char *)arena.base + off; off += (b2->n * b2->elem + 4095) & ~(size_t)4095; }
     d_nx.p = (double *)d_nx.vp; d_ny.p = (double *)d_ny.vp; d_distA.p = (double *)d_distA.vp; d_distB.p = (double *)d_distB.vp;
     d_sx.p = (double *)d_sx.vp; d_sy.p = (double *)d_sy.vp; d_qx.p = (double *)d_qx.vp; d_qy.p = (double *)d_qy.vp;
-    d_qbound.p = (double *)d_qbound.vp; d_pgxy.p = (double *)d_pgxy.vp; d_candval.p = (double *)d_candval.vp; d_radT2.p = (double *)d_radT2.vp; d_inj.p = (double *)d_inj.vp;
+    d_qbound.p = (double *)d_qbound.vp; d_pgxy.p = (double *)d_pgxy.vp; d_candxy.p = (double *)d_candxy.vp; d_candval.p = (double *)d_candval.vp; d_radT2.p = (double *)d_radT2.vp; d_inj.p = (double *)d_inj.vp;
     d_parent.p = (int *)d_parent.vp; d_qnn.p = (int *)d_qnn.vp; d_qvid.p = (int *)d_qvid.vp; d_pgid.p = (int *)d_pgid.vp;
     d_candid.p = (int *)d_candid.vp; d_gid.p = (int *)d_gid.vp; d_kdup.p = (int *)d_kdup.vp; d_kdrec.p = (KdRec *)d_kdrec.vp;
     d_gx.p = (double *)d_gx.vp; d_gy.p = (double *)d_gy.vp; d_rgcnt.p = (uint32_t *)d_rgcnt.vp; d_rgdir.p = (uint32_t *)d_rgdir.vp;
@@ -581,7 +581,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(d_loccur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locdcur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locgex.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locflags.reserve(2 * (8 * (size_t)K + 4096)));
         HIPCHK(d_gsnap.reserve((steps_max + 4) * 4)); HIPCHK(d_pendoff.reserve(pend_cap)); HIPCHK(d_pendn.reserve(pend_cap)); HIPCHK(d_pendcur.reserve(pend_cap));
         HIPCHK(d_pendstate.reserve(pend_cap)); HIPCHK(d_pendnew.reserve(pend_cap)); HIPCHK(d_pendpool.reserve(pool_cap)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_gndx.reserve(Nmax)); HIPCHK(d_gndy.reserve(Nmax));
-        HIPCHK(d_kqx.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kqy.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kqvid.reserve((steps_max + 2) * Kpad)); HIPCHK(d_candid.reserve(2 * (size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
+        HIPCHK(d_kqx.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kqy.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kqvid.reserve((steps_max + 2) * Kpad)); HIPCHK(d_candid.reserve(2 * (size_t)K * cand_cap)); HIPCHK(d_candxy.reserve(4 * (size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
         HIPCHK(d_gid.reserve(Nmax));
         HIPCHK(d_rep.reserve(kRepTotal));
         HIPCHK(d_kdrec.reserve(Nmax)); HIPCHK(d_gx.reserve(Nmax + 16)); HIPCHK(d_gy.reserve(Nmax + 16)); HIPCHK(d_kdup.reserve(Nmax)); HIPCHK(d_kddepth.reserve(Nmax)); HIPCHK(d_kdgexit.reserve(Nmax));
@@ -619,7 +619,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p; c.kq_nn = d_kqnn.p; c.kd_box = d_kdbox.p; c.loc_box = d_locbox.p; c.kd_losers = d_kdlosers.p; c.kd_hint = d_kdhint.p; c.g_snap = d_gsnap.p; c.loc_stride = 8 * K + 4096;
     c.pend_new = d_pendnew.p; c.pend_pool = d_pendpool.p; c.pend_off = d_pendoff.p; c.pend_n = d_pendn.p; c.pend_cur = d_pendcur.p; c.pend_state = d_pendstate.p;
     c.pend_cap = (uint32_t)std::min<uint64_t>(pend_cap, 0xFFFFFFFFull); c.pool_cap = (uint32_t)std::min<uint64_t>(pool_cap, 0xFFFFFFFFull);
-    c.cand_K = K; c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
+    c.cand_K = K; c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_xy = d_candxy.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
     c.rad_T2 = d_radT2.p;
     c.e_from = d_efrom.p; c.e_to = d_eto.p; c.e_tv = d_etv.p; c.e_cap = (uint32_t)d_efrom.n;
     c.rep = d_rep.p;
