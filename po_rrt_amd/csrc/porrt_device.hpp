@@ -517,7 +517,8 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 //   sparse   few nodes per region (young tree): lane <-> region, slot by slot
 //   pages    lane <-> slot, region after region (four pages in flight)
 template <class Visit>
-__device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double qy, double rho, uint32_t N, uint32_t lane, Visit visit) {
+__device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double qy, double rho, uint32_t N, uint32_t lane, Visit visit,
+                                          uint32_t skip_region = 0xFFFFFFFFu) {
     int cx0, cy0, cx1, cy1;
     rep_cell(rc, qx - rho, qy - rho, kRG, cx0, cy0);
     rep_cell(rc, qx + rho, qy + rho, kRG, cx1, cy1);
@@ -549,7 +550,7 @@ __device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double 
         if (r < nreg) {
             const uint32_t ry = r / w;
             reg = (y0 + ry) * kRG + x0 + (r - ry * w);
-            cnt = gcnt[reg];
+            cnt = reg == skip_region ? 0u : gcnt[reg];          // a region the caller has already been through
         }
         uint32_t cmax = cnt, npg = (cnt + kPage - 1) / kPage;
         for (int off = 32; off > 0; off >>= 1) {
@@ -636,18 +637,35 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
     {
         const double m = nn_bound_wave<PTO>(rc, N, sqx, sqy, world, lane);
         auto reach = as_global(rc.reachA);
-        scan_disc(rc, sqx, sqy, disc_radius(m, sqx, sqy), N, lane, [&](double x, double y, int id, bool ok) {
+        // thr: no node with d2 above it can win or tie (sqrt is monotone; the factor keeps rounded ties in), so the
+        // sqrt -- the expensive part -- is only taken for the few nodes that may improve the lane's best
+        double thr = m * (1.0 + 1e-9);
+        auto visit = [&](double x, double y, int id, bool ok) {
             if (!ok) return;
-            const double D = sqrt(dist2(x, y, sqx, sqy));        // the reference compares rounded distances
+            const double d2 = dist2(x, y, sqx, sqy);
+            if (d2 > thr) return;
             bool pass = true;
             if (PTO) pass = (reach[id] >> world) & 1ull;
-            if (pass && (D < bestD || (D == bestD && id < best))) { bestD = D; best = id; }
-        });
-        for (int off = 32; off > 0; off >>= 1) {
-            const double od = __shfl_xor(bestD, off);
-            const int oi = __shfl_xor(best, off);
-            if (od < bestD || (od == bestD && oi < best)) { bestD = od; best = oi; }
-        }
+            if (!pass) return;
+            const double D = sqrt(d2);                           // the reference compares rounded distances
+            if (D < bestD || (D == bestD && id < best)) { bestD = D; best = id; thr = d2 * (1.0 + 1e-15); }
+        };
+        auto wave_best = [&]() {
+            for (int off = 32; off > 0; off >>= 1) {
+                const double od = __shfl_xor(bestD, off), ot = __shfl_xor(thr, off);
+                const int oi = __shfl_xor(best, off);
+                if (od < bestD || (od == bestD && oi < best)) { bestD = od; best = oi; thr = ot; }
+            }
+        };
+        // the sample's own region first: the nearest node is almost always there, and what it yields shrinks the disc
+        // the remaining regions are taken from to a corner of what the pyramid's bound would have asked for
+        const uint32_t own = region_of(rc, sqx, sqy);
+        scan_disc(rc, sqx, sqy, 0.0, N, lane, visit);
+        wave_best();
+        double m2 = m;
+        if (best != 0x7FFFFFFF) { const double b2 = thr; m2 = b2 < m2 ? b2 : m2; }      // thr = d2(best) * (1 + 1e-15)
+        scan_disc(rc, sqx, sqy, disc_radius(m2, sqx, sqy), N, lane, visit, own);
+        wave_best();
     }
     const int nn = best == 0x7FFFFFFF ? 0 : best;   // nothing passed the filter: the root (nearest_neighbor.rs:90)
     const double fx = rc.nx[nn], fy = rc.ny[nn];
