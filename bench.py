@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--queries", type=int, default=16, help="independent queries advanced together per step and GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event roofline pass")
+    ap.add_argument("--no-single-query", action="store_true", help="skip the single-query (latency mode) reference run")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps run with per-kernel HIP events for `roofline`")
     args = ap.parse_args()
 
@@ -119,7 +120,7 @@ def main():
 
     # latency mode for reference: the same query alone (porrt_grow, one context), outside the timed region
     single = None
-    if rank == 0:
+    if rank == 0 and not args.no_single_query:
         eng.set_sampler((-1.0, -1.0), (1.0, 1.0), 777)
         cases.grow(eng, case, K=args.batch)
         ts = []
