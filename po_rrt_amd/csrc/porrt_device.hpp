@@ -1287,23 +1287,38 @@ __device__ __forceinline__ void kd_descend(const RunConst &rc, uint32_t Nsnap, d
 // The descent sees the tree as far as k_kd_claim has published it when the wave starts (cnt->kd_snap: nodes below
 // n_at[kd_snap], G as recorded in g_snap[kd_snap]); newer nodes are treated as absent and the claim rounds finish the
 // descent through them.  So this kernel depends on nothing but the steps' k_near and overlaps earlier groups' claims.
+// LPN = lanes per node: 64 (one wave per node: shortest latency, used when a launch has few nodes) or 1 (one thread
+// per node, the non-duplicate levels of G staged in LDS: 64x fewer waves, used when many contexts are grown together
+// and the GPU is short of wave slots, not of time).
+template <int LPN>
 __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t K, uint32_t nb_last,
                                                     uint32_t vwords, uint32_t lpar) {
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t lane = LPN == 64 ? (threadIdx.x & 63u) : 0u;
+    const uint32_t wid = LPN == 64 ? blockIdx.x * 4u + (threadIdx.x >> 6) : blockIdx.x * 256u + threadIdx.x;
     const uint32_t st = wid / K, k = wid - st * K;
-    if (st >= nsteps || k >= (st + 1 == nsteps ? nb_last : K)) return;
-    const uint32_t b = b0 + st;
+    bool active = st < nsteps && k < (st + 1 == nsteps ? nb_last : K);
+    const uint32_t b = b0 + (active ? st : 0u);
     // The new nodes are the valid samples (positions known since k_near), id = n_at[b] + rank in their step.
-    const size_t o2 = (size_t)b * rc.part_stride + k;
-    if (rc.kq_vid[o2] < 0) return;
-    const uint32_t bsnap = uni(__hip_atomic_load(&rc.cnt->kd_snap, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
-    const uint32_t Nsnap = uni(rc.n_at[bsnap]), N = uni(rc.n_at[b0]);
-    const uint32_t t = uni(rc.n_at[b] - N + rank_before(rc, b, vwords, k));
+    const size_t o2 = (size_t)b * rc.part_stride + (active ? k : 0u);
+    if (active && rc.kq_vid[o2] < 0) active = false;
+    const uint32_t bsnap = __hip_atomic_load(&rc.cnt->kd_snap, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t glen0 = rc.g_snap[4 * bsnap + 0], n_nd = rc.g_snap[4 * bsnap + 1];
+    constexpr uint32_t kNdLds = 1024;
+    __shared__ double s_ndx[LPN == 1 ? kNdLds : 1], s_ndy[LPN == 1 ? kNdLds : 1];
+    __shared__ uint32_t s_ndi[LPN == 1 ? kNdLds : 1];
+    if (LPN == 1) {
+        for (uint32_t t2 = threadIdx.x; t2 < n_nd && t2 < kNdLds; t2 += 256u) {
+            s_ndi[t2] = rc.g_nd[t2]; s_ndx[t2] = rc.g_nd_x[t2]; s_ndy[t2] = rc.g_nd_y[t2];
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    const uint32_t Nsnap = rc.n_at[bsnap], N = rc.n_at[b0];
+    const uint32_t t = rc.n_at[b] - N + rank_before(rc, b, vwords, k);
     const double px = rc.gp_x, py = rc.gp_y;
     const double vx = rc.kq_x[o2], vy = rc.kq_y[o2];
-    if (lane == 0) {   // the node's kd record exists from here on (k_kd_claim only links it)
+    if (lane == 0) {   // the node's kd record exists from here on (k_kd_link only links it)
         KdRec rec;
         rec.x = vx; rec.y = vy; rec.child[0] = kEmpty; rec.child[1] = kEmpty;
         rc.kd_rec[N + t] = rec;
@@ -1338,17 +1353,20 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
         // held by an exact duplicate of the goal point tests `x < p.x` (even depth) or `y < p.y` (odd depth), and
         // the goal point itself always goes right there, so all duplicate levels reduce to two comparisons against
         // the first duplicate of each parity; only the few non-duplicate levels (g_nd*) are real tests.
-        const uint32_t glen0 = uni(rc.g_snap[4 * bsnap + 0]), n_nd = uni(rc.g_snap[4 * bsnap + 1]);
         uint32_t E = 0xFFFFFFFFu, leftE = 0;
-        for (uint32_t s0 = lane; s0 < n_nd; s0 += 64u) {
-            const uint32_t ii = rc.g_nd[s0];
-            const double wx = rc.g_nd_x[s0], wy = rc.g_nd_y[s0];
+        for (uint32_t s0 = lane; s0 < n_nd; s0 += (uint32_t)LPN) {
+            uint32_t ii;
+            double wx, wy;
+            if (LPN == 1 && s0 < kNdLds) { ii = s_ndi[s0]; wx = s_ndx[s0]; wy = s_ndy[s0]; }
+            else { ii = rc.g_nd[s0]; wx = rc.g_nd_x[s0]; wy = rc.g_nd_y[s0]; }
             const bool gl = kd_left(px, py, wx, wy, ii), vl = kd_left(vx, vy, wx, wy, ii);
             if (vl != gl && ii < E) { E = ii; leftE = vl ? 1u : 0u; }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            const uint32_t oe = __shfl_xor(E, off), ol = __shfl_xor(leftE, off);
-            if (oe < E) { E = oe; leftE = ol; }
+        if (LPN == 64) {
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t oe = __shfl_xor(E, off), ol = __shfl_xor(leftE, off);
+                if (oe < E) { E = oe; leftE = ol; }
+            }
         }
         const uint32_t d0 = rc.g_snap[4 * bsnap + 2], d1 = rc.g_snap[4 * bsnap + 3];
         if (vx < px && d0 < E) { E = d0; leftE = 1u; }
