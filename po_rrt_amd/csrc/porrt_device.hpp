@@ -1594,26 +1594,50 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
 // bound includes the clamped border square.  hint = max over (depth, id), a commutative update.
 __global__ __launch_bounds__(256) void k_kd_hint(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords) {
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
+    // One thread per new node: late in a run a node's cell covers no whole square, or a few, and the thread raises
+    // them itself; the rare big cells (young tree) are parked in LDS and shared out to the workgroup's waves.
+    __shared__ uint32_t s_nbig, s_big_id[256];
+    __shared__ int s_big_r[256][4];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);
-    uint32_t n_new = 0;
-    for (uint32_t w = 0; w < vwords * nsteps; ++w) n_new += __popcll(rc.valid_mask[(size_t)b0 * vwords + w]);
-    if (t >= n_new) return;
-    const uint32_t id = rc.n_at[b0] + t;
-    const KdBox bx = rc.kd_box[id];
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t n_new = kd_group_size(rc, b0, nsteps, vwords);
+    if (threadIdx.x == 0) s_nbig = 0;
+    __syncthreads();
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
-    int lx, ly, ux, uy;
-    rep_cell(rc, bx.lox, bx.loy, kHG, lx, ly);
-    rep_cell(rc, bx.hix, bx.hiy, kHG, ux, uy);
-    const int ix0 = bx.lox == -INF ? 0 : lx + 1, ix1 = bx.hix == INF ? kHG - 1 : ux - 1;
-    const int iy0 = bx.loy == -INF ? 0 : ly + 1, iy1 = bx.hiy == INF ? kHG - 1 : uy - 1;
-    if (ix0 > ix1 || iy0 > iy1) return;
-    const uint32_t w = (uint32_t)(ix1 - ix0 + 1), n = w * (uint32_t)(iy1 - iy0 + 1);
-    const unsigned long long val = ((unsigned long long)rc.kd_depth[id] << 32) | id;
     auto gh = as_global(rc.kd_hint);
-    for (uint32_t i = lane; i < n; i += 64u) {
-        const uint32_t ry = i / w;
-        __hip_atomic_fetch_max(gh + (size_t)(iy0 + (int)ry) * kHG + ix0 + (int)(i - ry * w), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t N = rc.n_at[b0];
+    if (t < n_new) {
+        const uint32_t id = N + t;
+        const KdBox bx = rc.kd_box[id];
+        int lx, ly, ux, uy;
+        rep_cell(rc, bx.lox, bx.loy, kHG, lx, ly);
+        rep_cell(rc, bx.hix, bx.hiy, kHG, ux, uy);
+        const int ix0 = bx.lox == -INF ? 0 : lx + 1, ix1 = bx.hix == INF ? kHG - 1 : ux - 1;
+        const int iy0 = bx.loy == -INF ? 0 : ly + 1, iy1 = bx.hiy == INF ? kHG - 1 : uy - 1;
+        if (ix0 <= ix1 && iy0 <= iy1) {
+            const uint32_t w = (uint32_t)(ix1 - ix0 + 1), n = w * (uint32_t)(iy1 - iy0 + 1);
+            if (n <= 8u) {
+                const unsigned long long val = ((unsigned long long)rc.kd_depth[id] << 32) | id;
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint32_t ry = i / w;
+                    __hip_atomic_fetch_max(gh + (size_t)(iy0 + (int)ry) * kHG + ix0 + (int)(i - ry * w), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                const uint32_t q = atomicAdd(&s_nbig, 1u);
+                s_big_id[q] = id; s_big_r[q][0] = ix0; s_big_r[q][1] = ix1; s_big_r[q][2] = iy0; s_big_r[q][3] = iy1;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t q = threadIdx.x >> 6; q < s_nbig; q += 4u) {
+        const uint32_t id = s_big_id[q];
+        const int ix0 = s_big_r[q][0], ix1 = s_big_r[q][1], iy0 = s_big_r[q][2], iy1 = s_big_r[q][3];
+        const uint32_t w = (uint32_t)(ix1 - ix0 + 1), n = w * (uint32_t)(iy1 - iy0 + 1);
+        const unsigned long long val = ((unsigned long long)rc.kd_depth[id] << 32) | id;
+        for (uint32_t i = lane; i < n; i += 64u) {
+            const uint32_t ry = i / w;
+            __hip_atomic_fetch_max(gh + (size_t)(iy0 + (int)ry) * kHG + ix0 + (int)(i - ry * w), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

@@ -471,11 +471,11 @@ void porrt_ctx::launch_kd_group() {
     const uint32_t nsteps = kd_last_b - kd_b0 + 1, K = rc.cand_K, vwords = (K + 63) / 64;
     (void)hipStreamWaitEvent(stream2, ev_steered, 0);
     // few nodes: one wave per node (latency); many (several contexts at once): one thread per node (wave slots)
-    if ((uint64_t)nsteps * K * Q >= 8192u) hipLaunchKernelGGL(k_kd_locate<1>, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u);
+    if ((uint64_t)nsteps * K * Q >= 4096u) hipLaunchKernelGGL(k_kd_locate<1>, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u);
     else hipLaunchKernelGGL(k_kd_locate<64>, dim3((nsteps * K * 64 + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u);
     hipLaunchKernelGGL(k_kd_link, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords, 0u);
     hipLaunchKernelGGL(k_kd_claim, dim3(1, Q), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
-    hipLaunchKernelGGL(k_kd_hint, dim3((nsteps * K * 64 + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords);
+    hipLaunchKernelGGL(k_kd_hint, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords);
     (void)hipEventRecord(ev_step_done, stream);
     (void)hipStreamWaitEvent(stream2, ev_step_done, 0);
     hipLaunchKernelGGL(k_tie_fix, dim3(1, Q), dim3(1024), 0, stream2, rcp);
