@@ -632,14 +632,15 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
     uint32_t world = 0;
     if (PTO) world = rc.sworld[i0 + k];
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
-    double bestD = INF;
+    double bestD = INF, bestx = 0.0, besty = 0.0;
     int best = 0x7FFFFFFF;
+    // rrt.rs:121 uses the size before insertion, pto.rs:88 after it (loaded here, needed by the radius search below)
+    const double T2 = rc.rad_T2[N + (rc.mode == 1 ? 1u : 0u)];
     {
-        const double m = nn_bound_wave<PTO>(rc, N, sqx, sqy, world, lane);
         auto reach = as_global(rc.reachA);
         // thr: no node with d2 above it can win or tie (sqrt is monotone; the factor keeps rounded ties in), so the
         // sqrt -- the expensive part -- is only taken for the few nodes that may improve the lane's best
-        double thr = m * (1.0 + 1e-9);
+        double thr = INF;
         auto visit = [&](double x, double y, int id, bool ok) {
             if (!ok) return;
             const double d2 = dist2(x, y, sqx, sqy);
@@ -648,27 +649,30 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
             if (PTO) pass = (reach[id] >> world) & 1ull;
             if (!pass) return;
             const double D = sqrt(d2);                           // the reference compares rounded distances
-            if (D < bestD || (D == bestD && id < best)) { bestD = D; best = id; thr = d2 * (1.0 + 1e-15); }
+            if (D < bestD || (D == bestD && id < best)) { bestD = D; best = id; bestx = x; besty = y; thr = d2 * (1.0 + 1e-15); }
         };
         auto wave_best = [&]() {
             for (int off = 32; off > 0; off >>= 1) {
-                const double od = __shfl_xor(bestD, off), ot = __shfl_xor(thr, off);
+                const double od = __shfl_xor(bestD, off), ot = __shfl_xor(thr, off), ox = __shfl_xor(bestx, off), oy = __shfl_xor(besty, off);
                 const int oi = __shfl_xor(best, off);
-                if (od < bestD || (od == bestD && oi < best)) { bestD = od; best = oi; thr = ot; }
+                if (od < bestD || (od == bestD && oi < best)) { bestD = od; best = oi; thr = ot; bestx = ox; besty = oy; }
             }
         };
-        // the sample's own region first: the nearest node is almost always there, and what it yields shrinks the disc
-        // the remaining regions are taken from to a corner of what the pyramid's bound would have asked for
+        // The sample's own region first: the nearest node is almost always there, and its distance is the bound for
+        // the disc the remaining regions are taken from.  Only when the region holds nothing usable does the bound
+        // come from the pyramid.
         const uint32_t own = region_of(rc, sqx, sqy);
         scan_disc(rc, sqx, sqy, 0.0, N, lane, visit);
         wave_best();
-        double m2 = m;
-        if (best != 0x7FFFFFFF) { const double b2 = thr; m2 = b2 < m2 ? b2 : m2; }      // thr = d2(best) * (1 + 1e-15)
+        double m2;
+        if (best != 0x7FFFFFFF) m2 = thr;                        // d2(best) * (1 + 1e-15)
+        else { m2 = nn_bound_wave<PTO>(rc, N, sqx, sqy, world, lane); thr = m2 * (1.0 + 1e-9); }
         scan_disc(rc, sqx, sqy, disc_radius(m2, sqx, sqy), N, lane, visit, own);
         wave_best();
     }
     const int nn = best == 0x7FFFFFFF ? 0 : best;   // nothing passed the filter: the root (nearest_neighbor.rs:90)
-    const double fx = rc.nx[nn], fy = rc.ny[nn];
+    double fx = bestx, fy = besty;
+    if (best == 0x7FFFFFFF) { fx = rc.nx[0]; fy = rc.ny[0]; }
     double tx = sqx, ty = sqy;
     // common.rs:215-225
     double step = fabs(tx - fx);
@@ -700,8 +704,6 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
         if (err) atomicOr(&rc.cnt->err, err);
     }
     if (!valid) return;
-    // rrt.rs:121 uses the size before insertion, pto.rs:88 after it
-    const double T2 = rc.rad_T2[N + (rc.mode == 1 ? 1u : 0u)];
     auto cid = as_global(rc.cand_id) + cand_off(rc, b, k);
     auto cxy = as_global(reinterpret_cast<dbl2 *>(rc.cand_xy)) + cand_off(rc, b, k);
     const uint32_t cap = rc.cand_cap;

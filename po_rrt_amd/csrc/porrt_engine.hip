@@ -1055,16 +1055,17 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
     }
     const uint32_t vwords = (K + 63) / 64;
     for (int attempt = 0; attempt < 12; ++attempt) {
-        // every member: buffers, run constants, root, samples -- on its own stream
+        // every member: buffers, run constants, root, samples
         for (uint32_t q = 0; q < n; ++q) {
+            hipStream_t own = cs[q]->stream;
+            cs[q]->stream = L->stream;          // the members' preparation is queued on the leader's stream: no host sync
             int r = cs[q]->grow_once(starts + 2 * q, max_step, search_radius, n_iter, n_iter, K, mode, false, 1);
+            cs[q]->stream = own;
             if (r) { if (cs[q] != L) L->set_err(cs[q]->err); return r; }
             if (cs[q]->run_lds_bytes != L->run_lds_bytes) { L->set_err("porrt_grow_batch: the contexts' rasters need different LDS tiles (max_step * ppm differs)"); return PORRT_ERR_INVALID; }
         }
-        for (uint32_t q = 0; q < n; ++q) {
-            HIPCHK_CTX(L, hipStreamSynchronize(cs[q]->stream));
+        for (uint32_t q = 0; q < n; ++q)
             HIPCHK_CTX(L, hipMemcpyAsync(L->d_rcarr + q, &cs[q]->rc, sizeof(RunConst), hipMemcpyHostToDevice, L->stream));
-        }
         // the leader: all steps, one hipGraph (or eager), grid rows = contexts
         L->launch_rcp = L->d_rcarr;
         L->launch_Q = n;
