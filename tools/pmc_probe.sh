@@ -13,7 +13,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"].split("(")[0].split("::")[-1].replace("void ", "")
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     n[(k, r["Counter_Name"])] += 1
-for k in ("k_near<false>", "k_connect_rrt<true>", "k_kd_locate"):
+for k in ("k_near<false>", "k_connect_rrt<true>", "k_kd_locate<1>"):
     print(k, {c: "%.3g" % (v / max(n[(k, c)], 1)) for c, v in agg[k].items()})
 PY
 done
