@@ -596,9 +596,10 @@ __device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double 
                 dbl2 v[4];
                 int id[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {                 // unused slots read page 0 (valid memory, ignored)
-                    v[u] = gxy[(size_t)pg[u] * kPage + lane];
-                    id[u] = gid[(size_t)pg[u] * kPage + lane];
+                for (int u = 0; u < 4; ++u) {                 // only the filled slots are fetched
+                    const bool ld = lane < pc[u];
+                    v[u] = ld ? gxy[(size_t)pg[u] * kPage + lane] : dbl2{0.0, 0.0};
+                    id[u] = ld ? gid[(size_t)pg[u] * kPage + lane] : -1;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
