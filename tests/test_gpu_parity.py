@@ -184,6 +184,59 @@ def test_injected_samples_equal_seeded_stream(eng_mod):
         assert np.array_equal(a, b)
 
 
+def _injected(case, xy, K, eng_mod, **opts):
+    e = eng_mod.Engine()
+    for k, v in opts.items():
+        e.set_option(k, v)
+    cases.configure(e, case)
+    e.set_samples(xy)
+    cases.grow(e, case, K=K)
+    o = cases.configure(orc.Oracle(), case)
+    o.set_samples(xy)
+    cases.grow(o, case, K=K, algo=orc.ALGO_BATCHED_KD)
+    return e, o
+
+
+def test_dense_cluster_and_exact_duplicates(eng_mod):
+    """Every sample inside one small square: one region of the page grid takes all nodes (page chains through the
+    directory), neighbour lists are long, and a third of the samples are exact copies of earlier ones (kd chains of
+    identical points, equal-cost parents everywhere)."""
+    rng = np.random.default_rng(7)
+    n = 6000
+    xy = np.stack([rng.uniform(-0.02, 0.02, n), rng.uniform(-0.92, -0.88, n)], axis=1)
+    xy[::3] = xy[(np.arange(0, n, 3) // 7) * 2 + 1]          # exact duplicates of other samples
+    case = cases.cfg2(n - n // 100 - 5)
+    for K in (1024, 4096):
+        e, o = _injected(case, xy, K, eng_mod)
+        assert_same(e, o)
+        assert e.num_nodes() > 3000
+
+
+def test_max_batch_and_ragged_tail(eng_mod):
+    """batch_K = 4096 (the kd claim kernel's capacity per launch) with an iteration count that is no multiple of it."""
+    case = cases.cfg2(4096 * 3 + 17)
+    e, _ = run_gpu(eng_mod, case, 4096)
+    o, _ = run_orc(case, 4096)
+    assert_same(e, o)
+
+
+def test_points_outside_the_sampler_box(eng_mod):
+    """The goal (re-sampled every 100th iteration) lies outside the sampler's box, and so do the nodes steered towards
+    it: they fall into the clamped border cells of the region grid, the bound pyramid and the kd hint grid."""
+    case = cases.cfg2(12000)
+    for K in (256, 1024):
+        e = eng_mod.Engine()
+        cases.configure(e, case)
+        e.set_sampler((-0.5, -1.0), (0.5, 0.2), 3)
+        cases.grow(e, case, K=K)
+        o = cases.configure(orc.Oracle(), case)
+        o.set_sampler((-0.5, -1.0), (0.5, 0.2), 3)
+        cases.grow(o, case, K=K, algo=orc.ALGO_BATCHED_KD)
+        assert_same(e, o)
+        xy = e.tree()[0]
+        assert (xy[:, 0] > 0.5).any(), "the case is meant to put nodes outside the box"
+
+
 def test_sampler_state_persists_across_grows(eng_mod):
     """tamp_rrt.rs:196-232: one RRT object (one RNG stream) serves many plans."""
     case = cases.cfg1(700)
