@@ -162,6 +162,28 @@ public:
         for (size_t id : get_firstly_final_node_ids(tree, finals)) { auto p = tree.get_path_to(id); double c = path_cost(p); out.push_back({std::move(p), c}); }
         return {std::move(out), std::move(tree)};
     }
+    // Many independent queries at once (the TAMP layer's pattern, map_shelves_tamp_rrt.rs:163-291): every planner keeps
+    // its own map, sampler state and result; all of them advance in one launch sequence (porrt_grow_batch) with a fixed
+    // iteration budget.  Same results as calling plan() on each, several times the throughput.
+    template <class Goal>
+    static std::vector<std::pair<std::optional<Solution>, RRTTree>> plan_batch(const std::vector<RRT *> &planners, const std::vector<State> &starts,
+                                                                                const Goal &goal, double max_step, double search_radius, size_t n_iter) {
+        std::vector<porrt_ctx *> cs;
+        std::vector<double> st;
+        for (size_t q = 0; q < planners.size(); ++q) {
+            planners[q]->ctx_.set_goal(goal);
+            cs.push_back(planners[q]->ctx_.get());
+            st.push_back(starts[q][0]); st.push_back(starts[q][1]);
+        }
+        planners.at(0)->ctx_.check(porrt_grow_batch(cs.data(), (uint32_t)cs.size(), st.data(), max_step, search_radius, n_iter, planners[0]->batch_K,
+                                                    PORRT_MODE_RRT));
+        std::vector<std::pair<std::optional<Solution>, RRTTree>> out;
+        for (RRT *p : planners) {
+            auto [tree, finals] = p->read_tree();
+            out.push_back({get_best_solution(tree, finals), std::move(tree)});
+        }
+        return out;
+    }
 private:
     Context ctx_;
     template <class Goal>
@@ -169,6 +191,9 @@ private:
                                                       size_t n_iter_min, size_t n_iter_max) {                     // rrt.rs:102-174
         ctx_.set_goal(goal);
         ctx_.check(porrt_grow(ctx_.get(), start.data(), max_step, search_radius, n_iter_min, n_iter_max, batch_K, PORRT_MODE_RRT));
+        return read_tree();
+    }
+    std::pair<RRTTree, std::vector<size_t>> read_tree() {
         const size_t n = porrt_num_nodes(ctx_.get());
         std::vector<double> xy(2 * n), dist(n);
         std::vector<int64_t> parent(n);

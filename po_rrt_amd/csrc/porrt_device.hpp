@@ -107,7 +107,7 @@ struct RunConst {
     // per-sample step scratch
     double *q_x, *q_y;          // steered state
     double *kq_x, *kq_y;        // copy for the kd insertion ([step][sample])
-    int *kq_vid, *kq_nn;
+    int *kq_vid;
     int *q_nn;
     int *q_vid;
     uint32_t *cand_cnt;         // neighbour lists of the step: counts and ids are double-buffered by step parity
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
         rc.q_y[k] = ty;
         // copy for the kd insertion, which runs beside the following steps (one slice per step)
         const size_t o2 = (size_t)b * rc.part_stride + k;
-        rc.kq_x[o2] = tx; rc.kq_y[o2] = ty; rc.kq_vid[o2] = valid ? vid : -1; rc.kq_nn[o2] = nn;
+        rc.kq_x[o2] = tx; rc.kq_y[o2] = ty; rc.kq_vid[o2] = valid ? vid : -1;
         rc.q_nn[k] = nn;
         rc.q_vid[k] = valid ? vid : -1;
         if (valid) atomicOr(&rc.valid_mask[(size_t)b * vwords + (k >> 6)], 1ull << (k & 63u));

@@ -169,7 +169,7 @@ struct porrt_ctx {
     uint32_t opt_kd_group = 0;     // steps per kd insertion (0 = choose by K)
     uint32_t opt_cand_cap = 2048;
     // ---- device buffers
-    DevBuf<double> d_nx, d_ny, d_distA, d_distB, d_sx, d_sy, d_qx, d_qy, d_qbound, d_pgxy, d_candxy, d_candval, d_radT2, d_inj;
+    DevBuf<double> d_nx, d_ny, d_distA, d_distB, d_sx, d_sy, d_qx, d_qy, d_pgxy, d_candxy, d_candval, d_radT2, d_inj;
     DevBuf<int> d_parent, d_qnn, d_qvid, d_pgid, d_candid, d_gid, d_kdup;
     DevBuf<KdRec> d_kdrec;
     DevBuf<KdBox> d_kdbox, d_locbox;
@@ -177,7 +177,7 @@ struct porrt_ctx {
     DevBuf<int> d_loccur;
     DevBuf<uint32_t> d_locdcur, d_locgex, d_locflags, d_kdsurv;
     DevBuf<double> d_gx, d_gy, d_gndx, d_gndy, d_kqx, d_kqy;
-    DevBuf<int> d_kqvid, d_kqnn;
+    DevBuf<int> d_kqvid;
     DevBuf<uint32_t> d_rgcnt, d_rgdir, d_gsnap, d_pendoff, d_pendn, d_pendcur, d_pendstate;
     DevBuf<int> d_pendnew, d_pendpool;
     DevBuf<int> d_rep;
@@ -229,15 +229,13 @@ struct porrt_ctx {
     const RunConst *launch_rcp = nullptr;     // RunConst array the step kernels read (one row of the grid per entry)
     uint32_t launch_Q = 1;
     uint32_t commit_pend_b = 0xFFFFFFFFu, commit_pend_nb = 0;     // RRT*: step whose rewire phase 2 rides in the next k_near
-    hipStream_t stream3 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bound[2] = {nullptr, nullptr};
-    bool bound_pending[2] = {false, false};
+    hipEvent_t ev_join = nullptr;
     void join_side();
     void launch_kd_group();
     uint32_t kd_b0 = 0, kd_last_b = 0, kd_last_nb = 0, kd_group = 1, kd_gidx = 0;
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev_step_done = nullptr, ev_kd[2] = {nullptr, nullptr}, ev_steered = nullptr, ev_located = nullptr;
-    bool kd_pend[2] = {false, false}, loc_pending = false, side_active = false;
+    hipEvent_t ev_step_done = nullptr, ev_kd[2] = {nullptr, nullptr}, ev_steered = nullptr;
+    bool kd_pend[2] = {false, false}, side_active = false;
     // cached hipGraph of the steps up to n_iter_min
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_key[6] = {0, 0, 0, 0, 0, 0};
@@ -250,9 +248,9 @@ struct porrt_ctx {
 // every grow re-initialises what it uses, and the cached uploads are marked stale.
 int porrt_ctx::layout_buffers() {
     if (all_bufs.empty()) {
-        DevBufBase *list[] = {&d_nx, &d_ny, &d_distA, &d_distB, &d_sx, &d_sy, &d_qx, &d_qy, &d_qbound, &d_pgxy, &d_candxy, &d_candval, &d_radT2, &d_inj,
+        DevBufBase *list[] = {&d_nx, &d_ny, &d_distA, &d_distB, &d_sx, &d_sy, &d_qx, &d_qy, &d_pgxy, &d_candxy, &d_candval, &d_radT2, &d_inj,
                               &d_parent, &d_qnn, &d_qvid, &d_pgid, &d_candid, &d_gid, &d_kdup, &d_kdrec, &d_gx, &d_gy, &d_rgcnt,
-                              &d_rgdir, &d_rep, &d_kdbox, &d_locbox, &d_kdlosers, &d_kqnn, &d_kdhint, &d_gsnap, &d_pendoff, &d_pendn, &d_pendcur, &d_pendstate, &d_pendnew, &d_pendpool, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB,
+                              &d_rgdir, &d_rep, &d_kdbox, &d_locbox, &d_kdlosers, &d_kdhint, &d_gsnap, &d_pendoff, &d_pendn, &d_pendcur, &d_pendstate, &d_pendnew, &d_pendpool, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB,
                               &d_finalmask, &d_validmask, &d_vid, &d_finalflag, &d_cls, &d_nat, &d_sworld, &d_candcnt, &d_efrom,
                               &d_eto, &d_etv, &d_cnt, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags, &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid};
         for (DevBufBase *b2 : list) all_bufs.push_back(b2);
@@ -277,12 +275,12 @@ int porrt_ctx::layout_buffers() {
     for (DevBufBase *b2 : all_bufs) { b2->vp = (char *)arena.base + off; off += (b2->n * b2->elem + 4095) & ~(size_t)4095; }
     d_nx.p = (double *)d_nx.vp; d_ny.p = (double *)d_ny.vp; d_distA.p = (double *)d_distA.vp; d_distB.p = (double *)d_distB.vp;
     d_sx.p = (double *)d_sx.vp; d_sy.p = (double *)d_sy.vp; d_qx.p = (double *)d_qx.vp; d_qy.p = (double *)d_qy.vp;
-    d_qbound.p = (double *)d_qbound.vp; d_pgxy.p = (double *)d_pgxy.vp; d_candxy.p = (double *)d_candxy.vp; d_candval.p = (double *)d_candval.vp; d_radT2.p = (double *)d_radT2.vp; d_inj.p = (double *)d_inj.vp;
+    d_pgxy.p = (double *)d_pgxy.vp; d_candxy.p = (double *)d_candxy.vp; d_candval.p = (double *)d_candval.vp; d_radT2.p = (double *)d_radT2.vp; d_inj.p = (double *)d_inj.vp;
     d_parent.p = (int *)d_parent.vp; d_qnn.p = (int *)d_qnn.vp; d_qvid.p = (int *)d_qvid.vp; d_pgid.p = (int *)d_pgid.vp;
     d_candid.p = (int *)d_candid.vp; d_gid.p = (int *)d_gid.vp; d_kdup.p = (int *)d_kdup.vp; d_kdrec.p = (KdRec *)d_kdrec.vp;
     d_gx.p = (double *)d_gx.vp; d_gy.p = (double *)d_gy.vp; d_rgcnt.p = (uint32_t *)d_rgcnt.vp; d_rgdir.p = (uint32_t *)d_rgdir.vp;
     d_rep.p = (int *)d_rep.vp;
-    d_kdbox.p = (KdBox *)d_kdbox.vp; d_locbox.p = (KdBox *)d_locbox.vp; d_kdlosers.p = (KdMove *)d_kdlosers.vp; d_kqnn.p = (int *)d_kqnn.vp; d_kdhint.p = (unsigned long long *)d_kdhint.vp;
+    d_kdbox.p = (KdBox *)d_kdbox.vp; d_locbox.p = (KdBox *)d_locbox.vp; d_kdlosers.p = (KdMove *)d_kdlosers.vp; d_kdhint.p = (unsigned long long *)d_kdhint.vp;
     d_gsnap.p = (uint32_t *)d_gsnap.vp; d_pendoff.p = (uint32_t *)d_pendoff.vp; d_pendn.p = (uint32_t *)d_pendn.vp; d_pendcur.p = (uint32_t *)d_pendcur.vp;
     d_pendstate.p = (uint32_t *)d_pendstate.vp; d_pendnew.p = (int *)d_pendnew.vp; d_pendpool.p = (int *)d_pendpool.vp; d_kddepth.p = (uint32_t *)d_kddepth.vp; d_kdgexit.p = (uint32_t *)d_kdgexit.vp;
     d_reachA.p = (unsigned long long *)d_reachA.vp; d_reachB.p = (unsigned long long *)d_reachB.vp;
@@ -579,7 +577,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         const uint64_t rg_maxp = Nmax / kPage + 2, pg_cap = 2ull * kRegions + Nmax / kPage + 8;
         HIPCHK(d_rgcnt.reserve(kRegions)); HIPCHK(d_rgdir.reserve((size_t)kRegions * rg_maxp));
         HIPCHK(d_pgxy.reserve(2 * (size_t)pg_cap * kPage)); HIPCHK(d_pgid.reserve((size_t)pg_cap * kPage)); 
-        HIPCHK(d_candcnt.reserve(2 * (size_t)K)); HIPCHK(d_kdbox.reserve(Nmax)); HIPCHK(d_kdlosers.reserve(kClaimMax)); HIPCHK(d_locbox.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_kqnn.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kdhint.reserve((size_t)kHG * kHG));
+        HIPCHK(d_candcnt.reserve(2 * (size_t)K)); HIPCHK(d_kdbox.reserve(Nmax)); HIPCHK(d_kdlosers.reserve(kClaimMax)); HIPCHK(d_locbox.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_kdhint.reserve((size_t)kHG * kHG));
         HIPCHK(d_loccur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locdcur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locgex.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locflags.reserve(2 * (8 * (size_t)K + 4096)));
         HIPCHK(d_gsnap.reserve((steps_max + 4) * 4)); HIPCHK(d_pendoff.reserve(pend_cap)); HIPCHK(d_pendn.reserve(pend_cap)); HIPCHK(d_pendcur.reserve(pend_cap));
         HIPCHK(d_pendstate.reserve(pend_cap)); HIPCHK(d_pendnew.reserve(pend_cap)); HIPCHK(d_pendpool.reserve(pool_cap)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_gndx.reserve(Nmax)); HIPCHK(d_gndy.reserve(Nmax));
@@ -618,7 +616,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.q_x = d_qx.p; c.q_y = d_qy.p; c.q_nn = d_qnn.p; c.q_vid = d_qvid.p;
     c.rg_cnt = d_rgcnt.p; c.rg_dir = d_rgdir.p; c.pg_xy = d_pgxy.p; c.pg_id = d_pgid.p;
     c.rg_maxp = (uint32_t)(Nmax / kPage + 2); c.pg_cap = (uint32_t)(2ull * kRegions + Nmax / kPage + 8);
-    c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p; c.kq_nn = d_kqnn.p; c.kd_box = d_kdbox.p; c.loc_box = d_locbox.p; c.kd_losers = d_kdlosers.p; c.kd_hint = d_kdhint.p; c.g_snap = d_gsnap.p; c.loc_stride = 8 * K + 4096;
+    c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p; c.kd_box = d_kdbox.p; c.loc_box = d_locbox.p; c.kd_losers = d_kdlosers.p; c.kd_hint = d_kdhint.p; c.g_snap = d_gsnap.p; c.loc_stride = 8 * K + 4096;
     c.pend_new = d_pendnew.p; c.pend_pool = d_pendpool.p; c.pend_off = d_pendoff.p; c.pend_n = d_pendn.p; c.pend_cur = d_pendcur.p; c.pend_state = d_pendstate.p;
     c.pend_cap = (uint32_t)std::min<uint64_t>(pend_cap, 0xFFFFFFFFull); c.pool_cap = (uint32_t)std::min<uint64_t>(pool_cap, 0xFFFFFFFFull);
     c.cand_K = K; c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_xy = d_candxy.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
@@ -1190,12 +1188,7 @@ porrt_ctx *porrt_create(int device) {
         hipEventCreateWithFlags(&c->ev_kd[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_kd[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_steered, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_located, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_bound[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_bound[1], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
     c->crng.seed_from_u64(0);   // sample_space.rs:18
     c->drng.seed_from_u64(0);   // sample_space.rs:47
     c->validities[0] = 1;       // map_io.rs:108-111 init_without_zones
@@ -1215,12 +1208,8 @@ void porrt_destroy(porrt_ctx *c) {
     if (c->ev_step_done) (void)hipEventDestroy(c->ev_step_done);
     for (int p2 = 0; p2 < 2; ++p2) if (c->ev_kd[p2]) (void)hipEventDestroy(c->ev_kd[p2]);
     if (c->ev_steered) (void)hipEventDestroy(c->ev_steered);
-    if (c->ev_located) (void)hipEventDestroy(c->ev_located);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    for (int p2 = 0; p2 < 2; ++p2) if (c->ev_bound[p2]) (void)hipEventDestroy(c->ev_bound[p2]);
-    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->d_rcarr) (void)hipFree(c->d_rcarr);
     (void)hipStreamDestroy(c->stream);
     delete c;

@@ -50,10 +50,11 @@ def fnv_digest(xy, parent):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K", [1, 256])
-def test_cpp_rrt_plan_matches_oracle(exe, K):
+@pytest.mark.parametrize("K,nq", [(1, 1), (256, 1), (256, 3)])
+def test_cpp_rrt_plan_matches_oracle(exe, K, nq):
+    """nq > 1: RRT::plan_batch plans the query together with nq - 1 others; its own result must not change."""
     n = 400 if K == 1 else 3000
-    out = subprocess.run([exe, MAP, str(n), str(n), str(K), "5"], capture_output=True, text=True, timeout=120)
+    out = subprocess.run([exe, MAP, str(n), str(n), str(K), "5"] + ([str(nq)] if nq > 1 else []), capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     tok = out.stdout.split()
     case = cases.cfg2(n, seed=5)
