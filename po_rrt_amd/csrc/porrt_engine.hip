@@ -202,7 +202,7 @@ struct porrt_ctx {
     uint64_t n_iter = 0, n_nodes = 0, n_steps = 0;
     Counters counters;
     bool complete = false;
-    bool have_results = false, downloaded = false;
+    bool have_results = false;
     std::vector<double> h_nx, h_ny, h_dist;
     std::vector<int> h_parent;
     std::vector<unsigned long long> h_reach, h_finalmask;
@@ -222,7 +222,10 @@ struct porrt_ctx {
     size_t run_lds_bytes = 0;
     RunConst *d_rcarr = nullptr;      // leader of a porrt_grow_batch: the members' RunConst, one per grid row
     size_t rcarr_cap = 0;
-    int download();
+    enum : unsigned { DL_TREE = 1, DL_DIST = 2, DL_MASKS = 4, DL_EDGES = 8 };
+    int download(unsigned want);
+    unsigned got = 0;
+    uint64_t results_tag = 0, downloaded_tag = ~0ull;
     void launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, size_t lds_bytes, bool prof, size_t &ev_used,
                      uint32_t nxt2_i0, uint32_t nxt2_nb);
     void flush_commit();
@@ -527,7 +530,7 @@ int porrt_ctx::grow(const double start[2], double max_step, double search_radius
     if (n_iter_max + 2 >= 0x7FFFFFF0ull) { set_err("n_iter_max too large"); return PORRT_ERR_INVALID; }
     if (!(max_step > 0.0) || !(search_radius >= 0.0)) { set_err("max_step / search_radius"); return PORRT_ERR_INVALID; }
     have_results = false;
-    downloaded = false;
+    ++results_tag;
     // the sampler state must survive a capacity retry
     const Pcg64 c0 = crng, d0 = drng;
     const size_t ip0 = inj_pos, iw0 = inj_wpos;
@@ -898,7 +901,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     n_nodes = n_final_nodes;
     complete = mode == PORRT_MODE_PTO ? is_done() : hc.n_final > 0;
     have_results = true;
-    downloaded = false;
+    ++results_tag;
 
     // advance the persistent sampler state by what this grow consumed
     const uint64_t calls = i - i / 100;
@@ -948,24 +951,36 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     return rcode;
 }
 
-int porrt_ctx::download() {
+// Results are fetched lazily and in parts: a caller that only asks for the best path (porrt_best_solution) pays for
+// coordinates, parents and final flags; dist_root, masks, validity ids and edges come when a getter asks for them.
+int porrt_ctx::download(unsigned want) {
     if (!have_results) { set_err("no results: call porrt_grow first"); return PORRT_ERR_INVALID; }
-    if (downloaded) return PORRT_OK;
+    if (downloaded_tag != results_tag) { got = 0; downloaded_tag = results_tag; }
+    const unsigned need = want & ~got;
+    if (!need) return PORRT_OK;
     HIPCHK(hipSetDevice(device));
     const size_t N = n_nodes;
-    h_nx.resize(N); h_ny.resize(N); h_dist.resize(N); h_parent.resize(N); h_reach.resize(N); h_finalmask.resize(N);
-    h_vid.resize(N); h_finalflag.resize(N);
-    HIPCHK(hipMemcpy(h_nx.data(), d_nx.p, N * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(h_ny.data(), d_ny.p, N * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(h_dist.data(), d_distA.p, N * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(h_parent.data(), d_parent.p, N * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(h_reach.data(), d_reachA.p, N * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(h_finalmask.data(), d_finalmask.p, N * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(h_vid.data(), d_vid.p, N, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(h_finalflag.data(), d_finalflag.p, N, hipMemcpyDeviceToHost));
-    h_final_ids.clear();
-    for (size_t j = 0; j < N; ++j)
-        if (h_finalflag[j]) h_final_ids.push_back(j);   // ascending id == push order of the reference
+    if (need & DL_TREE) {
+        h_nx.resize(N); h_ny.resize(N); h_parent.resize(N); h_finalflag.resize(N);
+        HIPCHK(hipMemcpy(h_nx.data(), d_nx.p, N * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h_ny.data(), d_ny.p, N * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h_parent.data(), d_parent.p, N * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h_finalflag.data(), d_finalflag.p, N, hipMemcpyDeviceToHost));
+        h_final_ids.clear();
+        for (size_t j = 0; j < N; ++j)
+            if (h_finalflag[j]) h_final_ids.push_back(j);   // ascending id == push order of the reference
+    }
+    if (need & DL_DIST) {
+        h_dist.resize(N);
+        HIPCHK(hipMemcpy(h_dist.data(), d_distA.p, N * 8, hipMemcpyDeviceToHost));
+    }
+    if (need & DL_MASKS) {
+        h_reach.resize(N); h_finalmask.resize(N); h_vid.resize(N);
+        HIPCHK(hipMemcpy(h_reach.data(), d_reachA.p, N * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h_finalmask.data(), d_finalmask.p, N * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h_vid.data(), d_vid.p, N, hipMemcpyDeviceToHost));
+    }
+    if (!(need & DL_EDGES)) { got |= need; return PORRT_OK; }
     if (mode == PORRT_MODE_PTO) {
         const size_t E = counters.n_edges;
         std::vector<uint32_t> f(E), t(E), v(E);
@@ -984,7 +999,7 @@ int porrt_ctx::download() {
     } else {
         h_efrom.clear(); h_eto.clear(); h_etv.clear();
     }
-    downloaded = true;
+    got |= need;
     return PORRT_OK;
 }
 
@@ -1005,7 +1020,7 @@ int porrt_ctx::finish_batch_member(uint64_t n_iter_done, uint32_t steps, float d
     const unsigned long long all = rc.all_worlds;
     complete = mode == PORRT_MODE_PTO ? (hc.n_final > 0 && (hc.finality & all) == all) : hc.n_final > 0;
     have_results = true;
-    downloaded = false;
+    ++results_tag;
     const uint64_t calls = n_iter_done - n_iter_done / 100;
     if (has_inj) inj_pos += calls;
     else crng.advance((u128)2 * calls);
@@ -1038,7 +1053,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         for (uint32_t r = 0; r < q; ++r) if (cs[r] == cs[q]) { L->set_err("porrt_grow_batch: a context appears twice"); return PORRT_ERR_INVALID; }
         if (mode == PORRT_MODE_PTO && !cs[q]->has_grid) { cs[q]->set_err("PTO mode needs a grid"); return PORRT_ERR_INVALID; }
         cs[q]->have_results = false;
-        cs[q]->downloaded = false;
+        ++cs[q]->results_tag;
     }
     HIPCHK_CTX(L, hipSetDevice(L->device));
     std::vector<Pcg64> c0(n), d0(n);
@@ -1358,7 +1373,7 @@ uint64_t porrt_num_iterations(const porrt_ctx *c) { return c && c->have_results 
 int porrt_get_tree(const porrt_ctx *cc, double *xy, int64_t *parent, double *dist_root) {
     porrt_ctx *c = const_cast<porrt_ctx *>(cc);
     if (!c) return PORRT_ERR_INVALID;
-    int r = c->download();
+    int r = c->download(porrt_ctx::DL_TREE | (dist_root ? porrt_ctx::DL_DIST : 0u));
     if (r) return r;
     for (size_t j = 0; j < c->n_nodes; ++j) {
         if (xy) { xy[2 * j] = c->h_nx[j]; xy[2 * j + 1] = c->h_ny[j]; }
@@ -1373,7 +1388,7 @@ uint64_t porrt_num_final(const porrt_ctx *c) { return c && c->have_results ? c->
 int porrt_get_final_ids(const porrt_ctx *cc, uint64_t *ids) {
     porrt_ctx *c = const_cast<porrt_ctx *>(cc);
     if (!c) return PORRT_ERR_INVALID;
-    int r = c->download();
+    int r = c->download(porrt_ctx::DL_TREE);
     if (r) return r;
     for (size_t k = 0; k < c->h_final_ids.size(); ++k) ids[k] = c->h_final_ids[k];
     return PORRT_OK;
@@ -1382,7 +1397,7 @@ int porrt_get_final_ids(const porrt_ctx *cc, uint64_t *ids) {
 int porrt_get_final_masks(const porrt_ctx *cc, uint64_t *masks) {
     porrt_ctx *c = const_cast<porrt_ctx *>(cc);
     if (!c) return PORRT_ERR_INVALID;
-    int r = c->download();
+    int r = c->download(porrt_ctx::DL_TREE | porrt_ctx::DL_MASKS);
     if (r) return r;
     for (size_t k = 0; k < c->h_final_ids.size(); ++k) masks[k] = c->h_finalmask[c->h_final_ids[k]];
     return PORRT_OK;
@@ -1391,7 +1406,7 @@ int porrt_get_final_masks(const porrt_ctx *cc, uint64_t *masks) {
 int porrt_get_reach(const porrt_ctx *cc, uint64_t *masks) {
     porrt_ctx *c = const_cast<porrt_ctx *>(cc);
     if (!c) return PORRT_ERR_INVALID;
-    int r = c->download();
+    int r = c->download(porrt_ctx::DL_MASKS);
     if (r) return r;
     for (size_t j = 0; j < c->n_nodes; ++j) masks[j] = c->h_reach[j];
     return PORRT_OK;
@@ -1400,7 +1415,7 @@ int porrt_get_reach(const porrt_ctx *cc, uint64_t *masks) {
 int porrt_get_node_validity(const porrt_ctx *cc, uint32_t *v) {
     porrt_ctx *c = const_cast<porrt_ctx *>(cc);
     if (!c) return PORRT_ERR_INVALID;
-    int r = c->download();
+    int r = c->download(porrt_ctx::DL_MASKS);
     if (r) return r;
     for (size_t j = 0; j < c->n_nodes; ++j) v[j] = c->h_vid[j];
     return PORRT_OK;
@@ -1411,7 +1426,7 @@ uint64_t porrt_num_edges(const porrt_ctx *c) { return c && c->have_results && c-
 int porrt_get_edges(const porrt_ctx *cc, uint32_t *from, uint32_t *to, uint32_t *validity_id) {
     porrt_ctx *c = const_cast<porrt_ctx *>(cc);
     if (!c) return PORRT_ERR_INVALID;
-    int r = c->download();
+    int r = c->download(porrt_ctx::DL_EDGES);
     if (r) return r;
     for (size_t e = 0; e < c->h_efrom.size(); ++e) { from[e] = c->h_efrom[e]; to[e] = c->h_eto[e]; validity_id[e] = c->h_etv[e]; }
     return PORRT_OK;
@@ -1433,7 +1448,7 @@ int porrt_get_zone_positions(const porrt_ctx *c, double *xy) {
 // rrt.rs:183-193 (first final node of minimal path cost), 48-61, 223-227
 uint64_t porrt_best_solution(const porrt_ctx *cc, double *path_xy, uint64_t cap, double *cost) {
     porrt_ctx *c = const_cast<porrt_ctx *>(cc);
-    if (!c || c->download()) return 0;
+    if (!c || c->download(porrt_ctx::DL_TREE)) return 0;
     if (c->h_final_ids.empty()) return 0;
     uint64_t best_len = 0, best_id = 0;
     double best_cost = 0;
