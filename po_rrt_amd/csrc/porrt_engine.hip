@@ -219,6 +219,8 @@ struct porrt_ctx {
     int grow_once(const double start[2], double max_step, double search_radius, uint64_t n_iter_min, uint64_t n_iter_max,
                   uint32_t K, int mode, bool host_samples, int stage = 0);
     int finish_batch_member(uint64_t n_iter_done, uint32_t steps, float device_ms);
+    Counters batch_hc;
+    uint32_t batch_nodes = 0;
     size_t run_lds_bytes = 0;
     RunConst *d_rcarr = nullptr;      // leader of a porrt_grow_batch: the members' RunConst, one per grid row
     size_t rcarr_cap = 0;
@@ -251,11 +253,13 @@ struct porrt_ctx {
 // every grow re-initialises what it uses, and the cached uploads are marked stale.
 int porrt_ctx::layout_buffers() {
     if (all_bufs.empty()) {
-        DevBufBase *list[] = {&d_nx, &d_ny, &d_distA, &d_distB, &d_sx, &d_sy, &d_qx, &d_qy, &d_pgxy, &d_candxy, &d_candval, &d_radT2, &d_inj,
-                              &d_parent, &d_qnn, &d_qvid, &d_pgid, &d_candid, &d_gid, &d_kdup, &d_kdrec, &d_gx, &d_gy, &d_rgcnt,
-                              &d_rgdir, &d_rep, &d_kdbox, &d_locbox, &d_kdlosers, &d_kdhint, &d_gsnap, &d_pendoff, &d_pendn, &d_pendcur, &d_pendstate, &d_pendnew, &d_pendpool, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB,
-                              &d_finalmask, &d_validmask, &d_vid, &d_finalflag, &d_cls, &d_nat, &d_sworld, &d_candcnt, &d_efrom,
-                              &d_eto, &d_etv, &d_cnt, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags, &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid};
+        // the first five are zeroed together at the start of every grow (one memset over the span)
+        DevBufBase *list[] = {&d_cnt, &d_rgcnt, &d_validmask, &d_kdhint, &d_pendstate, &d_nx, &d_ny, &d_distA, &d_distB, &d_sx, &d_sy, &d_qx, &d_qy,
+                              &d_pgxy, &d_candxy, &d_candval, &d_radT2, &d_inj, &d_parent, &d_qnn, &d_qvid, &d_pgid, &d_candid, &d_gid, &d_kdup,
+                              &d_kdrec, &d_gx, &d_gy, &d_rgdir, &d_rep, &d_kdbox, &d_locbox, &d_kdlosers, &d_gsnap, &d_pendoff, &d_pendn, &d_pendcur,
+                              &d_pendnew, &d_pendpool, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB, &d_finalmask, &d_vid, &d_finalflag, &d_cls,
+                              &d_nat, &d_sworld, &d_candcnt, &d_efrom, &d_eto, &d_etv, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags,
+                              &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid};
         for (DevBufBase *b2 : list) all_bufs.push_back(b2);
     }
     bool grow_needed = false;
@@ -688,12 +692,17 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         double t0 = now_s();
         HIPCHK(hipMemcpyAsync(d_rc.p, &c, sizeof c, hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(d_jump.p, &jt, sizeof jt, hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemsetAsync(d_cnt.p, 0, sizeof(Counters), stream));
+        // counters, region counts, valid masks, kd hints (0 = the root: depth 0, id 0) and deferred-tie states lie next to
+        // each other in the arena: one memset
+        {
+            char *z0 = (char *)d_cnt.p, *z1 = (char *)d_pendstate.p + pend_cap * sizeof(uint32_t);
+            if (!((char *)d_rgcnt.p > z0 && (char *)d_validmask.p > (char *)d_rgcnt.p && (char *)d_kdhint.p > (char *)d_validmask.p &&
+                  (char *)d_pendstate.p > (char *)d_kdhint.p)) {
+                set_err("arena layout"); return PORRT_ERR_DEVICE;
+            }
+            HIPCHK(hipMemsetAsync(z0, 0, (size_t)(z1 - z0), stream));
+        }
         HIPCHK(hipMemsetAsync(d_rep.p, 0xFF, kRepTotal * sizeof(int), stream));
-        HIPCHK(hipMemsetAsync(d_rgcnt.p, 0, kRegions * sizeof(uint32_t), stream));
-        HIPCHK(hipMemsetAsync(d_pendstate.p, 0, pend_cap * sizeof(uint32_t), stream));
-        HIPCHK(hipMemsetAsync(d_kdhint.p, 0, (size_t)kHG * kHG * sizeof(unsigned long long), stream));   // the root: depth 0, id 0
-        HIPCHK(hipMemsetAsync(d_validmask.p, 0, (steps_max + 2) * vwords * sizeof(unsigned long long), stream));
         t_setup += now_s() - t0;
     }
     hipLaunchKernelGGL(k_init_root, dim3(1), dim3(1), 0, stream, d_rc.p, start[0], start[1], (unsigned long long)root_reach, root_vid);
@@ -1007,10 +1016,9 @@ int porrt_ctx::download(unsigned want) {
 // A member's bookkeeping after the leader of a porrt_grow_batch ran the steps (fixed iteration budget: the loop
 // condition is never consulted, n_iter_min == n_iter_max).
 int porrt_ctx::finish_batch_member(uint64_t n_iter_done, uint32_t steps, float device_ms) {
-    Counters hc;
-    uint32_t n_final_nodes = 0;
-    HIPCHK(hipMemcpy(&hc, d_cnt.p, sizeof hc, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&n_final_nodes, d_nat.p + steps, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // fetched by grow_batch for all members at once (batch_hc, batch_nodes)
+    const Counters hc = batch_hc;
+    const uint32_t n_final_nodes = batch_nodes;
     if (hc.err & ERR_CAND_OVERFLOW) return -100;
     if (hc.err & ERR_RNG_RETRY) { set_err("a float draw would have been redrawn: grow this context on its own"); return PORRT_ERR_INVALID; }
     counters = hc;
@@ -1132,6 +1140,10 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             steps = all_steps();
         }
         HIPCHK_CTX(L, hipEventRecord(e1, L->stream));
+        for (uint32_t q = 0; q < n; ++q) {          // every member's counters and final tree size, one sync for all
+            HIPCHK_CTX(L, hipMemcpyAsync(&cs[q]->batch_hc, cs[q]->d_cnt.p, sizeof(Counters), hipMemcpyDeviceToHost, L->stream));
+            HIPCHK_CTX(L, hipMemcpyAsync(&cs[q]->batch_nodes, cs[q]->d_nat.p + (uint32_t)((n_iter + K - 1) / K), sizeof(uint32_t), hipMemcpyDeviceToHost, L->stream));
+        }
         HIPCHK_CTX(L, hipStreamSynchronize(L->stream));
         {
             hipError_t e = hipGetLastError();
