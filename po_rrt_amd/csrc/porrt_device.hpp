@@ -491,7 +491,7 @@ __device__ __forceinline__ double nn_bound_wave(const RunConst &rc, uint32_t N, 
 // flight), hits are compacted with a ballot.
 __device__ __forceinline__ uint32_t rank_before(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k);
 __device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k, uint32_t lane);
-constexpr int kRG = 64;
+constexpr int kRG = 40;
 constexpr uint32_t kRegions = kRG * kRG;
 constexpr uint32_t kPage = 64;
 typedef double dbl2 __attribute__((ext_vector_type(2)));
