@@ -494,12 +494,13 @@ void porrt_ctx::launch_kd_group() {
     kd_b0 = kd_last_b + 1;
 }
 
-// steps whose new nodes are inserted into the kd structure together (about 2048 nodes: the kd kernels' run time is
-// set by the deepest descent, not by the node count, so two steps of K = 1024 cost little more than one; at most
-// kClaimMax nodes)
-static uint32_t kd_group_for(uint32_t K, uint32_t opt) {
+// steps whose new nodes are inserted into the kd structure together: the kd kernels' run time is set by the deepest
+// descent, not by the node count, so a single context takes as many steps as the claim kernel holds (kClaimMax
+// nodes: 7 % faster than half of that); with several contexts per launch the kernels are throughput bound and smaller
+// groups keep the structure (and the deferred ties) closer behind the steps.
+static uint32_t kd_group_for(uint32_t K, uint32_t opt, uint32_t Q) {
     const uint32_t cap = std::max<uint32_t>(1u, std::min<uint32_t>(8u, kClaimMax / K));
-    uint32_t g = std::max<uint32_t>(1u, std::min<uint32_t>(8u, 2048u / K));
+    uint32_t g = std::max<uint32_t>(1u, std::min<uint32_t>(8u, (Q > 1 ? 2048u : kClaimMax) / K));
     if (opt) g = std::min(opt, cap);
     return g;
 }
@@ -810,7 +811,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     commit_pend_b = 0xFFFFFFFFu;
     kd_b0 = 0; kd_last_b = 0; kd_last_nb = 0; kd_gidx = 0;
     kd_pend[0] = kd_pend[1] = false;
-    kd_group = kd_group_for(K, opt_kd_group);
+    kd_group = kd_group_for(K, opt_kd_group, 1);
     if (opt_graph && !prof && n_iter_min > 0) {
         // all steps up to n_iter_min as one hipGraph (two branches: main pipeline + kd insertion); the graph
         // only depends on the launch geometry, so it is instantiated once and replayed by later grows
@@ -1094,7 +1095,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         L->commit_pend_b = 0xFFFFFFFFu;
         L->kd_b0 = 0; L->kd_last_b = 0; L->kd_last_nb = 0; L->kd_gidx = 0;
         L->kd_pend[0] = L->kd_pend[1] = false;
-        L->kd_group = kd_group_for(K, L->opt_kd_group);
+        L->kd_group = kd_group_for(K, L->opt_kd_group, n);
         hipEvent_t e0, e1;
         HIPCHK_CTX(L, hipEventCreate(&e0));
         HIPCHK_CTX(L, hipEventCreate(&e1));

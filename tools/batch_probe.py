@@ -9,6 +9,8 @@ case = cases.cfg2(111500)
 for Q in [int(x) for x in os.environ.get("QS", "1,2,4,8,16").split(",")]:
     engs = [cases.configure(po_rrt_amd.Engine(0), cases.cfg2(111500, seed=100 + q)) for q in range(Q)]
     starts = [case.start] * Q
+    if os.environ.get("KDG"):
+        engs[0].set_option("kd_group", int(os.environ["KDG"]))
     for w in range(2):
         po_rrt_amd.Engine.grow_batch(engs, starts, case.max_step, case.search_radius, case.n_iter_min, 1024)
     R = 5
