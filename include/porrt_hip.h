@@ -114,8 +114,12 @@ int      porrt_get_final_ids(const porrt_ctx *ctx, uint64_t *ids);
 int      porrt_get_final_masks(const porrt_ctx *ctx, uint64_t *masks);
 /* PTO mode.  Replaces: Reachability::reachability (pto_reachability.rs:54-56),
  * PTONode.validity_id and the PTOGraph edges (pto_graph.rs:171-207): forward edges
- * (neighbour -> new node) sorted by (to, from); the reference also stores each
- * reverse edge with the same validity id (pto.rs:117-120). */
+ * (neighbour -> new node) in the order the reference adds them (pto.rs:103-114): new nodes
+ * ascending, and for one new node its neighbours in the order KdTree::nearest_neighbors lists
+ * them (kd pre-order, nearest_neighbor.rs:101-117) -- so that adjacency lists rebuilt from it
+ * equal the reference's element for element.  The reference also stores each reverse edge with
+ * the same validity id (pto.rs:117-120).  The order is restored on the host when the edges are
+ * first asked for (a kd-tree over the node coordinates); the growth itself does not need it. */
 int      porrt_get_reach(const porrt_ctx *ctx, uint64_t *masks /* N */);
 int      porrt_get_node_validity(const porrt_ctx *ctx, uint32_t *validity_ids /* N */);
 uint64_t porrt_num_edges(const porrt_ctx *ctx);

@@ -992,6 +992,12 @@ int porrt_ctx::download(unsigned want) {
     }
     if (!(need & DL_EDGES)) { got |= need; return PORRT_OK; }
     if (mode == PORRT_MODE_PTO) {
+        // Edges come back in the order PTOGraph's adjacency lists are filled (pto.rs:103-120): new nodes ascending, and
+        // for one new node its neighbours in the order KdTree::nearest_neighbors lists them -- kd pre-order
+        // (nearest_neighbor.rs:101-117).  The device only kept the edge set; the order is restored here, on demand, from
+        // the kd-tree of the node coordinates (sequential KdTree::add in id order, nearest_neighbor.rs:29-46).
+        int r = download(DL_TREE);
+        if (r) return r;
         const size_t E = counters.n_edges;
         std::vector<uint32_t> f(E), t(E), v(E);
         if (E) {
@@ -999,13 +1005,37 @@ int porrt_ctx::download(unsigned want) {
             HIPCHK(hipMemcpy(t.data(), d_eto.p, E * 4, hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(v.data(), d_etv.p, E * 4, hipMemcpyDeviceToHost));
         }
+        std::vector<int> ch0(N, -1), ch1(N, -1);
+        for (size_t id = 1; id < N; ++id) {
+            const double x = h_nx[id], y = h_ny[id];
+            size_t cur = 0;
+            for (uint32_t d = 0;; ++d) {
+                const bool left = (d & 1u) ? (y < h_ny[cur]) : (x < h_nx[cur]);
+                int &c = left ? ch0[cur] : ch1[cur];
+                if (c < 0) { c = (int)id; break; }
+                cur = (size_t)c;
+            }
+        }
+        std::vector<uint32_t> rank(N, 0);
+        {
+            std::vector<int> stack;
+            uint32_t next = 0;
+            if (N) stack.push_back(0);
+            while (!stack.empty()) {
+                const int n = stack.back();
+                stack.pop_back();
+                rank[n] = next++;
+                if (ch1[n] >= 0) stack.push_back(ch1[n]);      // left subtree first (popped first)
+                if (ch0[n] >= 0) stack.push_back(ch0[n]);
+            }
+        }
         std::vector<uint32_t> order(E);
-        for (size_t e = 0; e < E; ++e) order[e] = (uint32_t)e;
+        for (size_t e2 = 0; e2 < E; ++e2) order[e2] = (uint32_t)e2;
         std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b2) {
-            return t[a] != t[b2] ? t[a] < t[b2] : f[a] < f[b2];
+            return t[a] != t[b2] ? t[a] < t[b2] : rank[f[a]] < rank[f[b2]];
         });
         h_efrom.resize(E); h_eto.resize(E); h_etv.resize(E);
-        for (size_t e = 0; e < E; ++e) { h_efrom[e] = f[order[e]]; h_eto[e] = t[order[e]]; h_etv[e] = v[order[e]]; }
+        for (size_t e2 = 0; e2 < E; ++e2) { h_efrom[e2] = f[order[e2]]; h_eto[e2] = t[order[e2]]; h_etv[e2] = v[order[e2]]; }
     } else {
         h_efrom.clear(); h_eto.clear(); h_etv.clear();
     }

@@ -35,6 +35,23 @@ def run_orc(case, K, algo=orc.ALGO_BATCHED_KD):
     return o, rc
 
 
+def kd_preorder_rank(xy):
+    """pre-order position of every node in the reference's kd-tree (oracle kdtree.c, pinned by nearest_neighbor.rs KATs)"""
+    import ctypes as C
+    lib = orc.lib()
+    xy = np.ascontiguousarray(xy, dtype=np.float64)
+    kd = lib.orc_kd_new(xy[0], 0)
+    for j in range(1, len(xy)):
+        lib.orc_kd_add(kd, xy[j], j)
+    out = np.zeros(len(xy), dtype=np.uint64)
+    n = lib.orc_kd_radius(kd, xy[0], 1e300, out, len(out))
+    lib.orc_kd_free(kd)
+    assert n == len(xy)
+    rank = np.zeros(len(xy), dtype=np.int64)
+    rank[out.astype(np.int64)] = np.arange(len(xy))
+    return rank
+
+
 def assert_same(e, o, pto=False):
     assert e.num_iterations() == o.num_iterations()
     assert e.num_nodes() == o.num_nodes()
@@ -52,7 +69,9 @@ def assert_same(e, o, pto=False):
         assert np.array_equal(e.node_validity(), o.node_validity())
         fe, te, ve = e.edges()
         fo, to, vo = o.edges()
-        order = np.lexsort((fo, to))
+        # adjacency order (pto.rs:103-114): new nodes ascending, neighbours of one node in kd pre-order
+        rank = kd_preorder_rank(o.tree()[0])
+        order = np.lexsort((rank[fo], to))
         assert np.array_equal(fe, fo[order]) and np.array_equal(te, to[order]) and np.array_equal(ve, vo[order])
         assert e.is_final_set_complete() == o.is_final_set_complete()
 
@@ -103,6 +122,16 @@ def test_pto_matches_oracle(eng_mod, case, K):
     o, rco = run_orc(case, K)
     assert rce == rco
     assert_same(e, o, pto=True)
+
+
+def test_pto_k1_edge_order_is_the_reference_loop(eng_mod):
+    """K = 1 against the literal loop: the edges come back in exactly the order the reference adds them."""
+    case = PTO_SMALL[0]
+    e, _ = run_gpu(eng_mod, case, 1)
+    o, _ = run_orc(case, 1, algo=orc.ALGO_SEQ)
+    fe, te, ve = e.edges()
+    fo, to, vo = o.edges()
+    assert np.array_equal(fe, fo) and np.array_equal(te, to) and np.array_equal(ve, vo)
 
 
 def test_pto_k1_is_the_reference_loop(eng_mod):
