@@ -241,6 +241,23 @@ def test_dense_cluster_and_exact_duplicates(eng_mod):
         assert e.num_nodes() > 3000
 
 
+@pytest.mark.parametrize("K", [7, 100, 333])
+def test_odd_batch_sizes_and_early_termination(eng_mod, K):
+    """batch_K that is no multiple of the wave size, n_iter_min below one batch, and a loop condition (rrt.rs:109,
+    pto.rs:67) that ends the growth between n_iter_min and n_iter_max: the steps beyond n_iter_min are launched one by
+    one with the condition re-evaluated in between, as ref_batched does."""
+    c = cases.cfg2(50)
+    c.update(n_iter_min=50, n_iter_max=30000)
+    e, _ = run_gpu(eng_mod, c, K)
+    o, _ = run_orc(c, K)
+    assert_same(e, o)
+    assert e.num_iterations() < 30000, "the case is meant to stop on the goal, not on the budget"
+    p = cases.cfg3(40, 9000)
+    e, _ = run_gpu(eng_mod, p, K)
+    o, _ = run_orc(p, K)
+    assert_same(e, o, pto=True)
+
+
 def test_max_batch_and_ragged_tail(eng_mod):
     """batch_K = 4096 (the kd claim kernel's capacity per launch) with an iteration count that is no multiple of it."""
     case = cases.cfg2(4096 * 3 + 17)
