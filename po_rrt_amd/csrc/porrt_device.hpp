@@ -526,16 +526,16 @@ __device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double 
     const uint32_t w = uni((uint32_t)(cx1 - cx0 + 1)), nreg = w * uni((uint32_t)(cy1 - cy0 + 1));
     if (nreg * 16u > N) {
         auto gx = as_global(rc.nx), gy = as_global(rc.ny);
-        for (uint32_t j0 = 0; j0 < N; j0 += 256u) {
-            double x[4], y[4];
+        for (uint32_t j0 = 0; j0 < N; j0 += 128u) {
+            double x[2], y[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2; ++u) {
                 const uint32_t j = j0 + 64u * u + lane;
                 x[u] = gx[j < N ? j : 0u];
                 y[u] = gy[j < N ? j : 0u];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 2; ++u)
                 if (j0 + 64u * u < N) visit(x[u], y[u], (int)(j0 + 64u * u + lane), j0 + 64u * u + lane < N);
         }
         return;
@@ -560,17 +560,17 @@ __device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double 
         }
         cmax = uni(cmax); npg = uni(npg);
         if (cmax <= kPage && cmax < npg) {                   // sparse: own region, slots s .. s+3
-            for (uint32_t s0 = 0; s0 < cmax; s0 += 4) {
-                dbl2 v[4];
-                int id[4];
+            for (uint32_t s0 = 0; s0 < cmax; s0 += 2) {
+                dbl2 v[2];
+                int id[2];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 2; ++u) {
                     const uint32_t sl = s0 + u < cnt ? s0 + u : 0u;
                     v[u] = gxy[(size_t)reg * kPage + sl];
                     id[u] = gid[(size_t)reg * kPage + sl];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 2; ++u)
                     if (s0 + u < cmax) visit(v[u].x, v[u].y, id[u], s0 + u < cnt);
             }
             continue;
@@ -581,9 +581,9 @@ __device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double 
             if (!m) break;
             if (j && cnt > j * kPage) page = gdir[(size_t)reg * rc.rg_maxp + j];
             while (m) {
-                uint32_t pg[4], pc[4];
+                uint32_t pg[2], pc[2];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 2; ++u) {
                     pg[u] = 0; pc[u] = 0;
                     if (m) {
                         const uint32_t l = (uint32_t)__builtin_ctzll(m);
@@ -593,16 +593,16 @@ __device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double 
                         pc[u] = c < kPage ? c : kPage;
                     }
                 }
-                dbl2 v[4];
-                int id[4];
+                dbl2 v[2];
+                int id[2];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {                 // only the filled slots are fetched
+                for (int u = 0; u < 2; ++u) {                 // only the filled slots are fetched
                     const bool ld = lane < pc[u];
                     v[u] = ld ? gxy[(size_t)pg[u] * kPage + lane] : dbl2{0.0, 0.0};
                     id[u] = ld ? gid[(size_t)pg[u] * kPage + lane] : -1;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 2; ++u)
                     if (pc[u]) visit(v[u].x, v[u].y, id[u], lane < pc[u]);
             }
         }
