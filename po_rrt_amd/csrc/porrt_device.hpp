@@ -286,9 +286,13 @@ __device__ int traversed_class(const RunConst &rc, const Grid &grid, double ax, 
     const int ddx = ex - sx, ddy = ey - sy;
     int e = ddy - ddx;
     int worst = CLS_FREE;
+    // oct_from(o, x, y) is linear in (x, y): pi = fa x + fb y, pj = fc x + fd y (the same eight cases, as coefficients)
+    const int fa = (o == 0 || o == 7) ? 1 : ((o == 3 || o == 4) ? -1 : 0);
+    const int fb = (o == 1 || o == 6) ? 1 : ((o == 2 || o == 5) ? -1 : 0);
+    const int fc = (o == 1 || o == 2) ? 1 : ((o == 5 || o == 6) ? -1 : 0);
+    const int fd = (o == 0 || o == 3) ? 1 : ((o == 4 || o == 7) ? -1 : 0);
     for (int x = sx, y = sy; x <= ex; ++x) {
-        int pi, pj;
-        oct_from(o, x, y, pi, pj);
+        const int pi = fa * x + fb * y, pj = fc * x + fd * y;
         int c = grid.at((uint32_t)pi, (uint32_t)pj);
         if (rc.domain == 0) {
             if (c == CLS_HIGH0) return CLS_HIGH;       // lowest_pixel == 0: early return
