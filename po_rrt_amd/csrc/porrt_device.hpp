@@ -127,7 +127,7 @@ struct RunConst {
     KdRec *kd_rec;              // packed {x, y, child[2]}: one load per level of a descent
     KdBox *kd_box;              // the cell a node was inserted into: a point's root path passes the node iff it lies inside
     KdBox *loc_box;             // per new node of the step: cell of the empty slot k_kd_locate stopped at
-    uint32_t loc_stride;        // loc_* are double-buffered by group parity
+    uint32_t loc_stride;        // loc_* hold two groups (slot lpar of the kd kernels; one side stream uses slot 0 only)
     KdMove *kd_losers;          // nodes that lost the bid for their slot ([kClaimMax])
     // deferred equal-cost parents (see connect_rrt_sample / k_tie_fix)
     int *pend_new, *pend_pool;
@@ -1286,14 +1286,11 @@ __device__ __forceinline__ void kd_descend(const RunConst &rc, uint32_t Nsnap, d
     }
 }
 
-// `bsnap`: the descent sees the tree as it stood at the start of step bsnap <= b (nodes below n_at[bsnap], G as
-// recorded in g_snap[bsnap]); newer nodes are treated as absent and k_kd_claim's rounds finish the descent through
-// them.  That lets this kernel run beside the previous step's k_kd_claim.
 // One launch serves the new nodes of `nsteps` consecutive steps starting at step b0 (the structure is built beside the
 // steps and may lag them, so several steps' nodes are inserted together): wave -> (step, sample).
-// The descent sees the tree as far as k_kd_claim has published it when the wave starts (cnt->kd_snap: nodes below
-// n_at[kd_snap], G as recorded in g_snap[kd_snap]); newer nodes are treated as absent and the claim rounds finish the
-// descent through them.  So this kernel depends on nothing but the steps' k_near and overlaps earlier groups' claims.
+// The descent sees the tree as far as k_kd_claim has published it when the kernel starts (cnt->kd_snap: nodes below
+// n_at[kd_snap], G as recorded in g_snap[kd_snap]); newer nodes are treated as absent and k_kd_link / k_kd_claim
+// finish the descent through them (with one side stream the published state is always the whole tree before the group).
 // LPN = lanes per node: 64 (one wave per node: shortest latency, used when a launch has few nodes) or 1 (one thread
 // per node, the non-duplicate levels of G staged in LDS: 64x fewer waves, used when many contexts are grown together
 // and the GPU is short of wave slots, not of time).
@@ -1395,7 +1392,7 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
         }
     }
     if (lane == 0) {
-        const uint32_t lo = lpar * rc.loc_stride + t;       // two groups may be in flight
+        const uint32_t lo = lpar * rc.loc_stride + t;
         rc.loc_cur[lo] = cur;
         rc.loc_dcur[lo] = dcur;
         rc.loc_gex[lo] = gex;
