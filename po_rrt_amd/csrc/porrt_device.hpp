@@ -556,14 +556,16 @@ __device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double 
             reg = (y0 + ry) * kRG + x0 + (r - ry * w);
             cnt = reg == skip_region ? 0u : gcnt[reg];          // a region the caller has already been through
         }
-        uint32_t cmax = cnt, npg = (cnt + kPage - 1) / kPage;
-        for (int off = 32; off > 0; off >>= 1) {
-            const uint32_t o = __shfl_xor(cmax, off);
-            cmax = o > cmax ? o : cmax;
-            npg += __shfl_xor(npg, off);
-        }
-        cmax = uni(cmax); npg = uni(npg);
-        if (cmax <= kPage && cmax < npg) {                   // sparse: own region, slots s .. s+3
+        // sparse (lane <-> region, slot by slot) pays when every region of the group holds fewer nodes than the group has
+        // non-empty regions: then `max count` rounds of loads beat `regions` page loads.  Decided with ballots alone.
+        const uint32_t npg = (uint32_t)__popcll(__ballot(cnt > 0u));        // pages if no region needs a second one
+        if (__ballot(cnt >= npg || cnt > kPage) == 0ull && npg > 1u) {
+            uint32_t cmax = cnt;
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t o = __shfl_xor(cmax, off);
+                cmax = o > cmax ? o : cmax;
+            }
+            cmax = uni(cmax);
             for (uint32_t s0 = 0; s0 < cmax; s0 += 2) {
                 dbl2 v[2];
                 int id[2];
@@ -657,11 +659,18 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
             if (D < bestD || (D == bestD && id < best)) { bestD = D; best = id; bestx = x; besty = y; thr = d2 * (1.0 + 1e-15); }
         };
         auto wave_best = [&]() {
+            double rd = bestD;
+            int ri = best;
             for (int off = 32; off > 0; off >>= 1) {
-                const double od = __shfl_xor(bestD, off), ot = __shfl_xor(thr, off), ox = __shfl_xor(bestx, off), oy = __shfl_xor(besty, off);
-                const int oi = __shfl_xor(best, off);
-                if (od < bestD || (od == bestD && oi < best)) { bestD = od; best = oi; thr = ot; bestx = ox; besty = oy; }
+                const double od = __shfl_xor(rd, off);
+                const int oi = __shfl_xor(ri, off);
+                if (od < rd || (od == rd && oi < ri)) { rd = od; ri = oi; }
             }
+            // the lane that holds the winner hands over the rest (its threshold and the node's coordinates)
+            const unsigned long long own = __ballot(best == ri && bestD == rd);
+            const int src = own ? (int)__builtin_ctzll(own) : 0;
+            thr = __shfl(thr, src); bestx = __shfl(bestx, src); besty = __shfl(besty, src);
+            bestD = rd; best = ri;
         };
         // The sample's own region first: the nearest node is almost always there, and its distance is the bound for
         // the disc the remaining regions are taken from.  Only when the region holds nothing usable does the bound
