@@ -176,6 +176,8 @@ struct RunConst {
 template <class T>
 __device__ __forceinline__ GPTR(T) as_global(T *p) { return (GPTR(T))(uintptr_t)p; }
 template <class T>
+__device__ __forceinline__ GPTR(const T) as_global(const T *p) { return (GPTR(const T))(uintptr_t)p; }
+template <class T>
 __device__ __forceinline__ T g_atomic_add(GPTR(T) p, T v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T>
 __device__ __forceinline__ T g_atomic_or(GPTR(T) p, T v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -187,7 +189,7 @@ __device__ __forceinline__ T g_atomic_min(GPTR(T) p, T v) { return __hip_atomic_
 // neighbour list of sample k in step b (parity buffers)
 __device__ __forceinline__ size_t cand_off(const RunConst &rc, uint32_t b, uint32_t k) { return ((size_t)(b & 1u) * rc.cand_K + k) * rc.cand_cap; }
 __device__ __forceinline__ uint32_t cand_count(const RunConst &rc, uint32_t b, uint32_t k) {
-    const uint32_t c = rc.cand_cnt[(b & 1u) * rc.cand_K + k];
+    const uint32_t c = as_global(rc.cand_cnt)[(b & 1u) * rc.cand_K + k];
     return c < rc.cand_cap ? c : rc.cand_cap;
 }
 __device__ __forceinline__ unsigned long long f64_bits(double d) { return (unsigned long long)__double_as_longlong(d); }
@@ -316,7 +318,7 @@ __device__ __forceinline__ int state_class(const RunConst &rc, double x, double 
     uint32_t i, j;
     to_pixel(rc, x, y, i, j);
     if (i >= rc.H || j >= rc.W) { *err |= ERR_RASTER; return CLS_HIGH; }
-    int c = rc.cls[i * rc.W + j];
+    int c = as_global(rc.cls)[i * rc.W + j];
     if (c == CLS_BAD) { *err |= ERR_RASTER; return CLS_HIGH; }
     return c == CLS_HIGH0 ? CLS_HIGH : c;
 }
@@ -464,13 +466,13 @@ __device__ __forceinline__ double nn_bound_wave(const RunConst &rc, uint32_t N, 
         int r = -1;
         if (lane < 9u) {
             const int x = cx + (int)(lane % 3u) - 1, y = cy + (int)(lane / 3u) - 1;
-            if (x >= 0 && y >= 0 && x < G && y < G) r = rc.rep[rep_off(l) + y * G + x];
+            if (x >= 0 && y >= 0 && x < G && y < G) r = as_global(rc.rep)[rep_off(l) + y * G + x];
         }
         double d2 = INF;
         if (r >= 0 && (uint32_t)r < N) {
             bool pass = true;
-            if (PTO) pass = (rc.reachA[r] >> world) & 1ull;
-            if (pass) d2 = dist2(rc.nx[r], rc.ny[r], qx, qy);
+            if (PTO) pass = (as_global(rc.reachA)[r] >> world) & 1ull;
+            if (pass) d2 = dist2(as_global(rc.nx)[r], as_global(rc.ny)[r], qx, qy);
         }
         for (int off = 8; off > 0; off >>= 1) {           // lanes 0..15 hold everything
             const double o = __shfl_xor(d2, off);
@@ -634,10 +636,10 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
     }
     const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (k >= nb) return;
-    const uint32_t N = uni(rc.n_at[b]);
-    const double sqx = rc.sx[i0 + k], sqy = rc.sy[i0 + k];
+    const uint32_t N = uni(as_global(rc.n_at)[b]);
+    const double sqx = as_global(rc.sx)[i0 + k], sqy = as_global(rc.sy)[i0 + k];
     uint32_t world = 0;
-    if (PTO) world = rc.sworld[i0 + k];
+    if (PTO) world = as_global(rc.sworld)[i0 + k];
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
     double bestD = INF, bestx = 0.0, besty = 0.0;
     int best = 0x7FFFFFFF;
@@ -707,13 +709,13 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
         if (err) valid = false;
     }
     if (lane == 0) {
-        rc.q_x[k] = tx;
-        rc.q_y[k] = ty;
+        as_global(rc.q_x)[k] = tx;
+        as_global(rc.q_y)[k] = ty;
         // copy for the kd insertion, which runs beside the following steps (one slice per step)
         const size_t o2 = (size_t)b * rc.part_stride + k;
-        rc.kq_x[o2] = tx; rc.kq_y[o2] = ty; rc.kq_vid[o2] = valid ? vid : -1;
-        rc.q_nn[k] = nn;
-        rc.q_vid[k] = valid ? vid : -1;
+        as_global(rc.kq_x)[o2] = tx; as_global(rc.kq_y)[o2] = ty; as_global(rc.kq_vid)[o2] = valid ? vid : -1;
+        as_global(rc.q_nn)[k] = nn;
+        as_global(rc.q_vid)[k] = valid ? vid : -1;
         if (valid) atomicOr(&rc.valid_mask[(size_t)b * vwords + (k >> 6)], 1ull << (k & 63u));
         if (err) atomicOr(&rc.cnt->err, err);
     }
@@ -739,7 +741,7 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
         }
         tot += (uint32_t)__popcll(hm);
     });
-    if (lane == 0) rc.cand_cnt[(b & 1u) * rc.cand_K + k] = tot;
+    if (lane == 0) as_global(rc.cand_cnt)[(b & 1u) * rc.cand_K + k] = tot;
     if (over) atomicOr(&rc.cnt->err, (uint32_t)ERR_CAND_OVERFLOW);
 }
 
@@ -798,7 +800,7 @@ __device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, u
 // ------------------------------------------------------------------ connect
 __device__ __forceinline__ uint32_t rank_before(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k) {
     uint32_t r = 0;
-    const unsigned long long *vm = rc.valid_mask + (size_t)b * vwords;
+    auto vm = as_global(rc.valid_mask) + (size_t)b * vwords;
     for (uint32_t w = 0; w < (k >> 6); ++w) r += __popcll(vm[w]);
     r += __popcll(vm[k >> 6] & ((1ull << (k & 63u)) - 1ull));
     return r;
@@ -817,7 +819,7 @@ __device__ __forceinline__ TileGrid load_tile(const RunConst &rc, uint8_t *tile,
         const uint32_t ri = t / g.TW, rj = t - ri * g.TW;
         const int i = g.oi + (int)ri, j = g.oj + (int)rj;
         uint8_t c = CLS_BAD;
-        if (i >= 0 && j >= 0 && (uint32_t)i < rc.H && (uint32_t)j < rc.W) c = rc.cls[(uint32_t)i * rc.W + (uint32_t)j];
+        if (i >= 0 && j >= 0 && (uint32_t)i < rc.H && (uint32_t)j < rc.W) c = as_global(rc.cls)[(uint32_t)i * rc.W + (uint32_t)j];
         tile[t] = c;
     }
     return g;
@@ -967,9 +969,9 @@ template <int W, class Grid>
 __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const Grid &grid, uint32_t b, uint32_t vwords, uint32_t k,
                                    uint32_t cnt, uint32_t &err) {
     const uint32_t tl = tm.wave * 64u + tm.lane, TS = W * 64u;
-    const uint32_t N = rc.n_at[b];
+    const uint32_t N = as_global(rc.n_at)[b];
     const uint32_t id = N + rank_before(rc, b, vwords, k);
-    const double px = rc.q_x[k], py = rc.q_y[k];
+    const double px = as_global(rc.q_x)[k], py = as_global(rc.q_y)[k];
     // SquareGoal test (common.rs:336-345), lane g <-> goal g: the loads go out now, the answer is needed at the end
     double goal_d = __longlong_as_double(0x7FF0000000000000ll);
     unsigned long long goal_m = 0;
@@ -1184,7 +1186,7 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunCon
     if (blockIdx.x == gridDim.x - 1) { insert_step_pages(rc, b, nb, vwords); return; }    // the extra block
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t k = blockIdx.x * kConnectWaves + wv;
-    const bool active = k < nb && rc.q_vid[k < nb ? k : 0] >= 0;
+    const bool active = k < nb && as_global(rc.q_vid)[k < nb ? k : 0] >= 0;
     const uint32_t cnt = active ? cand_count(rc, b, k) : 0u;
     const bool heavy = active && cnt > kHeavyCand;
     if (lane == 0) s_heavy[wv] = heavy ? cnt : 0u;
@@ -1194,7 +1196,7 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunCon
     if (active && !heavy) {
         TileGrid grid;
         if (LDSGRID) {
-            grid = load_tile(rc, lds_tiles + wv * tile_bytes, rc.q_x[k], rc.q_y[k], lane, 64u);
+            grid = load_tile(rc, lds_tiles + wv * tile_bytes, as_global(rc.q_x)[k], as_global(rc.q_y)[k], lane, 64u);
             __builtin_amdgcn_wave_barrier();
         } else {
             grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0;
@@ -1223,17 +1225,18 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunCon
 // RRT*: rewire phase 2 for sample k of step b (one wave).  A pair wins iff its candidate equals the accumulated
 // minimum; among equal candidates the lowest new id wins (sequential order of the reference, strict `<`, rrt.rs:157).
 __device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k, uint32_t lane) {
-    if (!((rc.valid_mask[(size_t)b * vwords + (k >> 6)] >> (k & 63u)) & 1ull)) return;
-    const uint32_t N = rc.n_at[b];
+    if (!((as_global(rc.valid_mask)[(size_t)b * vwords + (k >> 6)] >> (k & 63u)) & 1ull)) return;
+    const uint32_t N = as_global(rc.n_at)[b];
     const int id = (int)(N + rank_before(rc, b, vwords, k));
     const uint32_t cnt = cand_count(rc, b, k);
-    const int *cid = rc.cand_id + cand_off(rc, b, k);
-    const double *cval = rc.cand_val + (size_t)k * rc.cand_cap;
+    auto cid = as_global(rc.cand_id) + cand_off(rc, b, k);
+    auto cval = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
+    auto gdB = as_global(rc.distB);
     for (uint32_t a = lane; a < cnt; a += 64) {
         const double via = cval[a];
         if (!(via >= 0.0)) continue;
         const int j = cid[a];
-        if (f64_bits(via) != f64_bits(rc.distB[j])) continue;
+        if (f64_bits(via) != f64_bits(gdB[j])) continue;
         int old = rc.parent[j];
         while (old < (int)N || id < old) {      // parents from before this step are always < N
             const int seen = atomicCAS(&rc.parent[j], old, id);
