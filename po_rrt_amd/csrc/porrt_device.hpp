@@ -1271,6 +1271,12 @@ __global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__
 enum : uint32_t { LOC_SIDE = 1u, LOC_ONPATH = 2u };
 constexpr int kHG = 128;             // hint grid squares per axis
 
+__device__ __forceinline__ KdBox load_box(const KdBox *p, size_t i) {
+    auto g = as_global(p);
+    KdBox b;
+    b.lox = g[i].lox; b.hix = g[i].hix; b.loy = g[i].loy; b.hiy = g[i].hiy;
+    return b;
+}
 __device__ __forceinline__ bool box_holds(const KdBox &bx, double x, double y) {
     return bx.lox <= x && x < bx.hix && bx.loy <= y && y < bx.hiy;
 }
@@ -1317,23 +1323,23 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
     const uint32_t b = b0 + (active ? st : 0u);
     // The new nodes are the valid samples (positions known since k_near), id = n_at[b] + rank in their step.
     const size_t o2 = (size_t)b * rc.part_stride + (active ? k : 0u);
-    if (active && rc.kq_vid[o2] < 0) active = false;
+    if (active && as_global(rc.kq_vid)[o2] < 0) active = false;
     const uint32_t bsnap = __hip_atomic_load(&rc.cnt->kd_snap, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t glen0 = rc.g_snap[4 * bsnap + 0], n_nd = rc.g_snap[4 * bsnap + 1];
+    const uint32_t glen0 = as_global(rc.g_snap)[4 * bsnap + 0], n_nd = as_global(rc.g_snap)[4 * bsnap + 1];
     constexpr uint32_t kNdLds = 1024;
     __shared__ double s_ndx[LPN == 1 ? kNdLds : 1], s_ndy[LPN == 1 ? kNdLds : 1];
     __shared__ uint32_t s_ndi[LPN == 1 ? kNdLds : 1];
     if (LPN == 1) {
         for (uint32_t t2 = threadIdx.x; t2 < n_nd && t2 < kNdLds; t2 += 256u) {
-            s_ndi[t2] = rc.g_nd[t2]; s_ndx[t2] = rc.g_nd_x[t2]; s_ndy[t2] = rc.g_nd_y[t2];
+            s_ndi[t2] = as_global(rc.g_nd)[t2]; s_ndx[t2] = as_global(rc.g_nd_x)[t2]; s_ndy[t2] = as_global(rc.g_nd_y)[t2];
         }
         __syncthreads();
     }
     if (!active) return;
-    const uint32_t Nsnap = rc.n_at[bsnap], N = rc.n_at[b0];
-    const uint32_t t = rc.n_at[b] - N + rank_before(rc, b, vwords, k);
+    const uint32_t Nsnap = as_global(rc.n_at)[bsnap], N = as_global(rc.n_at)[b0];
+    const uint32_t t = as_global(rc.n_at)[b] - N + rank_before(rc, b, vwords, k);
     const double px = rc.gp_x, py = rc.gp_y;
-    const double vx = rc.kq_x[o2], vy = rc.kq_y[o2];
+    const double vx = as_global(rc.kq_x)[o2], vy = as_global(rc.kq_y)[o2];
     if (lane == 0) {   // the node's kd record exists from here on (k_kd_link only links it)
         KdRec rec;
         rec.x = vx; rec.y = vy; rec.child[0] = kEmpty; rec.child[1] = kEmpty;
@@ -1347,20 +1353,20 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
         const unsigned long long hv = __hip_atomic_load(&rc.kd_hint[hy * kHG + hx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bu = (int)(uint32_t)hv;
         while ((uint32_t)bu >= Nsnap) bu = __hip_atomic_load(&rc.kd_up[bu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // newer than the snapshot
-        bd = (int)rc.kd_depth[bu];
-        if (!box_holds(rc.kd_box[bu], vx, vy)) bu = -1;     // cannot happen (see k_kd_hint); the long way is always right
+        bd = (int)as_global(rc.kd_depth)[bu];
+        if (!box_holds(load_box(rc.kd_box, (size_t)bu), vx, vy)) bu = -1;     // cannot happen (see k_kd_hint); the long way is always right
     }
     int cur;
     uint32_t dcur, side, gex = 0, flags = 0;
     KdBox bx;
     bool long_way = bu < 0;
     if (!long_way) {
-        const uint32_t ge = rc.kd_gexit[bu];
+        const uint32_t ge = as_global(rc.kd_gexit)[bu];
         if (ge & kOnG) long_way = true;
         else {
             cur = bu; dcur = (uint32_t)bd; gex = ge;
-            bx = rc.kd_box[bu];
-            side = kd_left(vx, vy, rc.kd_rec[bu].x, rc.kd_rec[bu].y, dcur) ? 0u : 1u;
+            bx = load_box(rc.kd_box, (size_t)bu);
+            side = kd_left(vx, vy, as_global(rc.kd_rec)[bu].x, as_global(rc.kd_rec)[bu].y, dcur) ? 0u : 1u;
             kd_descend(rc, Nsnap, vx, vy, cur, dcur, side, bx);
         }
     }
@@ -1374,7 +1380,7 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
             uint32_t ii;
             double wx, wy;
             if (LPN == 1 && s0 < kNdLds) { ii = s_ndi[s0]; wx = s_ndx[s0]; wy = s_ndy[s0]; }
-            else { ii = rc.g_nd[s0]; wx = rc.g_nd_x[s0]; wy = rc.g_nd_y[s0]; }
+            else { ii = as_global(rc.g_nd)[s0]; wx = as_global(rc.g_nd_x)[s0]; wy = as_global(rc.g_nd_y)[s0]; }
             const bool gl = kd_left(px, py, wx, wy, ii), vl = kd_left(vx, vy, wx, wy, ii);
             if (vl != gl && ii < E) { E = ii; leftE = vl ? 1u : 0u; }
         }
@@ -1384,22 +1390,23 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
                 if (oe < E) { E = oe; leftE = ol; }
             }
         }
-        const uint32_t d0 = rc.g_snap[4 * bsnap + 2], d1 = rc.g_snap[4 * bsnap + 3];
+        const uint32_t d0 = as_global(rc.g_snap)[4 * bsnap + 2], d1 = as_global(rc.g_snap)[4 * bsnap + 3];
         if (vx < px && d0 < E) { E = d0; leftE = 1u; }
         if (vy < py && d1 < E) { E = d1; leftE = 1u; }
         if (E == 0xFFFFFFFFu) {             // on G to its end: below the last node, on the goal point's side
             dcur = glen0 - 1;
-            cur = rc.g_id[dcur];
-            side = kd_left(px, py, rc.g_x[dcur], rc.g_y[dcur], dcur) ? 0u : 1u;
+            cur = as_global(rc.g_id)[dcur];
+            const double gxx = as_global(rc.g_x)[dcur], gyy = as_global(rc.g_y)[dcur];
+            side = kd_left(px, py, gxx, gyy, dcur) ? 0u : 1u;
             flags = LOC_ONPATH;
-            bx = rc.kd_box[cur];
-            box_cut(bx, rc.g_x[dcur], rc.g_y[dcur], dcur, side);
+            bx = load_box(rc.kd_box, (size_t)cur);
+            box_cut(bx, gxx, gyy, dcur, side);
         } else {
             dcur = E;
             gex = E;
-            cur = rc.g_id[E];
+            cur = as_global(rc.g_id)[E];
             side = leftE ? 0u : 1u;
-            bx = rc.kd_box[cur];
+            bx = load_box(rc.kd_box, (size_t)cur);
             kd_descend(rc, Nsnap, vx, vy, cur, dcur, side, bx);
         }
     }
