@@ -248,7 +248,7 @@ __device__ __forceinline__ void oct_from(int o, int x, int y, int &ox, int &oy) 
 struct GlobalGrid {
     const uint8_t *p;
     uint32_t W;
-    __device__ __forceinline__ int at(uint32_t i, uint32_t j) const { return p[i * W + j]; }
+    __device__ __forceinline__ int at(uint32_t i, uint32_t j) const { return as_global(p)[i * W + j]; }
 };
 struct TileGrid {
     const uint8_t *lds;     // TW x TW bytes
@@ -259,7 +259,7 @@ struct TileGrid {
     __device__ __forceinline__ int at(uint32_t i, uint32_t j) const {
         const uint32_t ri = (uint32_t)((int)i - oi), rj = (uint32_t)((int)j - oj);
         if (ri < TW && rj < TW) return lds[ri * TW + rj];
-        return glob[i * W + j];
+        return as_global(glob)[i * W + j];
     }
 };
 
