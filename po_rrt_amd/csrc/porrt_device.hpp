@@ -852,34 +852,34 @@ __device__ __forceinline__ bool kd_left(double x, double y, double wx, double wy
 // starts along the goal path G and leaves it at depth kd_gexit (or stays on it), which settles most pairs
 // in O(1); two nodes that leave G at the same node are compared by walking up to their common ancestor.
 __device__ bool kd_preorder_less(const RunConst &rc, int u, int v) {
-    const uint32_t gu = rc.kd_gexit[u], gv = rc.kd_gexit[v];
+    const uint32_t gu = as_global(rc.kd_gexit)[u], gv = as_global(rc.kd_gexit)[v];
     const bool ou = gu & kOnG, ov = gv & kOnG;
     const uint32_t iu = gu & ~kOnG, iv = gv & ~kOnG;
     if (ou && ov) return iu < iv;                       // both on G: the ancestor comes first
     if (ou) {                                           // u = G[iu]; v leaves G after G[iv]
         if (iu <= iv) return true;                      // u is an ancestor of v
         // u lies below G[iv] on the goal side, v on the other side
-        return !kd_left(rc.nx[v], rc.ny[v], rc.g_x[iv], rc.g_y[iv], iv);
+        return !kd_left(as_global(rc.nx)[v], as_global(rc.ny)[v], as_global(rc.g_x)[iv], as_global(rc.g_y)[iv], iv);
     }
     if (ov) {
         if (iv <= iu) return false;                     // v is an ancestor of u
-        return kd_left(rc.nx[u], rc.ny[u], rc.g_x[iu], rc.g_y[iu], iu);
+        return kd_left(as_global(rc.nx)[u], as_global(rc.ny)[u], as_global(rc.g_x)[iu], as_global(rc.g_y)[iu], iu);
     }
     if (iu != iv) {                                     // both off G: the one leaving first splits them
-        if (iu < iv) return kd_left(rc.nx[u], rc.ny[u], rc.g_x[iu], rc.g_y[iu], iu);
-        return !kd_left(rc.nx[v], rc.ny[v], rc.g_x[iv], rc.g_y[iv], iv);
+        if (iu < iv) return kd_left(as_global(rc.nx)[u], as_global(rc.ny)[u], as_global(rc.g_x)[iu], as_global(rc.g_y)[iu], iu);
+        return !kd_left(as_global(rc.nx)[v], as_global(rc.ny)[v], as_global(rc.g_x)[iv], as_global(rc.g_y)[iv], iv);
     }
     // same exit node, same (non-goal) side: plain LCA walk, bounded by the depth below the exit node
     int a = u, b = v;
-    uint32_t da = rc.kd_depth[a], db = rc.kd_depth[b];
+    uint32_t da = as_global(rc.kd_depth)[a], db = as_global(rc.kd_depth)[b];
     int a_from = -1, b_from = -1;       // 0 = came up from a left child, 1 = right
-    while (da > db) { const int p = rc.kd_up[a]; a_from = rc.kd_rec[p].child[1] == a; a = p; --da; }
-    while (db > da) { const int p = rc.kd_up[b]; b_from = rc.kd_rec[p].child[1] == b; b = p; --db; }
+    while (da > db) { const int p = as_global(rc.kd_up)[a]; a_from = as_global(rc.kd_rec)[p].child[1] == a; a = p; --da; }
+    while (db > da) { const int p = as_global(rc.kd_up)[b]; b_from = as_global(rc.kd_rec)[p].child[1] == b; b = p; --db; }
     if (a == b) return a_from >= 0 ? false : true;                 // the one that did not move is the ancestor
     while (a != b) {
-        const int pa = rc.kd_up[a], pb = rc.kd_up[b];
-        a_from = rc.kd_rec[pa].child[1] == a;
-        b_from = rc.kd_rec[pb].child[1] == b;
+        const int pa = as_global(rc.kd_up)[a], pb = as_global(rc.kd_up)[b];
+        a_from = as_global(rc.kd_rec)[pa].child[1] == a;
+        b_from = as_global(rc.kd_rec)[pb].child[1] == b;
         a = pa; b = pb;
     }
     return a_from < b_from;
@@ -1051,7 +1051,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
             uint32_t n_fresh = 0;
             each_tie([&](int j) {
                 if ((uint32_t)j >= kd_done) { ++n_fresh; return; }
-                if (rc.kd_gexit[j] & kOnG) on_min = j < on_min ? j : on_min;
+                if (as_global(rc.kd_gexit)[j] & kOnG) on_min = j < on_min ? j : on_min;
                 else if (off_best == kEmpty || kd_preorder_less(rc, j, off_best)) off_best = j;
             });
             on_min = tm.min_i(on_min);
