@@ -758,42 +758,42 @@ __device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, u
         s_np = 0; s_base = kRegions + rc.cnt->n_pages;
         uint32_t add = 0;
         for (uint32_t w = 0; w < vwords; ++w) add += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
-        rc.n_at[b + 1] = rc.n_at[b] + add;        // tree size at the start of the next step
+        as_global(rc.n_at)[b + 1] = as_global(rc.n_at)[b] + add;        // tree size at the start of the next step
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < nb; k += T)
-        if (rc.q_vid[k] >= 0) s_off[k] = (uint16_t)atomicAdd(&s_add[region_of(rc, rc.q_x[k], rc.q_y[k])], 1u);
+        if (rc.q_vid[k] >= 0) s_off[k] = (uint16_t)atomicAdd(&s_add[region_of(rc, as_global(rc.q_x)[k], as_global(rc.q_y)[k])], 1u);
     __syncthreads();
     for (uint32_t r = threadIdx.x; r < kRegions; r += T) {
         const uint32_t add = s_add[r];
         if (!add) continue;
-        const uint32_t old = rc.rg_cnt[r];
+        const uint32_t old = as_global(rc.rg_cnt)[r];
         const uint32_t p_old = old ? (old + kPage - 1) / kPage : 1u, p_new = (old + add + kPage - 1) / kPage;
         if (p_new > p_old) {
             const uint32_t need = p_new - p_old;
             const uint32_t at = s_base + atomicAdd(&s_np, need);
             if (at + need > rc.pg_cap || p_new > rc.rg_maxp) { atomicOr(&rc.cnt->err, (uint32_t)ERR_PAGE_OVERFLOW); continue; }
-            for (uint32_t i = 0; i < need; ++i) rc.rg_dir[(size_t)r * rc.rg_maxp + p_old + i] = at + i;
+            for (uint32_t i = 0; i < need; ++i) as_global(rc.rg_dir)[(size_t)r * rc.rg_maxp + p_old + i] = at + i;
         }
     }
     __syncthreads();
     if (rc.cnt->err & ERR_PAGE_OVERFLOW) return;
-    const uint32_t N = rc.n_at[b];
+    const uint32_t N = as_global(rc.n_at)[b];
     dbl2 *pxy = reinterpret_cast<dbl2 *>(rc.pg_xy);
     for (uint32_t k = threadIdx.x; k < nb; k += T) {
         if (rc.q_vid[k] < 0) continue;
-        const double x = rc.q_x[k], y = rc.q_y[k];
+        const double x = as_global(rc.q_x)[k], y = as_global(rc.q_y)[k];
         const uint32_t r = region_of(rc, x, y);
-        const uint32_t slot = rc.rg_cnt[r] + s_off[k], j = slot / kPage;
+        const uint32_t slot = as_global(rc.rg_cnt)[r] + s_off[k], j = slot / kPage;
         const uint32_t page = j ? __hip_atomic_load(&rc.rg_dir[(size_t)r * rc.rg_maxp + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : r;
         dbl2 v;
         v.x = x; v.y = y;
         pxy[(size_t)page * kPage + (slot % kPage)] = v;
-        rc.pg_id[(size_t)page * kPage + (slot % kPage)] = (int)(N + rank_before(rc, b, vwords, k));
+        as_global(rc.pg_id)[(size_t)page * kPage + (slot % kPage)] = (int)(N + rank_before(rc, b, vwords, k));
     }
     __syncthreads();
     for (uint32_t r = threadIdx.x; r < kRegions; r += T)
-        if (s_add[r]) rc.rg_cnt[r] += s_add[r];
+        if (s_add[r]) as_global(rc.rg_cnt)[r] += s_add[r];
     if (threadIdx.x == 0) rc.cnt->n_pages += s_np;
 }
 
@@ -1439,22 +1439,22 @@ constexpr uint32_t kClaimMax = 4096;
 __device__ __forceinline__ void kd_publish(const RunConst &rc, uint32_t N, const KdMove &m, int parent_id) {
     const int w = (int)(N + m.t);
     const uint32_t dw = m.dcur + 1u;
-    rc.kd_rec[parent_id].child[m.side] = w;
-    rc.kd_up[w] = parent_id;
-    rc.kd_depth[w] = dw;
+    as_global(rc.kd_rec)[parent_id].child[m.side] = w;
+    as_global(rc.kd_up)[w] = parent_id;
+    as_global(rc.kd_depth)[w] = dw;
     rc.kd_box[w] = m.box;
     if (m.onpath) {
-        if (dw + 8 < rc.g_cap) { rc.g_id[dw] = w; rc.g_x[dw] = m.vx; rc.g_y[dw] = m.vy; }
+        if (dw + 8 < rc.g_cap) { as_global(rc.g_id)[dw] = w; as_global(rc.g_x)[dw] = m.vx; as_global(rc.g_y)[dw] = m.vy; }
         else atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW);
-        rc.kd_gexit[w] = dw | kOnG;
+        as_global(rc.kd_gexit)[w] = dw | kOnG;
         atomicMax(&rc.cnt->g_len, dw + 1);
         if (m.vx == rc.gp_x && m.vy == rc.gp_y) atomicMin(&rc.cnt->g_first_dup[dw & 1u], dw);
         else {
             const uint32_t sl = atomicAdd(&rc.cnt->g_nd_len, 1u);
-            rc.g_nd[sl] = dw; rc.g_nd_x[sl] = m.vx; rc.g_nd_y[sl] = m.vy;
+            as_global(rc.g_nd)[sl] = dw; as_global(rc.g_nd_x)[sl] = m.vx; as_global(rc.g_nd_y)[sl] = m.vy;
         }
     } else {
-        rc.kd_gexit[w] = m.gex;
+        as_global(rc.kd_gexit)[w] = m.gex;
     }
 }
 
@@ -1475,26 +1475,26 @@ __device__ __forceinline__ uint32_t kd_group_size(const RunConst &rc, uint32_t b
 
 __global__ __launch_bounds__(256) void k_kd_link(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords, uint32_t lpar) {
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
-    const uint32_t N = rc.n_at[b0];
+    const uint32_t N = as_global(rc.n_at)[b0];
     const uint32_t n_new = kd_group_size(rc, b0, nsteps, vwords);
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n_new || n_new > kClaimMax) return;
     const uint32_t lo = lpar * rc.loc_stride + t;
     KdMove m;
     m.t = t;
-    const uint32_t fl = rc.loc_flags[lo];
+    const uint32_t fl = as_global(rc.loc_flags)[lo];
     m.onpath = fl & LOC_ONPATH;
     m.side = (fl & LOC_SIDE) ? 1u : 0u;
-    m.cur = rc.loc_cur[lo];
-    m.dcur = rc.loc_dcur[lo];
-    m.gex = rc.loc_gex[lo];
+    m.cur = as_global(rc.loc_cur)[lo];
+    m.dcur = as_global(rc.loc_dcur)[lo];
+    m.gex = as_global(rc.loc_gex)[lo];
     m.box = rc.loc_box[lo];
-    m.vx = rc.kd_rec[N + t].x;
-    m.vy = rc.kd_rec[N + t].y;
-    const int w = rc.kd_rec[m.cur].child[m.side];           // the bids were placed by k_kd_locate
+    m.vx = as_global(rc.kd_rec)[N + t].x;
+    m.vy = as_global(rc.kd_rec)[N + t].y;
+    const int w = as_global(rc.kd_rec)[m.cur].child[m.side];           // the bids were placed by k_kd_locate
     if (w == (int)(N + t)) { kd_publish(rc, N, m, m.cur); return; }
     if ((uint32_t)w < N) { atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW); return; }    // cannot happen: the slot was empty in the old tree
-    kd_step_below(rc, m, (uint32_t)w - N, rc.kd_rec[w].x, rc.kd_rec[w].y);
+    kd_step_below(rc, m, (uint32_t)w - N, as_global(rc.kd_rec)[w].x, as_global(rc.kd_rec)[w].y);
     rc.kd_losers[atomicAdd(&rc.cnt->n_losers, 1u)] = m;
 }
 
@@ -1503,7 +1503,7 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
     __shared__ int s_ch[kClaimMax][2];
     __shared__ uint32_t s_nact;
     __shared__ KdMove s_tail[64];
-    const uint32_t N = rc.n_at[b0], b = b0 + nsteps - 1u;
+    const uint32_t N = as_global(rc.n_at)[b0], b = b0 + nsteps - 1u;
     const uint32_t n_new = kd_group_size(rc, b0, nsteps, vwords);
     if (n_new > kClaimMax) { if (threadIdx.x == 0) atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW); return; }
     const uint32_t n_l = rc.cnt->n_losers;
@@ -1601,10 +1601,10 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
     if (threadIdx.x == 0) {
         rc.cnt->n_losers = 0;
         // G as the next k_kd_locate may see it
-        rc.g_snap[4 * (b + 1) + 0] = __hip_atomic_load(&rc.cnt->g_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        rc.g_snap[4 * (b + 1) + 1] = __hip_atomic_load(&rc.cnt->g_nd_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        rc.g_snap[4 * (b + 1) + 2] = __hip_atomic_load(&rc.cnt->g_first_dup[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        rc.g_snap[4 * (b + 1) + 3] = __hip_atomic_load(&rc.cnt->g_first_dup[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        as_global(rc.g_snap)[4 * (b + 1) + 0] = __hip_atomic_load(&rc.cnt->g_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        as_global(rc.g_snap)[4 * (b + 1) + 1] = __hip_atomic_load(&rc.cnt->g_nd_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        as_global(rc.g_snap)[4 * (b + 1) + 2] = __hip_atomic_load(&rc.cnt->g_first_dup[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        as_global(rc.g_snap)[4 * (b + 1) + 3] = __hip_atomic_load(&rc.cnt->g_first_dup[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
         __hip_atomic_store(&rc.cnt->kd_snap, b + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&rc.cnt->kd_done, N + n_new, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1628,7 +1628,7 @@ __global__ __launch_bounds__(256) void k_kd_hint(const RunConst *__restrict__ rc
     __syncthreads();
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
     auto gh = as_global(rc.kd_hint);
-    const uint32_t N = rc.n_at[b0];
+    const uint32_t N = as_global(rc.n_at)[b0];
     if (t < n_new) {
         const uint32_t id = N + t;
         const KdBox bx = rc.kd_box[id];
@@ -1640,7 +1640,7 @@ __global__ __launch_bounds__(256) void k_kd_hint(const RunConst *__restrict__ rc
         if (ix0 <= ix1 && iy0 <= iy1) {
             const uint32_t w = (uint32_t)(ix1 - ix0 + 1), n = w * (uint32_t)(iy1 - iy0 + 1);
             if (n <= 8u) {
-                const unsigned long long val = ((unsigned long long)rc.kd_depth[id] << 32) | id;
+                const unsigned long long val = ((unsigned long long)as_global(rc.kd_depth)[id] << 32) | id;
                 for (uint32_t i = 0; i < n; ++i) {
                     const uint32_t ry = i / w;
                     __hip_atomic_fetch_max(gh + (size_t)(iy0 + (int)ry) * kHG + ix0 + (int)(i - ry * w), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1656,7 +1656,7 @@ __global__ __launch_bounds__(256) void k_kd_hint(const RunConst *__restrict__ rc
         const uint32_t id = s_big_id[q];
         const int ix0 = s_big_r[q][0], ix1 = s_big_r[q][1], iy0 = s_big_r[q][2], iy1 = s_big_r[q][3];
         const uint32_t w = (uint32_t)(ix1 - ix0 + 1), n = w * (uint32_t)(iy1 - iy0 + 1);
-        const unsigned long long val = ((unsigned long long)rc.kd_depth[id] << 32) | id;
+        const unsigned long long val = ((unsigned long long)as_global(rc.kd_depth)[id] << 32) | id;
         for (uint32_t i = lane; i < n; i += 64u) {
             const uint32_t ry = i / w;
             __hip_atomic_fetch_max(gh + (size_t)(iy0 + (int)ry) * kHG + ix0 + (int)(i - ry * w), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1679,14 +1679,14 @@ __global__ __launch_bounds__(1024) void k_tie_fix(const RunConst *__restrict__ r
     tm.scr_d = nullptr; tm.scr_i = nullptr; tm.wave = 0; tm.lane = lane;
     for (uint32_t p = lo + wv; p < n; p += 16u) {
         if (__hip_atomic_load(&rc.pend_state[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1u) continue;
-        const uint32_t base = rc.pend_off[p], m = rc.pend_n[p];
+        const uint32_t base = as_global(rc.pend_off)[p], m = as_global(rc.pend_n)[p];
         int mx = -1;
-        for (uint32_t a = lane; a < m; a += 64u) { const int j = rc.pend_pool[base + a]; mx = j > mx ? j : mx; }
+        for (uint32_t a = lane; a < m; a += 64u) { const int j = as_global(rc.pend_pool)[base + a]; mx = j > mx ? j : mx; }
         mx = tm.max_i(mx);
         if ((uint32_t)mx >= kd_done) continue;
         int on_min = kEmpty, off_best = kEmpty;
         for (uint32_t a = lane; a < m; a += 64u) {
-            const int j = rc.pend_pool[base + a];
+            const int j = as_global(rc.pend_pool)[base + a];
             if (rc.kd_gexit[j] & kOnG) on_min = j < on_min ? j : on_min;
             else if (off_best == kEmpty || kd_preorder_less(rc, j, off_best)) off_best = j;
         }
@@ -1697,8 +1697,8 @@ __global__ __launch_bounds__(1024) void k_tie_fix(const RunConst *__restrict__ r
         else if (on_min == kEmpty) best = off_best;
         else best = kd_preorder_less(rc, on_min, off_best) ? on_min : off_best;
         if (lane == 0) {
-            atomicCAS(&rc.parent[rc.pend_new[p]], kParentPending, best);
-            rc.pend_state[p] = 2u;
+            atomicCAS(&rc.parent[as_global(rc.pend_new)[p]], kParentPending, best);
+            as_global(rc.pend_state)[p] = 2u;
             atomicAdd(&rc.cnt->n_deferred, 1u);
         }
     }
@@ -1719,8 +1719,8 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
     if (blockIdx.x == gridDim.x - 1) { insert_step_pages(rc, b, nb, vwords); return; }    // the extra block
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = blockIdx.x * kConnectWaves + (threadIdx.x >> 6);
-    if (k >= nb || rc.q_vid[k] < 0) return;
-    const double px = rc.q_x[k], py = rc.q_y[k];
+    if (k >= nb || as_global(rc.q_vid)[k] < 0) return;
+    const double px = as_global(rc.q_x)[k], py = as_global(rc.q_y)[k];
     GlobalGrid ggrid;
     ggrid.p = rc.cls; ggrid.W = rc.W;
     TileGrid grid;
@@ -1731,7 +1731,7 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
     } else {
         grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0;
     }
-    const uint32_t N = rc.n_at[b];
+    const uint32_t N = as_global(rc.n_at)[b];
     const uint32_t id = N + rank_before(rc, b, vwords, k);
     uint32_t cnt = cand_count(rc, b, k);
     int *cid = rc.cand_id + cand_off(rc, b, k);
@@ -1739,10 +1739,10 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
     dbl2 *cxy = reinterpret_cast<dbl2 *>(rc.cand_xy) + cand_off(rc, b, k);
     if (cnt == 0) {                       // pto.rs:99: nobody in range -> the nearest node
         if (lane == 0) {                  // lane 0 is also the only reader of slot 0
-            const int nn = rc.q_nn[k];
+            const int nn = as_global(rc.q_nn)[k];
             dbl2 v;
-            v.x = rc.nx[nn]; v.y = rc.ny[nn];
-            cid[0] = nn; cxy[0] = v; rc.cand_cnt[(b & 1u) * rc.cand_K + k] = 1;
+            v.x = as_global(rc.nx)[nn]; v.y = as_global(rc.ny)[nn];
+            cid[0] = nn; cxy[0] = v; as_global(rc.cand_cnt)[(b & 1u) * rc.cand_K + k] = 1;
         }
         cnt = 1;
     }
@@ -1756,7 +1756,7 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
         const int tv = class_to_validity(rc, cls);
         cval[a] = (double)tv;
         if (tv >= 0) {
-            r_new |= rc.reachA[j] & rc.validities[tv];      // pto.rs:111-114, pto_reachability.rs:42-52
+            r_new |= as_global(rc.reachA)[j] & rc.validities[tv];      // pto.rs:111-114, pto_reachability.rs:42-52
             ++n_edges;
         }
     }
@@ -1777,9 +1777,9 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
         const int j = cid[a];
         if (tv >= 0) {
             if (slot < rc.e_cap) {
-                rc.e_from[slot] = (uint32_t)j;
-                rc.e_to[slot] = id;
-                rc.e_tv[slot] = (uint32_t)tv;
+                as_global(rc.e_from)[slot] = (uint32_t)j;
+                as_global(rc.e_to)[slot] = id;
+                as_global(rc.e_tv)[slot] = (uint32_t)tv;
             } else {
                 err |= ERR_EDGE_OVERFLOW;
             }
@@ -1788,19 +1788,19 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
         }
     }
     if (lane == 0) {
-        rc.nx[id] = px;
-        rc.ny[id] = py;
+        as_global(rc.nx)[id] = px;
+        as_global(rc.ny)[id] = py;
         rep_insert(rc, px, py, (int)id);
-        rc.parent[id] = -1;
-        rc.distA[id] = 0.0;
-        rc.distB[id] = 0.0;
-        rc.vid[id] = (uint8_t)rc.q_vid[k];
-        rc.reachA[id] = r_new;
-        rc.reachB[id] = r_new;
+        as_global(rc.parent)[id] = -1;
+        as_global(rc.distA)[id] = 0.0;
+        as_global(rc.distB)[id] = 0.0;
+        as_global(rc.vid)[id] = (uint8_t)as_global(rc.q_vid)[k];
+        as_global(rc.reachA)[id] = r_new;
+        as_global(rc.reachB)[id] = r_new;
         unsigned long long mask = 0;
         const bool fin = goal_hit(rc, ggrid, px, py, mask, &err);
-        rc.final_flag[id] = fin ? 1 : 0;
-        rc.final_mask[id] = fin ? mask : 0ull;
+        as_global(rc.final_flag)[id] = fin ? 1 : 0;
+        as_global(rc.final_mask)[id] = fin ? mask : 0ull;
         if (fin) {
             atomicAdd(&rc.cnt->n_final, 1u);
             atomicOr(&rc.cnt->finality, r_new & mask);
@@ -1814,22 +1814,22 @@ __global__ __launch_bounds__(256) void k_commit_pto(const RunConst *__restrict__
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = (blockIdx.x * 256u + threadIdx.x) >> 6;
-    const uint32_t N = rc.n_at[b];
+    const uint32_t N = as_global(rc.n_at)[b];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         uint32_t add = 0;
         for (uint32_t w = 0; w < vwords; ++w) add += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
-        rc.n_at[b + 1] = N + add;
+        as_global(rc.n_at)[b + 1] = N + add;
     }
-    if (k >= nb || rc.q_vid[k] < 0) return;
+    if (k >= nb || as_global(rc.q_vid)[k] < 0) return;
     const uint32_t cnt = cand_count(rc, b, k);
     const int *cid = rc.cand_id + cand_off(rc, b, k);
     const double *cval = rc.cand_val + (size_t)k * rc.cand_cap;
     for (uint32_t a = lane; a < cnt; a += 64) {
         if ((int)cval[a] < 0) continue;
         const int j = cid[a];
-        const unsigned long long r = rc.reachB[j];
-        rc.reachA[j] = r;
-        if (rc.final_flag[j]) atomicOr(&rc.cnt->finality, r & rc.final_mask[j]);
+        const unsigned long long r = as_global(rc.reachB)[j];
+        as_global(rc.reachA)[j] = r;
+        if (rc.final_flag[j]) atomicOr(&rc.cnt->finality, r & as_global(rc.final_mask)[j]);
     }
 }
 
