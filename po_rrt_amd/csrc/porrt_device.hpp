@@ -630,11 +630,11 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t near_blocks = (nb + 3u) / 4u;
     if (blockIdx.x >= near_blocks) {
-        const uint32_t ck = (blockIdx.x - near_blocks) * 4u + (threadIdx.x >> 6);
+        const uint32_t ck = uni((blockIdx.x - near_blocks) * 4u + (threadIdx.x >> 6));     // wave-uniform: addresses in SGPRs
         if (!PTO && ck < cnb) commit_rrt_sample(rc, cb, vwords, ck, lane);
         return;
     }
-    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t k = uni(blockIdx.x * 4u + (threadIdx.x >> 6));       // wave-uniform: addresses in SGPRs
     if (k >= nb) return;
     const uint32_t N = uni(as_global(rc.n_at)[b]);
     const double sqx = as_global(rc.sx)[i0 + k], sqy = as_global(rc.sy)[i0 + k];
@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunCon
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     if (blockIdx.x == gridDim.x - 1) { insert_step_pages(rc, b, nb, vwords); return; }    // the extra block
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t k = blockIdx.x * kConnectWaves + wv;
+    const uint32_t k = uni(blockIdx.x * kConnectWaves + wv);
     const bool active = k < nb && as_global(rc.q_vid)[k < nb ? k : 0] >= 0;
     const uint32_t cnt = active ? cand_count(rc, b, k) : 0u;
     const bool heavy = active && cnt > kHeavyCand;
@@ -1249,7 +1249,7 @@ __device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vword
 
 // stand-alone form (last step of a launch sequence)
 __global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
-    const uint32_t k = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t k = uni((blockIdx.x * 256u + threadIdx.x) >> 6);
     if (k < nb) commit_rrt_sample(rcp[blockIdx.y], b, vwords, k, threadIdx.x & 63u);
 }
 
@@ -1718,7 +1718,7 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     if (blockIdx.x == gridDim.x - 1) { insert_step_pages(rc, b, nb, vwords); return; }    // the extra block
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t k = blockIdx.x * kConnectWaves + (threadIdx.x >> 6);
+    const uint32_t k = uni(blockIdx.x * kConnectWaves + (threadIdx.x >> 6));
     if (k >= nb || as_global(rc.q_vid)[k] < 0) return;
     const double px = as_global(rc.q_x)[k], py = as_global(rc.q_y)[k];
     GlobalGrid ggrid;
