@@ -515,6 +515,12 @@ __device__ __forceinline__ double disc_radius(double bound_d2, double qx, double
 }
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// a wave-uniform double, kept in scalar registers
+__device__ __forceinline__ double uni_d(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned long long lo = uni((uint32_t)b), hi = uni((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(lo | (hi << 32)));
+}
 
 // visit(x, y, id, ok): called by all 64 lanes together; ok = this lane holds a node.  Every node whose region
 // meets the box of the disc (q, rho) is visited exactly once.  q, rho and N (tree size) are wave-uniform.
@@ -637,9 +643,9 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
     const uint32_t k = uni(blockIdx.x * 4u + (threadIdx.x >> 6));       // wave-uniform: addresses in SGPRs
     if (k >= nb) return;
     const uint32_t N = uni(as_global(rc.n_at)[b]);
-    const double sqx = as_global(rc.sx)[i0 + k], sqy = as_global(rc.sy)[i0 + k];
+    const double sqx = uni_d(as_global(rc.sx)[i0 + k]), sqy = uni_d(as_global(rc.sy)[i0 + k]);
     uint32_t world = 0;
-    if (PTO) world = as_global(rc.sworld)[i0 + k];
+    if (PTO) world = uni(as_global(rc.sworld)[i0 + k]);
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
     double bestD = INF, bestx = 0.0, besty = 0.0;
     int best = 0x7FFFFFFF;
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
         // The sample's own region first: the nearest node is almost always there, and its distance is the bound for
         // the disc the remaining regions are taken from.  Only when the region holds nothing usable does the bound
         // come from the pyramid.
-        const uint32_t own = region_of(rc, sqx, sqy);
+        const uint32_t own = uni(region_of(rc, sqx, sqy));
         scan_disc(rc, sqx, sqy, 0.0, N, lane, visit);
         wave_best();
         double m2;
