@@ -975,9 +975,9 @@ template <int W, class Grid>
 __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const Grid &grid, uint32_t b, uint32_t vwords, uint32_t k,
                                    uint32_t cnt, uint32_t &err) {
     const uint32_t tl = tm.wave * 64u + tm.lane, TS = W * 64u;
-    const uint32_t N = as_global(rc.n_at)[b];
-    const uint32_t id = N + rank_before(rc, b, vwords, k);
-    const double px = as_global(rc.q_x)[k], py = as_global(rc.q_y)[k];
+    const uint32_t N = uni(as_global(rc.n_at)[b]);
+    const uint32_t id = uni(N + rank_before(rc, b, vwords, k));            // k is wave-uniform: scalars
+    const double px = uni_d(as_global(rc.q_x)[k]), py = uni_d(as_global(rc.q_y)[k]);
     // SquareGoal test (common.rs:336-345), lane g <-> goal g: the loads go out now, the answer is needed at the end
     double goal_d = __longlong_as_double(0x7FF0000000000000ll);
     unsigned long long goal_m = 0;
