@@ -978,16 +978,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     const uint32_t N = uni(as_global(rc.n_at)[b]);
     const uint32_t id = uni(N + rank_before(rc, b, vwords, k));            // k is wave-uniform: scalars
     const double px = uni_d(as_global(rc.q_x)[k]), py = uni_d(as_global(rc.q_y)[k]);
-    // SquareGoal test (common.rs:336-345), lane g <-> goal g: the loads go out now, the answer is needed at the end
-    double goal_d = __longlong_as_double(0x7FF0000000000000ll);
-    unsigned long long goal_m = 0;
     const int goal_kind = rc.goal_kind;
-    if (goal_kind == 1 && tm.lane < rc.G) {
-        goal_d = fabs(rc.gcx[tm.lane] - px);
-        goal_d += fabs(rc.gcy[tm.lane] - py);
-        goal_m = rc.gmask[tm.lane];
-    }
-    const double goal_l1 = rc.g_l1;
     auto cid = as_global(rc.cand_id) + cand_off(rc, b, k);            // read-only here
     auto cval = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
     auto cxy = as_global(reinterpret_cast<const dbl2 *>(rc.cand_xy)) + cand_off(rc, b, k);
@@ -1113,10 +1104,18 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     }
 
     // new node (rrt.rs:148, 30-37) and goal test (rrt.rs:165-167)
+    // SquareGoal test (common.rs:336-345), lane g <-> goal g; the goal table sits in the run constants (scalar cache)
     bool fin = false;
     unsigned long long fmask = 0;
     if (goal_kind == 1) {
-        const unsigned long long hits = __ballot(goal_d < goal_l1);      // first listed goal wins
+        double goal_d = __longlong_as_double(0x7FF0000000000000ll);
+        unsigned long long goal_m = 0;
+        if (tm.lane < rc.G) {
+            goal_d = fabs(rc.gcx[tm.lane] - px);
+            goal_d += fabs(rc.gcy[tm.lane] - py);
+            goal_m = rc.gmask[tm.lane];
+        }
+        const unsigned long long hits = __ballot(goal_d < rc.g_l1);      // first listed goal wins
         if (hits) { fin = true; fmask = __shfl(goal_m, (int)__builtin_ctzll(hits)); }
     }
     if (tl == 0) {
