@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
     uint32_t world = 0;
     if (PTO) world = uni(as_global(rc.sworld)[i0 + k]);
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
-    double bestD = INF, bestx = 0.0, besty = 0.0;
+    double bestD = INF;
     int best = 0x7FFFFFFF;
     // rrt.rs:121 uses the size before insertion, pto.rs:88 after it (loaded here, needed by the radius search below)
     const double T2 = rc.rad_T2[N + (rc.mode == 1 ? 1u : 0u)];
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
             if (PTO) pass = (reach[id] >> world) & 1ull;
             if (!pass) return;
             const double D = sqrt(d2);                           // the reference compares rounded distances
-            if (D < bestD || (D == bestD && id < best)) { bestD = D; best = id; bestx = x; besty = y; thr = d2 * (1.0 + 1e-15); }
+            if (D < bestD || (D == bestD && id < best)) { bestD = D; best = id; thr = d2 * (1.0 + 1e-15); }
         };
         auto wave_best = [&]() {
             double rd = bestD;
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
             // the lane that holds the winner hands over the rest (its threshold and the node's coordinates)
             const unsigned long long own = __ballot(best == ri && bestD == rd);
             const int src = own ? (int)__builtin_ctzll(own) : 0;
-            thr = __shfl(thr, src); bestx = __shfl(bestx, src); besty = __shfl(besty, src);
+            thr = __shfl(thr, src);
             bestD = rd; best = ri;
         };
         // The sample's own region first: the nearest node is almost always there, and its distance is the bound for
@@ -693,8 +693,7 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
         wave_best();
     }
     const int nn = best == 0x7FFFFFFF ? 0 : best;   // nothing passed the filter: the root (nearest_neighbor.rs:90)
-    double fx = bestx, fy = besty;
-    if (best == 0x7FFFFFFF) { fx = rc.nx[0]; fy = rc.ny[0]; }
+    const double fx = as_global(rc.nx)[nn], fy = as_global(rc.ny)[nn];
     double tx = sqx, ty = sqy;
     // common.rs:215-225
     double step = fabs(tx - fx);
