@@ -1241,13 +1241,14 @@ __device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vword
         if (!(via >= 0.0)) continue;
         const int j = cid[a];
         if (f64_bits(via) != f64_bits(gdB[j])) continue;
-        int old = rc.parent[j];
+        auto gpar = as_global(rc.parent) + j;
+        int old = *gpar;
         while (old < (int)N || id < old) {      // parents from before this step are always < N
-            const int seen = atomicCAS(&rc.parent[j], old, id);
-            if (seen == old) break;
-            old = seen;
+            int expect = old;
+            if (__hip_atomic_compare_exchange_strong(gpar, &expect, id, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            old = expect;
         }
-        rc.distA[j] = via;
+        as_global(rc.distA)[j] = via;
     }
 }
 
