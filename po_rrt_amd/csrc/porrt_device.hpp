@@ -981,10 +981,8 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     auto cid = as_global(rc.cand_id) + cand_off(rc, b, k);            // read-only here
     auto cval = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
     auto cxy = as_global(reinterpret_cast<const dbl2 *>(rc.cand_xy)) + cand_off(rc, b, k);
-    auto gnx = as_global(rc.nx), gny = as_global(rc.ny), gdA = as_global(rc.distA);
+    auto gdA = as_global(rc.distA);
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
-    GlobalGrid ggrid;
-    ggrid.p = rc.cls; ggrid.W = rc.W;
 
     // pass 1: raycast every neighbour, total cost through it (rrt.rs:124, 137-140)
     double bt = INF;
@@ -1015,7 +1013,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     if (nvalid == 0) {
         // rrt.rs:132-134: fall back to the nearest node, not collision-checked
         best = rc.q_nn[k];
-        best_cost = sqrt(dist2(gnx[best], gny[best], px, py));
+        best_cost = sqrt(dist2(as_global(rc.nx)[best], as_global(rc.ny)[best], px, py));
         dnew = gdA[best] + best_cost;
     } else {
         // equal totals: the reference keeps the first in kd-tree pre-order (rrt.rs:143-145).  The kd structure is
@@ -1097,7 +1095,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
             best_cost = __shfl(cost0, src);
             dnew = __shfl(tot0, src);
         } else {
-            best_cost = sqrt(dist2(gnx[best], gny[best], px, py));
+            best_cost = sqrt(dist2(as_global(rc.nx)[best], as_global(rc.ny)[best], px, py));
             dnew = gdA[best] + best_cost;
         }
     }
@@ -1120,7 +1118,11 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     if (tl == 0) {
         // everything that READS memory first (the memory counter is in order: a load's wait behind a store waits for
         // the store's round trip too), then nothing but stores
-        if (goal_kind == 2) fin = goal_hit(rc, ggrid, px, py, fmask, &err);
+        if (goal_kind == 2) {
+            GlobalGrid ggrid;
+            ggrid.p = rc.cls; ggrid.W = rc.W;
+            fin = goal_hit(rc, ggrid, px, py, fmask, &err);
+        }
         int rep_at[kRepLevels];
 #pragma unroll
         for (int l = 0; l < kRepLevels; ++l) {
@@ -1180,7 +1182,7 @@ constexpr uint32_t kHeavyCand = 256;     // samples with more neighbours than th
 // samples with more than kHeavyCand neighbours (the dense start of a tree, duplicates of the goal point) are
 // served one after the other by the whole workgroup as a 4-wave team.
 template <bool LDSGRID>
-__global__ __launch_bounds__(kConnectWaves * 64) void k_connect_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
+__global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_connect_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
                                                                      uint32_t vwords) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_tiles[];
     __shared__ double s_d[kConnectWaves];
