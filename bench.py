@@ -94,11 +94,10 @@ def main():
         agg["device_s"] += eng.metrics()["device_s"]
     t_loop = time.perf_counter() - t0
     # the one exchange of the job: who holds the best tree?  (download happens here, once per rank)
-    my_cost, best_e = float("inf"), eng
-    for e in engs:
-        sol = e.best_solution()
-        if sol is not None and sol[1] < my_cost:
-            my_cost, best_e = sol[1], e
+    # (each context's best path cost is evaluated on the device; only the winner's tree is fetched)
+    costs = po_rrt_amd.Engine.best_cost_batch(engs)
+    qbest = int(np.argmin(costs))          # first minimum, as get_best_solution picks among final nodes
+    my_cost, best_e = float(costs[qbest]), engs[qbest]
     xy, parent, dist_root = best_e.tree()
     from po_rrt_amd import sharding
     winner, win_cost, _, wparent, _ = sharding.exchange_best_tree(my_cost, xy, parent, dist_root,

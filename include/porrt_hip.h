@@ -134,6 +134,13 @@ int      porrt_get_zone_positions(const porrt_ctx *ctx, double *xy /* <= 64*2 */
  * get_path_cost 223-227): length of the best path (0 = "No solution found");
  * path_xy may be NULL to query the length. */
 uint64_t porrt_best_solution(const porrt_ctx *ctx, double *path_xy, uint64_t cap, double *cost);
+/* The cost (and final node) of that path alone, evaluated on the device without fetching the tree: same
+ * arithmetic, same first-minimum rule, bit-identical cost.  Lets a caller that holds many trees on the GPU
+ * (porrt_grow_batch) pick the one worth downloading.  Returns 1, or 0 for "No solution found". */
+int      porrt_best_cost(const porrt_ctx *ctx, double *cost, uint64_t *final_id);
+/* The same for the n contexts of the last porrt_grow_batch, in one launch (one workgroup per context);
+ * costs[q] = +inf where context q has no solution.  Other sets of contexts are evaluated one after the other. */
+int      porrt_best_cost_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, double *costs);
 
 /* ---- measurement */
 typedef struct {

@@ -79,6 +79,11 @@ struct Counters {
     uint32_t kd_snap;           // step up to whose start the kd structure is complete (release-stored by k_kd_claim)
 };
 
+struct BestCost {
+    unsigned long long cost_bits;   // f64 bits of the best cost (+inf bits when there is no final node)
+    uint32_t final_id, path_len, overflow, pad;
+};
+
 struct RunConst {
     // node SoA
     double *nx, *ny;
@@ -133,6 +138,11 @@ struct RunConst {
     int *pend_new, *pend_pool;
     uint32_t *pend_off, *pend_n, *pend_cur, *pend_state;
     uint32_t pend_cap, pool_cap;
+    // k_best_cost scratch (paths of the final nodes), its cursor and result slot
+    int *bc_scratch;
+    uint32_t bc_cap;
+    uint32_t *bc_cursor;
+    BestCost *bc_out;
     unsigned long long *kd_hint; // [kHG * kHG] (depth << 32 | id) of the deepest node whose cell covers the square
     int *kd_up;
     uint32_t *kd_depth;
@@ -1837,6 +1847,58 @@ __global__ __launch_bounds__(256) void k_commit_pto(const RunConst *__restrict__
         const unsigned long long r = as_global(rc.reachB)[j];
         as_global(rc.reachA)[j] = r;
         if (rc.final_flag[j]) atomicOr(&rc.cnt->finality, r & as_global(rc.final_mask)[j]);
+    }
+}
+
+// The cost of the best solution, on the device (rrt.rs:183-193, 48-61): for every final node the path to the root is
+// written into scratch (leaf to root), then summed from the root outwards exactly as the reference folds it, and the
+// workgroup keeps the first minimum in final-node order (ascending id, strict `<`).  One workgroup per context; the
+// caller falls back to the host walk if the scratch is too small.
+__global__ __launch_bounds__(1024) void k_best_cost(const RunConst *__restrict__ rcp, uint32_t nsteps) {
+    const RunConst &rc = rcp[blockIdx.y];
+    const uint32_t n_nodes = as_global(rc.n_at)[nsteps], cap = rc.bc_cap;
+    int *scratch = rc.bc_scratch;
+    uint32_t *cursor = rc.bc_cursor;
+    __shared__ unsigned long long s_cost[1024];
+    __shared__ uint32_t s_id[1024], s_len[1024];
+    auto gpar = as_global(rc.parent);
+    auto gx = as_global(rc.nx), gy = as_global(rc.ny);
+    auto gff = as_global(rc.final_flag);
+    const unsigned long long INF_BITS = 0x7FF0000000000000ull;
+    unsigned long long bc = INF_BITS;
+    uint32_t bid = 0xFFFFFFFFu, blen = 0, over = 0;
+    for (uint32_t f = threadIdx.x; f < n_nodes; f += 1024u) {          // ascending ids per thread
+        if (!gff[f]) continue;
+        uint32_t L = 0;
+        for (int p = (int)f; p >= 0; p = gpar[p]) { ++L; if (L > n_nodes) break; }
+        const uint32_t off = atomicAdd(cursor, L);
+        if (L > n_nodes || off + L > cap) { over = 1; continue; }
+        uint32_t q = off + L;
+        for (int p = (int)f; p >= 0; p = gpar[p]) scratch[--q] = p;     // scratch[off] = root ... scratch[off + L - 1] = f
+        double sum = 0.0;
+        for (uint32_t a = 0; a + 1 < L; ++a) {
+            const int u = scratch[off + a], v = scratch[off + a + 1];
+            sum += sqrt(dist2(gx[u], gy[u], gx[v], gy[v]));
+        }
+        const unsigned long long sb = f64_bits(sum);
+        if (sb < bc) { bc = sb; bid = f; blen = L; }                    // costs are >= 0: the bit patterns order like the values
+    }
+    s_cost[threadIdx.x] = bc; s_id[threadIdx.x] = bid; s_len[threadIdx.x] = blen;
+    const int any_over = __syncthreads_or((int)over);
+    for (uint32_t st = 512; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            const unsigned long long oc = s_cost[threadIdx.x + st];
+            const uint32_t oi = s_id[threadIdx.x + st];
+            if (oc < s_cost[threadIdx.x] || (oc == s_cost[threadIdx.x] && oi < s_id[threadIdx.x])) {
+                s_cost[threadIdx.x] = oc; s_id[threadIdx.x] = oi; s_len[threadIdx.x] = s_len[threadIdx.x + st];
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        BestCost r;
+        r.cost_bits = s_cost[0]; r.final_id = s_id[0]; r.path_len = s_len[0]; r.overflow = any_over ? 1u : 0u; r.pad = 0;
+        *rc.bc_out = r;
     }
 }
 

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <limits>
 #include <vector>
 
 using namespace porrt;
@@ -174,6 +175,9 @@ struct porrt_ctx {
     DevBuf<KdRec> d_kdrec;
     DevBuf<KdBox> d_kdbox, d_locbox;
     DevBuf<KdMove> d_kdlosers;
+    DevBuf<int> d_bcscratch;
+    DevBuf<BestCost> d_bcout;
+    DevBuf<uint32_t> d_bccursor;
     DevBuf<int> d_loccur;
     DevBuf<uint32_t> d_locdcur, d_locgex, d_locflags, d_kdsurv;
     DevBuf<double> d_gx, d_gy, d_gndx, d_gndy, d_kqx, d_kqy;
@@ -222,6 +226,10 @@ struct porrt_ctx {
     Counters batch_hc;
     uint32_t batch_nodes = 0;
     size_t run_lds_bytes = 0;
+    int best_cost_device(double *cost, uint64_t *final_id);
+    int read_best_cost(double *cost, uint64_t *final_id);
+    porrt_ctx *batch_leader = nullptr;     // set by porrt_grow_batch: the context whose RunConst array holds this one
+    uint32_t batch_slot = 0, batch_size = 0;
     RunConst *d_rcarr = nullptr;      // leader of a porrt_grow_batch: the members' RunConst, one per grid row
     size_t rcarr_cap = 0;
     enum : unsigned { DL_TREE = 1, DL_DIST = 2, DL_MASKS = 4, DL_EDGES = 8 };
@@ -259,7 +267,7 @@ int porrt_ctx::layout_buffers() {
                               &d_kdrec, &d_gx, &d_gy, &d_rgdir, &d_rep, &d_kdbox, &d_locbox, &d_kdlosers, &d_gsnap, &d_pendoff, &d_pendn, &d_pendcur,
                               &d_pendnew, &d_pendpool, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB, &d_finalmask, &d_vid, &d_finalflag, &d_cls,
                               &d_nat, &d_sworld, &d_candcnt, &d_efrom, &d_eto, &d_etv, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags,
-                              &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid};
+                              &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid, &d_bcscratch, &d_bcout, &d_bccursor};
         for (DevBufBase *b2 : list) all_bufs.push_back(b2);
     }
     bool grow_needed = false;
@@ -287,7 +295,7 @@ int porrt_ctx::layout_buffers() {
     d_candid.p = (int *)d_candid.vp; d_gid.p = (int *)d_gid.vp; d_kdup.p = (int *)d_kdup.vp; d_kdrec.p = (KdRec *)d_kdrec.vp;
     d_gx.p = (double *)d_gx.vp; d_gy.p = (double *)d_gy.vp; d_rgcnt.p = (uint32_t *)d_rgcnt.vp; d_rgdir.p = (uint32_t *)d_rgdir.vp;
     d_rep.p = (int *)d_rep.vp;
-    d_kdbox.p = (KdBox *)d_kdbox.vp; d_locbox.p = (KdBox *)d_locbox.vp; d_kdlosers.p = (KdMove *)d_kdlosers.vp; d_kdhint.p = (unsigned long long *)d_kdhint.vp;
+    d_kdbox.p = (KdBox *)d_kdbox.vp; d_locbox.p = (KdBox *)d_locbox.vp; d_kdlosers.p = (KdMove *)d_kdlosers.vp; d_bcscratch.p = (int *)d_bcscratch.vp; d_bcout.p = (BestCost *)d_bcout.vp; d_bccursor.p = (uint32_t *)d_bccursor.vp; d_kdhint.p = (unsigned long long *)d_kdhint.vp;
     d_gsnap.p = (uint32_t *)d_gsnap.vp; d_pendoff.p = (uint32_t *)d_pendoff.vp; d_pendn.p = (uint32_t *)d_pendn.vp; d_pendcur.p = (uint32_t *)d_pendcur.vp;
     d_pendstate.p = (uint32_t *)d_pendstate.vp; d_pendnew.p = (int *)d_pendnew.vp; d_pendpool.p = (int *)d_pendpool.vp; d_kddepth.p = (uint32_t *)d_kddepth.vp; d_kdgexit.p = (uint32_t *)d_kdgexit.vp;
     d_reachA.p = (unsigned long long *)d_reachA.vp; d_reachB.p = (unsigned long long *)d_reachB.vp;
@@ -535,6 +543,7 @@ int porrt_ctx::grow(const double start[2], double max_step, double search_radius
     if (n_iter_max + 2 >= 0x7FFFFFF0ull) { set_err("n_iter_max too large"); return PORRT_ERR_INVALID; }
     if (!(max_step > 0.0) || !(search_radius >= 0.0)) { set_err("max_step / search_radius"); return PORRT_ERR_INVALID; }
     have_results = false;
+    batch_leader = nullptr;
     ++results_tag;
     // the sampler state must survive a capacity retry
     const Pcg64 c0 = crng, d0 = drng;
@@ -585,7 +594,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         const uint64_t rg_maxp = Nmax / kPage + 2, pg_cap = 2ull * kRegions + Nmax / kPage + 8;
         HIPCHK(d_rgcnt.reserve(kRegions)); HIPCHK(d_rgdir.reserve((size_t)kRegions * rg_maxp));
         HIPCHK(d_pgxy.reserve(2 * (size_t)pg_cap * kPage)); HIPCHK(d_pgid.reserve((size_t)pg_cap * kPage)); 
-        HIPCHK(d_candcnt.reserve(2 * (size_t)K)); HIPCHK(d_kdbox.reserve(Nmax)); HIPCHK(d_kdlosers.reserve(kClaimMax)); HIPCHK(d_locbox.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_kdhint.reserve((size_t)kHG * kHG));
+        HIPCHK(d_candcnt.reserve(2 * (size_t)K)); HIPCHK(d_kdbox.reserve(Nmax)); HIPCHK(d_kdlosers.reserve(kClaimMax)); HIPCHK(d_bcscratch.reserve(8 * Nmax + 4096)); HIPCHK(d_bcout.reserve(1)); HIPCHK(d_bccursor.reserve(1)); HIPCHK(d_locbox.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_kdhint.reserve((size_t)kHG * kHG));
         HIPCHK(d_loccur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locdcur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locgex.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locflags.reserve(2 * (8 * (size_t)K + 4096)));
         HIPCHK(d_gsnap.reserve((steps_max + 4) * 4)); HIPCHK(d_pendoff.reserve(pend_cap)); HIPCHK(d_pendn.reserve(pend_cap)); HIPCHK(d_pendcur.reserve(pend_cap));
         HIPCHK(d_pendstate.reserve(pend_cap)); HIPCHK(d_pendnew.reserve(pend_cap)); HIPCHK(d_pendpool.reserve(pool_cap)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_gndx.reserve(Nmax)); HIPCHK(d_gndy.reserve(Nmax));
@@ -624,7 +633,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.q_x = d_qx.p; c.q_y = d_qy.p; c.q_nn = d_qnn.p; c.q_vid = d_qvid.p;
     c.rg_cnt = d_rgcnt.p; c.rg_dir = d_rgdir.p; c.pg_xy = d_pgxy.p; c.pg_id = d_pgid.p;
     c.rg_maxp = (uint32_t)(Nmax / kPage + 2); c.pg_cap = (uint32_t)(2ull * kRegions + Nmax / kPage + 8);
-    c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p; c.kd_box = d_kdbox.p; c.loc_box = d_locbox.p; c.kd_losers = d_kdlosers.p; c.kd_hint = d_kdhint.p; c.g_snap = d_gsnap.p; c.loc_stride = 8 * K + 4096;
+    c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p; c.kd_box = d_kdbox.p; c.loc_box = d_locbox.p; c.kd_losers = d_kdlosers.p; c.bc_scratch = d_bcscratch.p; c.bc_cap = (uint32_t)std::min<size_t>(d_bcscratch.n, 0xFFFFFFFFu); c.bc_cursor = d_bccursor.p; c.bc_out = d_bcout.p; c.kd_hint = d_kdhint.p; c.g_snap = d_gsnap.p; c.loc_stride = 8 * K + 4096;
     c.pend_new = d_pendnew.p; c.pend_pool = d_pendpool.p; c.pend_off = d_pendoff.p; c.pend_n = d_pendn.p; c.pend_cur = d_pendcur.p; c.pend_state = d_pendstate.p;
     c.pend_cap = (uint32_t)std::min<uint64_t>(pend_cap, 0xFFFFFFFFull); c.pool_cap = (uint32_t)std::min<uint64_t>(pool_cap, 0xFFFFFFFFull);
     c.cand_K = K; c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_xy = d_candxy.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
@@ -1044,6 +1053,29 @@ int porrt_ctx::download(unsigned want) {
 }
 
 // ========================================================================================== C ABI
+// Best path cost without downloading the tree (k_best_cost).  1 = found, 0 = no final node, -1 = scratch too small
+// (the caller then walks on the host), other negatives = errors.
+int porrt_ctx::read_best_cost(double *cost, uint64_t *final_id) {
+    BestCost r;
+    HIPCHK(hipMemcpy(&r, d_bcout.p, sizeof r, hipMemcpyDeviceToHost));
+    if (r.overflow) return -1;
+    if (r.final_id == 0xFFFFFFFFu) return 0;
+    double c;
+    memcpy(&c, &r.cost_bits, 8);
+    if (cost) *cost = c;
+    if (final_id) *final_id = r.final_id;
+    return 1;
+}
+
+int porrt_ctx::best_cost_device(double *cost, uint64_t *final_id) {
+    if (!have_results) { set_err("no results: call porrt_grow first"); return PORRT_ERR_INVALID; }
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemsetAsync(d_bccursor.p, 0, sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(k_best_cost, dim3(1, 1), dim3(1024), 0, stream, (const RunConst *)d_rc.p, (uint32_t)n_steps);
+    HIPCHK(hipStreamSynchronize(stream));
+    return read_best_cost(cost, final_id);
+}
+
 // A member's bookkeeping after the leader of a porrt_grow_batch ran the steps (fixed iteration budget: the loop
 // condition is never consulted, n_iter_min == n_iter_max).
 int porrt_ctx::finish_batch_member(uint64_t n_iter_done, uint32_t steps, float device_ms) {
@@ -1221,7 +1253,10 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             L->metrics.scan_s = scan; L->metrics.connect_s = conn; L->metrics.scan_launches = launches;
             L->metrics.scan_pairs = pairs; L->metrics.scan_bytes = bytes;
         }
-        if (!retry) return worst;
+        if (!retry) {
+            for (uint32_t q = 0; q < n; ++q) { cs[q]->batch_leader = L; cs[q]->batch_slot = q; cs[q]->batch_size = n; }
+            return worst;
+        }
         for (uint32_t q = 0; q < n; ++q) {          // neighbour lists overflowed somewhere: regrow them everywhere and replay
             cs[q]->opt_cand_cap = (uint32_t)std::min<uint64_t>((uint64_t)cs[q]->opt_cand_cap * 4, n_iter + 2);
             cs[q]->crng = c0[q]; cs[q]->drng = d0[q]; cs[q]->inj_pos = ip0[q]; cs[q]->inj_wpos = iw0[q];
@@ -1269,6 +1304,7 @@ void porrt_destroy(porrt_ctx *c) {
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->d_rcarr) (void)hipFree(c->d_rcarr);
+
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1522,6 +1558,47 @@ uint64_t porrt_best_solution(const porrt_ctx *cc, double *path_xy, uint64_t cap,
         }
     }
     return best_len;
+}
+
+// the cost of porrt_best_solution's path without fetching the tree (evaluated on the device; same arithmetic, same
+// first-minimum rule); falls back to the host walk when the device scratch is too small
+int porrt_best_cost(const porrt_ctx *cc, double *cost, uint64_t *final_id) {
+    porrt_ctx *c = const_cast<porrt_ctx *>(cc);
+    if (!c) return PORRT_ERR_INVALID;
+    int r = c->best_cost_device(cost, final_id);
+    if (r != -1) return r;
+    double hc = 0;
+    const uint64_t n = porrt_best_solution(cc, nullptr, 0, &hc);
+    if (!n) return 0;
+    if (cost) *cost = hc;
+    if (final_id) *final_id = ~0ull;        // not tracked by the host fallback
+    return 1;
+}
+
+// porrt_best_cost for the members of the last porrt_grow_batch in one kernel launch (one workgroup per context).
+// costs[q] = +inf where a member has no solution.  Members of different batches (or none) are evaluated one by one.
+int porrt_best_cost_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, double *costs) {
+    if (!ctxs || !n_ctx || !costs) return PORRT_ERR_INVALID;
+    porrt_ctx *L = ctxs[0] ? ctxs[0]->batch_leader : nullptr;
+    bool together = L != nullptr && L->batch_size == n_ctx;
+    for (uint32_t q = 0; q < n_ctx && together; ++q)
+        together = ctxs[q] && ctxs[q]->have_results && ctxs[q]->batch_leader == L && ctxs[q]->batch_slot == q && ctxs[q]->n_steps == L->n_steps;
+    const double inf = std::numeric_limits<double>::infinity();
+    if (together) {
+        if (hipSetDevice(L->device) != hipSuccess) return PORRT_ERR_DEVICE;
+        for (uint32_t q = 0; q < n_ctx; ++q) (void)hipMemsetAsync(ctxs[q]->d_bccursor.p, 0, sizeof(uint32_t), L->stream);
+        hipLaunchKernelGGL(k_best_cost, dim3(1, n_ctx), dim3(1024), 0, L->stream, (const RunConst *)L->d_rcarr, (uint32_t)L->n_steps);
+        if (hipStreamSynchronize(L->stream) != hipSuccess) return PORRT_ERR_DEVICE;
+    }
+    for (uint32_t q = 0; q < n_ctx; ++q) {
+        if (!ctxs[q]) return PORRT_ERR_INVALID;
+        double c = inf;
+        int r = together ? ctxs[q]->read_best_cost(&c, nullptr) : -1;
+        if (r == -1) r = porrt_best_cost(ctxs[q], &c, nullptr);
+        if (r < 0) return r;
+        costs[q] = r ? c : inf;
+    }
+    return PORRT_OK;
 }
 
 int porrt_get_metrics(const porrt_ctx *c, porrt_metrics *out) {

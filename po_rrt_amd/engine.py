@@ -28,7 +28,7 @@ SYMBOLS = [
     "porrt_set_observation_goal", "porrt_grow", "porrt_grow_batch", "porrt_num_nodes", "porrt_num_iterations", "porrt_get_tree",
     "porrt_num_final", "porrt_get_final_ids", "porrt_get_final_masks", "porrt_get_reach", "porrt_get_node_validity",
     "porrt_num_edges", "porrt_get_edges", "porrt_is_final_set_complete", "porrt_n_worlds", "porrt_get_validities",
-    "porrt_get_zone_positions", "porrt_best_solution", "porrt_get_metrics", "porrt_set_option", "porrt_selftest",
+    "porrt_get_zone_positions", "porrt_best_solution", "porrt_best_cost", "porrt_best_cost_batch", "porrt_get_metrics", "porrt_set_option", "porrt_selftest",
 ]
 
 
@@ -92,6 +92,8 @@ def load_library():
     sig("porrt_get_validities", C.c_int, vp, _u64p)
     sig("porrt_get_zone_positions", C.c_int, vp, _f64p)
     sig("porrt_best_solution", C.c_uint64, vp, vp, C.c_uint64, C.POINTER(C.c_double))
+    sig("porrt_best_cost", C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64))
+    sig("porrt_best_cost_batch", C.c_int, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_double))
     sig("porrt_get_metrics", C.c_int, vp, C.POINTER(Metrics))
     sig("porrt_set_option", C.c_int, vp, C.c_char_p, C.c_int64)
     sig("porrt_selftest", C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
@@ -246,6 +248,23 @@ class Engine:
         path = np.zeros((n, 2))
         self._l.porrt_best_solution(self._c, path.ctypes.data_as(C.c_void_p), n, C.byref(cost))
         return path, cost.value
+
+    def best_cost(self):
+        """cost of best_solution()'s path, evaluated on the device (no tree download); None = no solution"""
+        cost, fid = C.c_double(0.0), C.c_uint64(0)
+        r = self._chk(self._l.porrt_best_cost(self._c, C.byref(cost), C.byref(fid)))
+        return cost.value if r else None
+
+    @staticmethod
+    def best_cost_batch(engines):
+        """best_cost() of every engine (inf = no solution); one launch when they are the last grow_batch's members"""
+        n = len(engines)
+        arr = (C.c_void_p * n)(*[e._c for e in engines])
+        costs = np.zeros(n)
+        rc = engines[0]._l.porrt_best_cost_batch(arr, n, costs.ctypes.data_as(C.POINTER(C.c_double)))
+        if rc < 0:
+            engines[0]._chk(rc)
+        return costs
 
     def selftest(self, n=1 << 20):
         a, b = C.c_uint64(0), C.c_uint64(0)

@@ -180,7 +180,13 @@ def test_grow_batch_equals_separate_grows(eng_mod, graph):
         engs.append(cases.configure(e, c))
     for rep in range(2):                    # second round: sampler states moved on, the cached graph is replayed
         eng_mod.Engine.grow_batch(engs, [c.start for c in cs], cs[0].max_step, cs[0].search_radius, cs[0].n_iter_min, 1024)
+        costs = eng_mod.Engine.best_cost_batch(engs)          # one launch for the batch's members ...
+        for e, c in zip(engs, costs):
+            sol = e.best_solution()
+            assert (sol is None and np.isinf(c)) or (sol is not None and c == sol[1] == e.best_cost())
         if rep == 0:
+            mixed = eng_mod.Engine.best_cost_batch([engs[2], single[0]])      # ... one by one for any other set
+            assert mixed[0] == costs[2] and mixed[1] == costs[0]
             for e, s in zip(engs, single):
                 assert_same(e, s)
         else:
@@ -256,6 +262,23 @@ def test_odd_batch_sizes_and_early_termination(eng_mod, K):
     e, _ = run_gpu(eng_mod, p, K)
     o, _ = run_orc(p, K)
     assert_same(e, o, pto=True)
+
+
+def test_best_cost_on_the_device_equals_the_host_walk(eng_mod):
+    """porrt_best_cost (no tree download) against porrt_best_solution and the oracle: bit-identical cost."""
+    for case in (cases.cfg2(30000), cases.cfg1(3000), cases.empty_space(1000, 10000)):
+        e, _ = run_gpu(eng_mod, case, 1024)
+        bc = e.best_cost()
+        sol = e.best_solution()
+        o, _ = run_orc(case, 1024)
+        so = o.best_solution()
+        if sol is None:
+            assert bc is None and so is None
+        else:
+            assert bc == sol[1] == so[1]
+    c = cases.cfg2(300)                       # far too few iterations to reach the goal
+    e, _ = run_gpu(eng_mod, c, 64)
+    assert e.best_cost() is None and e.best_solution() is None
 
 
 def test_max_batch_and_ragged_tail(eng_mod):
