@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 
 int main(int argc, char **argv) {
@@ -29,6 +30,14 @@ int main(int argc, char **argv) {
                 all.push_back(others.back().get());
             }
             auto res = RRT::plan_batch(all, std::vector<State>(all.size(), State{0.0, -1.0}), goal, 0.1, 2.0, std::strtoull(argv[3], nullptr, 10));
+            const std::vector<double> costs = RRT::best_costs(all);        // device-side costs == the host walk's
+            for (size_t q = 0; q < all.size(); ++q) {
+                const bool found = res[q].first.has_value();
+                if (found ? costs[q] != res[q].first->second : costs[q] != std::numeric_limits<double>::infinity()) {
+                    std::fprintf(stderr, "best_costs[%zu] disagrees with get_best_solution\n", q);
+                    return 3;
+                }
+            }
             result = std::move(res[0].first);
             tree = std::move(res[0].second);
         } else {

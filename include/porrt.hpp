@@ -184,6 +184,15 @@ public:
         }
         return out;
     }
+    // Cost of each planner's best path (get_best_solution, rrt.rs:183-193) evaluated on the device without fetching the
+    // trees; +inf = "No solution found".  After plan_batch / a grow of all planners it is one kernel launch.
+    static std::vector<double> best_costs(const std::vector<RRT *> &planners) {
+        std::vector<porrt_ctx *> cs;
+        for (RRT *p : planners) cs.push_back(p->ctx_.get());
+        std::vector<double> costs(cs.size());
+        planners.at(0)->ctx_.check(porrt_best_cost_batch(cs.data(), (uint32_t)cs.size(), costs.data()));
+        return costs;
+    }
 private:
     Context ctx_;
     template <class Goal>

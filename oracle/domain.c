@@ -166,6 +166,7 @@ orc_ctx *orc_create(void) {
 
 void orc_destroy(orc_ctx *c) {
     if (!c) return;
+    orc_bg_release(c);
     free(c->occ); free(c->zones); free(c->inj_xy); free(c->inj_worlds);
     free(c->nx); free(c->ny); free(c->dist); free(c->parent); free(c->reach);
     free(c->node_validity); free(c->final_ids); free(c->final_masks); free(c->edges);

@@ -533,6 +533,7 @@ static int pto_batched(orc_ctx *c, const double start[2], double max_step, doubl
 int orc_grow(orc_ctx *c, const double start[2], double max_step, double search_radius,
              uint64_t n_iter_min, uint64_t n_iter_max, uint32_t batch_K, int mode, int algo) {
     int rc;
+    orc_bg_release(c);
     if (mode == ORC_MODE_RRT) {
         if (algo == ORC_ALGO_SEQ) rc = rrt_seq(c, start, max_step, search_radius, n_iter_min, n_iter_max);
         else rc = rrt_batched(c, start, max_step, search_radius, n_iter_min, n_iter_max, batch_K, algo == ORC_ALGO_BATCHED_KD);

@@ -58,6 +58,19 @@ def lib():
     sig("orc_set_observation_goal", C.c_int, vp, C.c_uint32)
     sig("orc_to_pixel", C.c_int, vp, _f64p, _u32p)
     sig("orc_state_class", C.c_int, vp, _f64p)
+    sig("orc_belief_hash", C.c_uint64, _f64p, C.c_uint32)
+    sig("orc_belief_successors", C.c_int, vp, _f64p, C.c_uint32, _f64p)
+    sig("orc_zone_observable", C.c_int, vp, _f64p, C.c_uint32)
+    sig("orc_observe", C.c_int64, vp, _f64p, _f64p, _f64p, C.c_size_t)
+    sig("orc_reachable_beliefs", C.c_int64, vp, _f64p, C.c_void_p, C.c_size_t)
+    sig("orc_build_belief_graph", C.c_int, vp, _f64p)
+    sig("orc_bg_num_beliefs", C.c_uint64, vp)
+    sig("orc_bg_num_nodes", C.c_uint64, vp)
+    sig("orc_bg_num_edges", C.c_uint64, vp)
+    sig("orc_bg_get_beliefs", C.c_int, vp, _f64p)
+    sig("orc_bg_get_types", C.c_int, vp, _u8p)
+    sig("orc_bg_get_children", C.c_int, vp, _u64p, _u32p)
+    sig("orc_bg_get_parents", C.c_int, vp, _u64p, _u32p)
     sig("orc_traversed_class", C.c_int, vp, _f64p, _f64p)
     sig("orc_n_zones", C.c_int, vp)
     sig("orc_n_worlds", C.c_int, vp)
@@ -314,6 +327,51 @@ class Oracle:
         if n:
             self._l.orc_get_edges(self._c, f, t, v)
         return f, t, v
+
+    # ---- belief space (belief.c; pto.rs:185-259)
+    def belief_hash(self, b):
+        b = _f64(b)
+        return self._l.orc_belief_hash(b, len(b))
+
+    def belief_successors(self, belief, zone):
+        nw = self.n_worlds()
+        out = np.zeros((2, nw))
+        k = self._l.orc_belief_successors(self._c, _f64(belief), zone, out)
+        return out[:k]
+
+    def zone_observable(self, xy, zone):
+        return self._l.orc_zone_observable(self._c, _f64(xy), zone)
+
+    def observe(self, xy, belief, cap=4096):
+        nw = self.n_worlds()
+        out = np.zeros((cap, nw))
+        k = self._l.orc_observe(self._c, _f64(xy), _f64(belief), out, cap)
+        if k < 0:
+            raise RuntimeError("observe failed (%d)" % k)
+        return out[:k]
+
+    def reachable_beliefs(self, start):
+        nw = self.n_worlds()
+        n = self._l.orc_reachable_beliefs(self._c, _f64(start), None, 0)
+        out = np.zeros((n, nw))
+        self._l.orc_reachable_beliefs(self._c, _f64(start), out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def build_belief_graph(self, start_belief):
+        self._chk(self._l.orc_build_belief_graph(self._c, _f64(start_belief)))
+
+    def belief_graph(self):
+        """beliefs [B, n_worlds], node types [N*B], (child_off, child_ids), (parent_off, parent_ids)"""
+        B, NB, E = (self._l.orc_bg_num_beliefs(self._c), self._l.orc_bg_num_nodes(self._c), self._l.orc_bg_num_edges(self._c))
+        beliefs = np.zeros((B, self.n_worlds()))
+        types = np.zeros(NB, dtype=np.uint8)
+        coff, poff = np.zeros(NB + 1, dtype=np.uint64), np.zeros(NB + 1, dtype=np.uint64)
+        cid, pid = np.zeros(max(E, 1), dtype=np.uint32), np.zeros(max(E, 1), dtype=np.uint32)
+        self._chk(self._l.orc_bg_get_beliefs(self._c, beliefs))
+        self._chk(self._l.orc_bg_get_types(self._c, types))
+        self._chk(self._l.orc_bg_get_children(self._c, coff, cid))
+        self._chk(self._l.orc_bg_get_parents(self._c, poff, pid))
+        return beliefs, types, (coff, cid[:E]), (poff, pid[:E])
 
     def is_final_set_complete(self):
         return bool(self._l.orc_is_final_set_complete(self._c))

@@ -59,6 +59,7 @@ struct orc_ctx {
     uint64_t n_edges, cap_edges;
     int complete;
     int oob; /* a raster access outside W x H happened (reference would panic) */
+    struct orc_bg *bg; /* belief.c: result of the last orc_build_belief_graph */
 };
 
 /* class of one pixel / point / segment in the ORC_* encoding; -1 = outside raster */

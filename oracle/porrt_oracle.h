@@ -159,6 +159,23 @@ uint64_t   orc_reach_get(const orc_reach *r, uint64_t id);
 int        orc_reach_is_final_set_complete(orc_reach *r);
 size_t     orc_reach_final_nodes_for_world(const orc_reach *r, uint32_t world, uint64_t *out, size_t cap);
 
+/* ------------------------------------------------------------------ belief.c
+ * PTO::build_belief_graph (pto.rs:185-259) and the belief-state functions it calls */
+uint64_t orc_belief_hash(const double *bs, uint32_t n);                                     /* common.rs:352-355 */
+int      orc_belief_successors(const orc_ctx *c, const double *belief, uint32_t zone, double *out /* 2*n_worlds */);
+int      orc_zone_observable(const orc_ctx *c, const double xy[2], uint32_t zone);
+int64_t  orc_observe(const orc_ctx *c, const double xy[2], const double *belief, double *out, size_t cap_vectors);
+int64_t  orc_reachable_beliefs(const orc_ctx *c, const double *start, double *out /* may be NULL */, size_t cap_vectors);
+int      orc_build_belief_graph(orc_ctx *c, const double *start_belief);
+void     orc_bg_release(orc_ctx *c);
+uint64_t orc_bg_num_beliefs(const orc_ctx *c);
+uint64_t orc_bg_num_nodes(const orc_ctx *c);      /* n_nodes * n_beliefs; belief node id = node * n_beliefs + belief */
+uint64_t orc_bg_num_edges(const orc_ctx *c);
+int      orc_bg_get_beliefs(const orc_ctx *c, double *out);
+int      orc_bg_get_types(const orc_ctx *c, uint8_t *out);      /* 0 Unknown, 1 Action, 2 Observation */
+int      orc_bg_get_children(const orc_ctx *c, uint64_t *off, uint32_t *ids);
+int      orc_bg_get_parents(const orc_ctx *c, uint64_t *off, uint32_t *ids);
+
 #ifdef __cplusplus
 }
 #endif
