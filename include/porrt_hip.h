@@ -142,6 +142,28 @@ int      porrt_best_cost(const porrt_ctx *ctx, double *cost, uint64_t *final_id)
  * costs[q] = +inf where context q has no solution.  Other sets of contexts are evaluated one after the other. */
 int      porrt_best_cost_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, double *costs);
 
+/* ---- belief-space expansion: PTO::build_belief_graph (src/pto.rs:185-259) on the graph of the last
+ * porrt_grow(mode PORRT_MODE_PTO) of this context, with PTOFuncs::reachable_belief_states (map_io.rs:515-546,
+ * map_shelves_io.rs:490-520), PTOFuncs::observe (map_io.rs:281-300, map_shelves_io.rs:242-265) and
+ * compute_compatibility (common.rs:266-276).  start_belief: one probability per world, summing to 1
+ * (assert_belief_state_validity, common.rs:279-281).
+ * Belief node id = graph node * n_beliefs + belief id -- the order of BeliefGraph::add_node at pto.rs:198-201;
+ * node_to_belief_nodes[node][belief] is Some(that id) iff the belief is compatible with the node's validity, i.e. iff
+ * the pair can have edges.  Children / parents come back as CSR lists in the reference's Vec::push order.
+ * The lists stay on the device for the rows that follow; the getters copy them out.
+ * Errors: the panics of the path ("no id corresponding to this belief state", hash collisions, raster faults in the
+ * visibility raycast) become negative return codes. */
+int      porrt_build_belief_graph(porrt_ctx *ctx, const double *start_belief, uint32_t n_worlds);
+uint64_t porrt_bg_num_beliefs(const porrt_ctx *ctx);                 /* reachable_belief_states().len() */
+uint64_t porrt_bg_num_nodes(const porrt_ctx *ctx);                   /* n graph nodes * n beliefs */
+uint64_t porrt_bg_num_edges(const porrt_ctx *ctx);
+int      porrt_bg_get_beliefs(const porrt_ctx *ctx, double *out /* n_beliefs * n_worlds */);
+int      porrt_bg_get_observable_zones(const porrt_ctx *ctx, uint64_t *masks /* per graph node: bit z = zone z seen */);
+int      porrt_bg_get_node_types(const porrt_ctx *ctx, uint8_t *types /* 0 Unknown, 1 Action, 2 Observation (belief_graph.rs:13-17) */);
+int      porrt_bg_get_children(const porrt_ctx *ctx, uint64_t *off /* n_nodes + 1 */, uint32_t *ids /* n_edges, may be NULL */);
+int      porrt_bg_get_parents(const porrt_ctx *ctx, uint64_t *off, uint32_t *ids);
+int      porrt_bg_get_seconds(const porrt_ctx *ctx, double *total_s, double *device_s, double *host_tables_s);
+
 /* ---- measurement */
 typedef struct {
     uint64_t n_iter;          /* iterations run */

@@ -219,6 +219,32 @@ int orc_build_belief_graph(orc_ctx *c, const double *start_belief) {
     uint32_t *aid = malloc((2 * c->n_edges + 1) * sizeof(uint32_t)), *aval = malloc((2 * c->n_edges + 1) * sizeof(uint32_t));
     uint64_t *fill = malloc((N + 1) * sizeof(uint64_t));
     memcpy(fill, aoff, (N + 1) * sizeof(uint64_t));
+    /* KdTree::nearest_neighbors lists the neighbours of one new node in kd pre-order (nearest_neighbor.rs:101-117);
+     * the sequential algorithm already logged its edges that way (no-op below), the batched ones logged the same
+     * sets in search order, so each group is put into pre-order of the kd-tree of all nodes (KdTree::add in id order;
+     * the relative pre-order of two nodes never changes once both are in the tree). */
+    {
+        uint64_t *pre = malloc(N * sizeof(uint64_t)), *rank = malloc(N * sizeof(uint64_t));
+        const double root[2] = {c->nx[0], c->ny[0]};
+        orc_kdtree *kd = orc_kd_new(root, 0);
+        for (size_t i = 1; i < N; ++i) { const double s[2] = {c->nx[i], c->ny[i]}; orc_kd_add(kd, s, i); }
+        size_t got = orc_kd_radius(kd, root, 1e300, pre, N);
+        orc_kd_free(kd);
+        if (got != N) { free(pre); free(rank); free(fill); free(aoff); free(aid); free(aval); free(bh); free(compat); bg_free(g); snprintf(c->err, sizeof c->err, "kd pre-order failed"); return -5; }
+        for (size_t k = 0; k < N; ++k) rank[pre[k]] = k;
+        for (uint64_t e = 0; e < c->n_edges;) {
+            uint64_t e1 = e;
+            while (e1 < c->n_edges && c->edges[e1].to == c->edges[e].to) ++e1;
+            for (uint64_t a = e + 1; a < e1; ++a) {            /* insertion sort of one neighbour list */
+                orc_edge x = c->edges[a];
+                uint64_t b = a;
+                while (b > e && rank[c->edges[b - 1].from] > rank[x.from]) { c->edges[b] = c->edges[b - 1]; --b; }
+                c->edges[b] = x;
+            }
+            e = e1;
+        }
+        free(pre); free(rank);
+    }
     for (uint64_t e = 0; e < c->n_edges;) {
         uint64_t e1 = e;
         while (e1 < c->n_edges && c->edges[e1].to == c->edges[e].to) ++e1;

@@ -11,6 +11,7 @@
 // No CPU fallback exists: without a HIP device porrt_create() fails.
 #include "../../include/porrt_hip.h"
 #include "porrt_device.hpp"
+#include "porrt_belief.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -227,6 +228,8 @@ struct porrt_ctx {
     uint32_t batch_nodes = 0;
     size_t run_lds_bytes = 0;
     int best_cost_device(double *cost, uint64_t *final_id);
+    BeliefGraphState bg;                   // porrt_build_belief_graph: result of the last build (device CSR)
+    int build_belief_graph(const double *start_belief, uint32_t n_worlds_in);
     int read_best_cost(double *cost, uint64_t *final_id);
     porrt_ctx *batch_leader = nullptr;     // set by porrt_grow_batch: the context whose RunConst array holds this one
     uint32_t batch_slot = 0, batch_size = 0;
@@ -544,6 +547,7 @@ int porrt_ctx::grow(const double start[2], double max_step, double search_radius
     if (!(max_step > 0.0) || !(search_radius >= 0.0)) { set_err("max_step / search_radius"); return PORRT_ERR_INVALID; }
     have_results = false;
     batch_leader = nullptr;
+    bg.release();
     ++results_tag;
     // the sampler state must survive a capacity retry
     const Pcg64 c0 = crng, d0 = drng;
@@ -1053,6 +1057,27 @@ int porrt_ctx::download(unsigned want) {
 }
 
 // ========================================================================================== C ABI
+// PTO::build_belief_graph (pto.rs:185-259) on the graph of the last grow; see porrt_belief.hpp.
+int porrt_ctx::build_belief_graph(const double *start_belief, uint32_t n_worlds_in) {
+    if (!have_results || mode != PORRT_MODE_PTO) { set_err("build_belief_graph: grow a PTO graph first (porrt_grow, mode PORRT_MODE_PTO)"); return PORRT_ERR_INVALID; }
+    if (!start_belief || (int)n_worlds_in != n_worlds) { set_err("build_belief_graph: the start belief needs one probability per world"); return PORRT_ERR_INVALID; }
+    HIPCHK(hipSetDevice(device));
+    int r = download(DL_EDGES | DL_MASKS);
+    if (r) return r;
+    BeliefInputs in{};
+    in.domain = domain; in.n_zones = n_zones; in.n_worlds = n_worlds; in.n_validities = n_validities;
+    in.validities = validities; in.zone_pos = zone_pos; in.visibility = visibility;
+    in.d_rc = d_rc.p;
+    in.N = (size_t)n_nodes; in.E = h_efrom.size();
+    in.d_nx = d_nx.p; in.d_ny = d_ny.p; in.d_vid = d_vid.p; in.h_vid = h_vid.data();
+    in.ef = h_efrom.data(); in.et = h_eto.data(); in.ev = h_etv.data();
+    in.stream = stream;
+    std::string e;
+    r = belief_graph_build(bg, in, start_belief, e);
+    if (r) { bg.release(); set_err(e); }
+    return r;
+}
+
 // Best path cost without downloading the tree (k_best_cost).  1 = found, 0 = no final node, -1 = scratch too small
 // (the caller then walks on the host), other negatives = errors.
 int porrt_ctx::read_best_cost(double *cost, uint64_t *final_id) {
@@ -1598,6 +1623,53 @@ int porrt_best_cost_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, double *costs)
         if (r < 0) return r;
         costs[q] = r ? c : inf;
     }
+    return PORRT_OK;
+}
+
+// ---- belief-space expansion (pto.rs:185-259)
+int porrt_build_belief_graph(porrt_ctx *c, const double *start_belief, uint32_t n_worlds) {
+    return c ? c->build_belief_graph(start_belief, n_worlds) : PORRT_ERR_INVALID;
+}
+uint64_t porrt_bg_num_beliefs(const porrt_ctx *c) { return c && c->bg.valid ? c->bg.B : 0; }
+uint64_t porrt_bg_num_nodes(const porrt_ctx *c) { return c && c->bg.valid ? c->bg.N * c->bg.B : 0; }
+uint64_t porrt_bg_num_edges(const porrt_ctx *c) { return c && c->bg.valid ? c->bg.n_edges : 0; }
+int porrt_bg_get_beliefs(const porrt_ctx *c, double *out) {
+    if (!c || !c->bg.valid || !out) return PORRT_ERR_INVALID;
+    memcpy(out, c->bg.beliefs.data(), c->bg.beliefs.size() * sizeof(double));
+    return PORRT_OK;
+}
+int porrt_bg_get_observable_zones(const porrt_ctx *c, uint64_t *masks) {
+    if (!c || !c->bg.valid || !masks) return PORRT_ERR_INVALID;
+    memcpy(masks, c->bg.h_vis.data(), c->bg.h_vis.size() * sizeof(uint64_t));
+    return PORRT_OK;
+}
+int porrt_bg_get_node_types(const porrt_ctx *cc, uint8_t *types) {
+    porrt_ctx *c = const_cast<porrt_ctx *>(cc);
+    if (!c || !c->bg.valid || !types) return PORRT_ERR_INVALID;
+    HIPCHK_CTX(c, hipSetDevice(c->device));
+    HIPCHK_CTX(c, hipMemcpy(types, c->bg.d_types, c->bg.N * c->bg.B, hipMemcpyDeviceToHost));
+    return PORRT_OK;
+}
+static int bg_get_csr(porrt_ctx *c, const unsigned long long *d_off, const uint32_t *d_ids, uint64_t *off, uint32_t *ids) {
+    if (!c || !c->bg.valid || !off) return PORRT_ERR_INVALID;
+    HIPCHK_CTX(c, hipSetDevice(c->device));
+    HIPCHK_CTX(c, hipMemcpy(off, d_off, (c->bg.N * c->bg.B + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (ids && c->bg.n_edges) HIPCHK_CTX(c, hipMemcpy(ids, d_ids, c->bg.n_edges * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return PORRT_OK;
+}
+int porrt_bg_get_children(const porrt_ctx *cc, uint64_t *off, uint32_t *ids) {
+    porrt_ctx *c = const_cast<porrt_ctx *>(cc);
+    return c ? bg_get_csr(c, c->bg.d_child_off, c->bg.d_child_id, off, ids) : PORRT_ERR_INVALID;
+}
+int porrt_bg_get_parents(const porrt_ctx *cc, uint64_t *off, uint32_t *ids) {
+    porrt_ctx *c = const_cast<porrt_ctx *>(cc);
+    return c ? bg_get_csr(c, c->bg.d_par_off, c->bg.d_par_id, off, ids) : PORRT_ERR_INVALID;
+}
+int porrt_bg_get_seconds(const porrt_ctx *c, double *total_s, double *device_s, double *host_tables_s) {
+    if (!c || !c->bg.valid) return PORRT_ERR_INVALID;
+    if (total_s) *total_s = c->bg.t_total;
+    if (device_s) *device_s = c->bg.t_device;
+    if (host_tables_s) *host_tables_s = c->bg.t_tables;
     return PORRT_OK;
 }
 

@@ -29,6 +29,8 @@ SYMBOLS = [
     "porrt_num_final", "porrt_get_final_ids", "porrt_get_final_masks", "porrt_get_reach", "porrt_get_node_validity",
     "porrt_num_edges", "porrt_get_edges", "porrt_is_final_set_complete", "porrt_n_worlds", "porrt_get_validities",
     "porrt_get_zone_positions", "porrt_best_solution", "porrt_best_cost", "porrt_best_cost_batch", "porrt_get_metrics", "porrt_set_option", "porrt_selftest",
+    "porrt_build_belief_graph", "porrt_bg_num_beliefs", "porrt_bg_num_nodes", "porrt_bg_num_edges", "porrt_bg_get_beliefs",
+    "porrt_bg_get_observable_zones", "porrt_bg_get_node_types", "porrt_bg_get_children", "porrt_bg_get_parents", "porrt_bg_get_seconds",
 ]
 
 
@@ -93,6 +95,16 @@ def load_library():
     sig("porrt_get_zone_positions", C.c_int, vp, _f64p)
     sig("porrt_best_solution", C.c_uint64, vp, vp, C.c_uint64, C.POINTER(C.c_double))
     sig("porrt_best_cost", C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64))
+    sig("porrt_build_belief_graph", C.c_int, vp, _f64p, C.c_uint32)
+    sig("porrt_bg_num_beliefs", C.c_uint64, vp)
+    sig("porrt_bg_num_nodes", C.c_uint64, vp)
+    sig("porrt_bg_num_edges", C.c_uint64, vp)
+    sig("porrt_bg_get_beliefs", C.c_int, vp, _f64p)
+    sig("porrt_bg_get_observable_zones", C.c_int, vp, _u64p)
+    sig("porrt_bg_get_node_types", C.c_int, vp, _u8p)
+    sig("porrt_bg_get_children", C.c_int, vp, _u64p, C.c_void_p)
+    sig("porrt_bg_get_parents", C.c_int, vp, _u64p, C.c_void_p)
+    sig("porrt_bg_get_seconds", C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
     sig("porrt_best_cost_batch", C.c_int, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_double))
     sig("porrt_get_metrics", C.c_int, vp, C.POINTER(Metrics))
     sig("porrt_set_option", C.c_int, vp, C.c_char_p, C.c_int64)
@@ -265,6 +277,37 @@ class Engine:
         if rc < 0:
             engines[0]._chk(rc)
         return costs
+
+    # ---- belief-space expansion (PTO::build_belief_graph, pto.rs:185-259)
+    def build_belief_graph(self, start_belief):
+        b = np.ascontiguousarray(start_belief, dtype=np.float64)
+        self._chk(self._l.porrt_build_belief_graph(self._c, b, len(b)))
+
+    def belief_graph(self, lists=True):
+        """beliefs [B, n_worlds], node types [N*B], (child_off, child_ids), (parent_off, parent_ids)"""
+        B, NB, E = (self._l.porrt_bg_num_beliefs(self._c), self._l.porrt_bg_num_nodes(self._c), self._l.porrt_bg_num_edges(self._c))
+        beliefs = np.zeros((B, self.n_worlds()))
+        types = np.zeros(NB, dtype=np.uint8)
+        coff, poff = np.zeros(NB + 1, dtype=np.uint64), np.zeros(NB + 1, dtype=np.uint64)
+        cid, pid = np.zeros(max(E, 1) if lists else 1, dtype=np.uint32), np.zeros(max(E, 1) if lists else 1, dtype=np.uint32)
+        self._chk(self._l.porrt_bg_get_beliefs(self._c, beliefs))
+        self._chk(self._l.porrt_bg_get_node_types(self._c, types))
+        self._chk(self._l.porrt_bg_get_children(self._c, coff, cid.ctypes.data_as(C.c_void_p) if lists else None))
+        self._chk(self._l.porrt_bg_get_parents(self._c, poff, pid.ctypes.data_as(C.c_void_p) if lists else None))
+        return beliefs, types, (coff, cid[:E] if lists else None), (poff, pid[:E] if lists else None)
+
+    def bg_num_edges(self):
+        return self._l.porrt_bg_num_edges(self._c)
+
+    def observable_zones(self):
+        m = np.zeros(self.num_nodes(), dtype=np.uint64)
+        self._chk(self._l.porrt_bg_get_observable_zones(self._c, m))
+        return m
+
+    def bg_seconds(self):
+        a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+        self._chk(self._l.porrt_bg_get_seconds(self._c, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(total_s=a.value, device_s=b.value, host_tables_s=c.value)
 
     def selftest(self, n=1 << 20):
         a, b = C.c_uint64(0), C.c_uint64(0)
