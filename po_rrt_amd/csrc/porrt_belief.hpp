@@ -10,8 +10,9 @@
 //          observation fold as a TABLE over (set of visible zones, belief): what observe() returns depends on the
 //          node only through the set of zones it sees, and a graph has a handful of distinct sets;
 //   device k_bg_vismask   which zones each node sees (distance test + one raycast per node and zone),
-//          k_bg_children  node type and children list of every belief node (count pass, scan, fill pass),
-//          k_bg_parents   parents list of every belief node (count pass, scan, fill pass).
+//          k_bg_children_count / k_bg_parents_count   node type, number of children / parents of every belief node,
+//          k_scan_*       offsets,
+//          k_bg_fill      the children / parents lists, written as contiguous runs per wave.
 // Lists come out in the reference's Vec::push order: children = observation children in fold order, or the PTO
 // adjacency order filtered; parents = observation parents by ascending belief id, then action parents by ascending
 // graph node id (the order of the two loops at pto.rs:211-257).  Belief node id = node * n_beliefs + belief
@@ -77,9 +78,8 @@ __global__ __launch_bounds__(256) void k_bg_vismask(const RunConst *__restrict__
     if (c != CLS_HIGH) atomicOr(&vis[node], 1ull << z);
 }
 
-// One thread per belief node (node, b).  FILL = false: type and number of children; FILL = true: the list.
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_bg_children(BgConst g) {
+// Count pass, one thread per belief node (node, b): its type and the number of its children.
+__global__ __launch_bounds__(256) void k_bg_children_count(BgConst g) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)g.N * g.B) return;
     const uint32_t node = (uint32_t)(i / g.B), b = (uint32_t)(i % g.B);
@@ -87,74 +87,151 @@ __global__ __launch_bounds__(256) void k_bg_children(BgConst g) {
     const unsigned long long cb = as_global(g.compat)[b];
     uint32_t cnt = 0;
     uint8_t type = BG_UNKNOWN;
-    uint32_t *out = nullptr;
-    if (FILL) out = g.child_id + as_global(g.child_off)[i];
     if ((cb >> v) & 1ull) {
         // observation edges (pto.rs:211-233): (node, b) -> (node, b') for every posterior b' != b of observe(node, b)
         const size_t row = (size_t)as_global(g.mask_idx)[node] * g.B + b;
         const uint32_t o0 = as_global(g.obs_off)[row], o1 = as_global(g.obs_off)[row + 1];
-        for (uint32_t k = o0; k < o1; ++k) {
-            const uint32_t c = as_global(g.obs_child)[k];
-            if ((as_global(g.compat)[c] >> v) & 1ull) {
-                if (FILL) as_global(out)[cnt] = node * g.B + c;
-                ++cnt;
-            }
-        }
+        for (uint32_t k = o0; k < o1; ++k) cnt += (uint32_t)((as_global(g.compat)[as_global(g.obs_child)[k]] >> v) & 1ull);
         if (cnt) type = BG_OBSERVATION;
         else {
             // action edges (pto.rs:235-257): (node, b) -> (child, b) where the child node and the edge are compatible with b
             const unsigned long long a0 = as_global(g.adj_off)[node], a1 = as_global(g.adj_off)[node + 1];
             for (unsigned long long k = a0; k < a1; ++k) {
-                const uint32_t c = as_global(g.adj_id)[k];
-                const uint32_t ev = as_global(g.adj_val)[k], cv = as_global(g.vid)[c];
-                if (((cb >> cv) & 1ull) && ((cb >> ev) & 1ull)) {
-                    if (FILL) as_global(out)[cnt] = c * g.B + b;
-                    ++cnt;
-                }
+                const uint32_t ev = as_global(g.adj_val)[k], cv = as_global(g.vid)[as_global(g.adj_id)[k]];
+                cnt += (uint32_t)(((cb >> cv) & 1ull) & ((cb >> ev) & 1ull));
             }
             if (cnt) type = BG_ACTION;
         }
     }
-    if (!FILL) {
-        as_global(g.types)[i] = type;
-        as_global(g.deg)[i] = cnt;
-    }
+    as_global(g.types)[i] = type;
+    as_global(g.deg)[i] = cnt;
 }
 
-// One thread per belief node (node, b): who points at it.  Needs the types of k_bg_children<false>.
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_bg_parents(BgConst g) {
+// Count pass, one thread per belief node (node, b): how many point at it.  Needs the types of k_bg_children_count.
+__global__ __launch_bounds__(256) void k_bg_parents_count(BgConst g) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)g.N * g.B) return;
     const uint32_t node = (uint32_t)(i / g.B), b = (uint32_t)(i % g.B);
     const uint32_t v = as_global(g.vid)[node];
     const unsigned long long cb = as_global(g.compat)[b];
     uint32_t cnt = 0;
-    uint32_t *out = nullptr;
-    if (FILL) out = g.par_id + as_global(g.par_off)[i];
     if ((cb >> v) & 1ull) {
-        // observation parents: beliefs b_p (ascending) of the same node whose posterior set holds b
         const size_t row = (size_t)as_global(g.mask_idx)[node] * g.B + b;
         const uint32_t o0 = as_global(g.robs_off)[row], o1 = as_global(g.robs_off)[row + 1];
-        for (uint32_t k = o0; k < o1; ++k) {
-            const uint32_t p = as_global(g.robs_par)[k];
-            if ((as_global(g.compat)[p] >> v) & 1ull) {
-                if (FILL) as_global(out)[cnt] = node * g.B + p;
-                ++cnt;
-            }
-        }
-        // action parents: neighbours (ascending id) that are action nodes for b, over a compatible edge
+        for (uint32_t k = o0; k < o1; ++k) cnt += (uint32_t)((as_global(g.compat)[as_global(g.robs_par)[k]] >> v) & 1ull);
         const unsigned long long a0 = as_global(g.radj_off)[node], a1 = as_global(g.radj_off)[node + 1];
         for (unsigned long long k = a0; k < a1; ++k) {
             const uint32_t p = as_global(g.radj_id)[k];
             const uint32_t ev = as_global(g.radj_val)[k], pv = as_global(g.vid)[p];
-            if (((cb >> pv) & 1ull) && ((cb >> ev) & 1ull) && as_global(g.types)[(size_t)p * g.B + b] != BG_OBSERVATION) {
-                if (FILL) as_global(out)[cnt] = p * g.B + b;
-                ++cnt;
+            if (((cb >> pv) & 1ull) && ((cb >> ev) & 1ull) && as_global(g.types)[(size_t)p * g.B + b] != BG_OBSERVATION) ++cnt;
+        }
+    }
+    as_global(g.deg)[i] = cnt;
+}
+
+// Fill pass.  A wave owns 64 consecutive belief nodes (rows) and walks the concatenation of their SOURCE lists, one
+// source element per lane: for the children of an observation node the posterior table row, for those of an action
+// node the PTO adjacency of its graph node; for parents the reverse table row followed by the neighbours by ascending
+// id.  Each lane evaluates the edge condition of its element; a ballot turns the survivors into positions (rank
+// inside the row = survivors of the same row in lower lanes + what the row carried over from the previous 64
+// elements), so what a wave stores per step is one contiguous run of the output array: the lists are written at
+// streaming rate however ragged the rows are.
+struct BgRow {
+    unsigned long long out;       // first output slot of the row
+    unsigned long long adj0;      // first adjacency element (action part)
+    unsigned long long cb;        // compatibility bits of the row's belief
+    uint32_t obs0, n_obs;         // table part: [obs0, obs0 + n_obs)
+    uint32_t node, b;
+    uint32_t v, pad;
+};
+constexpr uint32_t kFillWaves = 4;
+
+template <bool PARENTS>
+__global__ __launch_bounds__(64 * kFillWaves) void k_bg_fill(BgConst g) {
+    __shared__ BgRow rows[kFillWaves][64];
+    __shared__ uint32_t soff[kFillWaves][65];
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const size_t NB = (size_t)g.N * g.B;
+    const size_t i = ((size_t)blockIdx.x * kFillWaves + w) * 64 + lane;
+    // ---- this lane's row: where its source list lives and how long it is
+    uint32_t n_src = 0;
+    BgRow r{};
+    if (i < NB) {
+        r.node = (uint32_t)(i / g.B); r.b = (uint32_t)(i % g.B);
+        r.v = as_global(g.vid)[r.node];
+        r.cb = as_global(g.compat)[r.b];
+        r.out = as_global(PARENTS ? g.par_off : g.child_off)[i];
+        if ((r.cb >> r.v) & 1ull) {
+            const size_t trow = (size_t)as_global(g.mask_idx)[r.node] * g.B + r.b;
+            if (PARENTS) {
+                r.obs0 = as_global(g.robs_off)[trow];
+                r.n_obs = as_global(g.robs_off)[trow + 1] - r.obs0;
+                r.adj0 = as_global(g.radj_off)[r.node];
+                n_src = r.n_obs + (uint32_t)(as_global(g.radj_off)[r.node + 1] - r.adj0);
+            } else {
+                const uint8_t type = as_global(g.types)[i];
+                if (type == BG_OBSERVATION) {
+                    r.obs0 = as_global(g.obs_off)[trow];
+                    r.n_obs = as_global(g.obs_off)[trow + 1] - r.obs0;
+                    n_src = r.n_obs;
+                } else if (type == BG_ACTION) {
+                    r.adj0 = as_global(g.adj_off)[r.node];
+                    n_src = (uint32_t)(as_global(g.adj_off)[r.node + 1] - r.adj0);
+                }
             }
         }
     }
-    if (!FILL) as_global(g.deg)[i] = cnt;
+    rows[w][lane] = r;
+    uint32_t inc = n_src;                                  // inclusive scan over the wave's rows
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    soff[w][lane + 1] = inc;
+    if (lane == 0) soff[w][0] = 0;
+    const uint32_t total = __shfl(inc, 63, 64);
+    __syncthreads();                                       // (each wave only reads its own rows; every thread reaches this)
+    uint32_t carry_row = 0xFFFFFFFFu, carry_cnt = 0;
+    for (uint32_t q0 = 0; q0 < total; q0 += 64) {
+        const uint32_t q = q0 + lane;
+        const bool live = q < total;
+        uint32_t row = 0;
+        {   // last row whose first source index is <= q (rows with no sources are skipped by the "<=")
+            uint32_t lo = 0, hi = 64;
+            const uint32_t qq = live ? q : total - 1;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (soff[w][mid] <= qq) lo = mid; else hi = mid;
+            }
+            row = lo;
+        }
+        const BgRow &R = rows[w][row];
+        const uint32_t k = (live ? q : total - 1) - soff[w][row];
+        bool pass = false;
+        uint32_t value = 0;
+        if (live) {
+            if (k < R.n_obs) {
+                const uint32_t c = as_global(PARENTS ? g.robs_par : g.obs_child)[R.obs0 + k];
+                pass = (as_global(g.compat)[c] >> R.v) & 1ull;
+                value = R.node * g.B + c;
+            } else {
+                const unsigned long long e = R.adj0 + (k - R.n_obs);
+                const uint32_t c = as_global(PARENTS ? g.radj_id : g.adj_id)[e];
+                const uint32_t ev = as_global(PARENTS ? g.radj_val : g.adj_val)[e], cv = as_global(g.vid)[c];
+                pass = ((R.cb >> cv) & 1ull) && ((R.cb >> ev) & 1ull);
+                if (PARENTS && pass) pass = as_global(g.types)[(size_t)c * g.B + R.b] != BG_OBSERVATION;
+                value = c * g.B + R.b;
+            }
+        }
+        const unsigned long long ballot = __ballot(pass);
+        const uint32_t seg = k < lane ? lane - k : 0u;     // first lane of this row in this step
+        const unsigned long long below = (1ull << lane) - 1ull, before_seg = (1ull << seg) - 1ull;
+        uint32_t rank = (uint32_t)__popcll(ballot & below & ~before_seg);
+        if (row == carry_row) rank += carry_cnt;
+        if (pass) as_global(PARENTS ? g.par_id : g.child_id)[R.out + rank] = value;
+        carry_row = __shfl(row, 63, 64);
+        carry_cnt = __shfl(rank + (pass ? 1u : 0u), 63, 64);
+    }
 }
 
 // ---- exclusive scan of deg[n] (u32) into off[n+1] (u64): block totals, one block over the totals, apply
@@ -534,16 +611,17 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
         return r;
     const dim3 grid((unsigned)((NB + 255) / 256)), block(256);
     BG_HIP(hipEventRecord(ev2, s));
-    hipLaunchKernelGGL(k_bg_children<false>, grid, block, 0, s, c);
+    hipLaunchKernelGGL(k_bg_children_count, grid, block, 0, s, c);
     bg_scan(c.deg, NB, d_tot, c.child_off, s);
     unsigned long long n_edges = 0;
     BG_HIP(hipMemcpyAsync(&n_edges, c.child_off + NB, sizeof n_edges, hipMemcpyDeviceToHost, s));
     BG_HIP(hipStreamSynchronize(s));
     if ((r = bg_alloc(g, c.child_id, n_edges, err)) || (r = bg_alloc(g, c.par_id, n_edges, err))) return r;
-    hipLaunchKernelGGL(k_bg_children<true>, grid, block, 0, s, c);
-    hipLaunchKernelGGL(k_bg_parents<false>, grid, block, 0, s, c);
+    const dim3 fgrid((unsigned)((NB + 64 * kFillWaves - 1) / (64 * kFillWaves))), fblock(64 * kFillWaves);
+    hipLaunchKernelGGL(k_bg_fill<false>, fgrid, fblock, 0, s, c);
+    hipLaunchKernelGGL(k_bg_parents_count, grid, block, 0, s, c);
     bg_scan(c.deg, NB, d_tot, c.par_off, s);
-    hipLaunchKernelGGL(k_bg_parents<true>, grid, block, 0, s, c);
+    hipLaunchKernelGGL(k_bg_fill<true>, fgrid, fblock, 0, s, c);
     BG_HIP(hipEventRecord(ev3, s));
     unsigned long long n_par = 0;
     BG_HIP(hipMemcpyAsync(&n_par, c.par_off + NB, sizeof n_par, hipMemcpyDeviceToHost, s));
