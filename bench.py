@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event roofline pass")
     ap.add_argument("--no-single-query", action="store_true", help="skip the single-query (latency mode) reference run")
+    ap.add_argument("--no-belief", action="store_true", help="skip the belief-space expansion measurement (SURVEY 8f.1)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps run with per-kernel HIP events for `roofline`")
     args = ap.parse_args()
 
@@ -229,9 +230,58 @@ def main():
             }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(case, args)
+        if not args.no_belief and world == 1:
+            out["config"]["belief_space"] = belief_space(local_rank, not args.no_cpu_baseline)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def belief_space(device, with_cpu):
+    """The next row of the path (SURVEY 8f.1), outside the timed region: PTO::build_belief_graph (pto.rs:185-259) on the
+    12-shelf problem of main.rs:386-408 -- a PTO graph of 5000 iterations expanded over the 4095 reachable beliefs."""
+    import cases
+    import po_rrt_amd
+    case = cases.cfg4(5000, 5000)
+    case.update(start=(0.0, -0.3))
+    e = cases.configure(po_rrt_amd.Engine(device), case)
+    cases.grow(e, case, K=256)
+    prior = [1.0 / 12] * 12
+    runs = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        e.build_belief_graph(prior)
+        runs.append((time.perf_counter() - t0, e.bg_seconds()))
+    runs = sorted(runs[1:], key=lambda r: r[0])            # the first build also fetches and orders the PTO edges
+    wall, sec = runs[len(runs) // 2]
+    E, N = e.bg_num_edges(), e.num_nodes()
+    nb = N * 4095
+    list_bytes = 2 * 4.0 * E + 2 * 8.0 * (nb + 1) + nb     # both id arrays, both offset arrays, the node types
+    out = {
+        "what": "PTO::build_belief_graph: %d graph nodes x 4095 beliefs (12 shelves, uniform prior)" % N,
+        "belief_nodes": nb, "edges": E,
+        "ms_wall": 1e3 * wall, "ms_device": 1e3 * sec["device_s"], "ms_host_tables": 1e3 * sec["host_tables_s"],
+        "edges_per_s": E / wall,
+        "roofline": {"bound": "hbm", "kernel": "k_bg_fill + k_bg_*_count + k_scan_*", "achieved": list_bytes / sec["device_s"] / 1e9,
+                     "peak": 8000.0, "unit": "GB/s", "frac": list_bytes / sec["device_s"] / 1e9 / 8000.0,
+                     "algorithmic_bytes": list_bytes,
+                     "note": "bytes of the result (CSR ids, offsets, types) over the device time of all belief kernels (HIP events)"},
+    }
+    if with_cpu:
+        from oracle import orc
+        small = cases.cfg4(5000, 5000)
+        small.update(start=(0.0, -0.3))
+        o = cases.configure(orc.Oracle(), small)
+        cases.grow(o, small, K=256, algo=orc.ALGO_BATCHED_KD)
+        sample_prior = [0.125] * 8 + [0.0] * 4            # 255 beliefs: 1/16 of the workload, same graph
+        t0 = time.perf_counter()
+        o.build_belief_graph(sample_prior)
+        dt = time.perf_counter() - t0
+        Eo = int(o._l.orc_bg_num_edges(o._c))
+        out["cpu_baseline"] = {"value": Eo / dt, "unit": "edges/s", "cores": 1, "kind": "port",
+                               "sample": "the same PTO graph with 8 of the 12 worlds possible (255 beliefs, %d edges), %.2f s; "
+                                         "C restatement of pto.rs:185-259 (oracle/belief.c)" % (Eo, dt)}
+    return out
 
 
 def cpu_baseline(case, args):

@@ -162,7 +162,9 @@ int      porrt_bg_get_observable_zones(const porrt_ctx *ctx, uint64_t *masks /* 
 int      porrt_bg_get_node_types(const porrt_ctx *ctx, uint8_t *types /* 0 Unknown, 1 Action, 2 Observation (belief_graph.rs:13-17) */);
 int      porrt_bg_get_children(const porrt_ctx *ctx, uint64_t *off /* n_nodes + 1 */, uint32_t *ids /* n_edges, may be NULL */);
 int      porrt_bg_get_parents(const porrt_ctx *ctx, uint64_t *off, uint32_t *ids);
-int      porrt_bg_get_seconds(const porrt_ctx *ctx, double *total_s, double *device_s, double *host_tables_s);
+/* seconds of the last build: [0] total, [1] device kernels (HIP events), [2] host tables, [3] reachable beliefs,
+ * [4] observation fold table, [5] adjacency lists, [6] device allocation + uploads, [7] fetching the PTO edges */
+int      porrt_bg_get_seconds(const porrt_ctx *ctx, double *out, uint32_t n);
 
 /* ---- measurement */
 typedef struct {

@@ -29,6 +29,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -39,7 +40,7 @@ enum : uint8_t { BG_UNKNOWN = 0, BG_ACTION = 1, BG_OBSERVATION = 2 };     // bel
 
 // what the kernels read; all pointers are device memory
 struct BgConst {
-    uint32_t N, B, nz, n_masks;
+    uint32_t N, B, nz, n_masks, n_validities;
     const double *nx, *ny;            // node coordinates
     const uint8_t *vid;               // node validity id
     const double *zone_xy;            // [nz][2]
@@ -55,6 +56,7 @@ struct BgConst {
     const uint32_t *radj_id;
     const uint8_t *radj_val;
     uint8_t *types;                   // [N*B]
+    unsigned long long *obs_bits;     // [N*B/64+1]: bit i = belief node i is an observation node
     uint32_t *deg;                    // [N*B] scratch of the count passes
     unsigned long long *child_off, *par_off;  // [N*B+1]
     uint32_t *child_id, *par_id;
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(256) void k_bg_children_count(BgConst g) {
         else {
             // action edges (pto.rs:235-257): (node, b) -> (child, b) where the child node and the edge are compatible with b
             const unsigned long long a0 = as_global(g.adj_off)[node], a1 = as_global(g.adj_off)[node + 1];
+#pragma unroll 4
             for (unsigned long long k = a0; k < a1; ++k) {
                 const uint32_t ev = as_global(g.adj_val)[k], cv = as_global(g.vid)[as_global(g.adj_id)[k]];
                 cnt += (uint32_t)(((cb >> cv) & 1ull) & ((cb >> ev) & 1ull));
@@ -105,6 +108,8 @@ __global__ __launch_bounds__(256) void k_bg_children_count(BgConst g) {
     }
     as_global(g.types)[i] = type;
     as_global(g.deg)[i] = cnt;
+    const unsigned long long obs = __ballot(type == BG_OBSERVATION);     // blocks start at multiples of 256: a wave covers one aligned word
+    if ((threadIdx.x & 63u) == 0) as_global(g.obs_bits)[i >> 6] = obs;
 }
 
 // Count pass, one thread per belief node (node, b): how many point at it.  Needs the types of k_bg_children_count.
@@ -120,10 +125,13 @@ __global__ __launch_bounds__(256) void k_bg_parents_count(BgConst g) {
         const uint32_t o0 = as_global(g.robs_off)[row], o1 = as_global(g.robs_off)[row + 1];
         for (uint32_t k = o0; k < o1; ++k) cnt += (uint32_t)((as_global(g.compat)[as_global(g.robs_par)[k]] >> v) & 1ull);
         const unsigned long long a0 = as_global(g.radj_off)[node], a1 = as_global(g.radj_off)[node + 1];
+#pragma unroll 4
         for (unsigned long long k = a0; k < a1; ++k) {
             const uint32_t p = as_global(g.radj_id)[k];
             const uint32_t ev = as_global(g.radj_val)[k], pv = as_global(g.vid)[p];
-            if (((cb >> pv) & 1ull) && ((cb >> ev) & 1ull) && as_global(g.types)[(size_t)p * g.B + b] != BG_OBSERVATION) ++cnt;
+            const size_t bit = (size_t)p * g.B + b;
+            const unsigned long long word = as_global(g.obs_bits)[bit >> 6];
+            cnt += (uint32_t)(((cb >> pv) & 1ull) & ((cb >> ev) & 1ull) & (~(word >> (bit & 63)) & 1ull));
         }
     }
     as_global(g.deg)[i] = cnt;
@@ -192,45 +200,129 @@ __global__ __launch_bounds__(64 * kFillWaves) void k_bg_fill(BgConst g) {
     const uint32_t total = __shfl(inc, 63, 64);
     __syncthreads();                                       // (each wave only reads its own rows; every thread reaches this)
     uint32_t carry_row = 0xFFFFFFFFu, carry_cnt = 0;
-    for (uint32_t q0 = 0; q0 < total; q0 += 64) {
-        const uint32_t q = q0 + lane;
-        const bool live = q < total;
-        uint32_t row = 0;
-        {   // last row whose first source index is <= q (rows with no sources are skipped by the "<=")
-            uint32_t lo = 0, hi = 64;
-            const uint32_t qq = live ? q : total - 1;
+    constexpr uint32_t U = 4;                               // steps in flight: their loads are independent, only the ranks chain
+    // Common case, served without the search: the 64 rows are beliefs of ONE graph node and all of them walk its whole
+    // adjacency (no table part) -- row and element index are a division by the common length, node data are scalars.
+    const uint32_t d0 = __builtin_amdgcn_readfirstlane(n_src), node0 = __builtin_amdgcn_readfirstlane(r.node);
+    const bool same = __ballot(i < NB && n_src == d0 && r.node == node0 && r.n_obs == 0) == ~0ull;
+    if (same && d0 > 0 && d0 < (1u << 17)) {
+        const unsigned long long adj0 = __builtin_amdgcn_readfirstlane((uint32_t)r.adj0) |
+                                        ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(r.adj0 >> 32)) << 32);
+        const uint32_t b0 = __builtin_amdgcn_readfirstlane(r.b);
+        const float inv_d = 1.0f / (float)d0;
+        const bool one_validity = g.n_validities == 1;      // then every belief is compatible with every node and edge
+        for (uint32_t q0 = 0; q0 < total; q0 += 64 * U) {
+            uint32_t row[U], k[U], c[U], ev[U];
+            bool live[U], pass[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint32_t q = q0 + u * 64 + lane;
+                live[u] = q < total;
+                const uint32_t qq = live[u] ? q : total - 1;
+                uint32_t rr = (uint32_t)((float)qq * inv_d);          // qq < 2^23: off by one at most
+                if (rr * d0 > qq) --rr;
+                else if ((rr + 1) * d0 <= qq) ++rr;
+                row[u] = rr;
+                k[u] = qq - rr * d0;
+                c[u] = as_global(PARENTS ? g.radj_id : g.adj_id)[adj0 + k[u]];
+                ev[u] = one_validity ? 0u : (uint32_t)as_global(PARENTS ? g.radj_val : g.adj_val)[adj0 + k[u]];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                bool ok = live[u];
+                if (!one_validity) {
+                    const unsigned long long cb = rows[w][row[u]].cb;
+                    const uint32_t cv = as_global(g.vid)[c[u]];
+                    ok = ok && ((cb >> cv) & 1ull) && ((cb >> ev[u]) & 1ull);
+                }
+                if (PARENTS) {
+                    const size_t bit = (size_t)c[u] * g.B + (b0 + row[u]);
+                    ok = ok && !((as_global(g.obs_bits)[bit >> 6] >> (bit & 63)) & 1ull);
+                }
+                pass[u] = ok;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                if (q0 + u * 64 >= total) break;            // wave-uniform
+                const unsigned long long ballot = __ballot(pass[u]);
+                const uint32_t seg = k[u] < lane ? lane - k[u] : 0u;
+                const unsigned long long below = (1ull << lane) - 1ull, before_seg = (1ull << seg) - 1ull;
+                uint32_t rank = (uint32_t)__popcll(ballot & below & ~before_seg);
+                if (row[u] == carry_row) rank += carry_cnt;
+                if (pass[u]) as_global(PARENTS ? g.par_id : g.child_id)[rows[w][row[u]].out + rank] = c[u] * g.B + (b0 + row[u]);
+                carry_row = __shfl(row[u], 63, 64);
+                carry_cnt = __shfl(rank + (pass[u] ? 1u : 0u), 63, 64);
+            }
+        }
+        return;
+    }
+    for (uint32_t q0 = 0; q0 < total; q0 += 64 * U) {
+        uint32_t row[U], k[U], value[U];
+        bool live[U], pass[U];
+        unsigned long long out0[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t q = q0 + u * 64 + lane;
+            live[u] = q < total;
+            const uint32_t qq = live[u] ? q : total - 1;
+            uint32_t lo = 0, hi = 64;                       // last row whose first source index is <= q (empty rows are skipped by the "<=")
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) >> 1;
                 if (soff[w][mid] <= qq) lo = mid; else hi = mid;
             }
-            row = lo;
+            row[u] = lo;
+            k[u] = qq - soff[w][lo];
         }
-        const BgRow &R = rows[w][row];
-        const uint32_t k = (live ? q : total - 1) - soff[w][row];
-        bool pass = false;
-        uint32_t value = 0;
-        if (live) {
-            if (k < R.n_obs) {
-                const uint32_t c = as_global(PARENTS ? g.robs_par : g.obs_child)[R.obs0 + k];
-                pass = (as_global(g.compat)[c] >> R.v) & 1ull;
-                value = R.node * g.B + c;
-            } else {
-                const unsigned long long e = R.adj0 + (k - R.n_obs);
-                const uint32_t c = as_global(PARENTS ? g.radj_id : g.adj_id)[e];
-                const uint32_t ev = as_global(PARENTS ? g.radj_val : g.adj_val)[e], cv = as_global(g.vid)[c];
-                pass = ((R.cb >> cv) & 1ull) && ((R.cb >> ev) & 1ull);
-                if (PARENTS && pass) pass = as_global(g.types)[(size_t)c * g.B + R.b] != BG_OBSERVATION;
-                value = c * g.B + R.b;
+        uint32_t c[U], ev[U];
+        bool table[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const BgRow &R = rows[w][row[u]];
+            table[u] = k[u] < R.n_obs;
+            out0[u] = R.out;
+            c[u] = 0; ev[u] = 0;
+            if (live[u]) {
+                if (table[u]) c[u] = as_global(PARENTS ? g.robs_par : g.obs_child)[R.obs0 + k[u]];
+                else {
+                    const unsigned long long e = R.adj0 + (k[u] - R.n_obs);
+                    c[u] = as_global(PARENTS ? g.radj_id : g.adj_id)[e];
+                    ev[u] = as_global(PARENTS ? g.radj_val : g.adj_val)[e];
+                }
             }
         }
-        const unsigned long long ballot = __ballot(pass);
-        const uint32_t seg = k < lane ? lane - k : 0u;     // first lane of this row in this step
-        const unsigned long long below = (1ull << lane) - 1ull, before_seg = (1ull << seg) - 1ull;
-        uint32_t rank = (uint32_t)__popcll(ballot & below & ~before_seg);
-        if (row == carry_row) rank += carry_cnt;
-        if (pass) as_global(PARENTS ? g.par_id : g.child_id)[R.out + rank] = value;
-        carry_row = __shfl(row, 63, 64);
-        carry_cnt = __shfl(rank + (pass ? 1u : 0u), 63, 64);
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const BgRow &R = rows[w][row[u]];
+            pass[u] = false;
+            value[u] = 0;
+            if (live[u]) {
+                if (table[u]) {
+                    pass[u] = (as_global(g.compat)[c[u]] >> R.v) & 1ull;
+                    value[u] = R.node * g.B + c[u];
+                } else {
+                    const uint32_t cv = as_global(g.vid)[c[u]];
+                    bool ok = ((R.cb >> cv) & 1ull) && ((R.cb >> ev[u]) & 1ull);
+                    if (PARENTS) {
+                        const size_t bit = (size_t)c[u] * g.B + R.b;
+                        ok = ok && !((as_global(g.obs_bits)[bit >> 6] >> (bit & 63)) & 1ull);
+                    }
+                    pass[u] = ok;
+                    value[u] = c[u] * g.B + R.b;
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            if (q0 + u * 64 >= total) break;                // wave-uniform
+            const unsigned long long ballot = __ballot(pass[u]);
+            const uint32_t seg = k[u] < lane ? lane - k[u] : 0u;     // first lane of this row in this step
+            const unsigned long long below = (1ull << lane) - 1ull, before_seg = (1ull << seg) - 1ull;
+            uint32_t rank = (uint32_t)__popcll(ballot & below & ~before_seg);
+            if (row[u] == carry_row) rank += carry_cnt;
+            if (pass[u]) as_global(PARENTS ? g.par_id : g.child_id)[out0[u] + rank] = value[u];
+            carry_row = __shfl(row[u], 63, 64);
+            carry_cnt = __shfl(rank + (pass[u] ? 1u : 0u), 63, 64);
+        }
     }
 }
 
@@ -314,12 +406,16 @@ struct BeliefSpace {
     // common.rs:352-355 (usize arithmetic; a release build wraps)
     static uint64_t hash_of(const double *p, uint32_t n) {
         uint64_t h = 0, p10 = 1;
-        for (uint32_t i = 0; i < n; ++i) {
-            const double r = std::round(p[i] * 1000.0);
-            uint64_t q = 0;
-            if (r == r && r > 0.0) q = r >= 18446744073709551615.0 ? ~0ull : (uint64_t)r;
+        for (uint32_t i = 0; i < n; ++i, p10 *= 10) {
+            const double x = p[i] * 1000.0;
+            if (!(x > 0.0)) continue;                        // zero, negative and NaN all cast to 0
+            uint64_t q;
+            if (x >= 18446744073709551615.0) q = ~0ull;      // `as usize` saturates
+            else {
+                q = (uint64_t)x;                             // f64::round = half away from zero: trunc, then the exact remainder
+                if (x - (double)q >= 0.5) ++q;
+            }
             h += (p10 + 1) * q;
-            p10 *= 10;
         }
         return h;
     }
@@ -338,56 +434,95 @@ struct BeliefSpace {
                 o[w] = keep ? b[w] : 0.0;
                 sum = sum + o[w];
             }
-            bool nan = false;
-            for (uint32_t w = 0; w < nw; ++w) {
-                o[w] /= sum;
-                nan |= o[w] != o[w];
-            }
+            bool nan = sum != sum || sum == 0.0;             // x / 0 with x == 0 somewhere, or NaN inputs: a NaN posterior, dropped
+            if (!nan)
+                for (uint32_t w = 0; w < nw; ++w) {
+                    o[w] /= sum;
+                    nan |= o[w] != o[w];
+                }
             if (nan) out.resize(at0);
         }
     }
-    static std::string key_of(const double *p, uint32_t n) {          // exact equality of vectors (Vec::contains)
-        std::string k(n * sizeof(double), '\0');
-        for (uint32_t w = 0; w < n; ++w) {
-            const double v = p[w] == 0.0 ? 0.0 : p[w];
-            std::memcpy(&k[w * sizeof(double)], &v, sizeof(double));
+    // Vec::contains over the reachable list: exact equality of vectors, as an open-addressing table of list indices
+    struct ExactSet {
+        const BeliefSpace *bs;
+        std::vector<uint32_t> slot;                       // index + 1, 0 = empty
+        size_t used = 0;
+        static uint64_t mix(const double *p, uint32_t n) {
+            uint64_t h = 1469598103934665603ull;
+            for (uint32_t w = 0; w < n; ++w) {
+                const double v = p[w] == 0.0 ? 0.0 : p[w];  // -0.0 == 0.0
+                uint64_t u;
+                std::memcpy(&u, &v, 8);
+                h = (h ^ u) * 1099511628211ull;
+                h ^= h >> 29;
+            }
+            return h;
         }
-        return k;
-    }
+        bool equal(uint32_t id, const double *p) const {
+            const double *q = bs->at(id);
+            for (uint32_t w = 0; w < bs->nw; ++w) if (!(q[w] == p[w])) return false;
+            return true;
+        }
+        bool contains(const double *p) const {
+            const size_t m = slot.size() - 1;
+            for (size_t k = mix(p, bs->nw) & m;; k = (k + 1) & m) {
+                if (!slot[k]) return false;
+                if (equal(slot[k] - 1, p)) return true;
+            }
+        }
+        void insert(uint32_t id) {
+            if (2 * (used + 1) > slot.size()) {
+                std::vector<uint32_t> old;
+                old.swap(slot);
+                slot.assign(std::max<size_t>(64, 2 * old.size()), 0);
+                used = 0;
+                for (uint32_t v : old) if (v) insert(v - 1);
+            }
+            const size_t m = slot.size() - 1;
+            size_t k = mix(bs->at(id), bs->nw) & m;
+            while (slot[k]) k = (k + 1) & m;
+            slot[k] = id + 1;
+            ++used;
+        }
+    };
     // reachable_belief_states (map_io.rs:515-546): depth-first over (belief, zones still to check); a successor is new
     // when neither its exact vector nor its hash is known; note that the start's hash is never entered in the set
     int reach_from(const double *start, std::string &err) {
         vec.assign(start, start + nw);
-        std::unordered_set<std::string> exact{key_of(start, nw)};
+        ExactSet exact{this};
+        exact.slot.assign(64, 0);
+        exact.insert(0);
         std::unordered_set<uint64_t> hashes;
-        struct Item { std::vector<double> b; uint64_t zones; };
-        std::vector<Item> lifo;
-        lifo.push_back({std::vector<double>(start, start + nw), nz >= 64 ? ~0ull : ((1ull << nz) - 1)});
-        std::vector<double> succ;
-        while (!lifo.empty()) {
-            Item it = std::move(lifo.back());
-            lifo.pop_back();
+        std::vector<double> pool(start, start + nw);      // the LIFO's belief vectors, one after the other
+        std::vector<uint64_t> zones_of{nz >= 64 ? ~0ull : ((1ull << nz) - 1)};
+        std::vector<double> succ, cur(nw);
+        while (!zones_of.empty()) {
+            const uint64_t zones = zones_of.back();
+            std::memcpy(cur.data(), pool.data() + pool.size() - nw, nw * sizeof(double));
+            zones_of.pop_back();
+            pool.resize(pool.size() - nw);
             for (int z = 0; z < nz; ++z) {
-                if (!((it.zones >> z) & 1ull)) continue;
+                if (!((zones >> z) & 1ull)) continue;
                 succ.clear();
-                successors(it.b.data(), z, succ);
+                successors(cur.data(), z, succ);
                 for (size_t s = 0; s * nw < succ.size(); ++s) {
                     const double *v = succ.data() + s * nw;
-                    std::string k = key_of(v, nw);
-                    if (exact.count(k)) continue;
+                    if (exact.contains(v)) continue;
                     const uint64_t h = hash_of(v, nw);
-                    if (!hashes.count(h)) {
+                    if (hashes.insert(h).second) {
                         vec.insert(vec.end(), v, v + nw);
-                        exact.insert(std::move(k));
-                        hashes.insert(h);
+                        exact.insert((uint32_t)(vec.size() / nw - 1));
                     }
-                    lifo.push_back({std::vector<double>(v, v + nw), it.zones & ~(1ull << z)});
+                    pool.insert(pool.end(), v, v + nw);
+                    zones_of.push_back(zones & ~(1ull << z));
                 }
             }
         }
         const size_t B = vec.size() / nw;
         hash.resize(B);
         by_hash.clear();
+        by_hash.reserve(2 * B);
         for (size_t b = 0; b < B; ++b) {
             hash[b] = hash_of(at(b), nw);
             if (!by_hash.emplace(hash[b], (uint32_t)b).second) { err = "collision when hashing the belief states! (belief_graph.rs:82)"; return PORRT_ERR_INVALID; }
@@ -396,8 +531,8 @@ struct BeliefSpace {
     }
     // observe_impl for a node that sees exactly the zones of `mask`: posterior belief ids, in the reference's order,
     // without those that hash like the prior (pto.rs:217)
-    int posteriors(uint32_t b, uint64_t mask, std::vector<uint32_t> &out, std::string &err) const {
-        std::vector<double> cur(at(b), at(b) + nw), nxt;
+    int posteriors(uint32_t b, uint64_t mask, std::vector<uint32_t> &out, std::string &err, std::vector<double> &cur, std::vector<double> &nxt) const {
+        cur.assign(at(b), at(b) + nw);
         for (int z = 0; z < nz; ++z) {
             if (!((mask >> z) & 1ull)) continue;
             nxt.clear();
@@ -416,26 +551,54 @@ struct BeliefSpace {
     }
 };
 
+// What depends on the problem (domain, worlds, prior) but not on the graph: the reachable beliefs and, per set of
+// visible zones met so far, the posterior table.  Kept across builds of one context: replanning on a new graph
+// with the same prior pays for neither again.
+struct BeliefCache {
+    int domain = -1, nz = 0, nv = 0;
+    uint32_t nw = 0;
+    std::vector<uint64_t> validities;
+    std::vector<double> start;
+    BeliefSpace space;
+    std::vector<unsigned long long> compat;
+    struct Fold { std::vector<uint32_t> cnt, child; };        // per belief: number of posteriors; their ids one after the other
+    std::map<uint64_t, Fold> folds;
+    bool matches(int d, int z, int v, uint32_t w, const uint64_t *val, const double *st) const {
+        if (d != domain || z != nz || v != nv || w != nw) return false;
+        for (int k = 0; k < v; ++k) if (validities[k] != val[k]) return false;
+        return std::memcmp(start.data(), st, w * sizeof(double)) == 0;
+    }
+};
+
 // Result of the last build; owns its device memory.
 struct BeliefGraphState {
     bool valid = false;
+    BeliefCache cache;
     uint32_t nw = 0;
     size_t N = 0, B = 0;
     uint64_t n_edges = 0;
     std::vector<double> beliefs;
     std::vector<uint64_t> h_vis;                      // zones seen per node
-    double t_total = 0, t_device = 0, t_tables = 0;
-    std::vector<void *> owned;
+    double t_total = 0, t_device = 0, t_tables = 0, t_reach = 0, t_post = 0, t_adj = 0, t_alloc = 0, t_edges = 0;
+    // device buffers: a build asks for them in a fixed order; each slot keeps its allocation for the next build and
+    // only grows (hipFree / hipMalloc of GB-sized lists cost more than filling them)
+    struct Slot { void *p = nullptr; size_t bytes = 0; };
+    std::vector<Slot> slots;
+    size_t next_slot = 0;
     uint8_t *d_types = nullptr;
     unsigned long long *d_child_off = nullptr, *d_par_off = nullptr;
     uint32_t *d_child_id = nullptr, *d_par_id = nullptr;
-    void release() {
-        for (void *p : owned) (void)hipFree(p);
-        owned.clear();
+    void release() {                                   // the result is gone, the memory stays for the next build
+        next_slot = 0;
         valid = false;
         d_types = nullptr; d_child_off = d_par_off = nullptr; d_child_id = d_par_id = nullptr;
     }
-    ~BeliefGraphState() { release(); }
+    void free_device() {
+        release();
+        for (Slot &sl : slots) if (sl.p) (void)hipFree(sl.p);
+        slots.clear();
+    }
+    ~BeliefGraphState() { free_device(); }
 };
 
 struct BeliefInputs {
@@ -459,10 +622,17 @@ struct BeliefInputs {
 
 template <class T>
 static int bg_alloc(BeliefGraphState &g, T *&p, size_t n, std::string &err) {
-    void *q = nullptr;
-    BG_HIP(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
-    g.owned.push_back(q);
-    p = (T *)q;
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    if (g.next_slot == g.slots.size()) g.slots.emplace_back();
+    BeliefGraphState::Slot &sl = g.slots[g.next_slot++];
+    if (sl.bytes < bytes) {
+        if (sl.p) (void)hipFree(sl.p);
+        sl.p = nullptr; sl.bytes = 0;
+        const size_t want = bytes + bytes / 8;
+        BG_HIP(hipMalloc(&sl.p, want));
+        sl.bytes = want;
+    }
+    p = (T *)sl.p;
     return PORRT_OK;
 }
 template <class T>
@@ -496,24 +666,10 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
         for (int w = 0; w < in.n_worlds; ++w) s = start_belief[w] + s;
         if (!(std::fabs(s - 1.0) < 0.000001)) { err = "start belief state does not sum to 1"; return PORRT_ERR_INVALID; }
     }
-    BeliefSpace bs;
-    bs.domain = in.domain; bs.nz = in.n_zones; bs.nw = (uint32_t)in.n_worlds; bs.validities = in.validities;
-    int r = bs.reach_from(start_belief, err);
-    if (r) return r;
-    const size_t B = bs.size(), N = in.N;
-    if (N * B >= 0xFFFFFFFFull) { err = "build_belief_graph: more than 2^32 belief nodes"; return PORRT_ERR_INVALID; }
-    g.nw = bs.nw; g.N = N; g.B = B;
-    g.beliefs = bs.vec;
-    std::vector<unsigned long long> compat(B, 0);                   // compute_compatibility (common.rs:266-276)
-    for (size_t b = 0; b < B; ++b)
-        for (int v = 0; v < in.n_validities; ++v) {
-            bool ok = true;
-            for (uint32_t w = 0; w < bs.nw && ok; ++w) ok = !(bs.at(b)[w] > 0.0) || ((in.validities[v] >> w) & 1ull);
-            if (ok) compat[b] |= 1ull << v;
-        }
-
+    int r = PORRT_OK;
     BgConst c{};
-    c.N = (uint32_t)N; c.B = (uint32_t)B; c.nz = (uint32_t)in.n_zones;
+    const size_t N = in.N;
+    c.N = (uint32_t)N; c.B = 0; c.nz = (uint32_t)in.n_zones; c.n_validities = (uint32_t)in.n_validities;
     c.nx = in.d_nx; c.ny = in.d_ny; c.vid = in.d_vid; c.visibility = in.visibility;
     hipStream_t s = in.stream;
     hipEvent_t ev0, ev1, ev2, ev3;
@@ -538,6 +694,57 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
     uint32_t h_err = 0;
     BG_HIP(hipMemcpyAsync(g.h_vis.data(), d_vis, N * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     BG_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    // ... while the raycasts run: the belief states and the adjacency lists, which do not depend on them
+    const double tr0 = bg_now();
+    BeliefCache &bc = g.cache;
+    if (!bc.matches(in.domain, in.n_zones, in.n_validities, (uint32_t)in.n_worlds, in.validities, start_belief)) {
+        bc = BeliefCache();
+        bc.domain = in.domain; bc.nz = in.n_zones; bc.nv = in.n_validities; bc.nw = (uint32_t)in.n_worlds;
+        bc.validities.assign(in.validities, in.validities + in.n_validities);
+        bc.start.assign(start_belief, start_belief + in.n_worlds);
+        bc.space.domain = in.domain; bc.space.nz = in.n_zones; bc.space.nw = bc.nw; bc.space.validities = bc.validities.data();
+        r = bc.space.reach_from(start_belief, err);
+        if (r) { bc = BeliefCache(); (void)hipStreamSynchronize(s); return r; }          // the copies above target this frame
+        bc.compat.assign(bc.space.size(), 0);                       // compute_compatibility (common.rs:266-276)
+        for (size_t b = 0; b < bc.space.size(); ++b)
+            for (int v = 0; v < in.n_validities; ++v) {
+                bool ok = true;
+                for (uint32_t w = 0; w < bc.nw && ok; ++w) ok = !(bc.space.at(b)[w] > 0.0) || ((in.validities[v] >> w) & 1ull);
+                if (ok) bc.compat[b] |= 1ull << v;
+            }
+    }
+    const BeliefSpace &bs = bc.space;
+    const std::vector<unsigned long long> &compat = bc.compat;
+    g.t_reach = bg_now() - tr0;
+    const size_t B = bs.size();
+    c.B = (uint32_t)B;
+    if (N * B >= 0xFFFFFFFFull) { (void)hipStreamSynchronize(s); err = "build_belief_graph: more than 2^32 belief nodes"; return PORRT_ERR_INVALID; }
+    g.nw = bs.nw; g.N = N; g.B = B;
+    g.beliefs = bs.vec;
+
+    // PTOGraph::children in push order (pto.rs:111-120): per new node, first every add_edge(nbr, new), then every add_edge(new, nbr)
+    const double tj0 = bg_now();
+    std::vector<unsigned long long> adj_off(N + 1, 0);
+    for (size_t e = 0; e < in.E; ++e) { adj_off[in.ef[e] + 1]++; adj_off[in.et[e] + 1]++; }
+    for (size_t i = 0; i < N; ++i) adj_off[i + 1] += adj_off[i];
+    std::vector<uint32_t> adj_id(2 * in.E), radj_id(2 * in.E);
+    std::vector<uint8_t> adj_val(2 * in.E), radj_val(2 * in.E);
+    {
+        std::vector<unsigned long long> fill(adj_off.begin(), adj_off.end() - 1);
+        for (size_t e = 0; e < in.E;) {
+            size_t e1 = e;
+            while (e1 < in.E && in.et[e1] == in.et[e]) ++e1;
+            for (size_t k = e; k < e1; ++k) { const auto p = fill[in.ef[k]]++; adj_id[p] = in.et[k]; adj_val[p] = (uint8_t)in.ev[k]; }
+            for (size_t k = e; k < e1; ++k) { const auto p = fill[in.et[k]]++; adj_id[p] = in.ef[k]; adj_val[p] = (uint8_t)in.ev[k]; }
+            e = e1;
+        }
+        // the same lists by ascending neighbour id (the order in which the action-edge loop reaches a node's parents):
+        // walking the nodes upwards and appending u to each of its neighbours' lists leaves every list sorted
+        std::copy(adj_off.begin(), adj_off.end() - 1, fill.begin());
+        for (size_t u = 0; u < N; ++u)
+            for (auto k = adj_off[u]; k < adj_off[u + 1]; ++k) { const auto p = fill[adj_id[k]]++; radj_id[p] = (uint32_t)u; radj_val[p] = adj_val[k]; }
+    }
+    g.t_adj = bg_now() - tj0;
     BG_HIP(hipStreamSynchronize(s));
     if (h_err) { err = "observe: raster access the reference would panic on (image::get_pixel / two zones on one ray, map_io.rs:233)"; return PORRT_ERR_RASTER; }
 
@@ -554,45 +761,68 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
     const size_t M = masks.size();
     c.n_masks = (uint32_t)M;
     std::vector<uint32_t> obs_off(M * B + 1, 0), obs_child, robs_off(M * B + 1, 0), robs_par;
-    for (size_t m = 0; m < M; ++m) {
-        std::vector<std::vector<uint32_t>> rev(B);
-        for (size_t b = 0; b < B; ++b) {
-            if (masks[m]) {
-                if ((r = bs.posteriors((uint32_t)b, masks[m], obs_child, err))) return r;
-            }
-            obs_off[m * B + b + 1] = (uint32_t)obs_child.size();
-            for (uint32_t k = obs_off[m * B + b]; k < obs_off[m * B + b + 1]; ++k) rev[obs_child[k]].push_back((uint32_t)b);
-        }
-        for (size_t b = 0; b < B; ++b) {
-            robs_par.insert(robs_par.end(), rev[b].begin(), rev[b].end());
-            robs_off[m * B + b + 1] = (uint32_t)robs_par.size();
-        }
-    }
-    // PTOGraph::children in push order (pto.rs:111-120): per new node, first every add_edge(nbr, new), then every add_edge(new, nbr)
-    std::vector<unsigned long long> adj_off(N + 1, 0);
-    for (size_t e = 0; e < in.E; ++e) { adj_off[in.ef[e] + 1]++; adj_off[in.et[e] + 1]++; }
-    for (size_t i = 0; i < N; ++i) adj_off[i + 1] += adj_off[i];
-    std::vector<uint32_t> adj_id(2 * in.E), radj_id(2 * in.E);
-    std::vector<uint8_t> adj_val(2 * in.E), radj_val(2 * in.E);
     {
-        std::vector<unsigned long long> fill(adj_off.begin(), adj_off.end() - 1);
-        for (size_t e = 0; e < in.E;) {
-            size_t e1 = e;
-            while (e1 < in.E && in.et[e1] == in.et[e]) ++e1;
-            for (size_t k = e; k < e1; ++k) { const auto p = fill[in.ef[k]]++; adj_id[p] = in.et[k]; adj_val[p] = (uint8_t)in.ev[k]; }
-            for (size_t k = e; k < e1; ++k) { const auto p = fill[in.et[k]]++; adj_id[p] = in.ef[k]; adj_val[p] = (uint8_t)in.ev[k]; }
-            e = e1;
+        // the fold of every (new zone set, belief) pair, pairs split evenly over a few host threads; each thread
+        // appends to its own list, the lists are cut into the per-set tables in pair order
+        std::vector<uint64_t> fresh;
+        for (uint64_t m : masks) if (m && !bc.folds.count(m)) fresh.push_back(m);
+        const size_t pairs = fresh.size() * B;
+        if (pairs) {
+            unsigned nt = std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+            if (pairs < 8192) nt = 1;
+            std::vector<std::vector<uint32_t>> part(nt);
+            std::vector<uint32_t> cnt(pairs, 0);
+            std::vector<std::string> perr(nt);
+            std::vector<int> prc(nt, PORRT_OK);
+            auto work = [&](unsigned t) {
+                std::vector<double> cur, nxt;
+                const size_t p0 = pairs * t / nt, p1 = pairs * (t + 1) / nt;
+                for (size_t pr = p0; pr < p1; ++pr) {
+                    const size_t before = part[t].size();
+                    if ((prc[t] = bs.posteriors((uint32_t)(pr % B), fresh[pr / B], part[t], perr[t], cur, nxt))) return;
+                    cnt[pr] = (uint32_t)(part[t].size() - before);
+                }
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+            for (unsigned t = 0; t < nt; ++t) if (prc[t]) { err = perr[t]; return prc[t]; }
+            std::vector<uint32_t> all;
+            for (unsigned t = 0; t < nt; ++t) all.insert(all.end(), part[t].begin(), part[t].end());
+            size_t at = 0;
+            for (size_t f = 0; f < fresh.size(); ++f) {
+                BeliefCache::Fold &fd = bc.folds[fresh[f]];
+                fd.cnt.assign(cnt.begin() + f * B, cnt.begin() + (f + 1) * B);
+                size_t n = 0;
+                for (uint32_t v : fd.cnt) n += v;
+                fd.child.assign(all.begin() + at, all.begin() + at + n);
+                at += n;
+            }
         }
-        // the same lists by ascending neighbour id: the order in which the action-edge loop reaches a node's parents
-        std::vector<std::pair<uint32_t, uint8_t>> tmp;
-        for (size_t i = 0; i < N; ++i) {
-            tmp.clear();
-            for (auto k = adj_off[i]; k < adj_off[i + 1]; ++k) tmp.emplace_back(adj_id[k], adj_val[k]);
-            std::stable_sort(tmp.begin(), tmp.end(), [](const auto &a, const auto &b2) { return a.first < b2.first; });
-            for (size_t k = 0; k < tmp.size(); ++k) { radj_id[adj_off[i] + k] = tmp[k].first; radj_val[adj_off[i] + k] = tmp[k].second; }
+        for (size_t m = 0; m < M; ++m) {
+            if (!masks[m]) { for (size_t b = 0; b < B; ++b) obs_off[m * B + b + 1] = obs_off[m * B + b]; continue; }
+            const BeliefCache::Fold &fd = bc.folds[masks[m]];
+            for (size_t b = 0; b < B; ++b) obs_off[m * B + b + 1] = obs_off[m * B + b] + fd.cnt[b];
+            obs_child.insert(obs_child.end(), fd.child.begin(), fd.child.end());
+        }
+        // reverse table: for every posterior its priors, ascending (counting sort per zone set)
+        robs_par.resize(obs_child.size());
+        std::vector<uint32_t> cur(B);
+        for (size_t m = 0; m < M; ++m) {
+            const uint32_t lo = obs_off[m * B], hi = obs_off[(m + 1) * B];
+            std::fill(cur.begin(), cur.end(), 0u);
+            for (uint32_t k = lo; k < hi; ++k) cur[obs_child[k]]++;
+            uint32_t run = lo;
+            for (size_t b = 0; b < B; ++b) { robs_off[m * B + b] = run; const uint32_t n = cur[b]; cur[b] = run; run += n; }
+            robs_off[(m + 1) * B] = hi;
+            for (size_t b = 0; b < B; ++b)
+                for (uint32_t k = obs_off[m * B + b]; k < obs_off[m * B + b + 1]; ++k) robs_par[cur[obs_child[k]]++] = (uint32_t)b;
         }
     }
-    g.t_tables = bg_now() - tt0;
+    g.t_post = bg_now() - tt0;
+    g.t_tables = g.t_post + g.t_adj + g.t_reach;
+    const double ta0 = bg_now();
     if ((r = bg_upload(g, c.compat, compat, s, err)) || (r = bg_upload(g, c.mask_idx, mask_idx, s, err)) ||
         (r = bg_upload(g, c.obs_off, obs_off, s, err)) || (r = bg_upload(g, c.obs_child, obs_child, s, err)) ||
         (r = bg_upload(g, c.robs_off, robs_off, s, err)) || (r = bg_upload(g, c.robs_par, robs_par, s, err)) ||
@@ -606,17 +836,22 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
     const size_t NB = N * B;
     const size_t nblk = (NB + kScanTile - 1) / kScanTile;
     unsigned long long *d_tot = nullptr;
-    if ((r = bg_alloc(g, c.types, NB, err)) || (r = bg_alloc(g, c.deg, NB, err)) || (r = bg_alloc(g, c.child_off, NB + 1, err)) ||
+    if ((r = bg_alloc(g, c.types, NB, err)) || (r = bg_alloc(g, c.obs_bits, NB / 64 + 2, err)) || (r = bg_alloc(g, c.deg, NB, err)) || (r = bg_alloc(g, c.child_off, NB + 1, err)) ||
         (r = bg_alloc(g, c.par_off, NB + 1, err)) || (r = bg_alloc(g, d_tot, nblk + 1, err)))
         return r;
     const dim3 grid((unsigned)((NB + 255) / 256)), block(256);
+    g.t_alloc = bg_now() - ta0;
     BG_HIP(hipEventRecord(ev2, s));
     hipLaunchKernelGGL(k_bg_children_count, grid, block, 0, s, c);
     bg_scan(c.deg, NB, d_tot, c.child_off, s);
     unsigned long long n_edges = 0;
     BG_HIP(hipMemcpyAsync(&n_edges, c.child_off + NB, sizeof n_edges, hipMemcpyDeviceToHost, s));
     BG_HIP(hipStreamSynchronize(s));
-    if ((r = bg_alloc(g, c.child_id, n_edges, err)) || (r = bg_alloc(g, c.par_id, n_edges, err))) return r;
+    {
+        const double tb0 = bg_now();
+        if ((r = bg_alloc(g, c.child_id, n_edges, err)) || (r = bg_alloc(g, c.par_id, n_edges, err))) return r;
+        g.t_alloc += bg_now() - tb0;
+    }
     const dim3 fgrid((unsigned)((NB + 64 * kFillWaves - 1) / (64 * kFillWaves))), fblock(64 * kFillWaves);
     hipLaunchKernelGGL(k_bg_fill<false>, fgrid, fblock, 0, s, c);
     hipLaunchKernelGGL(k_bg_parents_count, grid, block, 0, s, c);

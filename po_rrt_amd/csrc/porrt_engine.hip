@@ -1062,8 +1062,10 @@ int porrt_ctx::build_belief_graph(const double *start_belief, uint32_t n_worlds_
     if (!have_results || mode != PORRT_MODE_PTO) { set_err("build_belief_graph: grow a PTO graph first (porrt_grow, mode PORRT_MODE_PTO)"); return PORRT_ERR_INVALID; }
     if (!start_belief || (int)n_worlds_in != n_worlds) { set_err("build_belief_graph: the start belief needs one probability per world"); return PORRT_ERR_INVALID; }
     HIPCHK(hipSetDevice(device));
+    const double te0 = now_s();
     int r = download(DL_EDGES | DL_MASKS);
     if (r) return r;
+    const double t_edges = now_s() - te0;
     BeliefInputs in{};
     in.domain = domain; in.n_zones = n_zones; in.n_worlds = n_worlds; in.n_validities = n_validities;
     in.validities = validities; in.zone_pos = zone_pos; in.visibility = visibility;
@@ -1075,6 +1077,7 @@ int porrt_ctx::build_belief_graph(const double *start_belief, uint32_t n_worlds_
     std::string e;
     r = belief_graph_build(bg, in, start_belief, e);
     if (r) { bg.release(); set_err(e); }
+    else { bg.t_edges = t_edges; bg.t_total += t_edges; }
     return r;
 }
 
@@ -1665,11 +1668,10 @@ int porrt_bg_get_parents(const porrt_ctx *cc, uint64_t *off, uint32_t *ids) {
     porrt_ctx *c = const_cast<porrt_ctx *>(cc);
     return c ? bg_get_csr(c, c->bg.d_par_off, c->bg.d_par_id, off, ids) : PORRT_ERR_INVALID;
 }
-int porrt_bg_get_seconds(const porrt_ctx *c, double *total_s, double *device_s, double *host_tables_s) {
-    if (!c || !c->bg.valid) return PORRT_ERR_INVALID;
-    if (total_s) *total_s = c->bg.t_total;
-    if (device_s) *device_s = c->bg.t_device;
-    if (host_tables_s) *host_tables_s = c->bg.t_tables;
+int porrt_bg_get_seconds(const porrt_ctx *c, double *out, uint32_t n) {
+    if (!c || !c->bg.valid || !out) return PORRT_ERR_INVALID;
+    const double v[8] = {c->bg.t_total, c->bg.t_device, c->bg.t_tables, c->bg.t_reach, c->bg.t_post, c->bg.t_adj, c->bg.t_alloc, c->bg.t_edges};
+    for (uint32_t k = 0; k < n && k < 8; ++k) out[k] = v[k];
     return PORRT_OK;
 }
 

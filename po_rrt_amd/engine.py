@@ -104,7 +104,7 @@ def load_library():
     sig("porrt_bg_get_node_types", C.c_int, vp, _u8p)
     sig("porrt_bg_get_children", C.c_int, vp, _u64p, C.c_void_p)
     sig("porrt_bg_get_parents", C.c_int, vp, _u64p, C.c_void_p)
-    sig("porrt_bg_get_seconds", C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+    sig("porrt_bg_get_seconds", C.c_int, vp, _f64p, C.c_uint32)
     sig("porrt_best_cost_batch", C.c_int, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_double))
     sig("porrt_get_metrics", C.c_int, vp, C.POINTER(Metrics))
     sig("porrt_set_option", C.c_int, vp, C.c_char_p, C.c_int64)
@@ -305,9 +305,10 @@ class Engine:
         return m
 
     def bg_seconds(self):
-        a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
-        self._chk(self._l.porrt_bg_get_seconds(self._c, C.byref(a), C.byref(b), C.byref(c)))
-        return dict(total_s=a.value, device_s=b.value, host_tables_s=c.value)
+        v = np.zeros(8)
+        self._chk(self._l.porrt_bg_get_seconds(self._c, v, 8))
+        keys = ("total_s", "device_s", "host_tables_s", "reach_s", "fold_table_s", "adjacency_s", "alloc_upload_s", "edges_fetch_s")
+        return dict(zip(keys, v.tolist()))
 
     def selftest(self, n=1 << 20):
         a, b = C.c_uint64(0), C.c_uint64(0)

@@ -29,4 +29,5 @@ for n_worlds_possible in (8, 12):
         print("worlds %2d  graph nodes %6d  belief nodes %9d  edges %11d  wall %.4f s  total %.4f  device %.4f  tables %.4f  "
               "lists %.1f GB/s (device time)" % (n_worlds_possible, e.num_nodes(), nb, E, wall, s["total_s"], s["device_s"],
                                                  s["host_tables_s"], bytes_out / max(s["device_s"], 1e-9) / 1e9), flush=True)
+        print("     " + "  ".join("%s %.2f ms" % (k[:-2], 1e3 * v) for k, v in s.items()), flush=True)
         del e
