@@ -56,7 +56,8 @@ struct BgConst {
     const uint32_t *radj_id;
     const uint8_t *radj_val;
     uint8_t *types;                   // [N*B]
-    unsigned long long *obs_bits;     // [N*B/64+1]: bit i = belief node i is an observation node
+    unsigned long long *obs_bits;     // [N*B/64+2]: bit node*B + b = belief node (node, b) is an observation node
+    unsigned long long *obs_bits_t;   // the same bits transposed: bit b*N + node (the parents fill reads one belief's row)
     uint32_t *deg;                    // [N*B] scratch of the count passes
     unsigned long long *child_off, *par_off;  // [N*B+1]
     uint32_t *child_id, *par_id;
@@ -78,6 +79,25 @@ __global__ __launch_bounds__(256) void k_bg_vismask(const RunConst *__restrict__
     const int c = traversed_class(rc, grid, x, y, zx, zy, &err);
     if (err) atomicOr(err_out, err);
     if (c != CLS_HIGH) atomicOr(&vis[node], 1ull << z);
+}
+
+// Sets the observation bit of belief node i = node * B + b in both planes (zeroed before the launch).  The lanes of a
+// wave hold consecutive i, so their bits fall into at most two words of the (node, b) plane: one ballot, two atomics.
+__device__ __forceinline__ void mark_obs(const BgConst &g, size_t i, uint32_t node, uint32_t b, bool is_obs) {
+    const unsigned long long ballot = __ballot(is_obs);
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long first = __ballot(true);
+    if (ballot && lane == (uint32_t)__ffsll((long long)first) - 1u) {
+        const size_t i0 = i - lane;                         // flat index lane 0 holds (or would hold)
+        const uint32_t sh = (uint32_t)(i0 & 63);
+        const unsigned long long lo = ballot << sh, hi = sh ? ballot >> (64 - sh) : 0ull;
+        if (lo) atomicOr(&g.obs_bits[i0 >> 6], lo);
+        if (hi) atomicOr(&g.obs_bits[(i0 >> 6) + 1], hi);
+    }
+    if (is_obs) {
+        const size_t t = (size_t)b * g.N + node;
+        atomicOr(&g.obs_bits_t[t >> 6], 1ull << (t & 63));
+    }
 }
 
 // Count pass, one thread per belief node (node, b): its type and the number of its children.
@@ -108,8 +128,7 @@ __global__ __launch_bounds__(256) void k_bg_children_count(BgConst g) {
     }
     as_global(g.types)[i] = type;
     as_global(g.deg)[i] = cnt;
-    const unsigned long long obs = __ballot(type == BG_OBSERVATION);     // blocks start at multiples of 256: a wave covers one aligned word
-    if ((threadIdx.x & 63u) == 0) as_global(g.obs_bits)[i >> 6] = obs;
+    mark_obs(g, i, node, b, type == BG_OBSERVATION);
 }
 
 // Count pass, one thread per belief node (node, b): how many point at it.  Needs the types of k_bg_children_count.
@@ -135,6 +154,67 @@ __global__ __launch_bounds__(256) void k_bg_parents_count(BgConst g) {
         }
     }
     as_global(g.deg)[i] = cnt;
+}
+
+// The same two count passes for many beliefs per node (B >= 256): a workgroup takes 256 beliefs of ONE graph node,
+// stages the node's neighbour list in LDS (id and the two validity bits an edge needs, 256 neighbours at a time) and
+// every thread walks the staged list for its belief -- the per-neighbour loads that all threads shared become one.
+template <bool PARENTS>
+__global__ __launch_bounds__(256) void k_bg_count_tiled(BgConst g, uint32_t chunks) {
+    __shared__ uint32_t s_id[256];
+    __shared__ unsigned long long s_req[256];
+    const uint32_t node = blockIdx.x / chunks, b = (blockIdx.x % chunks) * 256u + threadIdx.x;
+    const bool valid = b < g.B;
+    const uint32_t v = as_global(g.vid)[node];
+    const unsigned long long cb = valid ? as_global(g.compat)[b] : 0ull;
+    const bool rowok = valid && ((cb >> v) & 1ull);
+    const size_t i = (size_t)node * g.B + b;
+    uint32_t cnt = 0;
+    if (rowok) {
+        const size_t row = (size_t)as_global(g.mask_idx)[node] * g.B + b;
+        const uint32_t *off = PARENTS ? g.robs_off : g.obs_off, *lst = PARENTS ? g.robs_par : g.obs_child;
+        const uint32_t o0 = as_global(off)[row], o1 = as_global(off)[row + 1];
+        for (uint32_t k = o0; k < o1; ++k) cnt += (uint32_t)((as_global(g.compat)[as_global(lst)[k]] >> v) & 1ull);
+    }
+    const bool is_obs = !PARENTS && cnt > 0;
+    const unsigned long long a0 = as_global(PARENTS ? g.radj_off : g.adj_off)[node], a1 = as_global(PARENTS ? g.radj_off : g.adj_off)[node + 1];
+    uint32_t acnt = 0;
+    if (!PARENTS && g.n_validities == 1) {
+        if (rowok && !is_obs) acnt = (uint32_t)(a1 - a0);   // one validity: every edge of a compatible row passes
+    } else {
+        for (unsigned long long t0 = a0; t0 < a1; t0 += 256) {
+            __syncthreads();
+            if (t0 + threadIdx.x < a1) {
+                const uint32_t id = as_global(PARENTS ? g.radj_id : g.adj_id)[t0 + threadIdx.x];
+                const uint32_t ev = as_global(PARENTS ? g.radj_val : g.adj_val)[t0 + threadIdx.x];
+                s_id[threadIdx.x] = id;
+                s_req[threadIdx.x] = (1ull << as_global(g.vid)[id]) | (1ull << ev);
+            }
+            __syncthreads();
+            const uint32_t n = (uint32_t)(a1 - t0 < 256 ? a1 - t0 : 256);
+            if (rowok && !is_obs) {
+#pragma unroll 4
+                for (uint32_t j = 0; j < n; ++j) {
+                    const unsigned long long req = s_req[j];
+                    uint32_t ok = (cb & req) == req;
+                    if (PARENTS) {
+                        const size_t bit = (size_t)s_id[j] * g.B + b;
+                        ok &= (uint32_t)(~(as_global(g.obs_bits)[bit >> 6] >> (bit & 63)) & 1ull);
+                    }
+                    acnt += ok;
+                }
+            }
+        }
+    }
+    if (PARENTS) {
+        if (valid) as_global(g.deg)[i] = cnt + acnt;
+    } else {
+        if (valid) {
+            as_global(g.types)[i] = is_obs ? BG_OBSERVATION : (acnt ? BG_ACTION : BG_UNKNOWN);
+            as_global(g.deg)[i] = is_obs ? cnt : acnt;
+        }
+        mark_obs(g, i, node, b, is_obs);
+    }
 }
 
 // Fill pass.  A wave owns 64 consecutive belief nodes (rows) and walks the concatenation of their SOURCE lists, one
@@ -236,8 +316,8 @@ __global__ __launch_bounds__(64 * kFillWaves) void k_bg_fill(BgConst g) {
                     ok = ok && ((cb >> cv) & 1ull) && ((cb >> ev[u]) & 1ull);
                 }
                 if (PARENTS) {
-                    const size_t bit = (size_t)c[u] * g.B + (b0 + row[u]);
-                    ok = ok && !((as_global(g.obs_bits)[bit >> 6] >> (bit & 63)) & 1ull);
+                    const size_t bit = (size_t)(b0 + row[u]) * g.N + c[u];
+                    ok = ok && !((as_global(g.obs_bits_t)[bit >> 6] >> (bit & 63)) & 1ull);
                 }
                 pass[u] = ok;
             }
@@ -303,8 +383,8 @@ __global__ __launch_bounds__(64 * kFillWaves) void k_bg_fill(BgConst g) {
                     const uint32_t cv = as_global(g.vid)[c[u]];
                     bool ok = ((R.cb >> cv) & 1ull) && ((R.cb >> ev[u]) & 1ull);
                     if (PARENTS) {
-                        const size_t bit = (size_t)c[u] * g.B + R.b;
-                        ok = ok && !((as_global(g.obs_bits)[bit >> 6] >> (bit & 63)) & 1ull);
+                        const size_t bit = (size_t)R.b * g.N + c[u];
+                        ok = ok && !((as_global(g.obs_bits_t)[bit >> 6] >> (bit & 63)) & 1ull);
                     }
                     pass[u] = ok;
                     value[u] = c[u] * g.B + R.b;
@@ -836,13 +916,19 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
     const size_t NB = N * B;
     const size_t nblk = (NB + kScanTile - 1) / kScanTile;
     unsigned long long *d_tot = nullptr;
-    if ((r = bg_alloc(g, c.types, NB, err)) || (r = bg_alloc(g, c.obs_bits, NB / 64 + 2, err)) || (r = bg_alloc(g, c.deg, NB, err)) || (r = bg_alloc(g, c.child_off, NB + 1, err)) ||
+    if ((r = bg_alloc(g, c.types, NB, err)) || (r = bg_alloc(g, c.obs_bits, NB / 64 + 2, err)) || (r = bg_alloc(g, c.obs_bits_t, NB / 64 + 2, err)) || (r = bg_alloc(g, c.deg, NB, err)) || (r = bg_alloc(g, c.child_off, NB + 1, err)) ||
         (r = bg_alloc(g, c.par_off, NB + 1, err)) || (r = bg_alloc(g, d_tot, nblk + 1, err)))
         return r;
     const dim3 grid((unsigned)((NB + 255) / 256)), block(256);
     g.t_alloc = bg_now() - ta0;
     BG_HIP(hipEventRecord(ev2, s));
-    hipLaunchKernelGGL(k_bg_children_count, grid, block, 0, s, c);
+    BG_HIP(hipMemsetAsync(c.obs_bits, 0, (NB / 64 + 2) * sizeof(unsigned long long), s));
+    BG_HIP(hipMemsetAsync(c.obs_bits_t, 0, (NB / 64 + 2) * sizeof(unsigned long long), s));
+    const uint32_t chunks = (uint32_t)((B + 255) / 256);
+    const bool tiled = B >= 256 && (size_t)N * chunks < 0x7FFFFFFFull;
+    const dim3 tgrid((unsigned)(N * chunks));
+    if (tiled) hipLaunchKernelGGL(k_bg_count_tiled<false>, tgrid, block, 0, s, c, chunks);
+    else hipLaunchKernelGGL(k_bg_children_count, grid, block, 0, s, c);
     bg_scan(c.deg, NB, d_tot, c.child_off, s);
     unsigned long long n_edges = 0;
     BG_HIP(hipMemcpyAsync(&n_edges, c.child_off + NB, sizeof n_edges, hipMemcpyDeviceToHost, s));
@@ -854,6 +940,7 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
     }
     const dim3 fgrid((unsigned)((NB + 64 * kFillWaves - 1) / (64 * kFillWaves))), fblock(64 * kFillWaves);
     hipLaunchKernelGGL(k_bg_fill<false>, fgrid, fblock, 0, s, c);
+    // (the staged variant of the parents count measured 3.6 ms against 1.0 ms for the plain one at 18M belief nodes: not used)
     hipLaunchKernelGGL(k_bg_parents_count, grid, block, 0, s, c);
     bg_scan(c.deg, NB, d_tot, c.par_off, s);
     hipLaunchKernelGGL(k_bg_fill<true>, fgrid, fblock, 0, s, c);

@@ -69,6 +69,41 @@ def test_belief_graph_equals_oracle(eng_mod, name):
             assert int((int(vis[i]) >> z) & 1) == o.zone_observable(xy[i], z)
 
 
+def six_door_map():
+    """two rooms split by a wall with six doors (64 worlds, 729 reachable beliefs): exercises the many-beliefs kernels
+    with more than one world validity"""
+    import make_maps
+    a = np.full((200, 200), 255, np.uint8)
+    make_maps.rect(a, -1.0, 0.0, 1.0, 0.04, 0)
+    for x in (-0.85, -0.55, -0.25, 0.05, 0.35, 0.65):
+        make_maps.rect(a, x, 0.0, x + 0.12, 0.04, 128)
+    z, k = make_maps.door_zone_ids(a)
+    assert k == 6
+    return a, z
+
+
+def test_belief_graph_six_doors(eng_mod):
+    occ, zones = six_door_map()
+    objs = []
+    for mk in (eng_mod.Engine, orc.Oracle):
+        x = mk()
+        x.set_grid(occ, (-1.0, -1.0), (1.0, 1.0), cases.DOOR)
+        x.set_zones(zones, 0.45)
+        x.set_sampler((-1.0, -1.0), (1.0, 1.0), 11)
+        x.set_square_goal(np.array([(-0.5, 0.6)]), np.array([(1 << 64) - 1], dtype=np.uint64), 0.05)
+        objs.append(x)
+    e, o = objs
+    e.grow((0.5, -0.6), 0.05, 5.0, 1500, 1500, batch_K=64, mode=cases.PTO)
+    o.grow((0.5, -0.6), 0.05, 5.0, 1500, 1500, batch_K=64, mode=cases.PTO, algo=orc.ALGO_BATCHED_KD)
+    assert np.array_equal(e.tree()[1], o.tree()[1])
+    prior = [1.0 / 64] * 64
+    e.build_belief_graph(prior)
+    o.build_belief_graph(prior)
+    beliefs, types, _, _ = e.belief_graph(lists=False)
+    assert len(beliefs) >= 256 and (types == 2).any() and (types == 1).any()
+    assert_same_belief_graph(e, o)
+
+
 def test_rebuild_with_another_prior_and_after_another_grow(eng_mod):
     case = cases.cfg_door(1500, 1500)
     e, o = grown_pair(eng_mod, case, 64)
