@@ -1,0 +1,49 @@
+// Grows a belief-space graph and expands it over the reachable beliefs with the C++ mirror of the reference interface
+// (cf. src/pto.rs:466-490, test_plan_on_map1_2_goals: grow_graph, then build_belief_graph) and prints digests the tests
+// compare with the CPU oracle.
+// usage: plan_pto <map.pgm> <zone_ids.pgm> <n_iter> <batch_K> <seed>
+#include "../include/porrt.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+static uint64_t fnv(uint64_t h, uint64_t x) {
+    for (int b = 0; b < 8; ++b) { h ^= (x >> (8 * b)) & 0xff; h *= 1099511628211ull; }
+    return h;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 6) { std::fprintf(stderr, "usage: %s map.pgm zone_ids.pgm n_iter batch_K seed\n", argv[0]); return 2; }
+    using namespace po_rrt;
+    try {
+        auto m = MapShelfDomain::open(argv[1], {-1.0, -1.0}, {1.0, 1.0});
+        m.add_zones(argv[2], 0.5);
+        SquareGoal goal({{{0.68, -0.45}, 0b01}, {{0.68, 0.38}, 0b10}}, 0.05);
+        const uint64_t seed = std::strtoull(argv[5], nullptr, 10);
+        PTO pto(ContinuousSampler({-1.0, -1.0}, {1.0, 1.0}, seed), DiscreteSampler(0), m);
+        pto.batch_K = (uint32_t)std::atoi(argv[4]);
+        const size_t n_iter = std::strtoull(argv[3], nullptr, 10);
+        const bool ok = pto.grow_graph({-0.8, -0.8}, goal, 0.05, 5.0, n_iter, n_iter);
+        pto.build_belief_graph({0.5, 0.5});
+        const BeliefGraph &g = pto.belief_graph;
+        uint64_t hc = 1469598103934665603ull, hp = hc, ht = hc;
+        size_t n_some = 0;
+        for (size_t i = 0; i < g.n_nodes(); ++i) {
+            ht = fnv(ht, (uint64_t)g.node_type(i));
+            auto c = g.children(i);
+            hc = fnv(hc, (uint64_t)(c.second - c.first));
+            for (const uint32_t *p = c.first; p != c.second; ++p) hc = fnv(hc, *p);
+            auto q = g.parents(i);
+            hp = fnv(hp, (uint64_t)(q.second - q.first));
+            for (const uint32_t *p = q.first; p != q.second; ++p) hp = fnv(hp, *p);
+        }
+        for (auto &row : pto.node_to_belief_nodes) for (auto &x : row) n_some += x.has_value();
+        std::printf("complete %d nodes %zu beliefs %zu belief_nodes %zu edges %zu types %016llx children %016llx parents %016llx compatible %zu\n",
+                    ok ? 1 : 0, pto.graph.nodes.size(), g.n_beliefs(), g.n_nodes(), g.children_ids.size(), (unsigned long long)ht,
+                    (unsigned long long)hc, (unsigned long long)hp, n_some);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

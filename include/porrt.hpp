@@ -246,6 +246,32 @@ struct PTOGraph {
 };
 
 // pto.rs:15-149 (growth part) with the Reachability read-outs of pto_reachability.rs:54-90
+using BeliefState = std::vector<double>;                       // common.rs: one probability per world
+
+// common.rs:256-264
+inline bool is_compatible(const BeliefState &belief_state, WorldMask validity) {
+    for (size_t w = 0; w < belief_state.size(); ++w)
+        if (belief_state[w] > 0.0 && !((validity >> w) & 1)) return false;
+    return true;
+}
+
+enum class BeliefNodeType : uint8_t { Unknown = 0, Action = 1, Observation = 2 };     // belief_graph.rs:13-17
+
+// BeliefGraph (belief_graph.rs:19-71) in CSR form: node i has node_type(i), children(i), parents(i); its graph node is
+// i / n_beliefs, its belief reachable_belief_states[i % n_beliefs].
+struct BeliefGraph {
+    std::vector<BeliefState> reachable_belief_states;
+    std::vector<uint8_t> node_types;
+    std::vector<uint64_t> children_offsets, parents_offsets;
+    std::vector<uint32_t> children_ids, parents_ids;
+    size_t n_nodes() const { return node_types.size(); }
+    size_t n_beliefs() const { return reachable_belief_states.size(); }
+    BeliefNodeType node_type(size_t i) const { return (BeliefNodeType)node_types[i]; }
+    size_t belief_id(size_t i) const { return i % n_beliefs(); }
+    std::pair<const uint32_t *, const uint32_t *> children(size_t i) const { return {children_ids.data() + children_offsets[i], children_ids.data() + children_offsets[i + 1]}; }
+    std::pair<const uint32_t *, const uint32_t *> parents(size_t i) const { return {parents_ids.data() + parents_offsets[i], parents_ids.data() + parents_offsets[i + 1]}; }
+};
+
 class PTO {
 public:
     uint32_t batch_K = 256;
@@ -296,6 +322,33 @@ public:
         return out;
     }
     int n_worlds() const { return porrt_n_worlds(ctx_.get()); }
+
+    // PTO::build_belief_graph (pto.rs:185-259) on the graph of the last grow_graph.  belief_graph.nodes[i] is the belief
+    // node of graph node i / n_beliefs and belief i % n_beliefs (the add_node order of pto.rs:198-201); children and
+    // parents are views into the two id arrays, in the reference's Vec::push order.
+    void build_belief_graph(const BeliefState &start_belief_state) {
+        ctx_.check(porrt_build_belief_graph(ctx_.get(), start_belief_state.data(), (uint32_t)start_belief_state.size()));
+        BeliefGraph &g = belief_graph;
+        const size_t nb = porrt_bg_num_beliefs(ctx_.get()), nn = porrt_bg_num_nodes(ctx_.get()), ne = porrt_bg_num_edges(ctx_.get());
+        const size_t nw = (size_t)n_worlds();
+        std::vector<double> flat(nb * nw);
+        ctx_.check(porrt_bg_get_beliefs(ctx_.get(), flat.data()));
+        g.reachable_belief_states.assign(nb, BeliefState(nw));
+        for (size_t b = 0; b < nb; ++b) g.reachable_belief_states[b].assign(flat.begin() + b * nw, flat.begin() + (b + 1) * nw);
+        g.node_types.assign(nn, 0);
+        g.children_offsets.assign(nn + 1, 0); g.parents_offsets.assign(nn + 1, 0);
+        g.children_ids.assign(ne, 0); g.parents_ids.assign(ne, 0);
+        ctx_.check(porrt_bg_get_node_types(ctx_.get(), g.node_types.data()));
+        ctx_.check(porrt_bg_get_children(ctx_.get(), g.children_offsets.data(), g.children_ids.data()));
+        ctx_.check(porrt_bg_get_parents(ctx_.get(), g.parents_offsets.data(), g.parents_ids.data()));
+        // node_to_belief_nodes (pto.rs:196-208): Some(id) iff the belief is compatible with the node's validity
+        node_to_belief_nodes.assign(graph.nodes.size(), std::vector<std::optional<size_t>>(nb));
+        for (size_t n = 0; n < graph.nodes.size(); ++n)
+            for (size_t b = 0; b < nb; ++b)
+                if (is_compatible(g.reachable_belief_states[b], graph.validities[graph.nodes[n].validity_id])) node_to_belief_nodes[n][b] = n * nb + b;
+    }
+    BeliefGraph belief_graph;
+    std::vector<std::vector<std::optional<size_t>>> node_to_belief_nodes;
 private:
     Context ctx_;
     std::vector<uint64_t> reach_, final_ids_, final_masks_;

@@ -15,6 +15,7 @@ from oracle import orc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "build_tools", "plan_rrt")
+EXE_PTO = os.path.join(ROOT, "build_tools", "plan_pto")
 MAP = os.path.join(ROOT, "tests", "golden", "maps", "map_benchmark_like.pgm")
 
 
@@ -25,6 +26,11 @@ def exe():
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
     if not os.path.exists(EXE) or os.path.getmtime(EXE) < os.path.getmtime(os.path.join(ROOT, "include", "porrt.hpp")):
         subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-o", EXE, os.path.join(ROOT, "examples", "plan_rrt.cpp"),
+                        "-L" + os.path.join(ROOT, "po_rrt_amd"), "-lporrt_hip", "-Wl,-rpath," + os.path.join(ROOT, "po_rrt_amd")],
+                       check=True)
+    if not os.path.exists(EXE_PTO) or os.path.getmtime(EXE_PTO) < max(os.path.getmtime(os.path.join(ROOT, "include", "porrt.hpp")),
+                                                                     os.path.getmtime(os.path.join(ROOT, "examples", "plan_pto.cpp"))):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-o", EXE_PTO, os.path.join(ROOT, "examples", "plan_pto.cpp"),
                         "-L" + os.path.join(ROOT, "po_rrt_amd"), "-lporrt_hip", "-Wl,-rpath," + os.path.join(ROOT, "po_rrt_amd")],
                        check=True)
     return EXE
@@ -68,3 +74,38 @@ def test_cpp_rrt_plan_matches_oracle(exe, K, nq):
         assert "No solution found" in out.stdout
     else:
         assert int(tok[5]) == len(sol[0]) and float(tok[7]) == sol[1]
+
+
+def fnv_words(h, words):
+    for v in words:
+        v = int(v)
+        for b in range(8):
+            h ^= (v >> (8 * b)) & 0xFF
+            h = (h * 1099511628211) & (2 ** 64 - 1)
+    return h
+
+
+@pytest.mark.gpu
+def test_cpp_pto_belief_graph_matches_oracle(exe):
+    """PTO::grow_graph + PTO::build_belief_graph of the C++ mirror: digests of types, children and parents lists."""
+    n = 2500
+    out = subprocess.run([EXE_PTO, os.path.join(ROOT, "tests", "golden", "maps", "map1_2_goals_like.pgm"),
+                          os.path.join(ROOT, "tests", "golden", "maps", "map1_2_goals_like_zone_ids.pgm"), str(n), "64", "0"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    tok = out.stdout.split()
+    case = cases.cfg3(n, n)
+    o = cases.configure(orc.Oracle(), case)
+    rc = cases.grow(o, case, K=64, algo=orc.ALGO_BATCHED_KD)
+    o.build_belief_graph([0.5, 0.5])
+    beliefs, types, (coff, cid), (poff, pid) = o.belief_graph()
+    h0 = 1469598103934665603
+    hc, hp = h0, h0
+    for i in range(len(types)):
+        hc = fnv_words(fnv_words(hc, [coff[i + 1] - coff[i]]), cid[int(coff[i]):int(coff[i + 1])])
+        hp = fnv_words(fnv_words(hp, [poff[i + 1] - poff[i]]), pid[int(poff[i]):int(poff[i + 1])])
+    assert int(tok[1]) == (1 if rc == 0 else 0)
+    assert int(tok[3]) == o.num_nodes() and int(tok[5]) == len(beliefs) and int(tok[7]) == len(types) and int(tok[9]) == len(cid)
+    assert int(tok[11], 16) == fnv_words(h0, types)
+    assert int(tok[13], 16) == hc and int(tok[15], 16) == hp
+    assert int(tok[17]) == len(types)          # one validity in the shelf domain: every pair is compatible
