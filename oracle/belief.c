@@ -335,3 +335,12 @@ int orc_bg_get_parents(const orc_ctx *c, uint64_t *off, uint32_t *ids) {
     memcpy(ids, c->bg->pid, c->bg->n_edges * sizeof(uint32_t));
     return 0;
 }
+
+/* read-only view for dp.c */
+struct orc_bg_view { size_t B, NB; uint32_t nw; const double *beliefs; const uint8_t *types; const uint64_t *coff, *poff; const uint32_t *cid, *pid; };
+int orc_bg_view_get(const orc_ctx *c, struct orc_bg_view *v) {
+    if (!c->bg) return -1;
+    v->B = c->bg->B; v->NB = c->bg->NB; v->nw = c->bg->nw; v->beliefs = c->bg->beliefs; v->types = c->bg->types;
+    v->coff = c->bg->coff; v->poff = c->bg->poff; v->cid = c->bg->cid; v->pid = c->bg->pid;
+    return 0;
+}

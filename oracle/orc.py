@@ -64,6 +64,10 @@ def lib():
     sig("orc_observe", C.c_int64, vp, _f64p, _f64p, _f64p, C.c_size_t)
     sig("orc_reachable_beliefs", C.c_int64, vp, _f64p, C.c_void_p, C.c_size_t)
     sig("orc_build_belief_graph", C.c_int, vp, _f64p)
+    sig("orc_conditional_dijkstra", C.c_int, C.c_uint64, _f64p, _u32p, _f64p, C.c_uint32, _u8p, _u64p, _u32p, _u64p, _u32p, _u64p, C.c_uint64, _f64p)
+    sig("orc_extract_policy", C.c_int64, C.c_uint64, _f64p, _u32p, _u32p, _f64p, C.c_uint32, _u64p, _u32p, _f64p, _u64p, _i64p, _u8p, C.c_uint64)
+    sig("orc_bg_expected_costs", C.c_int, vp, _f64p)
+    sig("orc_bg_extract_policy", C.c_int64, vp, _f64p, _u64p, _i64p, _u8p, C.c_uint64)
     sig("orc_bg_num_beliefs", C.c_uint64, vp)
     sig("orc_bg_num_nodes", C.c_uint64, vp)
     sig("orc_bg_num_edges", C.c_uint64, vp)
@@ -373,6 +377,20 @@ class Oracle:
         self._chk(self._l.orc_bg_get_parents(self._c, poff, pid))
         return beliefs, types, (coff, cid[:E]), (poff, pid[:E])
 
+    def expected_costs(self):
+        """PTO::compute_expected_costs_to_goals on the last belief graph"""
+        d = np.zeros(self._l.orc_bg_num_nodes(self._c))
+        self._chk(self._l.orc_bg_expected_costs(self._c, d))
+        return d
+
+    def extract_policy(self, dist, cap=1 << 20):
+        """PTO::extract_policy: (original belief node id, parent policy node or -1, is_leaf) per policy node"""
+        oid, par, leaf = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.uint8)
+        n = self._l.orc_bg_extract_policy(self._c, np.ascontiguousarray(dist, dtype=np.float64), oid, par, leaf, cap)
+        if n < 0:
+            raise RuntimeError("extract_policy failed (%d)" % n)
+        return oid[:n], par[:n], leaf[:n]
+
     def is_final_set_complete(self):
         return bool(self._l.orc_is_final_set_complete(self._c))
 
@@ -391,3 +409,39 @@ class Oracle:
         if n:
             self._l.orc_firstly_final_ids(self._c, ids.ctypes.data_as(C.c_void_p), n)
         return ids
+
+
+def conditional_dijkstra(xy, belief_vec, beliefs, types, children, parents, finals):
+    """conditional_dijkstra (belief_graph.rs:89-175) on an explicit graph; children / parents are lists of lists;
+    belief_vec[i] = row of `beliefs` that node i carries"""
+    L = lib()
+    n = len(types)
+
+    def csr(lists):
+        off = np.zeros(n + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(x) for x in lists])
+        ids = np.array([v for x in lists for v in x] + [0], dtype=np.uint32)
+        return off, ids
+    coff, cid = csr(children)
+    poff, pid = csr(parents)
+    beliefs = np.ascontiguousarray(beliefs, dtype=np.float64)
+    dist = np.zeros(n)
+    rc = L.orc_conditional_dijkstra(n, np.ascontiguousarray(xy, dtype=np.float64), np.ascontiguousarray(belief_vec, dtype=np.uint32), beliefs,
+                                    beliefs.shape[1], np.ascontiguousarray(types, dtype=np.uint8), coff, cid, poff, pid,
+                                    np.ascontiguousarray(finals, dtype=np.uint64), len(finals), dist)
+    if rc:
+        raise RuntimeError("conditional_dijkstra failed (%d)" % rc)
+    return dist, (coff, cid), (poff, pid)
+
+
+def extract_policy(xy, belief_id, belief_vec, beliefs, children_csr, dist, cap=4096):
+    L = lib()
+    n = len(dist)
+    beliefs = np.ascontiguousarray(beliefs, dtype=np.float64)
+    oid, par, leaf = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.uint8)
+    k = L.orc_extract_policy(n, np.ascontiguousarray(xy, dtype=np.float64), np.ascontiguousarray(belief_id, dtype=np.uint32),
+                             np.ascontiguousarray(belief_vec, dtype=np.uint32), beliefs,
+                             beliefs.shape[1], children_csr[0], children_csr[1], np.ascontiguousarray(dist, dtype=np.float64), oid, par, leaf, cap)
+    if k < 0:
+        raise RuntimeError("extract_policy failed (%d)" % k)
+    return oid[:k], par[:k], leaf[:k]

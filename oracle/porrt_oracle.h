@@ -176,6 +176,17 @@ int      orc_bg_get_types(const orc_ctx *c, uint8_t *out);      /* 0 Unknown, 1 
 int      orc_bg_get_children(const orc_ctx *c, uint64_t *off, uint32_t *ids);
 int      orc_bg_get_parents(const orc_ctx *c, uint64_t *off, uint32_t *ids);
 
+/* ------------------------------------------------------------------ dp.c
+ * conditional_dijkstra / extract_policy (belief_graph.rs:89-263) on explicit graphs and on the context's belief graph */
+int      orc_conditional_dijkstra(uint64_t n, const double *xy, const uint32_t *belief_vec /* row of `beliefs` per node */, const double *beliefs, uint32_t nw,
+                                  const uint8_t *types, const uint64_t *coff, const uint32_t *cid, const uint64_t *poff, const uint32_t *pid,
+                                  const uint64_t *finals, uint64_t n_final, double *dist);
+int64_t  orc_extract_policy(uint64_t n, const double *xy, const uint32_t *belief_id, const uint32_t *belief_vec, const double *beliefs, uint32_t nw,
+                            const uint64_t *coff, const uint32_t *cid, const double *dist,
+                            uint64_t *original_id, int64_t *parent, uint8_t *is_leaf, uint64_t cap);
+int      orc_bg_expected_costs(const orc_ctx *c, double *dist);           /* PTO::compute_expected_costs_to_goals pto.rs:261-275 */
+int64_t  orc_bg_extract_policy(const orc_ctx *c, const double *dist, uint64_t *original_id, int64_t *parent, uint8_t *is_leaf, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

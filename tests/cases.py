@@ -104,3 +104,11 @@ def configure(eng, case):
 def grow(eng, case, K=1, **kw):
     return eng.grow(case.start, case.max_step, case.search_radius, case.n_iter_min, case.n_iter_max,
                     batch_K=K, mode=case.mode, **kw)
+
+
+def cfg3_near(n_iter=1500, seed=0):
+    """cfg3 with both goals on the start's side of the wall: a small graph already has a finite expected cost at the
+    root (the belief splits at the first shelf seen, one goal per world is reached)."""
+    c = cfg3(n_iter, n_iter, seed)
+    c.update(name="cfg3_near", goals=[(0.68, -0.45), (0.5, -0.8)], start=(0.2, -0.6))
+    return c
