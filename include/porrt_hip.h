@@ -166,6 +166,24 @@ int      porrt_bg_get_parents(const porrt_ctx *ctx, uint64_t *off, uint32_t *ids
  * [4] observation fold table, [5] adjacency lists, [6] device allocation + uploads, [7] fetching the PTO edges */
 int      porrt_bg_get_seconds(const porrt_ctx *ctx, double *out, uint32_t n);
 
+/* ---- expected costs to the goals over the belief graph: PTO::compute_expected_costs_to_goals (src/pto.rs:261-275) =
+ * the final belief nodes (final graph nodes x beliefs compatible with the node and with its finality), then
+ * conditional_dijkstra (src/belief_graph.rs:89-175) with cost_evaluator = norm2 (the PTOFuncs default,
+ * pto_graph.rs:150-152).  Runs on the belief graph of the last porrt_build_belief_graph, on the device; the costs stay
+ * there.  Bit-identical to the reference's queue-driven loop (the relaxation is monotone in f64: every order ends in
+ * the same fixpoint).  +inf = no policy from that belief node. */
+int      porrt_bg_compute_expected_costs(porrt_ctx *ctx);
+int      porrt_bg_get_expected_costs(const porrt_ctx *ctx, double *out /* porrt_bg_num_nodes() */);
+int      porrt_bg_expected_cost_of(const porrt_ctx *ctx, uint64_t belief_node, double *out);   /* [0] = policy.expected_costs */
+int      porrt_bg_get_dp_info(const porrt_ctx *ctx, double *total_s, double *device_s, uint32_t *sweeps);
+/* conditional_dijkstra on an explicit belief graph given as host arrays (the form of the reference's own tests,
+ * belief_graph.rs:502-567): node i has state xy[2i..], belief vector beliefs[belief_row[i]], type types[i]
+ * (1 Action, 2 Observation), children / parents as CSR in add_edge order.  No context needed. */
+int      porrt_conditional_dijkstra(int device, uint64_t n, const double *xy, const uint32_t *belief_row, const double *beliefs,
+                                    uint32_t n_belief_rows, uint32_t n_worlds, const uint8_t *types,
+                                    const uint64_t *child_off, const uint32_t *child_ids, const uint64_t *parent_off, const uint32_t *parent_ids,
+                                    const uint64_t *finals, uint64_t n_final, double *dist);
+
 /* ---- measurement */
 typedef struct {
     uint64_t n_iter;          /* iterations run */

@@ -6,4 +6,4 @@ behind a C ABI (include/porrt_hip.h, libporrt_hip.so: hand-written HIP for gfx95
 operator interface on top of it.
 """
 from .engine import (DOMAIN_DOOR, DOMAIN_SHELF, INCOMPLETE, MODE_PTO, MODE_RRT, OK, Engine, PorrtError,  # noqa: F401
-                     load_library)
+                     conditional_dijkstra, load_library)

@@ -668,6 +668,7 @@ struct BeliefGraphState {
     uint8_t *d_types = nullptr;
     unsigned long long *d_child_off = nullptr, *d_par_off = nullptr;
     uint32_t *d_child_id = nullptr, *d_par_id = nullptr;
+    const double *d_beliefs = nullptr;                // [B][nw]
     void release() {                                   // the result is gone, the memory stays for the next build
         next_slot = 0;
         valid = false;
@@ -903,6 +904,7 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
     g.t_post = bg_now() - tt0;
     g.t_tables = g.t_post + g.t_adj + g.t_reach;
     const double ta0 = bg_now();
+    if ((r = bg_upload(g, g.d_beliefs, bs.vec, s, err))) return r;
     if ((r = bg_upload(g, c.compat, compat, s, err)) || (r = bg_upload(g, c.mask_idx, mask_idx, s, err)) ||
         (r = bg_upload(g, c.obs_off, obs_off, s, err)) || (r = bg_upload(g, c.obs_child, obs_child, s, err)) ||
         (r = bg_upload(g, c.robs_off, robs_off, s, err)) || (r = bg_upload(g, c.robs_par, robs_par, s, err)) ||

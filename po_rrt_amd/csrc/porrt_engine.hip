@@ -12,6 +12,7 @@
 #include "../../include/porrt_hip.h"
 #include "porrt_device.hpp"
 #include "porrt_belief.hpp"
+#include "porrt_dp.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -230,6 +231,8 @@ struct porrt_ctx {
     int best_cost_device(double *cost, uint64_t *final_id);
     BeliefGraphState bg;                   // porrt_build_belief_graph: result of the last build (device CSR)
     int build_belief_graph(const double *start_belief, uint32_t n_worlds_in);
+    DpState dp;                            // porrt_bg_compute_expected_costs: dist per belief node (device)
+    int compute_expected_costs();
     int read_best_cost(double *cost, uint64_t *final_id);
     porrt_ctx *batch_leader = nullptr;     // set by porrt_grow_batch: the context whose RunConst array holds this one
     uint32_t batch_slot = 0, batch_size = 0;
@@ -548,6 +551,7 @@ int porrt_ctx::grow(const double start[2], double max_step, double search_radius
     have_results = false;
     batch_leader = nullptr;
     bg.release();
+    dp.release();
     ++results_tag;
     // the sampler state must survive a capacity retry
     const Pcg64 c0 = crng, d0 = drng;
@@ -1078,6 +1082,34 @@ int porrt_ctx::build_belief_graph(const double *start_belief, uint32_t n_worlds_
     r = belief_graph_build(bg, in, start_belief, e);
     if (r) { bg.release(); set_err(e); }
     else { bg.t_edges = t_edges; bg.t_total += t_edges; }
+    return r;
+}
+
+// PTO::compute_expected_costs_to_goals (pto.rs:261-275): the final belief nodes, then conditional_dijkstra on the device.
+int porrt_ctx::compute_expected_costs() {
+    if (!bg.valid) { set_err("compute_expected_costs: build the belief graph first (porrt_build_belief_graph)"); return PORRT_ERR_INVALID; }
+    HIPCHK(hipSetDevice(device));
+    int r = download(DL_TREE | DL_MASKS);
+    if (r) return r;
+    const BeliefSpace &bs = bg.cache.space;
+    const size_t B = bg.B;
+    std::vector<unsigned long long> finals;
+    for (uint64_t id : h_final_ids) {                 // final_nodes_with_validities(): push order = ascending id here
+        const uint64_t finality = h_finalmask[id];
+        for (size_t b = 0; b < B; ++b) {
+            if (!((bg.cache.compat[b] >> h_vid[id]) & 1ull)) continue;          // node_to_belief_nodes[final_id][b] is None
+            bool ok = true;                                                      // is_compatible(belief_state, validity)
+            for (uint32_t w = 0; w < bs.nw && ok; ++w) ok = !(bs.at(b)[w] > 0.0) || ((finality >> w) & 1ull);
+            if (ok) finals.push_back((unsigned long long)(id * B + b));
+        }
+    }
+    DpConst c{};
+    c.n = (unsigned long long)(bg.N * bg.B); c.B = (uint32_t)bg.B; c.nw = bg.nw;
+    c.nx = d_nx.p; c.ny = d_ny.p; c.bvec = nullptr; c.beliefs = bg.d_beliefs; c.types = bg.d_types;
+    c.child_off = bg.d_child_off; c.par_off = bg.d_par_off; c.child_id = bg.d_child_id; c.par_id = bg.d_par_id;
+    std::string e;
+    r = dp_run(dp, c, true, finals, stream, e);
+    if (r) set_err(e);
     return r;
 }
 
@@ -1673,6 +1705,72 @@ int porrt_bg_get_seconds(const porrt_ctx *c, double *out, uint32_t n) {
     const double v[8] = {c->bg.t_total, c->bg.t_device, c->bg.t_tables, c->bg.t_reach, c->bg.t_post, c->bg.t_adj, c->bg.t_alloc, c->bg.t_edges};
     for (uint32_t k = 0; k < n && k < 8; ++k) out[k] = v[k];
     return PORRT_OK;
+}
+
+// ---- expected costs over the belief graph (pto.rs:261-275, belief_graph.rs:89-175)
+int porrt_bg_compute_expected_costs(porrt_ctx *c) { return c ? c->compute_expected_costs() : PORRT_ERR_INVALID; }
+int porrt_bg_get_expected_costs(const porrt_ctx *cc, double *out) {
+    porrt_ctx *c = const_cast<porrt_ctx *>(cc);
+    if (!c || !c->dp.valid || !c->bg.valid || !out) return PORRT_ERR_INVALID;
+    HIPCHK_CTX(c, hipSetDevice(c->device));
+    HIPCHK_CTX(c, hipMemcpy(out, c->dp.d_dist, c->dp.n * sizeof(double), hipMemcpyDeviceToHost));
+    return PORRT_OK;
+}
+int porrt_bg_expected_cost_of(const porrt_ctx *cc, uint64_t belief_node, double *out) {
+    porrt_ctx *c = const_cast<porrt_ctx *>(cc);
+    if (!c || !c->dp.valid || !out || belief_node >= c->dp.n) return PORRT_ERR_INVALID;
+    HIPCHK_CTX(c, hipSetDevice(c->device));
+    HIPCHK_CTX(c, hipMemcpy(out, c->dp.d_dist + belief_node, sizeof(double), hipMemcpyDeviceToHost));
+    return PORRT_OK;
+}
+int porrt_bg_get_dp_info(const porrt_ctx *c, double *total_s, double *device_s, uint32_t *sweeps) {
+    if (!c || !c->dp.valid) return PORRT_ERR_INVALID;
+    if (total_s) *total_s = c->dp.t_total;
+    if (device_s) *device_s = c->dp.t_device;
+    if (sweeps) *sweeps = c->dp.sweeps;
+    return PORRT_OK;
+}
+
+// conditional_dijkstra on an explicit graph (host arrays in, dist out): the form the reference's own tests call it in
+int porrt_conditional_dijkstra(int device, uint64_t n, const double *xy, const uint32_t *belief_row, const double *beliefs, uint32_t n_belief_rows,
+                               uint32_t n_worlds, const uint8_t *types, const uint64_t *child_off, const uint32_t *child_ids,
+                               const uint64_t *parent_off, const uint32_t *parent_ids, const uint64_t *finals, uint64_t n_final, double *dist) {
+    if (!n || !xy || !belief_row || !beliefs || !types || !child_off || !parent_off || !dist || (n_final && !finals) || n >= 0xFFFFFFFFull)
+        return PORRT_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return PORRT_ERR_DEVICE;
+    for (uint64_t i = 0; i < n; ++i) if (belief_row[i] >= n_belief_rows) return PORRT_ERR_INVALID;
+    for (uint64_t k = 0; k < n_final; ++k) if (finals[k] >= n) return PORRT_ERR_INVALID;
+    const uint64_t nc = child_off[n], np = parent_off[n];
+    for (uint64_t k = 0; k < nc; ++k) if (child_ids[k] >= n) return PORRT_ERR_INVALID;
+    for (uint64_t k = 0; k < np; ++k) if (parent_ids[k] >= n) return PORRT_ERR_INVALID;
+    std::vector<double> hx(n), hy(n);
+    for (uint64_t i = 0; i < n; ++i) { hx[i] = xy[2 * i]; hy[i] = xy[2 * i + 1]; }
+    std::vector<void *> owned;
+    auto up = [&](const void *src, size_t bytes) -> void * {
+        void *d = nullptr;
+        if (hipMalloc(&d, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr;
+        owned.push_back(d);
+        if (bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return d;
+    };
+    DpConst c{};
+    c.n = n; c.B = 1; c.nw = n_worlds;
+    c.nx = (const double *)up(hx.data(), n * 8); c.ny = (const double *)up(hy.data(), n * 8);
+    c.bvec = (const uint32_t *)up(belief_row, n * 4);
+    c.beliefs = (const double *)up(beliefs, (size_t)n_belief_rows * n_worlds * 8);
+    c.types = (const uint8_t *)up(types, n);
+    c.child_off = (const unsigned long long *)up(child_off, (n + 1) * 8); c.par_off = (const unsigned long long *)up(parent_off, (n + 1) * 8);
+    c.child_id = (const uint32_t *)up(child_ids, nc * 4); c.par_id = (const uint32_t *)up(parent_ids, np * 4);
+    int r = PORRT_ERR_DEVICE;
+    if (c.nx && c.ny && c.bvec && c.beliefs && c.types && c.child_off && c.par_off && c.child_id && c.par_id) {
+        DpState st;
+        std::string err;
+        std::vector<unsigned long long> f(finals, finals + n_final);
+        r = dp_run(st, c, false, f, nullptr, err);
+        if (r == PORRT_OK && hipMemcpy(dist, st.d_dist, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) r = PORRT_ERR_DEVICE;
+    }
+    for (void *d : owned) (void)hipFree(d);
+    return r;
 }
 
 int porrt_get_metrics(const porrt_ctx *c, porrt_metrics *out) {

@@ -31,6 +31,7 @@ SYMBOLS = [
     "porrt_get_zone_positions", "porrt_best_solution", "porrt_best_cost", "porrt_best_cost_batch", "porrt_get_metrics", "porrt_set_option", "porrt_selftest",
     "porrt_build_belief_graph", "porrt_bg_num_beliefs", "porrt_bg_num_nodes", "porrt_bg_num_edges", "porrt_bg_get_beliefs",
     "porrt_bg_get_observable_zones", "porrt_bg_get_node_types", "porrt_bg_get_children", "porrt_bg_get_parents", "porrt_bg_get_seconds",
+    "porrt_bg_compute_expected_costs", "porrt_bg_get_expected_costs", "porrt_bg_expected_cost_of", "porrt_bg_get_dp_info", "porrt_conditional_dijkstra",
 ]
 
 
@@ -105,6 +106,12 @@ def load_library():
     sig("porrt_bg_get_children", C.c_int, vp, _u64p, C.c_void_p)
     sig("porrt_bg_get_parents", C.c_int, vp, _u64p, C.c_void_p)
     sig("porrt_bg_get_seconds", C.c_int, vp, _f64p, C.c_uint32)
+    sig("porrt_bg_compute_expected_costs", C.c_int, vp)
+    sig("porrt_bg_get_expected_costs", C.c_int, vp, _f64p)
+    sig("porrt_bg_expected_cost_of", C.c_int, vp, C.c_uint64, C.POINTER(C.c_double))
+    sig("porrt_bg_get_dp_info", C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32))
+    sig("porrt_conditional_dijkstra", C.c_int, C.c_int, C.c_uint64, _f64p, _u32p, _f64p, C.c_uint32, C.c_uint32, _u8p, _u64p, _u32p, _u64p, _u32p,
+        _u64p, C.c_uint64, _f64p)
     sig("porrt_best_cost_batch", C.c_int, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_double))
     sig("porrt_get_metrics", C.c_int, vp, C.POINTER(Metrics))
     sig("porrt_set_option", C.c_int, vp, C.c_char_p, C.c_int64)
@@ -310,6 +317,25 @@ class Engine:
         keys = ("total_s", "device_s", "host_tables_s", "reach_s", "fold_table_s", "adjacency_s", "alloc_upload_s", "edges_fetch_s")
         return dict(zip(keys, v.tolist()))
 
+    def compute_expected_costs(self):
+        """PTO::compute_expected_costs_to_goals on the device (pto.rs:261-275)"""
+        self._chk(self._l.porrt_bg_compute_expected_costs(self._c))
+
+    def expected_costs(self):
+        d = np.zeros(self._l.porrt_bg_num_nodes(self._c))
+        self._chk(self._l.porrt_bg_get_expected_costs(self._c, d))
+        return d
+
+    def expected_cost_of(self, belief_node=0):
+        v = C.c_double(0.0)
+        self._chk(self._l.porrt_bg_expected_cost_of(self._c, belief_node, C.byref(v)))
+        return v.value
+
+    def dp_info(self):
+        a, b, n = C.c_double(0), C.c_double(0), C.c_uint32(0)
+        self._chk(self._l.porrt_bg_get_dp_info(self._c, C.byref(a), C.byref(b), C.byref(n)))
+        return dict(total_s=a.value, device_s=b.value, sweeps=n.value)
+
     def selftest(self, n=1 << 20):
         a, b = C.c_uint64(0), C.c_uint64(0)
         self._chk(self._l.porrt_selftest(self._c, n, C.byref(a), C.byref(b)))
@@ -319,3 +345,25 @@ class Engine:
         m = Metrics()
         self._chk(self._l.porrt_get_metrics(self._c, C.byref(m)))
         return {k: getattr(m, k) for k, _ in Metrics._fields_}
+
+
+def conditional_dijkstra(xy, belief_row, beliefs, types, children, parents, finals, device=0):
+    """porrt_conditional_dijkstra: conditional_dijkstra (belief_graph.rs:89-175) of an explicit graph on the GPU;
+    children / parents are lists of lists in add_edge order"""
+    L = load_library()
+    n = len(types)
+
+    def csr(lists):
+        off = np.zeros(n + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(x) for x in lists])
+        return off, np.array([v for x in lists for v in x] + [0], dtype=np.uint32)
+    coff, cid = csr(children)
+    poff, pid = csr(parents)
+    beliefs = np.ascontiguousarray(beliefs, dtype=np.float64)
+    dist = np.zeros(n)
+    rc = L.porrt_conditional_dijkstra(device, n, np.ascontiguousarray(xy, dtype=np.float64), np.ascontiguousarray(belief_row, dtype=np.uint32),
+                                      beliefs, beliefs.shape[0], beliefs.shape[1], np.ascontiguousarray(types, dtype=np.uint8), coff, cid, poff, pid,
+                                      np.ascontiguousarray(finals, dtype=np.uint64), len(finals), dist)
+    if rc < 0:
+        raise RuntimeError("porrt_conditional_dijkstra failed (%d)" % rc)
+    return dist
