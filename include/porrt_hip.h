@@ -176,6 +176,14 @@ int      porrt_bg_compute_expected_costs(porrt_ctx *ctx);
 int      porrt_bg_get_expected_costs(const porrt_ctx *ctx, double *out /* porrt_bg_num_nodes() */);
 int      porrt_bg_expected_cost_of(const porrt_ctx *ctx, uint64_t belief_node, double *out);   /* [0] = policy.expected_costs */
 int      porrt_bg_get_dp_info(const porrt_ctx *ctx, double *total_s, double *device_s, uint32_t *sweeps);
+/* PTO::extract_policy (src/pto.rs:277-283; extract_policy / get_best_expected_children src/belief_graph.rs:177-263) from
+ * belief node 0.  Policy node k (in Policy::add_node order; node 0 is the root) has original_node_id original_ids[k],
+ * parent parents[k] (-1 for the root) and is a leaf (expected cost 0) iff is_leaf[k]; its state and belief follow from
+ * the id (graph node id / n_beliefs, belief id % n_beliefs).  Returns the number of policy nodes; the arrays are filled
+ * when cap holds them (call with cap 0 to size them).  *expected_costs = policy.expected_costs.  The walk is
+ * sequential and small: host code, reading one row of the device graph per step.  Error when the root has no finite
+ * expected cost (the reference would not terminate). */
+int64_t  porrt_bg_extract_policy(porrt_ctx *ctx, uint64_t *original_ids, int64_t *parents, uint8_t *is_leaf, uint64_t cap, double *expected_costs);
 /* conditional_dijkstra on an explicit belief graph given as host arrays (the form of the reference's own tests,
  * belief_graph.rs:502-567): node i has state xy[2i..], belief vector beliefs[belief_row[i]], type types[i]
  * (1 Action, 2 Observation), children / parents as CSR in add_edge order.  No context needed. */

@@ -112,6 +112,30 @@ __global__ __launch_bounds__(256) void k_dp_sweep(DpConst g, uint8_t *__restrict
     }
 }
 
+
+// One belief node's children with what get_best_expected_children (belief_graph.rs:214-263) needs of each: id, expected
+// cost, edge cost.  One workgroup; the policy walk on the host asks for one row at a time.
+struct DpRowItem { double dist, cost; uint32_t child, pad; };
+template <bool IMPLICIT>
+__global__ __launch_bounds__(256) void k_dp_row(DpConst g, unsigned long long bn, DpRowItem *__restrict__ out, uint32_t cap, uint32_t *__restrict__ count) {
+    const unsigned long long c0 = as_global(g.child_off)[bn], c1 = as_global(g.child_off)[bn + 1];
+    if (threadIdx.x == 0) *count = (uint32_t)(c1 - c0);
+    double ux, uy;
+    uint32_t urow;
+    dp_state<IMPLICIT>(g, bn, ux, uy, urow);
+    for (unsigned long long c = c0 + threadIdx.x; c < c1 && c - c0 < cap; c += blockDim.x) {
+        const unsigned long long v = as_global(g.child_id)[c];
+        double vx, vy;
+        uint32_t vrow;
+        dp_state<IMPLICIT>(g, v, vx, vy, vrow);
+        DpRowItem it;
+        it.child = (uint32_t)v; it.pad = 0;
+        it.dist = as_global(g.dist)[v];
+        it.cost = sqrt(dist2(ux, uy, vx, vy));
+        out[c - c0] = it;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 
 struct DpState {
@@ -127,13 +151,23 @@ struct DpState {
     uint32_t *d_flags = nullptr;
     unsigned long long *d_finals = nullptr;
     size_t finals_cap = 0;
-    void release() { valid = false; }
+    DpConst last{};                                   // the graph of the last run (device pointers), for the policy walk
+    DpRowItem *d_row = nullptr;
+    uint32_t *d_row_count = nullptr;
+    std::vector<uint64_t> pol_original;               // extract_policy: per policy node, in add_node order
+    std::vector<int64_t> pol_parent;
+    std::vector<uint8_t> pol_leaf;
+    bool have_policy = false;
+    void release() { valid = false; have_policy = false; }
     void free_device() {
         release();
         if (d_dist) (void)hipFree(d_dist);
         for (int k = 0; k < 2; ++k) if (d_dirty[k]) (void)hipFree(d_dirty[k]);
         if (d_flags) (void)hipFree(d_flags);
         if (d_finals) (void)hipFree(d_finals);
+        if (d_row) (void)hipFree(d_row);
+        if (d_row_count) (void)hipFree(d_row_count);
+        d_row = nullptr; d_row_count = nullptr;
         d_dist = nullptr; d_dirty[0] = d_dirty[1] = nullptr; d_flags = nullptr; d_finals = nullptr;
         dist_cap = dirty_cap = finals_cap = 0;
     }
@@ -212,10 +246,72 @@ static int dp_run(DpState &st, DpConst c, bool implicit, const std::vector<unsig
     if (h_flags[0] & DP_ERR_UNKNOWN_TYPE) { err = "node type should be know at this stage! (belief_graph.rs:138)"; return PORRT_ERR_INVALID; }
     if (h_flags[0] & DP_ERR_ZERO_PROBABILITY) { err = "assert!(p > 0.0) failed (belief_graph.rs:128)"; return PORRT_ERR_INVALID; }
     st.n = n;
+    st.last = c;
     st.sweeps = sweeps;
     st.t_device = 1e-3 * (double)ms;
     st.t_total = bg_now() - t0;
     st.valid = true;
+    return PORRT_OK;
+}
+
+constexpr uint32_t kDpRowCap = 1u << 16;
+
+// extract_policy (belief_graph.rs:177-212) with get_best_expected_children (214-263): a depth-first walk from belief
+// node 0 that keeps, per target belief, the child of least p * (cost + expected cost).  Sequential pointer chasing over
+// a few hundred nodes: host code, one row of the device graph fetched per step (k_dp_row).
+// belief_of(i) = clustering key of node i; p_of(parent, child) = transition_probability of their belief vectors.
+template <class BeliefOf, class ProbOf>
+static int dp_extract_policy(DpState &st, bool implicit, BeliefOf belief_of, ProbOf p_of, hipStream_t s, std::string &err) {
+    if (!st.valid) { err = "extract_policy: compute the expected costs first"; return PORRT_ERR_INVALID; }
+    if (!st.d_row) {
+        DP_HIP(hipMalloc((void **)&st.d_row, kDpRowCap * sizeof(DpRowItem)));
+        DP_HIP(hipMalloc((void **)&st.d_row_count, sizeof(uint32_t)));
+    }
+    st.pol_original.assign(1, 0);
+    st.pol_parent.assign(1, -1);
+    st.pol_leaf.assign(1, 0);
+    std::vector<std::pair<uint64_t, uint64_t>> lifo{{0, 0}};       // (policy node, belief node)
+    std::vector<DpRowItem> row;
+    double root_cost = 0.0;
+    DP_HIP(hipMemcpy(&root_cost, st.d_dist, sizeof(double), hipMemcpyDeviceToHost));
+    if (!(root_cost < __builtin_huge_val())) { err = "extract_policy: no policy from the root (its expected cost is infinite; the reference does not terminate here)"; return PORRT_ERR_INVALID; }
+    std::map<uint64_t, double> dist_of{{0, root_cost}};
+    while (!lifo.empty()) {
+        const auto [pol, bn] = lifo.back();
+        lifo.pop_back();
+        if (implicit) hipLaunchKernelGGL(k_dp_row<true>, dim3(1), dim3(256), 0, s, st.last, (unsigned long long)bn, st.d_row, kDpRowCap, st.d_row_count);
+        else hipLaunchKernelGGL(k_dp_row<false>, dim3(1), dim3(256), 0, s, st.last, (unsigned long long)bn, st.d_row, kDpRowCap, st.d_row_count);
+        uint32_t cnt = 0;
+        DP_HIP(hipMemcpyAsync(&cnt, st.d_row_count, sizeof cnt, hipMemcpyDeviceToHost, s));
+        DP_HIP(hipStreamSynchronize(s));
+        if (cnt > kDpRowCap) { err = "extract_policy: a belief node with more than 65536 children"; return PORRT_ERR_CAPACITY; }
+        row.resize(cnt);
+        if (cnt) DP_HIP(hipMemcpy(row.data(), st.d_row, cnt * sizeof(DpRowItem), hipMemcpyDeviceToHost));
+        // BTreeMap<belief_id, Vec<ChildWithCosts>>: clusters in ascending key order, members in children order
+        std::map<uint32_t, std::vector<uint32_t>> clusters;
+        for (uint32_t k = 0; k < cnt; ++k) clusters[belief_of(row[k].child)].push_back(k);
+        const double dist_bn = dist_of.count(bn) ? dist_of[bn] : 0.0;
+        for (auto &kv : clusters) {
+            uint32_t best = kv.second[0];
+            const double p = p_of(bn, row[best].child);
+            if (!(p > 0.0)) { err = "assert!(p > 0.0) failed (belief_graph.rs:244)"; return PORRT_ERR_INVALID; }
+            double best_cost = __builtin_huge_val();
+            for (uint32_t k : kv.second) {
+                const double cost = p * (row[k].cost + row[k].dist);
+                if (cost < best_cost) { best_cost = cost; best = k; }
+            }
+            if (!(p * row[best].dist <= dist_bn)) { err = "assert!(p * expected_costs_to_goals[best_id] <= expected_costs_to_goals[belief_node_id]) failed (belief_graph.rs:257)"; return PORRT_ERR_INVALID; }
+            const bool leaf = row[best].dist == 0.0;
+            const uint64_t id = st.pol_original.size();
+            st.pol_original.push_back(row[best].child);
+            st.pol_parent.push_back((int64_t)pol);
+            st.pol_leaf.push_back(leaf ? 1 : 0);
+            dist_of[row[best].child] = row[best].dist;
+            if (!leaf) lifo.push_back({id, (uint64_t)row[best].child});
+            if (st.pol_original.size() > (1u << 24)) { err = "extract_policy: more than 2^24 policy nodes"; return PORRT_ERR_CAPACITY; }
+        }
+    }
+    st.have_policy = true;
     return PORRT_OK;
 }
 

@@ -233,6 +233,7 @@ struct porrt_ctx {
     int build_belief_graph(const double *start_belief, uint32_t n_worlds_in);
     DpState dp;                            // porrt_bg_compute_expected_costs: dist per belief node (device)
     int compute_expected_costs();
+    int extract_policy();
     int read_best_cost(double *cost, uint64_t *final_id);
     porrt_ctx *batch_leader = nullptr;     // set by porrt_grow_batch: the context whose RunConst array holds this one
     uint32_t batch_slot = 0, batch_size = 0;
@@ -1113,6 +1114,25 @@ int porrt_ctx::compute_expected_costs() {
     return r;
 }
 
+// PTO::extract_policy (pto.rs:277-283, belief_graph.rs:177-263) on the expected costs of the last compute_expected_costs.
+int porrt_ctx::extract_policy() {
+    if (!bg.valid || !dp.valid) { set_err("extract_policy: compute the expected costs first (porrt_bg_compute_expected_costs)"); return PORRT_ERR_INVALID; }
+    HIPCHK(hipSetDevice(device));
+    const BeliefSpace &bs = bg.cache.space;
+    const size_t B = bg.B;
+    auto belief_of = [B](uint64_t i) { return (uint32_t)(i % B); };
+    auto p_of = [&bs, B](uint64_t parent, uint64_t child) {          // transition_probability (common.rs:187-190)
+        const double *pb = bs.at(parent % B), *cb = bs.at(child % B);
+        double s = 0.0;
+        for (uint32_t w = 0; w < bs.nw; ++w) s = s + (cb[w] > 0.0 ? pb[w] : 0.0);
+        return s;
+    };
+    std::string e;
+    int r = dp_extract_policy(dp, true, belief_of, p_of, stream, e);
+    if (r) set_err(e);
+    return r;
+}
+
 // Best path cost without downloading the tree (k_best_cost).  1 = found, 0 = no final node, -1 = scratch too small
 // (the caller then walks on the host), other negatives = errors.
 int porrt_ctx::read_best_cost(double *cost, uint64_t *final_id) {
@@ -1729,6 +1749,25 @@ int porrt_bg_get_dp_info(const porrt_ctx *c, double *total_s, double *device_s, 
     if (device_s) *device_s = c->dp.t_device;
     if (sweeps) *sweeps = c->dp.sweeps;
     return PORRT_OK;
+}
+
+// PTO::extract_policy: returns the number of policy nodes (or a negative error); fills the arrays when they hold that many
+int64_t porrt_bg_extract_policy(porrt_ctx *c, uint64_t *original_ids, int64_t *parents, uint8_t *is_leaf, uint64_t cap, double *expected_costs) {
+    if (!c) return PORRT_ERR_INVALID;
+    if (!c->dp.have_policy) {
+        int r = c->extract_policy();
+        if (r) return r;
+    }
+    const uint64_t n = c->dp.pol_original.size();
+    if (expected_costs && hipMemcpy(expected_costs, c->dp.d_dist, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return PORRT_ERR_DEVICE;
+    if (cap >= n) {
+        for (uint64_t k = 0; k < n; ++k) {
+            if (original_ids) original_ids[k] = c->dp.pol_original[k];
+            if (parents) parents[k] = c->dp.pol_parent[k];
+            if (is_leaf) is_leaf[k] = c->dp.pol_leaf[k];
+        }
+    }
+    return (int64_t)n;
 }
 
 // conditional_dijkstra on an explicit graph (host arrays in, dist out): the form the reference's own tests call it in

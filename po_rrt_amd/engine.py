@@ -31,7 +31,7 @@ SYMBOLS = [
     "porrt_get_zone_positions", "porrt_best_solution", "porrt_best_cost", "porrt_best_cost_batch", "porrt_get_metrics", "porrt_set_option", "porrt_selftest",
     "porrt_build_belief_graph", "porrt_bg_num_beliefs", "porrt_bg_num_nodes", "porrt_bg_num_edges", "porrt_bg_get_beliefs",
     "porrt_bg_get_observable_zones", "porrt_bg_get_node_types", "porrt_bg_get_children", "porrt_bg_get_parents", "porrt_bg_get_seconds",
-    "porrt_bg_compute_expected_costs", "porrt_bg_get_expected_costs", "porrt_bg_expected_cost_of", "porrt_bg_get_dp_info", "porrt_conditional_dijkstra",
+    "porrt_bg_compute_expected_costs", "porrt_bg_get_expected_costs", "porrt_bg_expected_cost_of", "porrt_bg_get_dp_info", "porrt_bg_extract_policy", "porrt_conditional_dijkstra",
 ]
 
 
@@ -110,6 +110,7 @@ def load_library():
     sig("porrt_bg_get_expected_costs", C.c_int, vp, _f64p)
     sig("porrt_bg_expected_cost_of", C.c_int, vp, C.c_uint64, C.POINTER(C.c_double))
     sig("porrt_bg_get_dp_info", C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32))
+    sig("porrt_bg_extract_policy", C.c_int64, vp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_double))
     sig("porrt_conditional_dijkstra", C.c_int, C.c_int, C.c_uint64, _f64p, _u32p, _f64p, C.c_uint32, C.c_uint32, _u8p, _u64p, _u32p, _u64p, _u32p,
         _u64p, C.c_uint64, _f64p)
     sig("porrt_best_cost_batch", C.c_int, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_double))
@@ -330,6 +331,16 @@ class Engine:
         v = C.c_double(0.0)
         self._chk(self._l.porrt_bg_expected_cost_of(self._c, belief_node, C.byref(v)))
         return v.value
+
+    def extract_policy(self):
+        """PTO::extract_policy: (original belief node ids, parents (-1 = root), leaf flags), expected cost of the root"""
+        cost = C.c_double(0.0)
+        n = self._l.porrt_bg_extract_policy(self._c, None, None, None, 0, C.byref(cost))
+        if n < 0:
+            self._chk(int(n))
+        oid, par, leaf = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.uint8)
+        self._l.porrt_bg_extract_policy(self._c, oid.ctypes.data_as(C.c_void_p), par.ctypes.data_as(C.c_void_p), leaf.ctypes.data_as(C.c_void_p), n, C.byref(cost))
+        return (oid, par, leaf), cost.value
 
     def dp_info(self):
         a, b, n = C.c_double(0), C.c_double(0), C.c_uint32(0)

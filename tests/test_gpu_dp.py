@@ -90,6 +90,15 @@ def test_expected_costs_equal_oracle(eng_mod, name):
     assert e.expected_cost_of(0) == do[0]
     info = e.dp_info()
     assert info["sweeps"] > 0
+    if np.isfinite(do[0]):                                   # PTO::extract_policy: the same policy tree, node for node
+        (oid, par, leaf), cost = e.extract_policy()
+        oo, po, lo = o.extract_policy(do)
+        assert cost == do[0]
+        assert np.array_equal(oid, oo) and np.array_equal(par, po) and np.array_equal(leaf, lo)
+        assert leaf.sum() >= 1 and par[0] == -1 and oid[0] == 0
+    else:
+        with pytest.raises(RuntimeError):
+            e.extract_policy()
     if name == "shelf_2_worlds_near_goals":
         assert np.isfinite(de[0]) and de[0] > 0.0            # a policy exists from the root
         assert (de == 0.0).sum() >= 2

@@ -30,4 +30,11 @@ for n_worlds_possible in (8, 12):
               "lists %.1f GB/s (device time)" % (n_worlds_possible, e.num_nodes(), nb, E, wall, s["total_s"], s["device_s"],
                                                  s["host_tables_s"], bytes_out / max(s["device_s"], 1e-9) / 1e9), flush=True)
         print("     " + "  ".join("%s %.2f ms" % (k[:-2], 1e3 * v) for k, v in s.items()), flush=True)
+        for rep in range(2):
+            t = time.perf_counter()
+            e.compute_expected_costs()
+            wall = time.perf_counter() - t
+        info = e.dp_info()
+        print("     expected costs: wall %.2f ms  device %.2f ms  %d sweeps  root cost %r" % (1e3 * wall, 1e3 * info["device_s"], info["sweeps"],
+                                                                                          e.expected_cost_of(0)), flush=True)
         del e
