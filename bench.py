@@ -238,11 +238,13 @@ def main():
 
 
 def belief_space(device, with_cpu):
-    """The next row of the path (SURVEY 8f.1), outside the timed region: PTO::build_belief_graph (pto.rs:185-259) on the
-    12-shelf problem of main.rs:386-408 -- a PTO graph of 5000 iterations expanded over the 4095 reachable beliefs."""
+    """The rows after the growth (SURVEY 8f.1-2), outside the timed region: PTO::plan_belief_space (pto.rs:151-183) on the
+    12-shelf problem of main.rs:386-408 -- a PTO graph of 20000 iterations expanded over the 4095 reachable beliefs
+    (build_belief_graph), expected costs to the goals (conditional_dijkstra), policy extraction."""
     import cases
     import po_rrt_amd
-    case = cases.cfg4(5000, 5000)
+    n_iter = 20000
+    case = cases.cfg4(n_iter, n_iter)
     case.update(start=(0.0, -0.3))
     e = cases.configure(po_rrt_amd.Engine(device), case)
     cases.grow(e, case, K=256)
@@ -252,35 +254,51 @@ def belief_space(device, with_cpu):
         t0 = time.perf_counter()
         e.build_belief_graph(prior)
         runs.append((time.perf_counter() - t0, e.bg_seconds()))
-    runs = sorted(runs[1:], key=lambda r: r[0])            # the first build also fetches and orders the PTO edges
+    first = runs[0][0]
+    runs = sorted(runs[1:], key=lambda r: r[0])            # the first build also computes the belief space of the prior
     wall, sec = runs[len(runs) // 2]
     E, N = e.bg_num_edges(), e.num_nodes()
     nb = N * 4095
     list_bytes = 2 * 4.0 * E + 2 * 8.0 * (nb + 1) + nb     # both id arrays, both offset arrays, the node types
+    dps = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        e.compute_expected_costs()
+        dps.append(time.perf_counter() - t0)
+    info = e.dp_info()
+    t0 = time.perf_counter()
+    (oid, par, leaf), root_cost = e.extract_policy()
+    t_policy = time.perf_counter() - t0
     out = {
-        "what": "PTO::build_belief_graph: %d graph nodes x 4095 beliefs (12 shelves, uniform prior)" % N,
+        "what": "PTO::plan_belief_space: %d graph nodes x 4095 beliefs (12 shelves, uniform prior)" % N,
         "belief_nodes": nb, "edges": E,
-        "ms_wall": 1e3 * wall, "ms_device": 1e3 * sec["device_s"], "ms_host_tables": 1e3 * sec["host_tables_s"],
-        "edges_per_s": E / wall,
-        "roofline": {"bound": "hbm", "kernel": "k_bg_fill + k_bg_*_count + k_scan_*", "achieved": list_bytes / sec["device_s"] / 1e9,
-                     "peak": 8000.0, "unit": "GB/s", "frac": list_bytes / sec["device_s"] / 1e9 / 8000.0,
-                     "algorithmic_bytes": list_bytes,
-                     "note": "bytes of the result (CSR ids, offsets, types) over the device time of all belief kernels (HIP events)"},
+        "build_belief_graph": {
+            "ms_wall": 1e3 * wall, "ms_first_build_with_this_prior": 1e3 * first, "ms_device": 1e3 * sec["device_s"],
+            "ms_host_tables": 1e3 * sec["host_tables_s"], "edges_per_s": E / wall,
+            "roofline": {"bound": "hbm", "kernel": "k_bg_fill + k_bg_*_count + k_scan_*", "achieved": list_bytes / sec["device_s"] / 1e9,
+                         "peak": 8000.0, "unit": "GB/s", "frac": list_bytes / sec["device_s"] / 1e9 / 8000.0, "algorithmic_bytes": list_bytes,
+                         "note": "bytes of the result (CSR ids, offsets, types) over the device time of all belief kernels (HIP events)"}},
+        "expected_costs": {"ms_wall": 1e3 * min(dps), "ms_device": 1e3 * info["device_s"], "sweeps": info["sweeps"], "root_cost": root_cost,
+                           "edge_relaxations_per_s_lower_bound": E / min(dps),
+                           "note": "conditional_dijkstra as sweeps to the same fixpoint; every edge is relaxed at least once"},
+        "extract_policy": {"ms_wall": 1e3 * t_policy, "policy_nodes": int(len(oid)), "leafs": int(leaf.sum())},
     }
     if with_cpu:
         from oracle import orc
-        small = cases.cfg4(5000, 5000)
-        small.update(start=(0.0, -0.3))
-        o = cases.configure(orc.Oracle(), small)
-        cases.grow(o, small, K=256, algo=orc.ALGO_BATCHED_KD)
+        o = cases.configure(orc.Oracle(), case)
+        cases.grow(o, case, K=256, algo=orc.ALGO_BATCHED_KD)
         sample_prior = [0.125] * 8 + [0.0] * 4            # 255 beliefs: 1/16 of the workload, same graph
         t0 = time.perf_counter()
         o.build_belief_graph(sample_prior)
         dt = time.perf_counter() - t0
         Eo = int(o._l.orc_bg_num_edges(o._c))
+        t0 = time.perf_counter()
+        d = o.expected_costs()
+        dt2 = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": Eo / dt, "unit": "edges/s", "cores": 1, "kind": "port",
-                               "sample": "the same PTO graph with 8 of the 12 worlds possible (255 beliefs, %d edges), %.2f s; "
-                                         "C restatement of pto.rs:185-259 (oracle/belief.c)" % (Eo, dt)}
+                               "sample": "the same PTO graph with 8 of the 12 worlds possible (255 beliefs, %d edges): build_belief_graph %.2f s, "
+                                         "conditional_dijkstra %.2f s (%.1f M edges/s; root cost %r); C restatement of pto.rs:185-275, "
+                                         "belief_graph.rs:89-175 (oracle/belief.c, oracle/dp.c)" % (Eo, dt, dt2, Eo / dt2 / 1e6, float(d[0]))}
     return out
 
 

@@ -38,6 +38,18 @@ int main(int argc, char **argv) {
             for (const uint32_t *p = q.first; p != q.second; ++p) hp = fnv(hp, *p);
         }
         for (auto &row : pto.node_to_belief_nodes) for (auto &x : row) n_some += x.has_value();
+        // pto.rs:480-490: compute_expected_costs_to_goals + extract_policy (only when a policy exists)
+        pto.compute_expected_costs_to_goals();
+        uint64_t hd = 1469598103934665603ull;
+        for (double d : pto.expected_costs_to_goals) { uint64_t u; std::memcpy(&u, &d, 8); hd = fnv(hd, u); }
+        size_t n_policy = 0, n_leafs = 0;
+        uint64_t hpol = 1469598103934665603ull;
+        if (pto.expected_costs_to_goals[0] < 1e300) {
+            Policy policy = pto.extract_policy();
+            n_policy = policy.nodes.size(); n_leafs = policy.leafs.size();
+            for (auto &pn : policy.nodes) { hpol = fnv(hpol, pn.original_node_id); hpol = fnv(hpol, pn.parent ? *pn.parent : ~0ull); }
+        }
+        std::printf("costs %016llx policy_nodes %zu leafs %zu policy %016llx ", (unsigned long long)hd, n_policy, n_leafs, (unsigned long long)hpol);
         std::printf("complete %d nodes %zu beliefs %zu belief_nodes %zu edges %zu types %016llx children %016llx parents %016llx compatible %zu\n",
                     ok ? 1 : 0, pto.graph.nodes.size(), g.n_beliefs(), g.n_nodes(), g.children_ids.size(), (unsigned long long)ht,
                     (unsigned long long)hc, (unsigned long long)hp, n_some);

@@ -272,6 +272,28 @@ struct BeliefGraph {
     std::pair<const uint32_t *, const uint32_t *> parents(size_t i) const { return {parents_ids.data() + parents_offsets[i], parents_ids.data() + parents_offsets[i + 1]}; }
 };
 
+// common.rs:24-40
+struct PolicyNode {
+    State state;
+    BeliefState belief_state;
+    std::optional<size_t> parent;
+    std::vector<size_t> children;
+    size_t original_node_id = 0;
+};
+struct Policy {
+    std::vector<PolicyNode> nodes;
+    std::vector<size_t> leafs;
+    double expected_costs = 0.0;
+    const PolicyNode &leaf(size_t id) const { return nodes[leafs[id]]; }                             // common.rs:66-68
+    std::vector<State> path_to_leaf(size_t id) const {                                               // common.rs:70-83
+        std::vector<State> path;
+        const PolicyNode *n = &leaf(id);
+        path.push_back(n->state);
+        while (n->parent) { n = &nodes[*n->parent]; path.push_back(n->state); }
+        return std::vector<State>(path.rbegin(), path.rend());
+    }
+};
+
 class PTO {
 public:
     uint32_t batch_K = 256;
@@ -349,6 +371,49 @@ public:
     }
     BeliefGraph belief_graph;
     std::vector<std::vector<std::optional<size_t>>> node_to_belief_nodes;
+
+    // pto.rs:261-275 (conditional_dijkstra, belief_graph.rs:89-175); the costs stay on the device, fetch = copy them out
+    void compute_expected_costs_to_goals(bool fetch = true) {
+        ctx_.check(porrt_bg_compute_expected_costs(ctx_.get()));
+        if (fetch) {
+            expected_costs_to_goals.assign(porrt_bg_num_nodes(ctx_.get()), 0.0);
+            ctx_.check(porrt_bg_get_expected_costs(ctx_.get(), expected_costs_to_goals.data()));
+        }
+    }
+    std::vector<double> expected_costs_to_goals;
+    // pto.rs:277-283 (extract_policy, belief_graph.rs:177-263)
+    Policy extract_policy() {
+        Policy policy;
+        const int64_t n = porrt_bg_extract_policy(ctx_.get(), nullptr, nullptr, nullptr, 0, &policy.expected_costs);
+        if (n < 0) ctx_.check((int)n);
+        std::vector<uint64_t> oid((size_t)n);
+        std::vector<int64_t> par((size_t)n);
+        std::vector<uint8_t> leaf((size_t)n);
+        porrt_bg_extract_policy(ctx_.get(), oid.data(), par.data(), leaf.data(), (uint64_t)n, nullptr);
+        const size_t nb = porrt_bg_num_beliefs(ctx_.get());
+        std::vector<double> flat(nb * (size_t)n_worlds());
+        ctx_.check(porrt_bg_get_beliefs(ctx_.get(), flat.data()));
+        for (size_t k = 0; k < (size_t)n; ++k) {
+            PolicyNode pn;
+            pn.state = graph.nodes[oid[k] / nb].state;
+            pn.belief_state.assign(flat.begin() + (oid[k] % nb) * n_worlds(), flat.begin() + (oid[k] % nb + 1) * n_worlds());
+            pn.original_node_id = (size_t)oid[k];
+            if (par[k] >= 0) { pn.parent = (size_t)par[k]; policy.nodes[(size_t)par[k]].children.push_back(k); }
+            policy.nodes.push_back(std::move(pn));
+            if (leaf[k]) policy.leafs.push_back(k);
+        }
+        return policy;
+    }
+    // pto.rs:151-183
+    Policy plan_belief_space(const BeliefState &start_belief_state) {
+        build_belief_graph_on_device(start_belief_state);
+        compute_expected_costs_to_goals(false);
+        return extract_policy();
+    }
+    // the expansion without copying the lists to the host (plan_belief_space only needs the policy)
+    void build_belief_graph_on_device(const BeliefState &start_belief_state) {
+        ctx_.check(porrt_build_belief_graph(ctx_.get(), start_belief_state.data(), (uint32_t)start_belief_state.size()));
+    }
 private:
     Context ctx_;
     std::vector<uint64_t> reach_, final_ids_, final_masks_;

@@ -88,12 +88,12 @@ def fnv_words(h, words):
 @pytest.mark.gpu
 def test_cpp_pto_belief_graph_matches_oracle(exe):
     """PTO::grow_graph + PTO::build_belief_graph of the C++ mirror: digests of types, children and parents lists."""
-    n = 2500
+    n = 16000                        # enough for both goals: a policy exists
     out = subprocess.run([EXE_PTO, os.path.join(ROOT, "tests", "golden", "maps", "map1_2_goals_like.pgm"),
                           os.path.join(ROOT, "tests", "golden", "maps", "map1_2_goals_like_zone_ids.pgm"), str(n), "64", "0"],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    tok = out.stdout.split()
+    head, tok = out.stdout.split()[:8], out.stdout.split()[8:]
     case = cases.cfg3(n, n)
     o = cases.configure(orc.Oracle(), case)
     rc = cases.grow(o, case, K=64, algo=orc.ALGO_BATCHED_KD)
@@ -109,3 +109,12 @@ def test_cpp_pto_belief_graph_matches_oracle(exe):
     assert int(tok[11], 16) == fnv_words(h0, types)
     assert int(tok[13], 16) == hc and int(tok[15], 16) == hp
     assert int(tok[17]) == len(types)          # one validity in the shelf domain: every pair is compatible
+    d = o.expected_costs()
+    assert int(head[1], 16) == fnv_words(h0, d.view(np.uint64))
+    assert np.isfinite(d[0])
+    oid, par, leaf = o.extract_policy(d)
+    assert int(head[3]) == len(oid) and int(head[5]) == int(leaf.sum())
+    hpol = h0
+    for k in range(len(oid)):
+        hpol = fnv_words(hpol, [oid[k], par[k] if par[k] >= 0 else 2 ** 64 - 1])
+    assert int(head[7], 16) == hpol
