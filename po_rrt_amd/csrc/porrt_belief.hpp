@@ -48,6 +48,7 @@ struct BgConst {
     const unsigned long long *compat; // [B]: bit v = belief compatible with world validity v
     const uint32_t *mask_idx;         // [N]: index of the node's visible-zone set
     const uint32_t *obs_off, *obs_child;      // [(n_masks*B)+1], children beliefs of (mask, belief) in fold order
+    const double *obs_p;                      // per table entry: transition_probability(belief, posterior) (common.rs:187-190)
     const uint32_t *robs_off, *robs_par;      // reverse: parent beliefs of (mask, belief), ascending
     const unsigned long long *adj_off;        // [N+1] PTO adjacency in push order
     const uint32_t *adj_id;
@@ -669,6 +670,9 @@ struct BeliefGraphState {
     unsigned long long *d_child_off = nullptr, *d_par_off = nullptr;
     uint32_t *d_child_id = nullptr, *d_par_id = nullptr;
     const double *d_beliefs = nullptr;                // [B][nw]
+    BgConst last{};                                   // device pointers of the last build (tables, adjacency, bit planes)
+    bool support_shrinks = false;                     // every posterior has fewer possible worlds than its prior (expected; checked)
+    std::vector<uint32_t> support;                    // per belief: number of worlds with p > 0
     void release() {                                   // the result is gone, the memory stays for the next build
         next_slot = 0;
         valid = false;
@@ -842,6 +846,7 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
     const size_t M = masks.size();
     c.n_masks = (uint32_t)M;
     std::vector<uint32_t> obs_off(M * B + 1, 0), obs_child, robs_off(M * B + 1, 0), robs_par;
+    std::vector<double> obs_p;
     {
         // the fold of every (new zone set, belief) pair, pairs split evenly over a few host threads; each thread
         // appends to its own list, the lists are cut into the per-set tables in pair order
@@ -887,6 +892,21 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
             for (size_t b = 0; b < B; ++b) obs_off[m * B + b + 1] = obs_off[m * B + b] + fd.cnt[b];
             obs_child.insert(obs_child.end(), fd.child.begin(), fd.child.end());
         }
+        // transition probabilities of the table entries, and the order the dynamic programming may rely on
+        obs_p.resize(obs_child.size());
+        g.support.assign(B, 0);
+        for (size_t b = 0; b < B; ++b)
+            for (uint32_t w = 0; w < bs.nw; ++w) g.support[b] += bs.at(b)[w] > 0.0;
+        g.support_shrinks = true;
+        for (size_t m = 0; m < M; ++m)
+            for (size_t b = 0; b < B; ++b)
+                for (uint32_t k = obs_off[m * B + b]; k < obs_off[m * B + b + 1]; ++k) {
+                    const double *pb = bs.at(b), *cbv = bs.at(obs_child[k]);
+                    double pr = 0.0;
+                    for (uint32_t w = 0; w < bs.nw; ++w) pr = pr + (cbv[w] > 0.0 ? pb[w] : 0.0);
+                    obs_p[k] = pr;
+                    if (g.support[obs_child[k]] >= g.support[b]) g.support_shrinks = false;
+                }
         // reverse table: for every posterior its priors, ascending (counting sort per zone set)
         robs_par.resize(obs_child.size());
         std::vector<uint32_t> cur(B);
@@ -906,7 +926,7 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
     const double ta0 = bg_now();
     if ((r = bg_upload(g, g.d_beliefs, bs.vec, s, err))) return r;
     if ((r = bg_upload(g, c.compat, compat, s, err)) || (r = bg_upload(g, c.mask_idx, mask_idx, s, err)) ||
-        (r = bg_upload(g, c.obs_off, obs_off, s, err)) || (r = bg_upload(g, c.obs_child, obs_child, s, err)) ||
+        (r = bg_upload(g, c.obs_off, obs_off, s, err)) || (r = bg_upload(g, c.obs_child, obs_child, s, err)) || (r = bg_upload(g, c.obs_p, obs_p, s, err)) ||
         (r = bg_upload(g, c.robs_off, robs_off, s, err)) || (r = bg_upload(g, c.robs_par, robs_par, s, err)) ||
         (r = bg_upload(g, c.adj_off, adj_off, s, err)) || (r = bg_upload(g, c.adj_id, adj_id, s, err)) ||
         (r = bg_upload(g, c.adj_val, adj_val, s, err)) || (r = bg_upload(g, c.radj_id, radj_id, s, err)) ||
@@ -957,6 +977,7 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
     BG_HIP(hipEventElapsedTime(&ms_b, ev2, ev3));
     (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(ev2); (void)hipEventDestroy(ev3);
     g.n_edges = n_edges;
+    g.last = c;
     g.d_types = c.types; g.d_child_off = c.child_off; g.d_par_off = c.par_off; g.d_child_id = c.child_id; g.d_par_id = c.par_id;
     g.t_device = 1e-3 * (double)(ms_a + ms_b);
     g.t_total = bg_now() - t0;

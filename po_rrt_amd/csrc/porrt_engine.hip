@@ -170,6 +170,7 @@ struct porrt_ctx {
     bool opt_profile = false;
     bool opt_graph = true;
     uint32_t opt_kd_group = 0;     // steps per kd insertion (0 = choose by K)
+    bool opt_dp_sweeps = false;            // "dp_sweeps": expected costs by whole-graph sweeps instead of layer by layer
     uint32_t opt_cand_cap = 2048;
     // ---- device buffers
     DevBuf<double> d_nx, d_ny, d_distA, d_distB, d_sx, d_sy, d_qx, d_qy, d_pgxy, d_candxy, d_candval, d_radT2, d_inj;
@@ -1109,7 +1110,10 @@ int porrt_ctx::compute_expected_costs() {
     c.nx = d_nx.p; c.ny = d_ny.p; c.bvec = nullptr; c.beliefs = bg.d_beliefs; c.types = bg.d_types;
     c.child_off = bg.d_child_off; c.par_off = bg.d_par_off; c.child_id = bg.d_child_id; c.par_id = bg.d_par_id;
     std::string e;
-    r = dp_run(dp, c, true, finals, stream, e);
+    // layers solved one after the other when observations always shrink the set of possible worlds (always, in the
+    // reference's domains; checked by the build), the general sweeps otherwise or on request (option "dp_sweeps")
+    if (bg.support_shrinks && !opt_dp_sweeps) r = dp_run_layered(dp, bg, c, finals, stream, e);
+    else r = dp_run(dp, c, true, finals, stream, e);
     if (r) set_err(e);
     return r;
 }
@@ -1864,6 +1868,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "profile")) c->opt_profile = value != 0;
     else if (!strcmp(name, "cand_cap")) c->opt_cand_cap = (uint32_t)std::max<int64_t>(64, std::min<int64_t>(value, 1 << 26));
     else if (!strcmp(name, "graph")) c->opt_graph = value != 0;
+    else if (!strcmp(name, "dp_sweeps")) c->opt_dp_sweeps = value != 0;
     else if (!strcmp(name, "kd_group")) c->opt_kd_group = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else { c->set_err(std::string("unknown option ") + name); return PORRT_ERR_INVALID; }
     return PORRT_OK;

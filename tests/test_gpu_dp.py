@@ -128,3 +128,27 @@ def test_recompute_after_rebuild(eng_mod):
     assert np.isfinite(d1[0]) and np.isfinite(d2[0]) and d1[0] != d2[0]
     e.compute_expected_costs()
     assert np.array_equal(e.expected_costs().view(np.uint64), d2.view(np.uint64))
+
+
+def test_layered_and_swept_evaluations_agree(eng_mod):
+    """the context path solves the layers one after the other; option dp_sweeps = the general whole-graph sweeps"""
+    case = cases.cfg_door(paper=True)
+    e = cases.configure(eng_mod.Engine(), case)
+    cases.grow(e, case, K=256)
+    e.build_belief_graph([1.0 / 16] * 16)
+    e.compute_expected_costs()
+    d1, levels = e.expected_costs(), e.dp_info()["sweeps"]
+    e.set_option("dp_sweeps", 1)
+    e.compute_expected_costs()
+    d2, sweeps = e.expected_costs(), e.dp_info()["sweeps"]
+    assert np.array_equal(d1.view(np.uint64), d2.view(np.uint64))
+    assert levels > 0 and sweeps > 0
+
+
+def test_large_graph_few_beliefs(eng_mod):
+    """many graph nodes, three beliefs: levels one or two beliefs wide"""
+    case = cases.cfg3(30000, 30000)
+    e, o, de, do = both(eng_mod, case, 256, [0.5, 0.5])
+    assert e.num_nodes() > 21000
+    assert np.array_equal(de.view(np.uint64), do.view(np.uint64))
+    assert np.isfinite(de[0])
