@@ -50,7 +50,7 @@ enum {
 };
 
 enum { PORRT_DOMAIN_SHELF = 0, PORRT_DOMAIN_DOOR = 1 };   /* MapShelfDomain / Map */
-enum { PORRT_MODE_RRT = 0, PORRT_MODE_PTO = 1 };          /* RRT::grow_tree / PTO::grow_graph */
+enum { PORRT_MODE_RRT = 0, PORRT_MODE_PTO = 1, PORRT_MODE_PRM = 2 };   /* RRT::grow_tree / PTO::grow_graph / PRM::grow_graph (results only) */
 
 /* ---- lifetime.  Replaces: RRT::new (rrt.rs:84-86) / PTO::new (pto.rs:37-53) --------- */
 porrt_ctx  *porrt_create(int device);      /* NULL when no HIP device is usable */
@@ -141,6 +141,17 @@ int      porrt_best_cost(const porrt_ctx *ctx, double *cost, uint64_t *final_id)
 /* The same for the n contexts of the last porrt_grow_batch, in one launch (one workgroup per context);
  * costs[q] = +inf where context q has no solution.  Other sets of contexts are evaluated one after the other. */
 int      porrt_best_cost_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, double *costs);
+
+/* ---- PRM* roadmap growth: PRM::init(start) + PRM::grow_graph(max_step, search_radius, n_iter) (src/prm.rs:33-109) on a
+ * grid-backed domain.  Every sample becomes a node (the reference neither steers nor checks the state; validity id 0),
+ * connected both ways to the earlier nodes within heuristic_radius(graph size) whose transition the domain's
+ * transition_validator accepts.  The roadmap depends on the sample stream only, so the whole of it is evaluated at once
+ * with the reference's sequential semantics (no batch size).  Samples: the context's sampler (its state moves on by
+ * n_iter draws) or the injected stream.  Results through the getters of a PTO graph: porrt_num_nodes (n_iter + 1, node 0
+ * = start), porrt_get_tree (coordinates; parents -1), porrt_num_edges / porrt_get_edges (the forward edges neighbour ->
+ * new node in the reference's adjacency order; PTOGraph gets add_edge(from, to, 0) and add_edge(to, from, 0), the third
+ * array is what transition_validator returned). */
+int      porrt_grow_prm(porrt_ctx *ctx, const double start[2], double max_step, double search_radius, uint64_t n_iter);
 
 /* ---- belief-space expansion: PTO::build_belief_graph (src/pto.rs:185-259) on the graph of the last
  * porrt_grow(mode PORRT_MODE_PTO) of this context, with PTOFuncs::reachable_belief_states (map_io.rs:515-546,

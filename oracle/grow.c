@@ -665,3 +665,40 @@ uint64_t orc_firstly_final_ids(const orc_ctx *c, uint64_t *ids, uint64_t cap) {
     free(is_first);
     return n;
 }
+
+/* PRM::init + PRM::grow_graph (prm.rs:33-109): every sample is a node (validity id 0, no steering, no state check),
+ * connected both ways to the kd-tree's radius neighbours whose transition is valid.  Edges are logged neighbour -> new
+ * with what transition_validator returned (the graph itself stores validity 0 for both directions, prm.rs:96-103). */
+int orc_prm_grow(orc_ctx *c, const double start[2], double max_step, double search_radius, uint64_t n_iter) {
+    orc_bg_release(c);
+    reset_outputs(c, ORC_MODE_PTO);
+    c->oob = 0;
+    if (!c->has_grid) {
+        snprintf(c->err, sizeof c->err, "PRM needs a grid");
+        return -1;
+    }
+    add_node(c, start, -1, 0.0, 0, 0);                                 /* prm.rs:33-36 */
+    orc_kdtree *kd = orc_kd_new(start, 0);
+    idvec nb = {0};
+    int rc = 0;
+    for (uint64_t i = 0; i < n_iter; ++i) {                            /* prm.rs:38-51 */
+        double ns[2];
+        if (orc_sample(c, ns)) { rc = -1; break; }                     /* continuous_sampler.sample() */
+        uint64_t id = add_node(c, ns, -1, 0.0, 0, 0);                  /* prm.rs:62 */
+        double radius = orc_heuristic_radius(c->n_nodes, max_step, search_radius, 2);   /* prm.rs:66 */
+        kd_radius_all(kd, ns, radius, &nb);                            /* prm.rs:73-75 */
+        orc_kd_add(kd, ns, id);                                        /* prm.rs:77 */
+        for (size_t a = 0; a < nb.n; ++a) {                            /* prm.rs:90-95 */
+            double s[2];
+            node_state(c, nb.v[a], s);
+            int tv = orc_transition_validity(c, s, ns);
+            if (c->oob) { rc = -1; snprintf(c->err, sizeof c->err, "raster access the reference would panic on"); break; }
+            if (tv >= 0) orc_ctx_push_edge(c, (uint32_t)nb.v[a], (uint32_t)id, (uint32_t)tv);
+        }
+        if (rc) break;
+    }
+    orc_kd_free(kd);
+    free(nb.v);
+    c->n_iter = n_iter;
+    return rc;
+}

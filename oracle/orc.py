@@ -58,6 +58,7 @@ def lib():
     sig("orc_set_observation_goal", C.c_int, vp, C.c_uint32)
     sig("orc_to_pixel", C.c_int, vp, _f64p, _u32p)
     sig("orc_state_class", C.c_int, vp, _f64p)
+    sig("orc_prm_grow", C.c_int, vp, _f64p, C.c_double, C.c_double, C.c_uint64)
     sig("orc_belief_hash", C.c_uint64, _f64p, C.c_uint32)
     sig("orc_belief_successors", C.c_int, vp, _f64p, C.c_uint32, _f64p)
     sig("orc_zone_observable", C.c_int, vp, _f64p, C.c_uint32)
@@ -331,6 +332,10 @@ class Oracle:
         if n:
             self._l.orc_get_edges(self._c, f, t, v)
         return f, t, v
+
+    def grow_prm(self, start, max_step, search_radius, n_iter):
+        """PRM::init + PRM::grow_graph (prm.rs:33-109)"""
+        return self._chk(self._l.orc_prm_grow(self._c, _f64(start), max_step, search_radius, n_iter))
 
     # ---- belief space (belief.c; pto.rs:185-259)
     def belief_hash(self, b):

@@ -159,6 +159,9 @@ uint64_t   orc_reach_get(const orc_reach *r, uint64_t id);
 int        orc_reach_is_final_set_complete(orc_reach *r);
 size_t     orc_reach_final_nodes_for_world(const orc_reach *r, uint32_t world, uint64_t *out, size_t cap);
 
+/* PRM::init + PRM::grow_graph (prm.rs:33-109); results through the PTO getters (nodes, forward edges) */
+int orc_prm_grow(orc_ctx *c, const double start[2], double max_step, double search_radius, uint64_t n_iter);
+
 /* ------------------------------------------------------------------ belief.c
  * PTO::build_belief_graph (pto.rs:185-259) and the belief-state functions it calls */
 uint64_t orc_belief_hash(const double *bs, uint32_t n);                                     /* common.rs:352-355 */

@@ -13,6 +13,7 @@
 #include "porrt_device.hpp"
 #include "porrt_belief.hpp"
 #include "porrt_dp.hpp"
+#include "porrt_prm.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -235,6 +236,8 @@ struct porrt_ctx {
     DpState dp;                            // porrt_bg_compute_expected_costs: dist per belief node (device)
     int compute_expected_costs();
     int extract_policy();
+    PrmState prm;                          // porrt_grow_prm: grid scratch
+    int grow_prm(const double start[2], double max_step, double search_radius, uint64_t n_iter);
     int read_best_cost(double *cost, uint64_t *final_id);
     porrt_ctx *batch_leader = nullptr;     // set by porrt_grow_batch: the context whose RunConst array holds this one
     uint32_t batch_slot = 0, batch_size = 0;
@@ -1010,7 +1013,7 @@ int porrt_ctx::download(unsigned want) {
         HIPCHK(hipMemcpy(h_vid.data(), d_vid.p, N, hipMemcpyDeviceToHost));
     }
     if (!(need & DL_EDGES)) { got |= need; return PORRT_OK; }
-    if (mode == PORRT_MODE_PTO) {
+    if (mode == PORRT_MODE_PTO || mode == PORRT_MODE_PRM) {
         // Edges come back in the order PTOGraph's adjacency lists are filled (pto.rs:103-120): new nodes ascending, and
         // for one new node its neighbours in the order KdTree::nearest_neighbors lists them -- kd pre-order
         // (nearest_neighbor.rs:101-117).  The device only kept the edge set; the order is restored here, on demand, from
@@ -1135,6 +1138,128 @@ int porrt_ctx::extract_policy() {
     int r = dp_extract_policy(dp, true, belief_of, p_of, stream, e);
     if (r) set_err(e);
     return r;
+}
+
+// PRM::init + PRM::grow_graph (prm.rs:33-109); see porrt_prm.hpp.
+int porrt_ctx::grow_prm(const double start[2], double max_step, double search_radius, uint64_t n_iter_) {
+    const uint64_t n_iter = n_iter_;
+    if (!has_grid) { set_err("PRM growth needs a grid-backed domain (porrt_set_grid)"); return PORRT_ERR_INVALID; }
+    if (!(max_step > 0.0) || !(search_radius > 0.0) || !start) { set_err("bad PRM parameters"); return PORRT_ERR_INVALID; }
+    if (n_iter + 1 >= 0x7FFFFFFFull) { set_err("too many PRM samples"); return PORRT_ERR_INVALID; }
+    HIPCHK(hipSetDevice(device));
+    const double t0 = now_s();
+    have_results = false;
+    batch_leader = nullptr;
+    bg.release();
+    dp.release();
+    ++results_tag;
+    const size_t N = (size_t)n_iter + 1;
+    // the nodes: start, then one sample per iteration (ContinuousSampler::sample: x, then y)
+    std::vector<double> hx(N), hy(N);
+    hx[0] = start[0]; hy[0] = start[1];
+    const bool has_inj = !inj_xy.empty();
+    for (size_t i = 1; i < N; ++i) {
+        if (has_inj) {
+            if (inj_pos >= inj_xy.size() / 2) { set_err("injected sample stream exhausted"); return PORRT_ERR_INVALID; }
+            hx[i] = inj_xy[2 * inj_pos]; hy[i] = inj_xy[2 * inj_pos + 1];
+            ++inj_pos;
+        } else {
+            hx[i] = crng.gen_range_f64(s_low[0], s_up[0]);
+            hy[i] = crng.gen_range_f64(s_low[1], s_up[1]);
+        }
+    }
+    double x0 = hx[0], x1 = hx[0], y0 = hy[0], y1 = hy[0];
+    for (size_t i = 1; i < N; ++i) { x0 = std::min(x0, hx[i]); x1 = std::max(x1, hx[i]); y0 = std::min(y0, hy[i]); y1 = std::max(y1, hy[i]); }
+    const uint64_t ecap = std::min<uint64_t>((uint64_t)N * 256 + 4096, 1ull << 30);
+    HIPCHK(d_nx.reserve(N)); HIPCHK(d_ny.reserve(N)); HIPCHK(d_distA.reserve(N)); HIPCHK(d_parent.reserve(N)); HIPCHK(d_reachA.reserve(N));
+    HIPCHK(d_vid.reserve(N)); HIPCHK(d_finalflag.reserve(N)); HIPCHK(d_finalmask.reserve(N)); HIPCHK(d_radT2.reserve(N + 8));
+    HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_cls.reserve((size_t)W * H + 16));
+    HIPCHK(d_efrom.reserve(ecap)); HIPCHK(d_eto.reserve(ecap)); HIPCHK(d_etv.reserve(ecap));
+    int r = layout_buffers();
+    if (r) return r;
+    cls_dirty = true;                                   // a re-layout loses the raster
+    if ((r = build_cls())) return r;
+    rad_uploaded = 0;
+    if ((r = ensure_radius_table(max_step, search_radius, N + 2))) return r;
+    HIPCHK(hipMemcpyAsync(d_nx.p, hx.data(), N * 8, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_ny.p, hy.data(), N * 8, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemsetAsync(d_parent.p, 0xFF, N * sizeof(int), stream));
+    HIPCHK(hipMemsetAsync(d_distA.p, 0, N * 8, stream));
+    HIPCHK(hipMemsetAsync(d_reachA.p, 0, N * 8, stream));
+    HIPCHK(hipMemsetAsync(d_finalmask.p, 0, N * 8, stream));
+    HIPCHK(hipMemsetAsync(d_vid.p, 0, N, stream));
+    HIPCHK(hipMemsetAsync(d_finalflag.p, 0, N, stream));
+    memset(&rc, 0, sizeof rc);
+    rc.nx = d_nx.p; rc.ny = d_ny.p; rc.vid = d_vid.p;
+    rc.cls = d_cls.p; rc.W = W; rc.H = H; rc.low0 = low[0]; rc.low1 = low[1]; rc.ppm = ppm; rc.domain = domain; rc.has_grid = has_grid;
+    rc.n_validities = n_validities;
+    for (int i = 0; i < n_validities; ++i) rc.validities[i] = validities[i];
+    rc.all_worlds = ones(n_worlds);
+    rc.visibility = visibility;
+    rc.rad_T2 = d_radT2.p;
+    HIPCHK(hipMemcpyAsync(d_rc.p, &rc, sizeof rc, hipMemcpyHostToDevice, stream));
+    // the grid: cells at least max_step wide (no radius exceeds max_step, common.rs:357-369)
+    const double ext = std::max(std::max(x1 - x0, y1 - y0), max_step);
+    uint32_t G = (uint32_t)std::min<double>(1024.0, std::max(1.0, std::floor(ext / max_step)));
+    const double cell = ext / (double)G;                // >= max_step
+    const size_t cells = (size_t)G * G;
+    const size_t nblk = (cells + kScanTile - 1) / kScanTile;
+    if (prm.cells_cap < cells) {
+        void *drop[] = {prm.d_cell_cnt, prm.d_cell_off, prm.d_tot};
+        for (void *q : drop) if (q) (void)hipFree(q);
+        prm.d_cell_cnt = nullptr; prm.d_cell_off = prm.d_tot = nullptr; prm.cells_cap = 0;
+        HIPCHK(hipMalloc((void **)&prm.d_cell_cnt, cells * sizeof(uint32_t)));
+        HIPCHK(hipMalloc((void **)&prm.d_cell_off, (cells + 1) * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc((void **)&prm.d_tot, (nblk + 2) * sizeof(unsigned long long)));
+        prm.cells_cap = cells;
+    }
+    if (prm.ids_cap < N) {
+        if (prm.d_cell_ids) (void)hipFree(prm.d_cell_ids);
+        prm.d_cell_ids = nullptr; prm.ids_cap = 0;
+        HIPCHK(hipMalloc((void **)&prm.d_cell_ids, (N + N / 8) * sizeof(uint32_t)));
+        prm.ids_cap = N + N / 8;
+    }
+    if (!prm.d_n_edges) { HIPCHK(hipMalloc((void **)&prm.d_n_edges, sizeof(unsigned long long))); HIPCHK(hipMalloc((void **)&prm.d_err, sizeof(uint32_t))); }
+    PrmConst p{};
+    p.N = (uint32_t)N; p.G = G; p.nx = d_nx.p; p.ny = d_ny.p; p.rad_T2 = d_radT2.p;
+    p.x0 = x0; p.y0 = y0; p.inv_cell = 1.0 / cell;
+    p.cell_cnt = prm.d_cell_cnt; p.cell_off = prm.d_cell_off; p.cell_ids = prm.d_cell_ids;
+    p.efrom = d_efrom.p; p.eto = d_eto.p; p.ev = d_etv.p; p.ecap = ecap; p.n_edges = prm.d_n_edges; p.err = prm.d_err;
+    hipEvent_t ev0, ev1;
+    HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
+    HIPCHK(hipEventRecord(ev0, stream));
+    HIPCHK(hipMemsetAsync(prm.d_cell_cnt, 0, cells * sizeof(uint32_t), stream));
+    HIPCHK(hipMemsetAsync(prm.d_n_edges, 0, sizeof(unsigned long long), stream));
+    HIPCHK(hipMemsetAsync(prm.d_err, 0, sizeof(uint32_t), stream));
+    const dim3 ngrid((unsigned)((N + 255) / 256)), block(256);
+    hipLaunchKernelGGL(k_prm_bin<false>, ngrid, block, 0, stream, p);
+    bg_scan(prm.d_cell_cnt, cells, prm.d_tot, prm.d_cell_off, stream);
+    HIPCHK(hipMemsetAsync(prm.d_cell_cnt, 0, cells * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(k_prm_bin<true>, ngrid, block, 0, stream, p);
+    if (N > 1) hipLaunchKernelGGL(k_prm_connect, dim3((unsigned)((N - 1 + 3) / 4)), block, 0, stream, (const RunConst *)d_rc.p, p);
+    HIPCHK(hipEventRecord(ev1, stream));
+    unsigned long long n_edges = 0;
+    uint32_t h_err = 0;
+    HIPCHK(hipMemcpyAsync(&n_edges, prm.d_n_edges, sizeof n_edges, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(&h_err, prm.d_err, sizeof h_err, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipGetLastError());
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+    if (h_err & ERR_RASTER) { set_err("raster access the reference would panic on (image::get_pixel out of range, door pixel without zone, two zones on one segment)"); return PORRT_ERR_RASTER; }
+    if (n_edges > ecap) { set_err("PRM edge list outgrew its capacity (256 per node)"); return PORRT_ERR_CAPACITY; }
+    memset(&counters, 0, sizeof counters);
+    counters.n_edges = (uint32_t)n_edges;
+    mode = PORRT_MODE_PRM;
+    n_nodes = N; this->n_iter = n_iter_; n_steps = 0;
+    complete = false;
+    prm.t_device = 1e-3 * (double)ms;
+    prm.t_total = now_s() - t0;
+    memset(&metrics, 0, sizeof metrics);
+    metrics.n_iter = n_iter_; metrics.n_nodes = N; metrics.total_s = prm.t_total; metrics.device_s = prm.t_device;
+    have_results = true;
+    return PORRT_OK;
 }
 
 // Best path cost without downloading the tree (k_best_cost).  1 = found, 0 = no final node, -1 = scratch too small
@@ -1584,7 +1709,7 @@ int porrt_get_node_validity(const porrt_ctx *cc, uint32_t *v) {
     return PORRT_OK;
 }
 
-uint64_t porrt_num_edges(const porrt_ctx *c) { return c && c->have_results && c->mode == PORRT_MODE_PTO ? c->counters.n_edges : 0; }
+uint64_t porrt_num_edges(const porrt_ctx *c) { return c && c->have_results && (c->mode == PORRT_MODE_PTO || c->mode == PORRT_MODE_PRM) ? c->counters.n_edges : 0; }
 
 int porrt_get_edges(const porrt_ctx *cc, uint32_t *from, uint32_t *to, uint32_t *validity_id) {
     porrt_ctx *c = const_cast<porrt_ctx *>(cc);
@@ -1683,6 +1808,10 @@ int porrt_best_cost_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, double *costs)
         costs[q] = r ? c : inf;
     }
     return PORRT_OK;
+}
+
+int porrt_grow_prm(porrt_ctx *c, const double start[2], double max_step, double search_radius, uint64_t n_iter) {
+    return c ? c->grow_prm(start, max_step, search_radius, n_iter) : PORRT_ERR_INVALID;
 }
 
 // ---- belief-space expansion (pto.rs:185-259)

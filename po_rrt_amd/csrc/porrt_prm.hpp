@@ -1,0 +1,108 @@
+// porrt_prm.hpp -- PRM* roadmap growth on the device: PRM::grow_graph / PRM::add_sample (src/prm.rs:38-109).
+//
+// The reference adds every sample as a node (no steering, no state check, validity id 0), asks its kd-tree for the
+// nodes within heuristic_radius(n) of it -- n the graph size with the new node -- and connects, both ways, the ones
+// whose transition PTOFuncs::transition_validator accepts.  The samples do not depend on the graph, so the whole
+// roadmap is a function of the sample stream alone:
+//     edge (j -> i), j < i   <=>   norm2(x_j, x_i) <= heuristic_radius(i + 1)  and  transition_validator(x_j -> x_i) is Some
+// and every node's neighbourhood can be evaluated at once -- no batching contract, the sequential semantics exactly.
+// Device: bucket all nodes into a uniform grid whose cells are at least max_step wide (count, scan, fill), then one
+// wave per node scans the 3 x 3 cells around it for earlier nodes inside its radius (the exact squared-distance
+// threshold the growth kernels use, rad_T2), raycasts the hits (traversed_class, neighbour -> new node as the
+// reference orders the arguments) and appends the edges.  The order inside a neighbour list (kd pre-order,
+// nearest_neighbor.rs:101-117) is restored on the host when the edges are asked for, as for the belief-space graphs.
+#pragma once
+#include "porrt_belief.hpp"
+
+namespace porrt {
+
+struct PrmConst {
+    uint32_t N, G;
+    const double *nx, *ny;
+    const double *rad_T2;             // [graph size] -> largest squared distance inside heuristic_radius
+    double x0, y0, inv_cell;
+    uint32_t *cell_cnt;               // [G*G] (count pass: sizes; fill pass: cursors)
+    const unsigned long long *cell_off;   // [G*G + 1]
+    uint32_t *cell_ids;               // [N]
+    uint32_t *efrom, *eto, *ev;
+    unsigned long long ecap;
+    unsigned long long *n_edges;
+    uint32_t *err;
+};
+
+__device__ __forceinline__ uint32_t prm_cell_coord(double v, double v0, double inv_cell, uint32_t G) {
+    const double t = (v - v0) * inv_cell;
+    if (!(t > 0.0)) return 0u;
+    const uint32_t c = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;       // monotone in v, clamped: a disc scan over cells is exhaustive
+    return c < G ? c : G - 1;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_prm_bin(PrmConst p) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.N) return;
+    const uint32_t cx = prm_cell_coord(as_global(p.nx)[i], p.x0, p.inv_cell, p.G), cy = prm_cell_coord(as_global(p.ny)[i], p.y0, p.inv_cell, p.G);
+    const uint32_t cell = cy * p.G + cx;
+    const uint32_t at = atomicAdd(&p.cell_cnt[cell], 1u);
+    if (FILL) as_global(p.cell_ids)[as_global(p.cell_off)[cell] + at] = i;
+}
+
+// One wave per node i >= 1 (node 0 is the start, PRM::init): its earlier neighbours.
+__global__ __launch_bounds__(256) void k_prm_connect(const RunConst *__restrict__ rcp, PrmConst p) {
+    const RunConst &rc = *rcp;
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / 64u + 1u, lane = threadIdx.x & 63u;
+    if (i >= p.N) return;
+    const double px = as_global(p.nx)[i], py = as_global(p.ny)[i];
+    const double T2 = as_global(p.rad_T2)[i + 1];                           // heuristic_radius(self.graph.nodes.len()) with the new node in
+    const uint32_t cx = prm_cell_coord(px, p.x0, p.inv_cell, p.G), cy = prm_cell_coord(py, p.y0, p.inv_cell, p.G);
+    const uint32_t x_lo = cx ? cx - 1 : 0, x_hi = cx + 1 < p.G ? cx + 1 : p.G - 1, y_lo = cy ? cy - 1 : 0, y_hi = cy + 1 < p.G ? cy + 1 : p.G - 1;
+    GlobalGrid grid{rc.cls, rc.W};
+    uint32_t err = 0;
+    for (uint32_t yy = y_lo; yy <= y_hi; ++yy) {
+        // the cells of one row are adjacent in the sorted list: one run per row
+        const unsigned long long r0 = as_global(p.cell_off)[yy * p.G + x_lo], r1 = as_global(p.cell_off)[yy * p.G + x_hi + 1];
+        for (unsigned long long q0 = r0; q0 < r1; q0 += 64) {
+            const unsigned long long q = q0 + lane;
+            bool hit = false;
+            uint32_t j = 0, vid = 0;
+            if (q < r1) {
+                j = as_global(p.cell_ids)[q];
+                if (j < i) {
+                    const double ax = as_global(p.nx)[j], ay = as_global(p.ny)[j];
+                    if (dist2(ax, ay, px, py) <= T2) {                       // norm2(node, new_state) <= radius
+                        const int cls = traversed_class(rc, grid, ax, ay, px, py, &err);    // transition_validator(node, new_node)
+                        const int v = class_to_validity(rc, cls);
+                        hit = v >= 0;
+                        vid = hit ? (uint32_t)v : 0u;
+                    }
+                }
+            }
+            const unsigned long long ballot = __ballot(hit);
+            if (ballot) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(p.n_edges, (unsigned long long)__popcll(ballot));
+                base = __shfl(base, 0, 64);
+                const unsigned long long at = base + (unsigned long long)__popcll(ballot & ((1ull << lane) - 1ull));
+                if (hit && at < p.ecap) { as_global(p.efrom)[at] = j; as_global(p.eto)[at] = i; as_global(p.ev)[at] = vid; }
+            }
+        }
+    }
+    if (err) atomicOr(p.err, err);
+}
+
+struct PrmState {
+    uint32_t *d_cell_cnt = nullptr;
+    unsigned long long *d_cell_off = nullptr, *d_tot = nullptr, *d_n_edges = nullptr;
+    uint32_t *d_cell_ids = nullptr, *d_err = nullptr;
+    size_t cells_cap = 0, ids_cap = 0;
+    double t_device = 0, t_total = 0;
+    void free_device() {
+        void *all[] = {d_cell_cnt, d_cell_off, d_tot, d_n_edges, d_cell_ids, d_err};
+        for (void *q : all) if (q) (void)hipFree(q);
+        d_cell_cnt = nullptr; d_cell_off = d_tot = d_n_edges = nullptr; d_cell_ids = d_err = nullptr;
+        cells_cap = ids_cap = 0;
+    }
+    ~PrmState() { free_device(); }
+};
+
+} // namespace porrt
