@@ -232,6 +232,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(case, args)
         if not args.no_belief and world == 1:
             out["config"]["belief_space"] = belief_space(local_rank, not args.no_cpu_baseline)
+            out["config"]["prm_roadmap"] = prm_roadmap(local_rank, not args.no_cpu_baseline)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -299,6 +300,37 @@ def belief_space(device, with_cpu):
                                "sample": "the same PTO graph with 8 of the 12 worlds possible (255 beliefs, %d edges): build_belief_graph %.2f s, "
                                          "conditional_dijkstra %.2f s (%.1f M edges/s; root cost %r); C restatement of pto.rs:185-275, "
                                          "belief_graph.rs:89-175 (oracle/belief.c, oracle/dp.c)" % (Eo, dt, dt2, Eo / dt2 / 1e6, float(d[0]))}
+    return out
+
+
+def prm_roadmap(device, with_cpu):
+    """SURVEY 8f.3, outside the timed region: PRM::grow_graph (prm.rs:38-109) -- a 200 000-sample PRM* roadmap on the
+    benchmark map (max_step 0.1, search_radius 2.0 as the RRT* workload)."""
+    import cases
+    import po_rrt_amd
+    n = 200000
+    e = po_rrt_amd.Engine(device)
+    e.set_grid(cases.load_map("map_benchmark_like"), (-1.0, -1.0), (1.0, 1.0), cases.SHELF)
+    ts = []
+    for rep in range(4):
+        e.set_sampler((-1.0, -1.0), (1.0, 1.0), rep)
+        t0 = time.perf_counter()
+        e.grow_prm((0.0, -0.8), 0.1, 2.0, n)
+        ts.append((time.perf_counter() - t0, e.metrics()["device_s"], len(e.edges()[0]) if rep == 3 else 0))
+    wall, dev, _ = sorted(ts[1:])[1]
+    E = ts[3][2]
+    out = {"what": "PRM::grow_graph, %d samples -> %d forward edges" % (n, E), "ms_wall": 1e3 * wall, "ms_device": 1e3 * dev,
+           "nodes_per_s": n / wall, "edges_per_s": E / wall}
+    if with_cpu:
+        from oracle import orc
+        o = orc.Oracle()
+        o.set_grid(cases.load_map("map_benchmark_like"), (-1.0, -1.0), (1.0, 1.0), cases.SHELF)
+        o.set_sampler((-1.0, -1.0), (1.0, 1.0), 3)
+        t0 = time.perf_counter()
+        o.grow_prm((0.0, -0.8), 0.1, 2.0, n)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n / dt, "unit": "nodes/s", "cores": 1, "kind": "port",
+                               "sample": "the full workload, %.2f s; C restatement of prm.rs:33-109 with the reference's kd-tree" % dt}
     return out
 
 

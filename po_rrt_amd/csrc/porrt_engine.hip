@@ -1198,49 +1198,63 @@ int porrt_ctx::grow_prm(const double start[2], double max_step, double search_ra
     rc.visibility = visibility;
     rc.rad_T2 = d_radT2.p;
     HIPCHK(hipMemcpyAsync(d_rc.p, &rc, sizeof rc, hipMemcpyHostToDevice, stream));
-    // the grid: cells at least max_step wide (no radius exceeds max_step, common.rs:357-369)
+    // the grid: cells about as wide as the radius of the last nodes (the smallest; most nodes are near it); a node scans
+    // the window of cells its own radius reaches
     const double ext = std::max(std::max(x1 - x0, y1 - y0), max_step);
-    uint32_t G = (uint32_t)std::min<double>(1024.0, std::max(1.0, std::floor(ext / max_step)));
-    const double cell = ext / (double)G;                // >= max_step
+    const double r_last = std::sqrt(std::max(radT2[N], 0.0));
+    uint32_t G = (uint32_t)std::min<double>(1024.0, std::max(1.0, std::floor(ext / std::max(r_last, ext / 1024.0))));
+    const double cell = ext / (double)G;
     const size_t cells = (size_t)G * G;
-    const size_t nblk = (cells + kScanTile - 1) / kScanTile;
+    const size_t nblk = (std::max(cells, N) + kScanTile - 1) / kScanTile;
     if (prm.cells_cap < cells) {
-        void *drop[] = {prm.d_cell_cnt, prm.d_cell_off, prm.d_tot};
+        void *drop[] = {prm.d_cell_cnt, prm.d_cell_off};
         for (void *q : drop) if (q) (void)hipFree(q);
-        prm.d_cell_cnt = nullptr; prm.d_cell_off = prm.d_tot = nullptr; prm.cells_cap = 0;
+        prm.d_cell_cnt = nullptr; prm.d_cell_off = nullptr; prm.cells_cap = 0;
         HIPCHK(hipMalloc((void **)&prm.d_cell_cnt, cells * sizeof(uint32_t)));
         HIPCHK(hipMalloc((void **)&prm.d_cell_off, (cells + 1) * sizeof(unsigned long long)));
-        HIPCHK(hipMalloc((void **)&prm.d_tot, (nblk + 2) * sizeof(unsigned long long)));
         prm.cells_cap = cells;
     }
     if (prm.ids_cap < N) {
-        if (prm.d_cell_ids) (void)hipFree(prm.d_cell_ids);
-        prm.d_cell_ids = nullptr; prm.ids_cap = 0;
-        HIPCHK(hipMalloc((void **)&prm.d_cell_ids, (N + N / 8) * sizeof(uint32_t)));
-        prm.ids_cap = N + N / 8;
+        void *drop[] = {prm.d_cell_ids, prm.d_deg, prm.d_edge_off};
+        for (void *q : drop) if (q) (void)hipFree(q);
+        prm.d_cell_ids = prm.d_deg = nullptr; prm.d_edge_off = nullptr; prm.ids_cap = 0;
+        const size_t cap = N + N / 8 + 1;
+        HIPCHK(hipMalloc((void **)&prm.d_cell_ids, cap * sizeof(uint32_t)));
+        HIPCHK(hipMalloc((void **)&prm.d_deg, cap * sizeof(uint32_t)));
+        HIPCHK(hipMalloc((void **)&prm.d_edge_off, (cap + 1) * sizeof(unsigned long long)));
+        prm.ids_cap = cap - 1;
     }
-    if (!prm.d_n_edges) { HIPCHK(hipMalloc((void **)&prm.d_n_edges, sizeof(unsigned long long))); HIPCHK(hipMalloc((void **)&prm.d_err, sizeof(uint32_t))); }
+    if (prm.d_tot) (void)hipFree(prm.d_tot);
+    prm.d_tot = nullptr;
+    HIPCHK(hipMalloc((void **)&prm.d_tot, (nblk + 2) * sizeof(unsigned long long)));
+    if (!prm.d_err) HIPCHK(hipMalloc((void **)&prm.d_err, sizeof(uint32_t)));
     PrmConst p{};
     p.N = (uint32_t)N; p.G = G; p.nx = d_nx.p; p.ny = d_ny.p; p.rad_T2 = d_radT2.p;
     p.x0 = x0; p.y0 = y0; p.inv_cell = 1.0 / cell;
     p.cell_cnt = prm.d_cell_cnt; p.cell_off = prm.d_cell_off; p.cell_ids = prm.d_cell_ids;
-    p.efrom = d_efrom.p; p.eto = d_eto.p; p.ev = d_etv.p; p.ecap = ecap; p.n_edges = prm.d_n_edges; p.err = prm.d_err;
+    p.efrom = d_efrom.p; p.eto = d_eto.p; p.ev = d_etv.p; p.deg = prm.d_deg; p.edge_off = prm.d_edge_off; p.err = prm.d_err;
     hipEvent_t ev0, ev1;
     HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
     HIPCHK(hipEventRecord(ev0, stream));
     HIPCHK(hipMemsetAsync(prm.d_cell_cnt, 0, cells * sizeof(uint32_t), stream));
-    HIPCHK(hipMemsetAsync(prm.d_n_edges, 0, sizeof(unsigned long long), stream));
+    HIPCHK(hipMemsetAsync(prm.d_deg, 0, N * sizeof(uint32_t), stream));
     HIPCHK(hipMemsetAsync(prm.d_err, 0, sizeof(uint32_t), stream));
-    const dim3 ngrid((unsigned)((N + 255) / 256)), block(256);
+    const dim3 ngrid((unsigned)((N + 255) / 256)), block(256), wgrid((unsigned)((N - 1 + 3) / 4));
     hipLaunchKernelGGL(k_prm_bin<false>, ngrid, block, 0, stream, p);
     bg_scan(prm.d_cell_cnt, cells, prm.d_tot, prm.d_cell_off, stream);
     HIPCHK(hipMemsetAsync(prm.d_cell_cnt, 0, cells * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(k_prm_bin<true>, ngrid, block, 0, stream, p);
-    if (N > 1) hipLaunchKernelGGL(k_prm_connect, dim3((unsigned)((N - 1 + 3) / 4)), block, 0, stream, (const RunConst *)d_rc.p, p);
-    HIPCHK(hipEventRecord(ev1, stream));
     unsigned long long n_edges = 0;
     uint32_t h_err = 0;
-    HIPCHK(hipMemcpyAsync(&n_edges, prm.d_n_edges, sizeof n_edges, hipMemcpyDeviceToHost, stream));
+    if (N > 1) {
+        hipLaunchKernelGGL(k_prm_connect<false>, wgrid, block, 0, stream, (const RunConst *)d_rc.p, p);
+        bg_scan(prm.d_deg, N, prm.d_tot, prm.d_edge_off, stream);
+        HIPCHK(hipMemcpyAsync(&n_edges, prm.d_edge_off + N, sizeof n_edges, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (n_edges > ecap) { set_err("PRM edge list outgrew its capacity (256 per node)"); return PORRT_ERR_CAPACITY; }
+        hipLaunchKernelGGL(k_prm_connect<true>, wgrid, block, 0, stream, (const RunConst *)d_rc.p, p);
+    }
+    HIPCHK(hipEventRecord(ev1, stream));
     HIPCHK(hipMemcpyAsync(&h_err, prm.d_err, sizeof h_err, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     HIPCHK(hipGetLastError());
@@ -1248,7 +1262,6 @@ int porrt_ctx::grow_prm(const double start[2], double max_step, double search_ra
     HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
     (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
     if (h_err & ERR_RASTER) { set_err("raster access the reference would panic on (image::get_pixel out of range, door pixel without zone, two zones on one segment)"); return PORRT_ERR_RASTER; }
-    if (n_edges > ecap) { set_err("PRM edge list outgrew its capacity (256 per node)"); return PORRT_ERR_CAPACITY; }
     memset(&counters, 0, sizeof counters);
     counters.n_edges = (uint32_t)n_edges;
     mode = PORRT_MODE_PRM;

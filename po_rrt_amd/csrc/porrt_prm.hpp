@@ -6,10 +6,10 @@
 // roadmap is a function of the sample stream alone:
 //     edge (j -> i), j < i   <=>   norm2(x_j, x_i) <= heuristic_radius(i + 1)  and  transition_validator(x_j -> x_i) is Some
 // and every node's neighbourhood can be evaluated at once -- no batching contract, the sequential semantics exactly.
-// Device: bucket all nodes into a uniform grid whose cells are at least max_step wide (count, scan, fill), then one
-// wave per node scans the 3 x 3 cells around it for earlier nodes inside its radius (the exact squared-distance
+// Device: bucket all nodes into a uniform grid with cells about as wide as the final radius (count, scan, fill), then one
+// wave per node scans the window of cells its own radius reaches for earlier nodes inside that radius (the exact squared-distance
 // threshold the growth kernels use, rad_T2), raycasts the hits (traversed_class, neighbour -> new node as the
-// reference orders the arguments) and appends the edges.  The order inside a neighbour list (kd pre-order,
+// reference orders the arguments); a count pass, a scan and a fill pass produce the edge list without a shared cursor.  The order inside a neighbour list (kd pre-order,
 // nearest_neighbor.rs:101-117) is restored on the host when the edges are asked for, as for the belief-space graphs.
 #pragma once
 #include "porrt_belief.hpp"
@@ -25,8 +25,8 @@ struct PrmConst {
     const unsigned long long *cell_off;   // [G*G + 1]
     uint32_t *cell_ids;               // [N]
     uint32_t *efrom, *eto, *ev;
-    unsigned long long ecap;
-    unsigned long long *n_edges;
+    uint32_t *deg;                    // [N] number of earlier neighbours per node (count pass)
+    const unsigned long long *edge_off;   // [N + 1] (fill pass)
     uint32_t *err;
 };
 
@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256) void k_prm_bin(PrmConst p) {
     if (FILL) as_global(p.cell_ids)[as_global(p.cell_off)[cell] + at] = i;
 }
 
-// One wave per node i >= 1 (node 0 is the start, PRM::init): its earlier neighbours.
+// One wave per node i >= 1 (node 0 is the start, PRM::init): its earlier neighbours.  FILL = false counts them, FILL =
+// true (after the scan of the counts) writes them: no shared cursor, and the edge list comes out grouped by new node.
+template <bool FILL>
 __global__ __launch_bounds__(256) void k_prm_connect(const RunConst *__restrict__ rcp, PrmConst p) {
     const RunConst &rc = *rcp;
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / 64u + 1u, lane = threadIdx.x & 63u;
@@ -55,9 +57,13 @@ __global__ __launch_bounds__(256) void k_prm_connect(const RunConst *__restrict_
     const double px = as_global(p.nx)[i], py = as_global(p.ny)[i];
     const double T2 = as_global(p.rad_T2)[i + 1];                           // heuristic_radius(self.graph.nodes.len()) with the new node in
     const uint32_t cx = prm_cell_coord(px, p.x0, p.inv_cell, p.G), cy = prm_cell_coord(py, p.y0, p.inv_cell, p.G);
-    const uint32_t x_lo = cx ? cx - 1 : 0, x_hi = cx + 1 < p.G ? cx + 1 : p.G - 1, y_lo = cy ? cy - 1 : 0, y_hi = cy + 1 < p.G ? cy + 1 : p.G - 1;
+    // cells a disc of this node's radius can touch: the cell coordinate is monotone, so |difference| <= floor(r / cell) + 1
+    const double rw = T2 > 0.0 ? sqrt(T2) * p.inv_cell : 0.0;
+    const uint32_t w = rw >= (double)p.G ? p.G : (uint32_t)rw + 1u;
+    const uint32_t x_lo = cx > w ? cx - w : 0, x_hi = cx + w < p.G ? cx + w : p.G - 1, y_lo = cy > w ? cy - w : 0, y_hi = cy + w < p.G ? cy + w : p.G - 1;
     GlobalGrid grid{rc.cls, rc.W};
-    uint32_t err = 0;
+    uint32_t err = 0, total = 0;
+    const unsigned long long out0 = FILL ? as_global(p.edge_off)[i] : 0ull;
     for (uint32_t yy = y_lo; yy <= y_hi; ++yy) {
         // the cells of one row are adjacent in the sorted list: one run per row
         const unsigned long long r0 = as_global(p.cell_off)[yy * p.G + x_lo], r1 = as_global(p.cell_off)[yy * p.G + x_hi + 1];
@@ -78,28 +84,27 @@ __global__ __launch_bounds__(256) void k_prm_connect(const RunConst *__restrict_
                 }
             }
             const unsigned long long ballot = __ballot(hit);
-            if (ballot) {
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(p.n_edges, (unsigned long long)__popcll(ballot));
-                base = __shfl(base, 0, 64);
-                const unsigned long long at = base + (unsigned long long)__popcll(ballot & ((1ull << lane) - 1ull));
-                if (hit && at < p.ecap) { as_global(p.efrom)[at] = j; as_global(p.eto)[at] = i; as_global(p.ev)[at] = vid; }
+            if (FILL && hit) {
+                const unsigned long long at = out0 + total + (unsigned long long)__popcll(ballot & ((1ull << lane) - 1ull));
+                as_global(p.efrom)[at] = j; as_global(p.eto)[at] = i; as_global(p.ev)[at] = vid;
             }
+            total += (uint32_t)__popcll(ballot);
         }
     }
+    if (!FILL && lane == 0) as_global(p.deg)[i] = total;
     if (err) atomicOr(p.err, err);
 }
 
 struct PrmState {
     uint32_t *d_cell_cnt = nullptr;
-    unsigned long long *d_cell_off = nullptr, *d_tot = nullptr, *d_n_edges = nullptr;
-    uint32_t *d_cell_ids = nullptr, *d_err = nullptr;
+    unsigned long long *d_cell_off = nullptr, *d_tot = nullptr, *d_edge_off = nullptr;
+    uint32_t *d_cell_ids = nullptr, *d_err = nullptr, *d_deg = nullptr;
     size_t cells_cap = 0, ids_cap = 0;
     double t_device = 0, t_total = 0;
     void free_device() {
-        void *all[] = {d_cell_cnt, d_cell_off, d_tot, d_n_edges, d_cell_ids, d_err};
+        void *all[] = {d_cell_cnt, d_cell_off, d_tot, d_edge_off, d_cell_ids, d_err, d_deg};
         for (void *q : all) if (q) (void)hipFree(q);
-        d_cell_cnt = nullptr; d_cell_off = d_tot = d_n_edges = nullptr; d_cell_ids = d_err = nullptr;
+        d_cell_cnt = nullptr; d_cell_off = d_tot = d_edge_off = nullptr; d_cell_ids = d_err = d_deg = nullptr;
         cells_cap = ids_cap = 0;
     }
     ~PrmState() { free_device(); }
