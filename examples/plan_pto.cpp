@@ -53,6 +53,18 @@ int main(int argc, char **argv) {
         std::printf("complete %d nodes %zu beliefs %zu belief_nodes %zu edges %zu types %016llx children %016llx parents %016llx compatible %zu\n",
                     ok ? 1 : 0, pto.graph.nodes.size(), g.n_beliefs(), g.n_nodes(), g.children_ids.size(), (unsigned long long)ht,
                     (unsigned long long)hc, (unsigned long long)hp, n_some);
+        // prm.rs:146-170: a PRM* roadmap on the same domain
+        PRM prm(ContinuousSampler({-1.0, -1.0}, {1.0, 1.0}, seed + 100), m);
+        prm.init({-0.8, -0.8});
+        prm.grow_graph(0.05, 5.0, 2000);
+        uint64_t hr = 1469598103934665603ull;
+        size_t n_arcs = 0;
+        for (auto &nd : prm.graph.nodes) {
+            hr = fnv(hr, nd.children.size());
+            for (auto &c : nd.children) hr = fnv(hr, c.id);
+            n_arcs += nd.children.size();
+        }
+        std::printf("prm_nodes %zu prm_arcs %zu prm %016llx\n", prm.graph.nodes.size(), n_arcs, (unsigned long long)hr);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

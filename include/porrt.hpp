@@ -419,4 +419,42 @@ private:
     std::vector<uint64_t> reach_, final_ids_, final_masks_;
 };
 
+// prm.rs:13-109.  init(start) + grow_graph(...) build one roadmap per call pair (porrt_grow_prm evaluates all samples at
+// once; growing an existing roadmap further is a new call with the full iteration count on a sampler reset to its seed).
+class PRM {
+public:
+    PTOGraph graph;
+    size_t n_it = 0;
+    PRM(const ContinuousSampler &cs, const GridDomain &fns, int device = 0) : ctx_(device) {
+        ctx_.set_domain(fns);
+        ctx_.check(porrt_set_sampler(ctx_.get(), cs.low.data(), cs.up.data(), cs.seed));
+    }
+    void init(State start) { start_ = start; }                                                        // prm.rs:33-36
+    void grow_graph(double max_step, double search_radius, size_t n_iter) {                          // prm.rs:38-51
+        ctx_.check(porrt_grow_prm(ctx_.get(), start_.data(), max_step, search_radius, n_iter));
+        n_it += n_iter;
+        const size_t n = porrt_num_nodes(ctx_.get());
+        std::vector<double> xy(2 * n);
+        ctx_.check(porrt_get_tree(ctx_.get(), xy.data(), nullptr, nullptr));
+        uint64_t val[65];
+        int nv = porrt_get_validities(ctx_.get(), val);
+        graph.validities.assign(val, val + nv);
+        graph.nodes.assign(n, PTONode{});
+        for (size_t j = 0; j < n; ++j) { graph.nodes[j].state = {xy[2 * j], xy[2 * j + 1]}; graph.nodes[j].validity_id = 0; }
+        const size_t E = porrt_num_edges(ctx_.get());
+        std::vector<uint32_t> f(E), t(E), v(E);
+        if (E) ctx_.check(porrt_get_edges(ctx_.get(), f.data(), t.data(), v.data()));
+        for (size_t e0 = 0; e0 < E;) {             // prm.rs:96-103: neighbour -> new for all, then new -> neighbour; validity 0
+            size_t e1 = e0;
+            while (e1 < E && t[e1] == t[e0]) ++e1;
+            for (size_t e = e0; e < e1; ++e) graph.add_edge(f[e], t[e], 0);
+            for (size_t e = e0; e < e1; ++e) graph.add_edge(t[e], f[e], 0);
+            e0 = e1;
+        }
+    }
+private:
+    Context ctx_;
+    State start_{0.0, 0.0};
+};
+
 } // namespace po_rrt

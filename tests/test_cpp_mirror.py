@@ -118,3 +118,26 @@ def test_cpp_pto_belief_graph_matches_oracle(exe):
     for k in range(len(oid)):
         hpol = fnv_words(hpol, [oid[k], par[k] if par[k] >= 0 else 2 ** 64 - 1])
     assert int(head[7], 16) == hpol
+    # the PRM roadmap printed on the second line: adjacency lists in the reference's push order
+    tok2 = out.stdout.splitlines()[1].split()
+    o2 = orc.Oracle()
+    o2.set_grid(cases.load_map("map1_2_goals_like"), (-1.0, -1.0), (1.0, 1.0), cases.SHELF)
+    o2.set_zones(cases.load_map("map1_2_goals_like_zone_ids"), 0.5)
+    o2.set_sampler((-1.0, -1.0), (1.0, 1.0), 100)
+    o2.grow_prm((-0.8, -0.8), 0.05, 5.0, 2000)
+    f, t, _ = o2.edges()
+    adj = [[] for _ in range(o2.num_nodes())]
+    e0 = 0
+    while e0 < len(t):
+        e1 = e0
+        while e1 < len(t) and t[e1] == t[e0]:
+            e1 += 1
+        for k in range(e0, e1):
+            adj[f[k]].append(int(t[k]))
+        for k in range(e0, e1):
+            adj[t[k]].append(int(f[k]))
+        e0 = e1
+    hr = h0
+    for a in adj:
+        hr = fnv_words(fnv_words(hr, [len(a)]), a)
+    assert int(tok2[1]) == o2.num_nodes() and int(tok2[3]) == 2 * len(f) and int(tok2[5], 16) == hr
