@@ -56,7 +56,7 @@ int main(int argc, char **argv) {
         // prm.rs:146-170: a PRM* roadmap on the same domain
         PRM prm(ContinuousSampler({-1.0, -1.0}, {1.0, 1.0}, seed + 100), m);
         prm.init({-0.8, -0.8});
-        prm.grow_graph(0.05, 5.0, 2000);
+        prm.grow_graph(0.1, 5.0, 2000);
         uint64_t hr = 1469598103934665603ull;
         size_t n_arcs = 0;
         for (auto &nd : prm.graph.nodes) {
@@ -64,7 +64,11 @@ int main(int argc, char **argv) {
             for (auto &c : nd.children) hr = fnv(hr, c.id);
             n_arcs += nd.children.size();
         }
-        std::printf("prm_nodes %zu prm_arcs %zu prm %016llx\n", prm.graph.nodes.size(), n_arcs, (unsigned long long)hr);
+        auto path = prm.plan_path({-0.8, -0.8}, {-0.5, 0.5});
+        uint64_t hpath = 1469598103934665603ull;
+        for (auto &st : path) for (double v : st) { uint64_t u; std::memcpy(&u, &v, 8); hpath = fnv(hpath, u); }
+        std::printf("prm_nodes %zu prm_arcs %zu prm %016llx path_len %zu path %016llx\n", prm.graph.nodes.size(), n_arcs, (unsigned long long)hr,
+                    path.size(), (unsigned long long)hpath);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -452,6 +452,16 @@ public:
             e0 = e1;
         }
     }
+    // prm.rs:111-123: empty when start and goal are not connected
+    std::vector<State> plan_path(State start, State goal) {
+        const int64_t n = porrt_prm_plan_path(ctx_.get(), start.data(), goal.data(), nullptr, 0);
+        if (n < 0) ctx_.check((int)n);
+        std::vector<double> xy(2 * (size_t)n);
+        if (n) porrt_prm_plan_path(ctx_.get(), start.data(), goal.data(), xy.data(), (uint64_t)n);
+        std::vector<State> path((size_t)n);
+        for (size_t k = 0; k < (size_t)n; ++k) path[k] = {xy[2 * k], xy[2 * k + 1]};
+        return path;
+    }
 private:
     Context ctx_;
     State start_{0.0, 0.0};

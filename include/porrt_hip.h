@@ -152,6 +152,11 @@ int      porrt_best_cost_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, double *c
  * new node in the reference's adjacency order; PTOGraph gets add_edge(from, to, 0) and add_edge(to, from, 0), the third
  * array is what transition_validator returned). */
 int      porrt_grow_prm(porrt_ctx *ctx, const double start[2], double max_step, double search_radius, uint64_t n_iter);
+/* PRM::plan_path (src/prm.rs:111-123) on that roadmap: the kd-tree's nearest nodes of start and goal
+ * (nearest_neighbor.rs:48-91), dijkstra from the goal (src/pto_graph.rs:275-303; run as device sweeps to the same
+ * fixpoint), extract_path (pto_graph.rs:305-326).  Returns the number of states of the path (0 = start and goal are not
+ * connected: the reference returns an empty Vec); path_xy receives min(cap, that number) states. */
+int64_t  porrt_prm_plan_path(porrt_ctx *ctx, const double start[2], const double goal[2], double *path_xy, uint64_t cap);
 
 /* ---- belief-space expansion: PTO::build_belief_graph (src/pto.rs:185-259) on the graph of the last
  * porrt_grow(mode PORRT_MODE_PTO) of this context, with PTOFuncs::reachable_belief_states (map_io.rs:515-546,

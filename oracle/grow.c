@@ -702,3 +702,66 @@ int orc_prm_grow(orc_ctx *c, const double start[2], double max_step, double sear
     c->n_iter = n_iter;
     return rc;
 }
+
+/* PRM::plan_path (prm.rs:111-123): nearest roadmap nodes of start and goal, dijkstra from the goal (pto_graph.rs:275-303),
+ * extract_path (pto_graph.rs:305-326: from the start, always to the first parent of least cost-to-goal + edge).
+ * Works on the roadmap of the last orc_prm_grow.  Returns the number of states written to path_xy (0 = no path: the
+ * reference returns an empty Vec), -1 on error, the needed count if cap is too small. */
+int64_t orc_prm_plan_path(orc_ctx *c, const double start[2], const double goal[2], double *path_xy, uint64_t cap) {
+    const uint64_t N = c->n_nodes;
+    if (!N) return -1;
+    const double root[2] = {c->nx[0], c->ny[0]};
+    orc_kdtree *kd = orc_kd_new(root, 0);
+    for (uint64_t i = 1; i < N; ++i) { const double s[2] = {c->nx[i], c->ny[i]}; orc_kd_add(kd, s, i); }
+    const uint64_t kd_start = orc_kd_nearest(kd, start, NULL, 0), kd_goal = orc_kd_nearest(kd, goal, NULL, 0);
+    orc_kd_free(kd);
+    /* PTOGraph parents lists in push order (prm.rs:96-103): for one new node, add_edge(nbr, new) for all, then add_edge(new, nbr) */
+    uint64_t *off = calloc(N + 1, sizeof(uint64_t));
+    for (uint64_t e = 0; e < c->n_edges; ++e) { off[c->edges[e].from + 1]++; off[c->edges[e].to + 1]++; }
+    for (uint64_t i = 0; i < N; ++i) off[i + 1] += off[i];
+    uint32_t *par = malloc((2 * c->n_edges + 1) * sizeof(uint32_t));
+    uint64_t *fill = malloc((N + 1) * sizeof(uint64_t));
+    memcpy(fill, off, (N + 1) * sizeof(uint64_t));
+    for (uint64_t e = 0; e < c->n_edges;) {
+        uint64_t e1 = e;
+        while (e1 < c->n_edges && c->edges[e1].to == c->edges[e].to) ++e1;
+        for (uint64_t k = e; k < e1; ++k) par[fill[c->edges[k].to]++] = c->edges[k].from;      /* parents of new: its neighbours */
+        for (uint64_t k = e; k < e1; ++k) par[fill[c->edges[k].from]++] = c->edges[k].to;      /* parents of each neighbour: new */
+        e = e1;
+    }
+    free(fill);
+    double *xy = malloc(N * 2 * sizeof(double)), *dist = malloc(N * sizeof(double));
+    uint32_t *row = calloc(N, sizeof(uint32_t));
+    uint8_t *types = malloc(N);
+    for (uint64_t i = 0; i < N; ++i) { xy[2 * i] = c->nx[i]; xy[2 * i + 1] = c->ny[i]; types[i] = 1; }
+    const double one = 1.0;
+    const uint64_t fin = kd_goal;
+    /* dijkstra == conditional_dijkstra without observation nodes; the adjacency is symmetric, children == parents */
+    int rc = orc_conditional_dijkstra(N, xy, row, &one, 1, types, off, par, off, par, &fin, 1, dist);
+    int64_t n_path = -1;
+    if (!rc) {
+        if (isinf(dist[kd_start])) n_path = 0;                          /* prm.rs:117-119 */
+        else {
+            uint64_t node = kd_start;
+            n_path = 0;
+            for (uint64_t guard = 0; guard <= N; ++guard) {
+                if ((uint64_t)n_path < cap) { path_xy[2 * n_path] = c->nx[node]; path_xy[2 * n_path + 1] = c->ny[node]; }
+                ++n_path;
+                if (dist[node] == 0.0) break;
+                uint64_t best = 0;
+                double best_cost = 0.0;
+                int have = 0;
+                for (uint64_t k = off[node]; k < off[node + 1]; ++k) {
+                    const uint64_t p = par[k];
+                    const double cost = dist[p] + orc_norm2(xy + 2 * p, xy + 2 * node);
+                    if (!have || cost < best_cost) { best = p; best_cost = cost; have = 1; }     /* min_by: the first minimum */
+                }
+                if (!have) { n_path = -1; break; }
+                node = best;
+                if (guard == N) n_path = -1;                            /* zero-length cycle: the reference would not terminate */
+            }
+        }
+    }
+    free(off); free(par); free(xy); free(dist); free(row); free(types);
+    return n_path;
+}

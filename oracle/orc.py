@@ -59,6 +59,7 @@ def lib():
     sig("orc_to_pixel", C.c_int, vp, _f64p, _u32p)
     sig("orc_state_class", C.c_int, vp, _f64p)
     sig("orc_prm_grow", C.c_int, vp, _f64p, C.c_double, C.c_double, C.c_uint64)
+    sig("orc_prm_plan_path", C.c_int64, vp, _f64p, _f64p, _f64p, C.c_uint64)
     sig("orc_belief_hash", C.c_uint64, _f64p, C.c_uint32)
     sig("orc_belief_successors", C.c_int, vp, _f64p, C.c_uint32, _f64p)
     sig("orc_zone_observable", C.c_int, vp, _f64p, C.c_uint32)
@@ -336,6 +337,15 @@ class Oracle:
     def grow_prm(self, start, max_step, search_radius, n_iter):
         """PRM::init + PRM::grow_graph (prm.rs:33-109)"""
         return self._chk(self._l.orc_prm_grow(self._c, _f64(start), max_step, search_radius, n_iter))
+
+    def prm_plan_path(self, start, goal):
+        """PRM::plan_path (prm.rs:111-123): list of states, empty when the goal is not connected"""
+        cap = self.num_nodes() + 1
+        out = np.zeros((cap, 2))
+        n = self._l.orc_prm_plan_path(self._c, _f64(start), _f64(goal), out, cap)
+        if n < 0:
+            raise RuntimeError("plan_path failed")
+        return out[:n]
 
     # ---- belief space (belief.c; pto.rs:185-259)
     def belief_hash(self, b):

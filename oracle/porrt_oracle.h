@@ -161,6 +161,8 @@ size_t     orc_reach_final_nodes_for_world(const orc_reach *r, uint32_t world, u
 
 /* PRM::init + PRM::grow_graph (prm.rs:33-109); results through the PTO getters (nodes, forward edges) */
 int orc_prm_grow(orc_ctx *c, const double start[2], double max_step, double search_radius, uint64_t n_iter);
+/* PRM::plan_path (prm.rs:111-123; dijkstra / extract_path pto_graph.rs:275-326) on that roadmap */
+int64_t orc_prm_plan_path(orc_ctx *c, const double start[2], const double goal[2], double *path_xy, uint64_t cap);
 
 /* ------------------------------------------------------------------ belief.c
  * PTO::build_belief_graph (pto.rs:185-259) and the belief-state functions it calls */

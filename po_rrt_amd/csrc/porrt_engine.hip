@@ -238,6 +238,7 @@ struct porrt_ctx {
     int extract_policy();
     PrmState prm;                          // porrt_grow_prm: grid scratch
     int grow_prm(const double start[2], double max_step, double search_radius, uint64_t n_iter);
+    int64_t prm_plan_path(const double start[2], const double goal[2], double *path_xy, uint64_t cap);
     int read_best_cost(double *cost, uint64_t *final_id);
     porrt_ctx *batch_leader = nullptr;     // set by porrt_grow_batch: the context whose RunConst array holds this one
     uint32_t batch_slot = 0, batch_size = 0;
@@ -1275,6 +1276,112 @@ int porrt_ctx::grow_prm(const double start[2], double max_step, double search_ra
     return PORRT_OK;
 }
 
+// KdTree::nearest_neighbor (nearest_neighbor.rs:48-91) on the kd-tree of the nodes in id order: strict improvement, the
+// side of the query first -- the literal traversal, so that equal distances resolve as in the reference.
+namespace {
+struct HostKd {
+    const std::vector<double> &x, &y;
+    std::vector<int> left, right;
+    HostKd(const std::vector<double> &xs, const std::vector<double> &ys) : x(xs), y(ys), left(xs.size(), -1), right(xs.size(), -1) {
+        for (size_t id = 1; id < x.size(); ++id) {                 // KdTree::add (nearest_neighbor.rs:29-46)
+            size_t cur = 0;
+            for (uint32_t d = 0;; ++d) {
+                const bool l = (d & 1u) ? (y[id] < y[cur]) : (x[id] < x[cur]);
+                int &c = l ? left[cur] : right[cur];
+                if (c < 0) { c = (int)id; break; }
+                cur = (size_t)c;
+            }
+        }
+    }
+    static double norm2(double ax, double ay, double bx, double by) {
+        double d2 = 0.0;
+        const double dx = bx - ax, dy = by - ay;
+        d2 += dx * dx;
+        d2 += dy * dy;
+        return std::sqrt(d2);
+    }
+    size_t nearest(double qx, double qy) const {
+        double dmin = std::numeric_limits<double>::infinity();
+        size_t best = 0;
+        struct Frame { int node; uint32_t axis; int stage; };
+        std::vector<Frame> st{{0, 0, 0}};
+        while (!st.empty()) {                                       // the recursion of `inner`, unrolled
+            Frame &f = st.back();
+            const int n = f.node;
+            const double s = f.axis ? y[n] : x[n], q = f.axis ? qy : qx;
+            const bool left_first = q < s;
+            if (f.stage == 0) {
+                const double d = norm2(x[n], y[n], qx, qy);
+                if (d < dmin) { dmin = d; best = (size_t)n; }
+            }
+            if (f.stage >= 2) { st.pop_back(); continue; }
+            const int stage = f.stage++;
+            const bool go_left = (stage == 0) == left_first;        // first the query's side, then the other
+            const uint32_t next_axis = (f.axis + 1) % 2;
+            if (go_left) { if (q - dmin < s && left[n] >= 0) st.push_back({left[n], next_axis, 0}); }
+            else { if (q + dmin >= s && right[n] >= 0) st.push_back({right[n], next_axis, 0}); }
+        }
+        return best;
+    }
+};
+} // namespace
+
+// PRM::plan_path (prm.rs:111-123): dijkstra from the goal's nearest node (pto_graph.rs:275-303 == conditional_dijkstra
+// without observation nodes: the device sweeps), extract_path on the host (pto_graph.rs:305-326).
+int64_t porrt_ctx::prm_plan_path(const double start[2], const double goal[2], double *path_xy, uint64_t cap) {
+    if (!have_results || mode != PORRT_MODE_PRM) { set_err("plan_path: grow a roadmap first (porrt_grow_prm)"); return PORRT_ERR_INVALID; }
+    if (!start || !goal) { set_err("plan_path: start and goal"); return PORRT_ERR_INVALID; }
+    int r = download(DL_TREE | DL_EDGES);
+    if (r) return r;
+    const size_t N = n_nodes, E = h_efrom.size();
+    HostKd kd(h_nx, h_ny);
+    const size_t kd_start = kd.nearest(start[0], start[1]), kd_goal = kd.nearest(goal[0], goal[1]);
+    // PTOGraph::parents in push order (prm.rs:96-103); the adjacency is symmetric, so these are the children lists too
+    std::vector<uint64_t> off(N + 1, 0);
+    for (size_t e = 0; e < E; ++e) { off[h_efrom[e] + 1]++; off[h_eto[e] + 1]++; }
+    for (size_t i = 0; i < N; ++i) off[i + 1] += off[i];
+    std::vector<uint32_t> par(2 * E + 1);
+    {
+        std::vector<uint64_t> fill(off.begin(), off.end() - 1);
+        for (size_t e = 0; e < E;) {
+            size_t e1 = e;
+            while (e1 < E && h_eto[e1] == h_eto[e]) ++e1;
+            for (size_t k = e; k < e1; ++k) par[fill[h_eto[k]]++] = h_efrom[k];
+            for (size_t k = e; k < e1; ++k) par[fill[h_efrom[k]]++] = h_eto[k];
+            e = e1;
+        }
+    }
+    std::vector<double> xy(2 * N), dist(N);
+    for (size_t i = 0; i < N; ++i) { xy[2 * i] = h_nx[i]; xy[2 * i + 1] = h_ny[i]; }
+    std::vector<uint32_t> row(N, 0);
+    std::vector<uint8_t> types(N, BG_ACTION);
+    const double one = 1.0;
+    const uint64_t fin = kd_goal;
+    r = porrt_conditional_dijkstra(device, N, xy.data(), row.data(), &one, 1, 1, types.data(), off.data(), par.data(), off.data(), par.data(), &fin, 1,
+                                   dist.data());
+    if (r) { set_err("plan_path: the shortest-path sweeps failed"); return r; }
+    if (std::isinf(dist[kd_start])) return 0;                       // prm.rs:117-119: an empty path
+    uint64_t n_path = 0;
+    size_t node = kd_start;
+    for (size_t guard = 0;; ++guard) {
+        if (n_path < cap && path_xy) { path_xy[2 * n_path] = h_nx[node]; path_xy[2 * n_path + 1] = h_ny[node]; }
+        ++n_path;
+        if (dist[node] == 0.0) break;
+        if (guard > N) { set_err("plan_path: zero-length cycle (the reference would not terminate)"); return PORRT_ERR_INVALID; }
+        size_t best = 0;
+        double best_cost = 0.0;
+        bool have = false;
+        for (uint64_t k = off[node]; k < off[node + 1]; ++k) {      // min_by: the first minimum over the parents list
+            const size_t p2 = par[k];
+            const double cost = dist[p2] + HostKd::norm2(h_nx[p2], h_ny[p2], h_nx[node], h_ny[node]);
+            if (!have || cost < best_cost) { best = p2; best_cost = cost; have = true; }
+        }
+        if (!have) { set_err("plan_path: node without parents"); return PORRT_ERR_INVALID; }
+        node = best;
+    }
+    return (int64_t)n_path;
+}
+
 // Best path cost without downloading the tree (k_best_cost).  1 = found, 0 = no final node, -1 = scratch too small
 // (the caller then walks on the host), other negatives = errors.
 int porrt_ctx::read_best_cost(double *cost, uint64_t *final_id) {
@@ -1825,6 +1932,10 @@ int porrt_best_cost_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, double *costs)
 
 int porrt_grow_prm(porrt_ctx *c, const double start[2], double max_step, double search_radius, uint64_t n_iter) {
     return c ? c->grow_prm(start, max_step, search_radius, n_iter) : PORRT_ERR_INVALID;
+}
+
+int64_t porrt_prm_plan_path(porrt_ctx *c, const double start[2], const double goal[2], double *path_xy, uint64_t cap) {
+    return c ? c->prm_plan_path(start, goal, path_xy, cap) : PORRT_ERR_INVALID;
 }
 
 // ---- belief-space expansion (pto.rs:185-259)

@@ -25,7 +25,7 @@ _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 SYMBOLS = [
     "porrt_create", "porrt_destroy", "porrt_last_error", "porrt_set_grid", "porrt_set_zones", "porrt_set_sampler",
     "porrt_set_discrete_seed", "porrt_set_samples", "porrt_set_worlds", "porrt_set_square_goal",
-    "porrt_set_observation_goal", "porrt_grow", "porrt_grow_batch", "porrt_grow_prm", "porrt_num_nodes", "porrt_num_iterations", "porrt_get_tree",
+    "porrt_set_observation_goal", "porrt_grow", "porrt_grow_batch", "porrt_grow_prm", "porrt_prm_plan_path", "porrt_num_nodes", "porrt_num_iterations", "porrt_get_tree",
     "porrt_num_final", "porrt_get_final_ids", "porrt_get_final_masks", "porrt_get_reach", "porrt_get_node_validity",
     "porrt_num_edges", "porrt_get_edges", "porrt_is_final_set_complete", "porrt_n_worlds", "porrt_get_validities",
     "porrt_get_zone_positions", "porrt_best_solution", "porrt_best_cost", "porrt_best_cost_batch", "porrt_get_metrics", "porrt_set_option", "porrt_selftest",
@@ -97,6 +97,7 @@ def load_library():
     sig("porrt_best_solution", C.c_uint64, vp, vp, C.c_uint64, C.POINTER(C.c_double))
     sig("porrt_best_cost", C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64))
     sig("porrt_grow_prm", C.c_int, vp, _f64p, C.c_double, C.c_double, C.c_uint64)
+    sig("porrt_prm_plan_path", C.c_int64, vp, _f64p, _f64p, C.c_void_p, C.c_uint64)
     sig("porrt_build_belief_graph", C.c_int, vp, _f64p, C.c_uint32)
     sig("porrt_bg_num_beliefs", C.c_uint64, vp)
     sig("porrt_bg_num_nodes", C.c_uint64, vp)
@@ -290,6 +291,17 @@ class Engine:
     def grow_prm(self, start, max_step, search_radius, n_iter):
         """PRM::init + PRM::grow_graph (prm.rs:33-109); nodes and edges through tree() / edges()"""
         return self._chk(self._l.porrt_grow_prm(self._c, np.ascontiguousarray(start, dtype=np.float64), max_step, search_radius, n_iter))
+
+    def prm_plan_path(self, start, goal):
+        """PRM::plan_path (prm.rs:111-123): array of states, empty when start and goal are not connected"""
+        a, b = np.ascontiguousarray(start, dtype=np.float64), np.ascontiguousarray(goal, dtype=np.float64)
+        n = self._l.porrt_prm_plan_path(self._c, a, b, None, 0)
+        if n < 0:
+            self._chk(int(n))
+        out = np.zeros((n, 2))
+        if n:
+            self._l.porrt_prm_plan_path(self._c, a, b, out.ctypes.data_as(C.c_void_p), n)
+        return out
 
     # ---- belief-space expansion (PTO::build_belief_graph, pto.rs:185-259)
     def build_belief_graph(self, start_belief):

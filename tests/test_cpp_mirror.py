@@ -124,7 +124,7 @@ def test_cpp_pto_belief_graph_matches_oracle(exe):
     o2.set_grid(cases.load_map("map1_2_goals_like"), (-1.0, -1.0), (1.0, 1.0), cases.SHELF)
     o2.set_zones(cases.load_map("map1_2_goals_like_zone_ids"), 0.5)
     o2.set_sampler((-1.0, -1.0), (1.0, 1.0), 100)
-    o2.grow_prm((-0.8, -0.8), 0.05, 5.0, 2000)
+    o2.grow_prm((-0.8, -0.8), 0.1, 5.0, 2000)
     f, t, _ = o2.edges()
     adj = [[] for _ in range(o2.num_nodes())]
     e0 = 0
@@ -141,3 +141,5 @@ def test_cpp_pto_belief_graph_matches_oracle(exe):
     for a in adj:
         hr = fnv_words(fnv_words(hr, [len(a)]), a)
     assert int(tok2[1]) == o2.num_nodes() and int(tok2[3]) == 2 * len(f) and int(tok2[5], 16) == hr
+    path = o2.prm_plan_path((-0.8, -0.8), (-0.5, 0.5))
+    assert int(tok2[7]) == len(path) > 2 and int(tok2[9], 16) == fnv_words(h0, path.reshape(-1).view(np.uint64))

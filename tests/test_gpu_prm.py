@@ -101,3 +101,22 @@ def test_prm_errors(eng_mod):
     e.set_sampler((-1.0, -1.0), (1.0, 1.0), 0)
     with pytest.raises(RuntimeError):
         e.grow_prm((0.0, 0.0), 0.1, 5.0, 100)                   # no grid
+
+
+def test_prm_plan_path_equals_oracle(eng_mod):
+    """PRM::plan_path (prm.rs:111-123): nearest nodes, dijkstra from the goal, extract_path"""
+    e, o = pair(eng_mod, "map_benchmark_like", None, cases.SHELF, 0.0, 9)
+    e.grow_prm((0.0, -0.8), 0.1, 2.0, 8000)
+    o.grow_prm((0.0, -0.8), 0.1, 2.0, 8000)
+    for start, goal in (((0.0, -0.8), (0.9, 0.0)), ((-0.7, 0.7), (0.7, -0.7)), ((0.3, 0.3), (0.3, 0.3)), ((0.0, -0.8), (2.0, 2.0))):
+        pe, po = e.prm_plan_path(start, goal), o.prm_plan_path(start, goal)
+        assert pe.shape == po.shape and np.array_equal(pe.view(np.uint64), po.view(np.uint64))
+    assert len(e.prm_plan_path((0.0, -0.8), (0.9, 0.0))) > 5
+    # a roadmap whose samples are walled off from the start: no path
+    e2, o2 = pair(eng_mod, "door_map_like", "door_map_like_zone_ids", cases.DOOR, 0.3, 3)
+    e2.grow_prm((0.5, -0.6), 0.05, 5.0, 300)
+    o2.grow_prm((0.5, -0.6), 0.05, 5.0, 300)
+    pe, po = e2.prm_plan_path((0.5, -0.6), (-0.5, 0.6)), o2.prm_plan_path((0.5, -0.6), (-0.5, 0.6))
+    assert pe.shape == po.shape and np.array_equal(pe, po)
+    with pytest.raises(RuntimeError):
+        cases.configure(eng_mod.Engine(), cases.cfg2(100)).prm_plan_path((0.0, 0.0), (0.5, 0.5))      # no roadmap
