@@ -182,3 +182,40 @@ def test_properties_at_size(eng_mod):
         assert (int(src[k] // B), int(c64[k] // B)) in pairs
     n_act_nodes = int((types == 1).sum())
     assert int(act.sum()) == sum(int(coff[i + 1] - coff[i]) for i in np.flatnonzero(types == 1)[:1000]) or n_act_nodes > 1000
+
+
+def test_edge_cases_no_zones_single_world_tiny_graphs(eng_mod):
+    """no zones (one world, one belief), a graph of the root alone, a roadmap of the start alone"""
+    case = cases.Case(cases.cfg_door(300, 300), zones=None, visibility=0.0, masks=[1], goals=[(0.5, -0.4)])
+    e = cases.configure(eng_mod.Engine(), case)
+    o = cases.configure(orc.Oracle(), case)
+    cases.grow(e, case, K=64)
+    cases.grow(o, case, K=64, algo=orc.ALGO_BATCHED_KD)
+    e.build_belief_graph([1.0])
+    o.build_belief_graph([1.0])
+    assert_same_belief_graph(e, o)
+    beliefs, types, (coff, cid), _ = e.belief_graph()
+    assert len(beliefs) == 1 and not (types == 2).any() and len(cid) > 0
+    e.compute_expected_costs()
+    assert np.array_equal(e.expected_costs().view(np.uint64), o.expected_costs().view(np.uint64))
+    # zero iterations: the graph is the root
+    c0 = cases.Case(cases.cfg3(0, 0))
+    e0 = cases.configure(eng_mod.Engine(), c0)
+    o0 = cases.configure(orc.Oracle(), c0)
+    cases.grow(e0, c0, K=64)
+    cases.grow(o0, c0, K=64, algo=orc.ALGO_BATCHED_KD)
+    assert e0.num_nodes() == 1
+    e0.build_belief_graph([0.5, 0.5])
+    o0.build_belief_graph([0.5, 0.5])
+    assert_same_belief_graph(e0, o0)
+    assert e0.bg_num_edges() == 0
+    e0.compute_expected_costs()
+    assert np.all(np.isinf(e0.expected_costs()))
+    with pytest.raises(RuntimeError):
+        e0.extract_policy()                                    # no policy from the root
+    # a roadmap without samples, and its path queries
+    e0.grow_prm((-0.8, -0.8), 0.05, 5.0, 0)
+    o0.grow_prm((-0.8, -0.8), 0.05, 5.0, 0)
+    assert e0.num_nodes() == 1 and len(e0.edges()[0]) == 0
+    pe, po = e0.prm_plan_path((0.0, 0.0), (0.5, 0.5)), o0.prm_plan_path((0.0, 0.0), (0.5, 0.5))
+    assert pe.shape == po.shape == (1, 2) and np.array_equal(pe, po)      # start and goal snap to the one node: a path of one state
