@@ -182,28 +182,32 @@ __device__ __forceinline__ bool dp_level_thread(const DpLevelConst &L, uint32_t 
     return true;
 }
 
-// Start of a level: observation nodes get their value (a sum over finished, deeper levels); everything is marked to be
-// looked at by the first sweep.
+// Start of a level: observation nodes get their value (a sum over finished, deeper levels).  Every node with a finite
+// value (those and the finals) is a source: its neighbours are marked for the first sweep.
 __global__ __launch_bounds__(256) void k_dp_level_init(DpLevelConst L, uint32_t p0, uint32_t W, uint8_t *__restrict__ dirty) {
     uint32_t n, p;
     if (!dp_level_thread(L, p0, W, n, p)) return;
     const BgConst &g = L.g;
     const size_t ip = (size_t)n * g.B + p;
-    as_global(dirty)[ip] = 1;
     const uint32_t b = as_global(L.belief_at)[p], vn = as_global(g.vid)[n];
     const unsigned long long cb = as_global(g.compat)[b];
     if (!((cb >> vn) & 1ull)) return;
+    double v = as_global(L.dist_p)[ip];
     const size_t bit = (size_t)n * g.B + b;
-    if (!((as_global(g.obs_bits)[bit >> 6] >> (bit & 63)) & 1ull)) return;
-    if (as_global(L.dist_p)[ip] == 0.0) return;                                     // a final node stays at 0
-    const size_t trow = (size_t)as_global(g.mask_idx)[n] * g.B + b;
-    double alt = 0.0;
-    for (uint32_t k = as_global(g.obs_off)[trow]; k < as_global(g.obs_off)[trow + 1]; ++k) {
-        const uint32_t c = as_global(g.obs_child)[k];
-        if ((as_global(g.compat)[c] >> vn) & 1ull)                                  // cost(u, vv) = norm2 of equal states = 0
-            alt = alt + as_global(g.obs_p)[k] * (0.0 + as_global(L.dist_p)[(size_t)n * g.B + as_global(L.rank)[c]]);
+    if (v != 0.0 && ((as_global(g.obs_bits)[bit >> 6] >> (bit & 63)) & 1ull)) {   // (a final node stays at 0)
+        const size_t trow = (size_t)as_global(g.mask_idx)[n] * g.B + b;
+        double alt = 0.0;
+        for (uint32_t k = as_global(g.obs_off)[trow]; k < as_global(g.obs_off)[trow + 1]; ++k) {
+            const uint32_t c = as_global(g.obs_child)[k];
+            if ((as_global(g.compat)[c] >> vn) & 1ull)                              // cost(u, vv) = norm2 of equal states = 0
+                alt = alt + as_global(g.obs_p)[k] * (0.0 + as_global(L.dist_p)[(size_t)n * g.B + as_global(L.rank)[c]]);
+        }
+        as_global(L.dist_p)[ip] = alt;
+        v = alt;
     }
-    as_global(L.dist_p)[ip] = alt;
+    if (v < __builtin_huge_val())
+        for (unsigned long long k = as_global(g.adj_off)[n]; k < as_global(g.adj_off)[n + 1]; ++k)
+            as_global(dirty)[(size_t)as_global(g.adj_id)[k] * g.B + p] = 1;
 }
 
 // One sweep over a level: action nodes whose neighbours improved take the best of (edge + neighbour).
