@@ -210,39 +210,62 @@ __global__ __launch_bounds__(256) void k_dp_level_init(DpLevelConst L, uint32_t 
             as_global(dirty)[(size_t)as_global(g.adj_id)[k] * g.B + p] = 1;
 }
 
-// One sweep over a level: action nodes whose neighbours improved take the best of (edge + neighbour).
+// One sweep over a level: action nodes whose neighbours improved take the best of (edge + neighbour).  Four lanes share a
+// row (lane = part * 16 + row-in-wave: the 16 rows of a wave are consecutive beliefs of one node, so each part still
+// reads 128 contiguous bytes per neighbour) and split its neighbour list, which quarters the chain of dependent loads
+// that sets the duration of a sweep over a small level (13.8 ms instead of 23 for the 255-belief problem); a large
+// level is bandwidth bound and keeps one lane per row (PARTS = 1: 512 contiguous bytes per neighbour).
+template <uint32_t kDpParts>
 __global__ __launch_bounds__(256) void k_dp_level_sweep(DpLevelConst L, uint32_t p0, uint32_t W, uint8_t *__restrict__ dirty_in,
                                                         uint8_t *__restrict__ dirty_out, uint32_t slot) {
-    uint32_t n, p;
-    if (!dp_level_thread(L, p0, W, n, p)) return;
     const BgConst &g = L.g;
+    constexpr uint32_t kDpRowsPerWave = 64 / kDpParts;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 64;
+    const uint32_t lane = threadIdx.x & 63u, part = lane / kDpRowsPerWave;
+    const size_t row = wave * kDpRowsPerWave + (lane % kDpRowsPerWave);
+    const bool in_range = row < (size_t)g.N * W;
+    const uint32_t n = in_range ? (uint32_t)(row / W) : 0u, p = p0 + (in_range ? (uint32_t)(row % W) : 0u);
     const size_t ip = (size_t)n * g.B + p;
-    if (!as_global(dirty_in)[ip]) return;
-    as_global(dirty_in)[ip] = 0;
-    const uint32_t b = as_global(L.belief_at)[p], vn = as_global(g.vid)[n];
-    const unsigned long long cb = as_global(g.compat)[b];
-    if (!((cb >> vn) & 1ull)) return;
-    const size_t bit = (size_t)n * g.B + b;
-    if ((as_global(g.obs_bits)[bit >> 6] >> (bit & 63)) & 1ull) return;            // observation nodes do not move
-    const double old = as_global(L.dist_p)[ip];
-    if (old == 0.0) return;
+    bool active = in_range && as_global(dirty_in)[ip] != 0;
+    double old = 0.0;
+    unsigned long long cb = 0;
+    if (active) {
+        const uint32_t b = as_global(L.belief_at)[p], vn = as_global(g.vid)[n];
+        cb = as_global(g.compat)[b];
+        const size_t bit = (size_t)n * g.B + b;
+        old = as_global(L.dist_p)[ip];
+        // (observation nodes and finals do not move)
+        active = ((cb >> vn) & 1ull) && !((as_global(g.obs_bits)[bit >> 6] >> (bit & 63)) & 1ull) && old != 0.0;
+    }
+    const bool was_dirty = in_range && as_global(dirty_in)[ip] != 0;
+    if (!__ballot(was_dirty)) return;
     const bool one_validity = g.n_validities == 1;
     const unsigned long long a0 = as_global(g.adj_off)[n], a1 = as_global(g.adj_off)[n + 1];
-    double best = old;
+    double best = __builtin_huge_val();
+    if (active) {
 #pragma unroll 4
-    for (unsigned long long k = a0; k < a1; ++k) {
-        const uint32_t c = as_global(g.adj_id)[k];
-        bool ok = true;
-        if (!one_validity) ok = ((cb >> as_global(g.vid)[c]) & 1ull) && ((cb >> as_global(g.adj_val)[k]) & 1ull);
-        const double a = as_global(L.adj_w)[k] + as_global(L.dist_p)[(size_t)c * g.B + p];
-        best = (ok && a < best) ? a : best;
+        for (unsigned long long k = a0 + part; k < a1; k += kDpParts) {
+            const uint32_t c = as_global(g.adj_id)[k];
+            bool ok = true;
+            if (!one_validity) ok = ((cb >> as_global(g.vid)[c]) & 1ull) && ((cb >> as_global(g.adj_val)[k]) & 1ull);
+            const double a = as_global(L.adj_w)[k] + as_global(L.dist_p)[(size_t)c * g.B + p];
+            best = (ok && a < best) ? a : best;
+        }
     }
-    if (best < old) {
-        as_global(L.dist_p)[ip] = best;
-        for (unsigned long long k = a0; k < a1; ++k)                                // whoever may use this node as a child
+    for (uint32_t d = kDpRowsPerWave; d < 64; d <<= 1) {                            // the parts of a row sit 16 lanes apart
+        const double o = __shfl_xor(best, d, 64);
+        best = o < best ? o : best;
+    }
+    const bool improved = active && best < old;
+    if (improved) {
+        if (part == 0) {
+            as_global(L.dist_p)[ip] = best;
+            as_global(L.flags)[1 + slot] = 1;
+        }
+        for (unsigned long long k = a0 + part; k < a1; k += kDpParts)               // whoever may use this node as a child
             as_global(dirty_out)[(size_t)as_global(g.adj_id)[k] * g.B + p] = 1;
-        as_global(L.flags)[1 + slot] = 1;
     }
+    if (was_dirty && part == 0) as_global(dirty_in)[ip] = 0;
 }
 
 // dist[n * B + b] = dist_p[n * B + rank[b]]
@@ -454,12 +477,15 @@ static int dp_run_layered(DpState &st, BeliefGraphState &bg, DpConst c, const st
     for (auto &lv : levels) {
         const uint32_t p0 = lv.first, W = lv.second - lv.first;
         const dim3 grid((unsigned)(((size_t)N * W + 255) / 256)), block(256);
+        const bool split = (size_t)N * W < (2u << 20);                                 // small level: latency bound
+        const dim3 sgrid((unsigned)(((size_t)N * W * (split ? 4 : 1) + 255) / 256));
         hipLaunchKernelGGL(k_dp_level_init, grid, block, 0, s, L, p0, W, st.d_dirty[0]);
         int cur = 0;
         for (bool more = true; more;) {
             DP_HIP(hipMemsetAsync(st.d_flags + 1, 0, kDpGroup * sizeof(uint32_t), s));
             for (uint32_t k = 0; k < kDpGroup; ++k, cur ^= 1)
-                hipLaunchKernelGGL(k_dp_level_sweep, grid, block, 0, s, L, p0, W, st.d_dirty[cur], st.d_dirty[cur ^ 1], k);
+                if (split) hipLaunchKernelGGL(k_dp_level_sweep<4>, sgrid, block, 0, s, L, p0, W, st.d_dirty[cur], st.d_dirty[cur ^ 1], k);
+                else hipLaunchKernelGGL(k_dp_level_sweep<1>, sgrid, block, 0, s, L, p0, W, st.d_dirty[cur], st.d_dirty[cur ^ 1], k);
             sweeps += kDpGroup;
             DP_HIP(hipMemcpyAsync(h_flags, st.d_flags, sizeof h_flags, hipMemcpyDeviceToHost, s));
             DP_HIP(hipStreamSynchronize(s));
