@@ -220,11 +220,22 @@ __global__ __launch_bounds__(256) void k_dp_level_sweep(DpLevelConst L, uint32_t
                                                         uint8_t *__restrict__ dirty_out, uint32_t slot) {
     const BgConst &g = L.g;
     constexpr uint32_t kDpRowsPerWave = 64 / kDpParts;
-    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 64;
     const uint32_t lane = threadIdx.x & 63u, part = lane / kDpRowsPerWave;
-    const size_t row = wave * kDpRowsPerWave + (lane % kDpRowsPerWave);
-    const bool in_range = row < (size_t)g.N * W;
-    const uint32_t n = in_range ? (uint32_t)(row / W) : 0u, p = p0 + (in_range ? (uint32_t)(row % W) : 0u);
+    bool in_range;
+    uint32_t n, p;
+    if (kDpParts == 1) {
+        // a workgroup = 256 consecutive beliefs of ONE graph node: the node index is a scalar, no per-thread division
+        const uint32_t chunks = (W + 255u) / 256u, off = (blockIdx.x % chunks) * 256u + threadIdx.x;
+        n = blockIdx.x / chunks;
+        in_range = off < W;
+        p = p0 + (in_range ? off : 0u);
+    } else {
+        const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 64;
+        const size_t row = wave * kDpRowsPerWave + (lane % kDpRowsPerWave);
+        in_range = row < (size_t)g.N * W;
+        n = in_range ? (uint32_t)(row / W) : 0u;
+        p = p0 + (in_range ? (uint32_t)(row % W) : 0u);
+    }
     const size_t ip = (size_t)n * g.B + p;
     bool active = in_range && as_global(dirty_in)[ip] != 0;
     double old = 0.0;
@@ -478,7 +489,7 @@ static int dp_run_layered(DpState &st, BeliefGraphState &bg, DpConst c, const st
         const uint32_t p0 = lv.first, W = lv.second - lv.first;
         const dim3 grid((unsigned)(((size_t)N * W + 255) / 256)), block(256);
         const bool split = (size_t)N * W < (2u << 20);                                 // small level: latency bound
-        const dim3 sgrid((unsigned)(((size_t)N * W * (split ? 4 : 1) + 255) / 256));
+        const dim3 sgrid(split ? (unsigned)(((size_t)N * W * 4 + 255) / 256) : (unsigned)(N * ((W + 255) / 256)));
         hipLaunchKernelGGL(k_dp_level_init, grid, block, 0, s, L, p0, W, st.d_dirty[0]);
         int cur = 0;
         for (bool more = true; more;) {
