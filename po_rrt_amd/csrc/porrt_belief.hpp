@@ -105,7 +105,7 @@ __device__ __forceinline__ void mark_obs(const BgConst &g, size_t i, uint32_t no
 __global__ __launch_bounds__(256) void k_bg_children_count(BgConst g) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)g.N * g.B) return;
-    const uint32_t node = (uint32_t)(i / g.B), b = (uint32_t)(i % g.B);
+    const uint32_t i32 = (uint32_t)i, node = i32 / g.B, b = i32 - node * g.B;          // N * B < 2^32 (checked by the build)
     const uint32_t v = as_global(g.vid)[node];
     const unsigned long long cb = as_global(g.compat)[b];
     uint32_t cnt = 0;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_bg_children_count(BgConst g) {
 __global__ __launch_bounds__(256) void k_bg_parents_count(BgConst g) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)g.N * g.B) return;
-    const uint32_t node = (uint32_t)(i / g.B), b = (uint32_t)(i % g.B);
+    const uint32_t i32 = (uint32_t)i, node = i32 / g.B, b = i32 - node * g.B;          // N * B < 2^32 (checked by the build)
     const uint32_t v = as_global(g.vid)[node];
     const unsigned long long cb = as_global(g.compat)[b];
     uint32_t cnt = 0;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64 * kFillWaves) void k_bg_fill(BgConst g) {
     uint32_t n_src = 0;
     BgRow r{};
     if (i < NB) {
-        r.node = (uint32_t)(i / g.B); r.b = (uint32_t)(i % g.B);
+        r.node = (uint32_t)i / g.B; r.b = (uint32_t)i - r.node * g.B;              // N * B < 2^32 (checked by the build)
         r.v = as_global(g.vid)[r.node];
         r.cb = as_global(g.compat)[r.b];
         r.out = as_global(PARENTS ? g.par_off : g.child_off)[i];

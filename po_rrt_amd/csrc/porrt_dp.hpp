@@ -54,9 +54,9 @@ __global__ __launch_bounds__(256) void k_dp_set_finals(DpConst g, const unsigned
 template <bool IMPLICIT>
 __device__ __forceinline__ void dp_state(const DpConst &g, unsigned long long i, double &x, double &y, uint32_t &row) {
     if (IMPLICIT) {
-        const uint32_t node = (uint32_t)(i / g.B);
+        const uint32_t node = (uint32_t)i / g.B;                  // the context's graph has fewer than 2^32 belief nodes
         x = as_global(g.nx)[node]; y = as_global(g.ny)[node];
-        row = (uint32_t)(i % g.B);
+        row = (uint32_t)i - node * g.B;
     } else {
         x = as_global(g.nx)[i]; y = as_global(g.ny)[i];
         row = as_global(g.bvec)[i];
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(256) void k_dp_level_finals(DpLevelConst L, const u
 __device__ __forceinline__ bool dp_level_thread(const DpLevelConst &L, uint32_t p0, uint32_t W, uint32_t &n, uint32_t &p) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)L.g.N * W) return false;
-    n = (uint32_t)(t / W);
-    p = p0 + (uint32_t)(t % W);
+    n = (uint32_t)t / W;                                      // N * W < 2^32
+    p = p0 + ((uint32_t)t - n * W);
     return true;
 }
 
@@ -233,8 +233,8 @@ __global__ __launch_bounds__(256) void k_dp_level_sweep(DpLevelConst L, uint32_t
         const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 64;
         const size_t row = wave * kDpRowsPerWave + (lane % kDpRowsPerWave);
         in_range = row < (size_t)g.N * W;
-        n = in_range ? (uint32_t)(row / W) : 0u;
-        p = p0 + (in_range ? (uint32_t)(row % W) : 0u);
+        n = in_range ? (uint32_t)row / W : 0u;
+        p = p0 + (in_range ? (uint32_t)row - n * W : 0u);
     }
     const size_t ip = (size_t)n * g.B + p;
     bool active = in_range && as_global(dirty_in)[ip] != 0;
@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256) void k_dp_level_sweep(DpLevelConst L, uint32_t
 __global__ __launch_bounds__(256) void k_dp_unpermute(DpLevelConst L, double *__restrict__ dist) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)L.g.N * L.g.B) return;
-    const size_t n = i / L.g.B;
-    as_global(dist)[i] = as_global(L.dist_p)[n * L.g.B + as_global(L.rank)[i % L.g.B]];
+    const uint32_t n = (uint32_t)i / L.g.B, b = (uint32_t)i - n * L.g.B;
+    as_global(dist)[i] = as_global(L.dist_p)[(size_t)n * L.g.B + as_global(L.rank)[b]];
 }
 
 // ------------------------------------------------------------------------------------------------ host side
