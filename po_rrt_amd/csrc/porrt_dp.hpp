@@ -119,11 +119,11 @@ struct DpRowItem { double dist, cost; uint32_t child, pad; };
 template <bool IMPLICIT>
 __global__ __launch_bounds__(256) void k_dp_row(DpConst g, unsigned long long bn, DpRowItem *__restrict__ out, uint32_t cap, uint32_t *__restrict__ count) {
     const unsigned long long c0 = as_global(g.child_off)[bn], c1 = as_global(g.child_off)[bn + 1];
-    if (threadIdx.x == 0) *count = (uint32_t)(c1 - c0);
+    if (threadIdx.x == 0) { *count = (uint32_t)(c1 - c0); DpRowItem h; h.child = (uint32_t)(c1 - c0); h.pad = 0; h.dist = 0.0; h.cost = 0.0; out[0] = h; }   // item 0 = the count
     double ux, uy;
     uint32_t urow;
     dp_state<IMPLICIT>(g, bn, ux, uy, urow);
-    for (unsigned long long c = c0 + threadIdx.x; c < c1 && c - c0 < cap; c += blockDim.x) {
+    for (unsigned long long c = c0 + threadIdx.x; c < c1 && c - c0 + 1 < cap; c += blockDim.x) {
         const unsigned long long v = as_global(g.child_id)[c];
         double vx, vy;
         uint32_t vrow;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_dp_row(DpConst g, unsigned long long bn
         it.child = (uint32_t)v; it.pad = 0;
         it.dist = as_global(g.dist)[v];
         it.cost = sqrt(dist2(ux, uy, vx, vy));
-        out[c - c0] = it;
+        out[1 + (c - c0)] = it;
     }
 }
 
@@ -540,7 +540,7 @@ static int dp_extract_policy(DpState &st, bool implicit, BeliefOf belief_of, Pro
     st.pol_parent.assign(1, -1);
     st.pol_leaf.assign(1, 0);
     std::vector<std::pair<uint64_t, uint64_t>> lifo{{0, 0}};       // (policy node, belief node)
-    std::vector<DpRowItem> row;
+    std::vector<DpRowItem> row, fetch;
     double root_cost = 0.0;
     DP_HIP(hipMemcpy(&root_cost, st.d_dist, sizeof(double), hipMemcpyDeviceToHost));
     if (!(root_cost < __builtin_huge_val())) { err = "extract_policy: no policy from the root (its expected cost is infinite; the reference does not terminate here)"; return PORRT_ERR_INVALID; }
@@ -550,12 +550,19 @@ static int dp_extract_policy(DpState &st, bool implicit, BeliefOf belief_of, Pro
         lifo.pop_back();
         if (implicit) hipLaunchKernelGGL(k_dp_row<true>, dim3(1), dim3(256), 0, s, st.last, (unsigned long long)bn, st.d_row, kDpRowCap, st.d_row_count);
         else hipLaunchKernelGGL(k_dp_row<false>, dim3(1), dim3(256), 0, s, st.last, (unsigned long long)bn, st.d_row, kDpRowCap, st.d_row_count);
-        uint32_t cnt = 0;
-        DP_HIP(hipMemcpyAsync(&cnt, st.d_row_count, sizeof cnt, hipMemcpyDeviceToHost, s));
+        // one copy brings the count (item 0) and the first 255 children; longer rows need a second one
+        constexpr uint32_t kFirst = 256;
+        std::vector<DpRowItem> &buf = fetch;
+        buf.resize(kFirst);
+        DP_HIP(hipMemcpyAsync(buf.data(), st.d_row, kFirst * sizeof(DpRowItem), hipMemcpyDeviceToHost, s));
         DP_HIP(hipStreamSynchronize(s));
-        if (cnt > kDpRowCap) { err = "extract_policy: a belief node with more than 65536 children"; return PORRT_ERR_CAPACITY; }
-        row.resize(cnt);
-        if (cnt) DP_HIP(hipMemcpy(row.data(), st.d_row, cnt * sizeof(DpRowItem), hipMemcpyDeviceToHost));
+        const uint32_t cnt = buf[0].child;
+        if (cnt + 1 > kDpRowCap) { err = "extract_policy: a belief node with more than 65535 children"; return PORRT_ERR_CAPACITY; }
+        row.assign(buf.begin() + 1, buf.begin() + 1 + std::min<uint32_t>(cnt, kFirst - 1));
+        if (cnt > kFirst - 1) {
+            row.resize(cnt);
+            DP_HIP(hipMemcpy(row.data() + (kFirst - 1), st.d_row + kFirst, (cnt - (kFirst - 1)) * sizeof(DpRowItem), hipMemcpyDeviceToHost));
+        }
         // BTreeMap<belief_id, Vec<ChildWithCosts>>: clusters in ascending key order, members in children order
         std::map<uint32_t, std::vector<uint32_t>> clusters;
         for (uint32_t k = 0; k < cnt; ++k) clusters[belief_of(row[k].child)].push_back(k);
