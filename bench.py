@@ -241,6 +241,17 @@ def main():
         dist.destroy_process_group()
 
 
+def belief_traffic():
+    """HBM bytes of one belief-graph build from the committed counter passes (tools/profile_belief.sh: two builds of this size)"""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r1_belief_pmc_traffic.json")))
+    except Exception:
+        return None
+    ks = [v for k, v in pm.items() if k.startswith("k_bg_") or k.startswith("k_scan_")]
+    builds = max(1, min((v["launches"] for k, v in pm.items() if k.startswith("k_bg_fill")), default=2))
+    return sum((2.0 * v["fetch_bytes_per_launch_raw"] + v["write_bytes_per_launch"]) * v["launches"] for v in ks) / builds if ks else None
+
+
 def belief_space(device, with_cpu):
     """The rows after the growth (SURVEY 8f.1-2), outside the timed region: PTO::plan_belief_space (pto.rs:151-183) on the
     12-shelf problem of main.rs:386-408 -- a PTO graph of 20000 iterations expanded over the 4095 reachable beliefs
@@ -281,7 +292,10 @@ def belief_space(device, with_cpu):
             "ms_host_tables": 1e3 * sec["host_tables_s"], "edges_per_s": E / wall,
             "roofline": {"bound": "hbm", "kernel": "k_bg_fill + k_bg_*_count + k_scan_*", "achieved": list_bytes / sec["device_s"] / 1e9,
                          "peak": 8000.0, "unit": "GB/s", "frac": list_bytes / sec["device_s"] / 1e9 / 8000.0, "algorithmic_bytes": list_bytes,
-                         "note": "bytes of the result (CSR ids, offsets, types) over the device time of all belief kernels (HIP events)"}},
+                         "traffic": belief_traffic(),
+                         "note": "bytes of the result (CSR ids, offsets, types) over the device time of all belief kernels (HIP events); "
+                                 "traffic = HBM bytes of one build (2 x FETCH_SIZE + WRITE_SIZE summed over the k_bg_* and k_scan_* launches, "
+                                 "separate --pmc passes on the same graph, profiles/r1_belief_pmc_traffic.json)"}},
         "expected_costs": {"ms_wall": 1e3 * min(dps), "ms_device": 1e3 * info["device_s"], "sweeps": info["sweeps"], "root_cost": root_cost,
                            "edge_relaxations_per_s_lower_bound": E / min(dps),
                            "note": "conditional_dijkstra as sweeps to the same fixpoint; every edge is relaxed at least once"},

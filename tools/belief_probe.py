@@ -11,7 +11,7 @@ import cases  # noqa: E402
 import po_rrt_amd  # noqa: E402
 
 iters = [int(a) for a in sys.argv[1:]] or [2000, 5000]
-for n_worlds_possible in (8, 12):
+for n_worlds_possible in [int(w) for w in os.environ.get("WORLDS", "8,12").split(",")]:
     for n in iters:
         case = cases.cfg4(n, n)
         case.update(start=(0.0, -0.3))
