@@ -270,8 +270,14 @@ def belief_space(device, with_cpu):
         e.build_belief_graph(prior)
         runs.append((time.perf_counter() - t0, e.bg_seconds()))
     first = runs[0][0]
-    runs = sorted(runs[1:], key=lambda r: r[0])            # the first build also computes the belief space of the prior
-    wall, sec = runs[len(runs) // 2]
+    same_graph = sorted(r[0] for r in runs[1:])[1]         # rebuilt on the same graph: its adjacency lists are kept as well
+    fresh = []
+    for _ in range(3):                                     # the usual case: a new graph, the prior already known to the context
+        cases.grow(e, case, K=256)                         # (the sampler moved on: another graph of the same size)
+        t0 = time.perf_counter()
+        e.build_belief_graph(prior)
+        fresh.append((time.perf_counter() - t0, e.bg_seconds()))
+    wall, sec = sorted(fresh, key=lambda r: r[0])[1]
     E, N = e.bg_num_edges(), e.num_nodes()
     nb = N * 4095
     list_bytes = 2 * 4.0 * E + 2 * 8.0 * (nb + 1) + nb     # both id arrays, both offset arrays, the node types
@@ -288,7 +294,8 @@ def belief_space(device, with_cpu):
         "what": "PTO::plan_belief_space: %d graph nodes x 4095 beliefs (12 shelves, uniform prior)" % N,
         "belief_nodes": nb, "edges": E,
         "build_belief_graph": {
-            "ms_wall": 1e3 * wall, "ms_first_build_with_this_prior": 1e3 * first, "ms_device": 1e3 * sec["device_s"],
+            "ms_wall": 1e3 * wall, "ms_first_build_with_this_prior": 1e3 * first, "ms_rebuild_on_the_same_graph": 1e3 * same_graph,
+            "ms_device": 1e3 * sec["device_s"],
             "ms_host_tables": 1e3 * sec["host_tables_s"], "edges_per_s": E / wall,
             "roofline": {"bound": "hbm", "kernel": "k_bg_fill + k_bg_*_count + k_scan_*", "achieved": list_bytes / sec["device_s"] / 1e9,
                          "peak": 8000.0, "unit": "GB/s", "frac": list_bytes / sec["device_s"] / 1e9 / 8000.0, "algorithmic_bytes": list_bytes,

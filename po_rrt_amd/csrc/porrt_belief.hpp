@@ -671,6 +671,10 @@ struct BeliefGraphState {
     uint32_t *d_child_id = nullptr, *d_par_id = nullptr;
     const double *d_beliefs = nullptr;                // [B][nw]
     BgConst last{};                                   // device pointers of the last build (tables, adjacency, bit planes)
+    uint64_t adj_tag = ~0ull;                         // PTO adjacency lists of the graph with this tag (another prior reuses them)
+    std::vector<unsigned long long> h_adj_off;
+    std::vector<uint32_t> h_adj_id, h_radj_id;
+    std::vector<uint8_t> h_adj_val, h_radj_val;
     bool support_shrinks = false;                     // every posterior has fewer possible worlds than its prior (expected; checked)
     std::vector<uint32_t> support;                    // per belief: number of worlds with p > 0
     void release() {                                   // the result is gone, the memory stays for the next build
@@ -696,6 +700,7 @@ struct BeliefInputs {
     const double *d_nx, *d_ny;
     const uint8_t *d_vid, *h_vid;
     const uint32_t *ef, *et, *ev;                     // forward edges, to ascending, from in kd pre-order (porrt_get_edges)
+    uint64_t graph_tag;                               // changes with every grow: what depends on the graph alone is kept across builds
     hipStream_t stream;
 };
 
@@ -809,12 +814,15 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
 
     // PTOGraph::children in push order (pto.rs:111-120): per new node, first every add_edge(nbr, new), then every add_edge(new, nbr)
     const double tj0 = bg_now();
-    std::vector<unsigned long long> adj_off(N + 1, 0);
-    for (size_t e = 0; e < in.E; ++e) { adj_off[in.ef[e] + 1]++; adj_off[in.et[e] + 1]++; }
-    for (size_t i = 0; i < N; ++i) adj_off[i + 1] += adj_off[i];
-    std::vector<uint32_t> adj_id(2 * in.E), radj_id(2 * in.E);
-    std::vector<uint8_t> adj_val(2 * in.E), radj_val(2 * in.E);
-    {
+    std::vector<unsigned long long> &adj_off = g.h_adj_off;
+    std::vector<uint32_t> &adj_id = g.h_adj_id, &radj_id = g.h_radj_id;
+    std::vector<uint8_t> &adj_val = g.h_adj_val, &radj_val = g.h_radj_val;
+    if (g.adj_tag != in.graph_tag || adj_off.size() != N + 1) {
+        adj_off.assign(N + 1, 0);
+        for (size_t e = 0; e < in.E; ++e) { adj_off[in.ef[e] + 1]++; adj_off[in.et[e] + 1]++; }
+        for (size_t i = 0; i < N; ++i) adj_off[i + 1] += adj_off[i];
+        adj_id.assign(2 * in.E, 0); radj_id.assign(2 * in.E, 0);
+        adj_val.assign(2 * in.E, 0); radj_val.assign(2 * in.E, 0);
         std::vector<unsigned long long> fill(adj_off.begin(), adj_off.end() - 1);
         for (size_t e = 0; e < in.E;) {
             size_t e1 = e;
@@ -828,6 +836,7 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
         std::copy(adj_off.begin(), adj_off.end() - 1, fill.begin());
         for (size_t u = 0; u < N; ++u)
             for (auto k = adj_off[u]; k < adj_off[u + 1]; ++k) { const auto p = fill[adj_id[k]]++; radj_id[p] = (uint32_t)u; radj_val[p] = adj_val[k]; }
+        g.adj_tag = in.graph_tag;
     }
     g.t_adj = bg_now() - tj0;
     BG_HIP(hipStreamSynchronize(s));

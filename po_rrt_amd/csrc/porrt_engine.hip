@@ -1052,11 +1052,17 @@ int porrt_ctx::download(unsigned want) {
                 if (ch0[n] >= 0) stack.push_back(ch0[n]);
             }
         }
+        // bucket by new node (counting sort), then each short neighbour list by pre-order rank
+        std::vector<uint64_t> off(N + 1, 0);
+        for (size_t e2 = 0; e2 < E; ++e2) off[t[e2] + 1]++;
+        for (size_t j = 0; j < N; ++j) off[j + 1] += off[j];
         std::vector<uint32_t> order(E);
-        for (size_t e2 = 0; e2 < E; ++e2) order[e2] = (uint32_t)e2;
-        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b2) {
-            return t[a] != t[b2] ? t[a] < t[b2] : rank[f[a]] < rank[f[b2]];
-        });
+        {
+            std::vector<uint64_t> fill(off.begin(), off.end() - 1);
+            for (size_t e2 = 0; e2 < E; ++e2) order[fill[t[e2]]++] = (uint32_t)e2;
+        }
+        for (size_t j = 0; j < N; ++j)
+            std::sort(order.begin() + off[j], order.begin() + off[j + 1], [&](uint32_t a, uint32_t b2) { return rank[f[a]] < rank[f[b2]]; });
         h_efrom.resize(E); h_eto.resize(E); h_etv.resize(E);
         for (size_t e2 = 0; e2 < E; ++e2) { h_efrom[e2] = f[order[e2]]; h_eto[e2] = t[order[e2]]; h_etv[e2] = v[order[e2]]; }
     } else {
@@ -1083,6 +1089,7 @@ int porrt_ctx::build_belief_graph(const double *start_belief, uint32_t n_worlds_
     in.N = (size_t)n_nodes; in.E = h_efrom.size();
     in.d_nx = d_nx.p; in.d_ny = d_ny.p; in.d_vid = d_vid.p; in.h_vid = h_vid.data();
     in.ef = h_efrom.data(); in.et = h_eto.data(); in.ev = h_etv.data();
+    in.graph_tag = results_tag;
     in.stream = stream;
     std::string e;
     r = belief_graph_build(bg, in, start_belief, e);
