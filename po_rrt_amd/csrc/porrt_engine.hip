@@ -1061,10 +1061,17 @@ int porrt_ctx::download(unsigned want) {
             std::vector<uint64_t> fill(off.begin(), off.end() - 1);
             for (size_t e2 = 0; e2 < E; ++e2) order[fill[t[e2]]++] = (uint32_t)e2;
         }
-        for (size_t j = 0; j < N; ++j)
-            std::sort(order.begin() + off[j], order.begin() + off[j + 1], [&](uint32_t a, uint32_t b2) { return rank[f[a]] < rank[f[b2]]; });
         h_efrom.resize(E); h_eto.resize(E); h_etv.resize(E);
-        for (size_t e2 = 0; e2 < E; ++e2) { h_efrom[e2] = f[order[e2]]; h_eto[e2] = t[order[e2]]; h_etv[e2] = v[order[e2]]; }
+        auto finish = [&](size_t j0, size_t j1) {          // node ranges are independent: a few host threads
+            for (size_t j = j0; j < j1; ++j)
+                std::sort(order.begin() + off[j], order.begin() + off[j + 1], [&](uint32_t a, uint32_t b2) { return rank[f[a]] < rank[f[b2]]; });
+            for (size_t e2 = off[j0]; e2 < off[j1]; ++e2) { h_efrom[e2] = f[order[e2]]; h_eto[e2] = t[order[e2]]; h_etv[e2] = v[order[e2]]; }
+        };
+        const unsigned nt = E > (1u << 16) ? std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nt; ++k) th.emplace_back(finish, N * k / nt, N * (k + 1) / nt);
+        finish(0, N / nt);
+        for (auto &x : th) x.join();
     } else {
         h_efrom.clear(); h_eto.clear(); h_etv.clear();
     }
