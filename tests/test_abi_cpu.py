@@ -56,3 +56,24 @@ def test_product_never_imports_the_oracle():
                 assert not pat.search(src), "%s references the oracle" % f
     hdr = open(os.path.join(ROOT, "include", "porrt_hip.h")).read()
     assert not pat.search(hdr)
+
+
+def test_null_context_is_an_error_not_a_crash(lib):
+    """Every entry point of the widened rows rejects a NULL context with a negative code (no device is touched)."""
+    import ctypes as C
+    import numpy as np
+    z = np.zeros(4)
+    assert lib.porrt_build_belief_graph(None, z, 4) < 0
+    assert lib.porrt_bg_compute_expected_costs(None) < 0
+    assert lib.porrt_bg_extract_policy(None, None, None, None, 0, None) < 0
+    assert lib.porrt_grow_prm(None, z, 0.1, 2.0, 10) < 0
+    assert lib.porrt_prm_plan_path(None, z, z, None, 0) < 0
+    assert lib.porrt_bg_get_expected_costs(None, z) < 0
+    assert lib.porrt_bg_num_edges(None) == 0 and lib.porrt_bg_num_nodes(None) == 0 and lib.porrt_bg_num_beliefs(None) == 0
+    d = C.c_double(0.0)
+    assert lib.porrt_best_cost(None, C.byref(d), None) < 0
+    # the explicit-graph entry validates its arrays before looking for a device
+    one = np.array([0.0, 0.0])
+    assert lib.porrt_conditional_dijkstra(0, 0, one, np.zeros(1, dtype=np.uint32), np.ones((1, 1)), 1, 1, np.ones(1, dtype=np.uint8),
+                                          np.zeros(2, dtype=np.uint64), np.zeros(1, dtype=np.uint32), np.zeros(2, dtype=np.uint64),
+                                          np.zeros(1, dtype=np.uint32), np.zeros(1, dtype=np.uint64), 0, np.zeros(1)) < 0      # n = 0
