@@ -671,10 +671,6 @@ struct BeliefGraphState {
     uint32_t *d_child_id = nullptr, *d_par_id = nullptr;
     const double *d_beliefs = nullptr;                // [B][nw]
     BgConst last{};                                   // device pointers of the last build (tables, adjacency, bit planes)
-    uint64_t adj_tag = ~0ull;                         // PTO adjacency lists of the graph with this tag (another prior reuses them)
-    std::vector<unsigned long long> h_adj_off;
-    std::vector<uint32_t> h_adj_id, h_radj_id;
-    std::vector<uint8_t> h_adj_val, h_radj_val;
     bool support_shrinks = false;                     // every posterior has fewer possible worlds than its prior (expected; checked)
     std::vector<uint32_t> support;                    // per belief: number of worlds with p > 0
     void release() {                                   // the result is gone, the memory stays for the next build
@@ -699,8 +695,11 @@ struct BeliefInputs {
     size_t N, E;
     const double *d_nx, *d_ny;
     const uint8_t *d_vid, *h_vid;
-    const uint32_t *ef, *et, *ev;                     // forward edges, to ascending, from in kd pre-order (porrt_get_edges)
-    uint64_t graph_tag;                               // changes with every grow: what depends on the graph alone is kept across builds
+    // PTO adjacency on the device (porrt_edges.hpp): children lists in push order, the same edges by ascending neighbour
+    const unsigned long long *d_adj_off;
+    const uint32_t *d_adj_id, *d_radj_id;
+    const uint8_t *d_adj_val, *d_radj_val;
+    uint64_t graph_tag;
     hipStream_t stream;
 };
 
@@ -812,32 +811,7 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
     g.nw = bs.nw; g.N = N; g.B = B;
     g.beliefs = bs.vec;
 
-    // PTOGraph::children in push order (pto.rs:111-120): per new node, first every add_edge(nbr, new), then every add_edge(new, nbr)
     const double tj0 = bg_now();
-    std::vector<unsigned long long> &adj_off = g.h_adj_off;
-    std::vector<uint32_t> &adj_id = g.h_adj_id, &radj_id = g.h_radj_id;
-    std::vector<uint8_t> &adj_val = g.h_adj_val, &radj_val = g.h_radj_val;
-    if (g.adj_tag != in.graph_tag || adj_off.size() != N + 1) {
-        adj_off.assign(N + 1, 0);
-        for (size_t e = 0; e < in.E; ++e) { adj_off[in.ef[e] + 1]++; adj_off[in.et[e] + 1]++; }
-        for (size_t i = 0; i < N; ++i) adj_off[i + 1] += adj_off[i];
-        adj_id.assign(2 * in.E, 0); radj_id.assign(2 * in.E, 0);
-        adj_val.assign(2 * in.E, 0); radj_val.assign(2 * in.E, 0);
-        std::vector<unsigned long long> fill(adj_off.begin(), adj_off.end() - 1);
-        for (size_t e = 0; e < in.E;) {
-            size_t e1 = e;
-            while (e1 < in.E && in.et[e1] == in.et[e]) ++e1;
-            for (size_t k = e; k < e1; ++k) { const auto p = fill[in.ef[k]]++; adj_id[p] = in.et[k]; adj_val[p] = (uint8_t)in.ev[k]; }
-            for (size_t k = e; k < e1; ++k) { const auto p = fill[in.et[k]]++; adj_id[p] = in.ef[k]; adj_val[p] = (uint8_t)in.ev[k]; }
-            e = e1;
-        }
-        // the same lists by ascending neighbour id (the order in which the action-edge loop reaches a node's parents):
-        // walking the nodes upwards and appending u to each of its neighbours' lists leaves every list sorted
-        std::copy(adj_off.begin(), adj_off.end() - 1, fill.begin());
-        for (size_t u = 0; u < N; ++u)
-            for (auto k = adj_off[u]; k < adj_off[u + 1]; ++k) { const auto p = fill[adj_id[k]]++; radj_id[p] = (uint32_t)u; radj_val[p] = adj_val[k]; }
-        g.adj_tag = in.graph_tag;
-    }
     g.t_adj = bg_now() - tj0;
     BG_HIP(hipStreamSynchronize(s));
     if (h_err) { err = "observe: raster access the reference would panic on (image::get_pixel / two zones on one ray, map_io.rs:233)"; return PORRT_ERR_RASTER; }
@@ -937,10 +911,9 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
     if ((r = bg_upload(g, c.compat, compat, s, err)) || (r = bg_upload(g, c.mask_idx, mask_idx, s, err)) ||
         (r = bg_upload(g, c.obs_off, obs_off, s, err)) || (r = bg_upload(g, c.obs_child, obs_child, s, err)) || (r = bg_upload(g, c.obs_p, obs_p, s, err)) ||
         (r = bg_upload(g, c.robs_off, robs_off, s, err)) || (r = bg_upload(g, c.robs_par, robs_par, s, err)) ||
-        (r = bg_upload(g, c.adj_off, adj_off, s, err)) || (r = bg_upload(g, c.adj_id, adj_id, s, err)) ||
-        (r = bg_upload(g, c.adj_val, adj_val, s, err)) || (r = bg_upload(g, c.radj_id, radj_id, s, err)) ||
-        (r = bg_upload(g, c.radj_val, radj_val, s, err)))
+        false)
         return r;
+    c.adj_off = in.d_adj_off; c.adj_id = in.d_adj_id; c.adj_val = in.d_adj_val; c.radj_id = in.d_radj_id; c.radj_val = in.d_radj_val;
     c.radj_off = c.adj_off;
 
     // 3. children and parents lists

@@ -14,6 +14,7 @@
 #include "porrt_belief.hpp"
 #include "porrt_dp.hpp"
 #include "porrt_prm.hpp"
+#include "porrt_edges.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -237,6 +238,8 @@ struct porrt_ctx {
     int compute_expected_costs();
     int extract_policy();
     PrmState prm;                          // porrt_grow_prm: grid scratch
+    EdgeOrderState eo;                     // adjacency order of the last PTO graph / roadmap (device)
+    int ensure_edge_order();
     int grow_prm(const double start[2], double max_step, double search_radius, uint64_t n_iter);
     int64_t prm_plan_path(const double start[2], const double goal[2], double *path_xy, uint64_t cap);
     int read_best_cost(double *cost, uint64_t *final_id);
@@ -1017,61 +1020,17 @@ int porrt_ctx::download(unsigned want) {
     if (mode == PORRT_MODE_PTO || mode == PORRT_MODE_PRM) {
         // Edges come back in the order PTOGraph's adjacency lists are filled (pto.rs:103-120): new nodes ascending, and
         // for one new node its neighbours in the order KdTree::nearest_neighbors lists them -- kd pre-order
-        // (nearest_neighbor.rs:101-117).  The device only kept the edge set; the order is restored here, on demand, from
-        // the kd-tree of the node coordinates (sequential KdTree::add in id order, nearest_neighbor.rs:29-46).
-        int r = download(DL_TREE);
+        // (nearest_neighbor.rs:101-117).  The growth kernels only kept the edge set; the order is restored on the device
+        // (porrt_edges.hpp) and copied out here.
+        int r = ensure_edge_order();
         if (r) return r;
         const size_t E = counters.n_edges;
-        std::vector<uint32_t> f(E), t(E), v(E);
-        if (E) {
-            HIPCHK(hipMemcpy(f.data(), d_efrom.p, E * 4, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(t.data(), d_eto.p, E * 4, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(v.data(), d_etv.p, E * 4, hipMemcpyDeviceToHost));
-        }
-        std::vector<int> ch0(N, -1), ch1(N, -1);
-        for (size_t id = 1; id < N; ++id) {
-            const double x = h_nx[id], y = h_ny[id];
-            size_t cur = 0;
-            for (uint32_t d = 0;; ++d) {
-                const bool left = (d & 1u) ? (y < h_ny[cur]) : (x < h_nx[cur]);
-                int &c = left ? ch0[cur] : ch1[cur];
-                if (c < 0) { c = (int)id; break; }
-                cur = (size_t)c;
-            }
-        }
-        std::vector<uint32_t> rank(N, 0);
-        {
-            std::vector<int> stack;
-            uint32_t next = 0;
-            if (N) stack.push_back(0);
-            while (!stack.empty()) {
-                const int n = stack.back();
-                stack.pop_back();
-                rank[n] = next++;
-                if (ch1[n] >= 0) stack.push_back(ch1[n]);      // left subtree first (popped first)
-                if (ch0[n] >= 0) stack.push_back(ch0[n]);
-            }
-        }
-        // bucket by new node (counting sort), then each short neighbour list by pre-order rank
-        std::vector<uint64_t> off(N + 1, 0);
-        for (size_t e2 = 0; e2 < E; ++e2) off[t[e2] + 1]++;
-        for (size_t j = 0; j < N; ++j) off[j + 1] += off[j];
-        std::vector<uint32_t> order(E);
-        {
-            std::vector<uint64_t> fill(off.begin(), off.end() - 1);
-            for (size_t e2 = 0; e2 < E; ++e2) order[fill[t[e2]]++] = (uint32_t)e2;
-        }
         h_efrom.resize(E); h_eto.resize(E); h_etv.resize(E);
-        auto finish = [&](size_t j0, size_t j1) {          // node ranges are independent: a few host threads
-            for (size_t j = j0; j < j1; ++j)
-                std::sort(order.begin() + off[j], order.begin() + off[j + 1], [&](uint32_t a, uint32_t b2) { return rank[f[a]] < rank[f[b2]]; });
-            for (size_t e2 = off[j0]; e2 < off[j1]; ++e2) { h_efrom[e2] = f[order[e2]]; h_eto[e2] = t[order[e2]]; h_etv[e2] = v[order[e2]]; }
-        };
-        const unsigned nt = E > (1u << 16) ? std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-        std::vector<std::thread> th;
-        for (unsigned k = 1; k < nt; ++k) th.emplace_back(finish, N * k / nt, N * (k + 1) / nt);
-        finish(0, N / nt);
-        for (auto &x : th) x.join();
+        if (E) {
+            HIPCHK(hipMemcpy(h_efrom.data(), eo.d_from, E * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(h_eto.data(), eo.d_to, E * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(h_etv.data(), eo.d_val, E * 4, hipMemcpyDeviceToHost));
+        }
     } else {
         h_efrom.clear(); h_eto.clear(); h_etv.clear();
     }
@@ -1080,22 +1039,60 @@ int porrt_ctx::download(unsigned want) {
 }
 
 // ========================================================================================== C ABI
+// The pre-order rank of every node in the kd-tree of the coordinates (sequential KdTree::add in id order,
+// nearest_neighbor.rs:29-46) on the host, then the edge order and the adjacency lists on the device (porrt_edges.hpp).
+int porrt_ctx::ensure_edge_order() {
+    if (eo.tag == results_tag) return PORRT_OK;
+    int r = download(DL_TREE);
+    if (r) return r;
+    const size_t N = n_nodes;
+    std::vector<int> ch0(N, -1), ch1(N, -1);
+    for (size_t id = 1; id < N; ++id) {
+        const double x = h_nx[id], y = h_ny[id];
+        size_t cur = 0;
+        for (uint32_t d = 0;; ++d) {
+            const bool left = (d & 1u) ? (y < h_ny[cur]) : (x < h_nx[cur]);
+            int &c = left ? ch0[cur] : ch1[cur];
+            if (c < 0) { c = (int)id; break; }
+            cur = (size_t)c;
+        }
+    }
+    std::vector<uint32_t> rank(N, 0);
+    {
+        std::vector<int> stack;
+        uint32_t next = 0;
+        if (N) stack.push_back(0);
+        while (!stack.empty()) {
+            const int n = stack.back();
+            stack.pop_back();
+            rank[n] = next++;
+            if (ch1[n] >= 0) stack.push_back(ch1[n]);      // left subtree first (popped first)
+            if (ch0[n] >= 0) stack.push_back(ch0[n]);
+        }
+    }
+    std::string e;
+    r = edge_order_build(eo, results_tag, N, (size_t)counters.n_edges, d_efrom.p, d_eto.p, d_etv.p, rank, stream, e);
+    if (r) set_err(e);
+    return r;
+}
+
 // PTO::build_belief_graph (pto.rs:185-259) on the graph of the last grow; see porrt_belief.hpp.
 int porrt_ctx::build_belief_graph(const double *start_belief, uint32_t n_worlds_in) {
     if (!have_results || mode != PORRT_MODE_PTO) { set_err("build_belief_graph: grow a PTO graph first (porrt_grow, mode PORRT_MODE_PTO)"); return PORRT_ERR_INVALID; }
     if (!start_belief || (int)n_worlds_in != n_worlds) { set_err("build_belief_graph: the start belief needs one probability per world"); return PORRT_ERR_INVALID; }
     HIPCHK(hipSetDevice(device));
     const double te0 = now_s();
-    int r = download(DL_EDGES | DL_MASKS);
+    int r = download(DL_TREE | DL_MASKS);
     if (r) return r;
+    if ((r = ensure_edge_order())) return r;
     const double t_edges = now_s() - te0;
     BeliefInputs in{};
     in.domain = domain; in.n_zones = n_zones; in.n_worlds = n_worlds; in.n_validities = n_validities;
     in.validities = validities; in.zone_pos = zone_pos; in.visibility = visibility;
     in.d_rc = d_rc.p;
-    in.N = (size_t)n_nodes; in.E = h_efrom.size();
+    in.N = (size_t)n_nodes; in.E = (size_t)counters.n_edges;
     in.d_nx = d_nx.p; in.d_ny = d_ny.p; in.d_vid = d_vid.p; in.h_vid = h_vid.data();
-    in.ef = h_efrom.data(); in.et = h_eto.data(); in.ev = h_etv.data();
+    in.d_adj_off = eo.d_adj_off; in.d_adj_id = eo.d_adj_id; in.d_adj_val = eo.d_adj_val; in.d_radj_id = eo.d_radj_id; in.d_radj_val = eo.d_radj_val;
     in.graph_tag = results_tag;
     in.stream = stream;
     std::string e;
