@@ -343,8 +343,11 @@ def prm_roadmap(device, with_cpu):
         ts.append((time.perf_counter() - t0, e.metrics()["device_s"], len(e.edges()[0]) if rep == 3 else 0))
     wall, dev, _ = sorted(ts[1:])[1]
     E = ts[3][2]
+    t0 = time.perf_counter()
+    path = e.prm_plan_path((0.0, -0.8), (0.9, 0.0))        # PRM::plan_path on that roadmap (edges already ordered and fetched)
+    t_path = time.perf_counter() - t0
     out = {"what": "PRM::grow_graph, %d samples -> %d forward edges" % (n, E), "ms_wall": 1e3 * wall, "ms_device": 1e3 * dev,
-           "nodes_per_s": n / wall, "edges_per_s": E / wall}
+           "nodes_per_s": n / wall, "edges_per_s": E / wall, "plan_path": {"ms_wall": 1e3 * t_path, "states": int(len(path))}}
     if with_cpu:
         from oracle import orc
         o = orc.Oracle()
@@ -353,8 +356,12 @@ def prm_roadmap(device, with_cpu):
         t0 = time.perf_counter()
         o.grow_prm((0.0, -0.8), 0.1, 2.0, n)
         dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        po = o.prm_plan_path((0.0, -0.8), (0.9, 0.0))
+        dt2 = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": n / dt, "unit": "nodes/s", "cores": 1, "kind": "port",
-                               "sample": "the full workload, %.2f s; C restatement of prm.rs:33-109 with the reference's kd-tree" % dt}
+                               "sample": "the full workload, %.2f s (plan_path: %.2f s, %d states); C restatement of prm.rs:33-123 with the "
+                                         "reference's kd-tree" % (dt, dt2, len(po))}
     return out
 
 

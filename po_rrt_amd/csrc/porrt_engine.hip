@@ -23,6 +23,7 @@
 #include <cstring>
 #include <string>
 #include <limits>
+#include <memory>
 #include <vector>
 
 using namespace porrt;
@@ -239,6 +240,8 @@ struct porrt_ctx {
     int extract_policy();
     PrmState prm;                          // porrt_grow_prm: grid scratch
     EdgeOrderState eo;                     // adjacency order of the last PTO graph / roadmap (device)
+    std::shared_ptr<void> host_kd;         // the kd-tree of the node coordinates on the host (pre-order ranks, nearest nodes)
+    uint64_t host_kd_tag = ~0ull;
     int ensure_edge_order();
     int grow_prm(const double start[2], double max_step, double search_radius, uint64_t n_iter);
     int64_t prm_plan_path(const double start[2], const double goal[2], double *path_xy, uint64_t cap);
@@ -1039,6 +1042,63 @@ int porrt_ctx::download(unsigned want) {
 }
 
 // ========================================================================================== C ABI
+// KdTree::nearest_neighbor (nearest_neighbor.rs:48-91) on the kd-tree of the nodes in id order: strict improvement, the
+// side of the query first -- the literal traversal, so that equal distances resolve as in the reference.
+namespace {
+struct HostKd {
+    const std::vector<double> &x, &y;
+    std::vector<int> left, right;
+    HostKd(const std::vector<double> &xs, const std::vector<double> &ys) : x(xs), y(ys), left(xs.size(), -1), right(xs.size(), -1) {
+        for (size_t id = 1; id < x.size(); ++id) {                 // KdTree::add (nearest_neighbor.rs:29-46)
+            size_t cur = 0;
+            for (uint32_t d = 0;; ++d) {
+                const bool l = (d & 1u) ? (y[id] < y[cur]) : (x[id] < x[cur]);
+                int &c = l ? left[cur] : right[cur];
+                if (c < 0) { c = (int)id; break; }
+                cur = (size_t)c;
+            }
+        }
+    }
+    static double norm2(double ax, double ay, double bx, double by) {
+        double d2 = 0.0;
+        const double dx = bx - ax, dy = by - ay;
+        d2 += dx * dx;
+        d2 += dy * dy;
+        return std::sqrt(d2);
+    }
+    size_t nearest(double qx, double qy) const {
+        double dmin = std::numeric_limits<double>::infinity();
+        size_t best = 0;
+        struct Frame { int node; uint32_t axis; int stage; };
+        std::vector<Frame> st{{0, 0, 0}};
+        while (!st.empty()) {                                       // the recursion of `inner`, unrolled
+            Frame &f = st.back();
+            const int n = f.node;
+            const double s = f.axis ? y[n] : x[n], q = f.axis ? qy : qx;
+            const bool left_first = q < s;
+            if (f.stage == 0) {
+                const double d = norm2(x[n], y[n], qx, qy);
+                if (d < dmin) { dmin = d; best = (size_t)n; }
+            }
+            if (f.stage >= 2) { st.pop_back(); continue; }
+            const int stage = f.stage++;
+            const bool go_left = (stage == 0) == left_first;        // first the query's side, then the other
+            const uint32_t next_axis = (f.axis + 1) % 2;
+            if (go_left) { if (q - dmin < s && left[n] >= 0) st.push_back({left[n], next_axis, 0}); }
+            else { if (q + dmin >= s && right[n] >= 0) st.push_back({right[n], next_axis, 0}); }
+        }
+        return best;
+    }
+};
+static HostKd *host_kd_of(porrt_ctx *c) {                            // built once per graph
+    if (c->host_kd_tag != c->results_tag || !c->host_kd) {
+        c->host_kd = std::shared_ptr<void>(new HostKd(c->h_nx, c->h_ny), [](void *p) { delete (HostKd *)p; });
+        c->host_kd_tag = c->results_tag;
+    }
+    return (HostKd *)c->host_kd.get();
+}
+} // namespace
+
 // The pre-order rank of every node in the kd-tree of the coordinates (sequential KdTree::add in id order,
 // nearest_neighbor.rs:29-46) on the host, then the edge order and the adjacency lists on the device (porrt_edges.hpp).
 int porrt_ctx::ensure_edge_order() {
@@ -1046,17 +1106,8 @@ int porrt_ctx::ensure_edge_order() {
     int r = download(DL_TREE);
     if (r) return r;
     const size_t N = n_nodes;
-    std::vector<int> ch0(N, -1), ch1(N, -1);
-    for (size_t id = 1; id < N; ++id) {
-        const double x = h_nx[id], y = h_ny[id];
-        size_t cur = 0;
-        for (uint32_t d = 0;; ++d) {
-            const bool left = (d & 1u) ? (y < h_ny[cur]) : (x < h_nx[cur]);
-            int &c = left ? ch0[cur] : ch1[cur];
-            if (c < 0) { c = (int)id; break; }
-            cur = (size_t)c;
-        }
-    }
+    const HostKd *kd = host_kd_of(this);
+    const std::vector<int> &ch0 = kd->left, &ch1 = kd->right;
     std::vector<uint32_t> rank(N, 0);
     {
         std::vector<int> stack;
@@ -1287,103 +1338,79 @@ int porrt_ctx::grow_prm(const double start[2], double max_step, double search_ra
     return PORRT_OK;
 }
 
-// KdTree::nearest_neighbor (nearest_neighbor.rs:48-91) on the kd-tree of the nodes in id order: strict improvement, the
-// side of the query first -- the literal traversal, so that equal distances resolve as in the reference.
-namespace {
-struct HostKd {
-    const std::vector<double> &x, &y;
-    std::vector<int> left, right;
-    HostKd(const std::vector<double> &xs, const std::vector<double> &ys) : x(xs), y(ys), left(xs.size(), -1), right(xs.size(), -1) {
-        for (size_t id = 1; id < x.size(); ++id) {                 // KdTree::add (nearest_neighbor.rs:29-46)
-            size_t cur = 0;
-            for (uint32_t d = 0;; ++d) {
-                const bool l = (d & 1u) ? (y[id] < y[cur]) : (x[id] < x[cur]);
-                int &c = l ? left[cur] : right[cur];
-                if (c < 0) { c = (int)id; break; }
-                cur = (size_t)c;
-            }
-        }
-    }
-    static double norm2(double ax, double ay, double bx, double by) {
-        double d2 = 0.0;
-        const double dx = bx - ax, dy = by - ay;
-        d2 += dx * dx;
-        d2 += dy * dy;
-        return std::sqrt(d2);
-    }
-    size_t nearest(double qx, double qy) const {
-        double dmin = std::numeric_limits<double>::infinity();
-        size_t best = 0;
-        struct Frame { int node; uint32_t axis; int stage; };
-        std::vector<Frame> st{{0, 0, 0}};
-        while (!st.empty()) {                                       // the recursion of `inner`, unrolled
-            Frame &f = st.back();
-            const int n = f.node;
-            const double s = f.axis ? y[n] : x[n], q = f.axis ? qy : qx;
-            const bool left_first = q < s;
-            if (f.stage == 0) {
-                const double d = norm2(x[n], y[n], qx, qy);
-                if (d < dmin) { dmin = d; best = (size_t)n; }
-            }
-            if (f.stage >= 2) { st.pop_back(); continue; }
-            const int stage = f.stage++;
-            const bool go_left = (stage == 0) == left_first;        // first the query's side, then the other
-            const uint32_t next_axis = (f.axis + 1) % 2;
-            if (go_left) { if (q - dmin < s && left[n] >= 0) st.push_back({left[n], next_axis, 0}); }
-            else { if (q + dmin >= s && right[n] >= 0) st.push_back({right[n], next_axis, 0}); }
-        }
-        return best;
-    }
-};
-} // namespace
-
 // PRM::plan_path (prm.rs:111-123): dijkstra from the goal's nearest node (pto_graph.rs:275-303 == conditional_dijkstra
 // without observation nodes: the device sweeps), extract_path on the host (pto_graph.rs:305-326).
 int64_t porrt_ctx::prm_plan_path(const double start[2], const double goal[2], double *path_xy, uint64_t cap) {
     if (!have_results || mode != PORRT_MODE_PRM) { set_err("plan_path: grow a roadmap first (porrt_grow_prm)"); return PORRT_ERR_INVALID; }
     if (!start || !goal) { set_err("plan_path: start and goal"); return PORRT_ERR_INVALID; }
-    int r = download(DL_TREE | DL_EDGES);
+    HIPCHK(hipSetDevice(device));
+    int r = download(DL_TREE);
     if (r) return r;
-    const size_t N = n_nodes, E = h_efrom.size();
-    HostKd kd(h_nx, h_ny);
-    const size_t kd_start = kd.nearest(start[0], start[1]), kd_goal = kd.nearest(goal[0], goal[1]);
-    // PTOGraph::parents in push order (prm.rs:96-103); the adjacency is symmetric, so these are the children lists too
-    std::vector<uint64_t> off(N + 1, 0);
-    for (size_t e = 0; e < E; ++e) { off[h_efrom[e] + 1]++; off[h_eto[e] + 1]++; }
-    for (size_t i = 0; i < N; ++i) off[i + 1] += off[i];
-    std::vector<uint32_t> par(2 * E + 1);
-    {
-        std::vector<uint64_t> fill(off.begin(), off.end() - 1);
-        for (size_t e = 0; e < E;) {
-            size_t e1 = e;
-            while (e1 < E && h_eto[e1] == h_eto[e]) ++e1;
-            for (size_t k = e; k < e1; ++k) par[fill[h_eto[k]]++] = h_efrom[k];
-            for (size_t k = e; k < e1; ++k) par[fill[h_efrom[k]]++] = h_eto[k];
-            e = e1;
-        }
+    if ((r = ensure_edge_order())) return r;                        // PTOGraph::parents in push order, on the device
+    const size_t N = n_nodes, E2 = 2 * (size_t)counters.n_edges;
+    const HostKd *kd = host_kd_of(this);
+    const size_t kd_start = kd->nearest(start[0], start[1]), kd_goal = kd->nearest(goal[0], goal[1]);
+    if (prm.w_cap < E2 + 1) {
+        if (prm.d_w) (void)hipFree(prm.d_w);
+        prm.d_w = nullptr; prm.w_cap = 0;
+        HIPCHK(hipMalloc((void **)&prm.d_w, (E2 + E2 / 8 + 1) * sizeof(double)));
+        prm.w_cap = E2 + E2 / 8 + 1;
+        prm.w_tag = ~0ull;
     }
-    std::vector<double> xy(2 * N), dist(N);
-    for (size_t i = 0; i < N; ++i) { xy[2 * i] = h_nx[i]; xy[2 * i + 1] = h_ny[i]; }
-    std::vector<uint32_t> row(N, 0);
-    std::vector<uint8_t> types(N, BG_ACTION);
-    const double one = 1.0;
-    const uint64_t fin = kd_goal;
-    r = porrt_conditional_dijkstra(device, N, xy.data(), row.data(), &one, 1, 1, types.data(), off.data(), par.data(), off.data(), par.data(), &fin, 1,
-                                   dist.data());
-    if (r) { set_err("plan_path: the shortest-path sweeps failed"); return r; }
+    if (prm.dist_cap < N) {
+        void *drop[] = {prm.d_dist, prm.d_dirty[0], prm.d_dirty[1]};
+        for (void *q : drop) if (q) (void)hipFree(q);
+        prm.d_dist = nullptr; prm.d_dirty[0] = prm.d_dirty[1] = nullptr; prm.dist_cap = 0;
+        HIPCHK(hipMalloc((void **)&prm.d_dist, (N + N / 8 + 1) * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&prm.d_dirty[0], N + N / 8 + 1));
+        HIPCHK(hipMalloc((void **)&prm.d_dirty[1], N + N / 8 + 1));
+        prm.dist_cap = N + N / 8 + 1;
+    }
+    if (!prm.d_flags) HIPCHK(hipMalloc((void **)&prm.d_flags, 8 * sizeof(uint32_t)));
+    const dim3 grid((unsigned)((N + 255) / 256)), block(256);
+    if (prm.w_tag != results_tag) {
+        hipLaunchKernelGGL(k_prm_weights, grid, block, 0, stream, (uint32_t)N, (const unsigned long long *)eo.d_adj_off, (const uint32_t *)eo.d_adj_id,
+                           (const double *)d_nx.p, (const double *)d_ny.p, prm.d_w);
+        prm.w_tag = results_tag;
+    }
+    // dijkstra from the goal's node (pto_graph.rs:275-303): sweeps until nothing changes, eight between two looks
+    HIPCHK(hipMemsetAsync(prm.d_dirty[0], 0, N, stream));
+    HIPCHK(hipMemsetAsync(prm.d_dirty[1], 0, N, stream));
+    hipLaunchKernelGGL(k_prm_sssp_init, grid, block, 0, stream, (uint32_t)N, (uint32_t)kd_goal, (const unsigned long long *)eo.d_adj_off,
+                       (const uint32_t *)eo.d_adj_id, prm.d_dist, prm.d_dirty[0], prm.d_dirty[1]);
+    int cur = 1;                                                    // the init marked the goal's neighbours in buffer 1
+    uint32_t h_flags[8];
+    for (uint64_t sweeps = 0;; sweeps += 8) {
+        HIPCHK(hipMemsetAsync(prm.d_flags, 0, sizeof h_flags, stream));
+        for (uint32_t k = 0; k < 8; ++k, cur ^= 1)
+            hipLaunchKernelGGL(k_prm_sssp_sweep, grid, block, 0, stream, (uint32_t)N, (const unsigned long long *)eo.d_adj_off, (const uint32_t *)eo.d_adj_id,
+                               (const double *)prm.d_w, prm.d_dist, prm.d_dirty[cur], prm.d_dirty[cur ^ 1], prm.d_flags, k);
+        HIPCHK(hipMemcpyAsync(h_flags, prm.d_flags, sizeof h_flags, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (!h_flags[7]) break;
+        if (sweeps > 16u * 1000u * 1000u) { set_err("plan_path: no fixpoint"); return PORRT_ERR_DEVICE; }
+    }
+    std::vector<double> dist(N);
+    HIPCHK(hipMemcpy(dist.data(), prm.d_dist, N * sizeof(double), hipMemcpyDeviceToHost));
     if (std::isinf(dist[kd_start])) return 0;                       // prm.rs:117-119: an empty path
+    // extract_path (pto_graph.rs:305-326): from the start always to the first parent of least cost-to-goal + edge; the
+    // parents lists of the few path nodes are read from the device adjacency
     uint64_t n_path = 0;
     size_t node = kd_start;
+    std::vector<uint32_t> par;
     for (size_t guard = 0;; ++guard) {
         if (n_path < cap && path_xy) { path_xy[2 * n_path] = h_nx[node]; path_xy[2 * n_path + 1] = h_ny[node]; }
         ++n_path;
         if (dist[node] == 0.0) break;
         if (guard > N) { set_err("plan_path: zero-length cycle (the reference would not terminate)"); return PORRT_ERR_INVALID; }
+        unsigned long long off[2];
+        HIPCHK(hipMemcpy(off, eo.d_adj_off + node, sizeof off, hipMemcpyDeviceToHost));
+        par.resize(off[1] - off[0]);
+        if (!par.empty()) HIPCHK(hipMemcpy(par.data(), eo.d_adj_id + off[0], par.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         size_t best = 0;
         double best_cost = 0.0;
         bool have = false;
-        for (uint64_t k = off[node]; k < off[node + 1]; ++k) {      // min_by: the first minimum over the parents list
-            const size_t p2 = par[k];
+        for (uint32_t p2 : par) {                                   // min_by: the first minimum over the parents list
             const double cost = dist[p2] + HostKd::norm2(h_nx[p2], h_ny[p2], h_nx[node], h_ny[node]);
             if (!have || cost < best_cost) { best = p2; best_cost = cost; have = true; }
         }

@@ -95,16 +95,68 @@ __global__ __launch_bounds__(256) void k_prm_connect(const RunConst *__restrict_
     if (err) atomicOr(p.err, err);
 }
 
+// ---- PRM::plan_path: dijkstra from the goal's node (pto_graph.rs:275-303) as sweeps over the roadmap's device adjacency
+// (the same monotone relaxation as the expected costs, porrt_dp.hpp: any order ends in the same fixpoint).
+__global__ __launch_bounds__(256) void k_prm_weights(uint32_t N, const unsigned long long *__restrict__ adj_off, const uint32_t *__restrict__ adj_id,
+                                                     const double *__restrict__ nx, const double *__restrict__ ny, double *__restrict__ w) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const double x = as_global(nx)[n], y = as_global(ny)[n];
+    for (unsigned long long k = as_global(adj_off)[n]; k < as_global(adj_off)[n + 1]; ++k) {
+        const uint32_t c = as_global(adj_id)[k];
+        w[k] = sqrt(dist2(x, y, as_global(nx)[c], as_global(ny)[c]));          // cost_evaluator(u.state, v.state) = norm2
+    }
+}
+
+__global__ __launch_bounds__(256) void k_prm_sssp_init(uint32_t N, uint32_t goal, const unsigned long long *__restrict__ adj_off,
+                                                       const uint32_t *__restrict__ adj_id, double *__restrict__ dist, uint8_t *__restrict__ dirty_a,
+                                                       uint8_t *__restrict__ dirty_b) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    dist[n] = n == goal ? 0.0 : __builtin_huge_val();
+    if (n == goal)                                           // (both flag arrays were zeroed by the host before this launch)
+        for (unsigned long long k = adj_off[n]; k < adj_off[n + 1]; ++k) dirty_b[adj_id[k]] = 1;       // evaluated by the first sweep (which reads b)
+}
+
+__global__ __launch_bounds__(256) void k_prm_sssp_sweep(uint32_t N, const unsigned long long *__restrict__ adj_off, const uint32_t *__restrict__ adj_id,
+                                                        const double *__restrict__ w, double *__restrict__ dist, uint8_t *__restrict__ dirty_in,
+                                                        uint8_t *__restrict__ dirty_out, uint32_t *__restrict__ flags, uint32_t slot) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N || !as_global(dirty_in)[n]) return;
+    as_global(dirty_in)[n] = 0;
+    const double old = as_global(dist)[n];
+    if (old == 0.0) return;
+    const unsigned long long a0 = as_global(adj_off)[n], a1 = as_global(adj_off)[n + 1];
+    double best = old;
+#pragma unroll 4
+    for (unsigned long long k = a0; k < a1; ++k) {
+        const double a = as_global(dist)[as_global(adj_id)[k]] + as_global(w)[k];     // dist[v] + cost(u, v)
+        best = a < best ? a : best;
+    }
+    if (best < old) {
+        as_global(dist)[n] = best;
+        for (unsigned long long k = a0; k < a1; ++k) as_global(dirty_out)[as_global(adj_id)[k]] = 1;
+        as_global(flags)[slot] = 1;
+    }
+}
+
 struct PrmState {
     uint32_t *d_cell_cnt = nullptr;
     unsigned long long *d_cell_off = nullptr, *d_tot = nullptr, *d_edge_off = nullptr;
     uint32_t *d_cell_ids = nullptr, *d_err = nullptr, *d_deg = nullptr;
     size_t cells_cap = 0, ids_cap = 0;
     double t_device = 0, t_total = 0;
+    // plan_path: edge weights, costs to the goal, sweep flags
+    double *d_w = nullptr, *d_dist = nullptr;
+    uint8_t *d_dirty[2] = {nullptr, nullptr};
+    uint32_t *d_flags = nullptr;
+    size_t w_cap = 0, dist_cap = 0;
+    uint64_t w_tag = ~0ull;
     void free_device() {
-        void *all[] = {d_cell_cnt, d_cell_off, d_tot, d_edge_off, d_cell_ids, d_err, d_deg};
+        void *all[] = {d_cell_cnt, d_cell_off, d_tot, d_edge_off, d_cell_ids, d_err, d_deg, d_w, d_dist, d_dirty[0], d_dirty[1], d_flags};
         for (void *q : all) if (q) (void)hipFree(q);
         d_cell_cnt = nullptr; d_cell_off = d_tot = d_edge_off = nullptr; d_cell_ids = d_err = d_deg = nullptr;
+        d_w = d_dist = nullptr; d_dirty[0] = d_dirty[1] = nullptr; d_flags = nullptr; w_cap = dist_cap = 0; w_tag = ~0ull;
         cells_cap = ids_cap = 0;
     }
     ~PrmState() { free_device(); }
