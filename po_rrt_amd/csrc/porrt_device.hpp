@@ -1902,4 +1902,16 @@ __global__ __launch_bounds__(1024) void k_best_cost(const RunConst *__restrict__
     }
 }
 
+// porrt_grow_batch: every member's counters and final tree size into one array, so that the host needs one copy
+struct BatchOut { Counters cnt; uint32_t nodes, pad; };
+__global__ __launch_bounds__(64) void k_batch_gather(const RunConst *__restrict__ rcp, uint32_t steps, BatchOut *__restrict__ out) {
+    if (threadIdx.x) return;
+    const RunConst &rc = rcp[blockIdx.x];
+    BatchOut o;
+    o.cnt = *rc.cnt;
+    o.nodes = rc.n_at[steps];
+    o.pad = 0;
+    out[blockIdx.x] = o;
+}
+
 } // namespace porrt

@@ -231,6 +231,8 @@ struct porrt_ctx {
     int finish_batch_member(uint64_t n_iter_done, uint32_t steps, float device_ms);
     Counters batch_hc;
     uint32_t batch_nodes = 0;
+    BatchOut *d_batch_out = nullptr;       // leader of a batch: gathered counters of the members
+    size_t batch_out_cap = 0;
     size_t run_lds_bytes = 0;
     int best_cost_device(double *cost, uint64_t *final_id);
     BeliefGraphState bg;                   // porrt_build_belief_graph: result of the last build (device CSR)
@@ -1570,11 +1572,18 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             steps = all_steps();
         }
         HIPCHK_CTX(L, hipEventRecord(e1, L->stream));
-        for (uint32_t q = 0; q < n; ++q) {          // every member's counters and final tree size, one sync for all
-            HIPCHK_CTX(L, hipMemcpyAsync(&cs[q]->batch_hc, cs[q]->d_cnt.p, sizeof(Counters), hipMemcpyDeviceToHost, L->stream));
-            HIPCHK_CTX(L, hipMemcpyAsync(&cs[q]->batch_nodes, cs[q]->d_nat.p + (uint32_t)((n_iter + K - 1) / K), sizeof(uint32_t), hipMemcpyDeviceToHost, L->stream));
+        // every member's counters and final tree size: gathered on the device, one copy, one sync for all
+        if (L->batch_out_cap < n) {
+            if (L->d_batch_out) (void)hipFree(L->d_batch_out);
+            L->d_batch_out = nullptr; L->batch_out_cap = 0;
+            HIPCHK_CTX(L, hipMalloc((void **)&L->d_batch_out, (size_t)n * sizeof(BatchOut)));
+            L->batch_out_cap = n;
         }
+        hipLaunchKernelGGL(k_batch_gather, dim3(n), dim3(64), 0, L->stream, (const RunConst *)L->d_rcarr, (uint32_t)((n_iter + K - 1) / K), L->d_batch_out);
+        std::vector<BatchOut> h_out(n);
+        HIPCHK_CTX(L, hipMemcpyAsync(h_out.data(), L->d_batch_out, (size_t)n * sizeof(BatchOut), hipMemcpyDeviceToHost, L->stream));
         HIPCHK_CTX(L, hipStreamSynchronize(L->stream));
+        for (uint32_t q = 0; q < n; ++q) { cs[q]->batch_hc = h_out[q].cnt; cs[q]->batch_nodes = h_out[q].nodes; }
         {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) { L->set_err(std::string("kernel launch: ") + hipGetErrorString(e)); return PORRT_ERR_DEVICE; }
@@ -1671,6 +1680,7 @@ void porrt_destroy(porrt_ctx *c) {
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->d_rcarr) (void)hipFree(c->d_rcarr);
+    if (c->d_batch_out) (void)hipFree(c->d_batch_out);
 
     (void)hipStreamDestroy(c->stream);
     delete c;
