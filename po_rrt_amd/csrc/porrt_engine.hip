@@ -232,6 +232,7 @@ struct porrt_ctx {
     Counters batch_hc;
     uint32_t batch_nodes = 0;
     BatchOut *d_batch_out = nullptr;       // leader of a batch: gathered counters of the members
+    std::vector<RunConst> rc_staging;      // leader of a batch: the members' RunConst, uploaded in one copy
     size_t batch_out_cap = 0;
     size_t run_lds_bytes = 0;
     int best_cost_device(double *cost, uint64_t *final_id);
@@ -708,6 +709,17 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         root_reach = validities[root_vid];
     }
 
+    // LDS tile per wave for the raycasts: every neighbour lies within radius <= max_step of the new node
+    size_t lds_bytes = 0;
+    {
+        double rpx = max_step * ppm;
+        if (has_grid && rpx < (double)(kTileRMax - 2)) {
+            c.tile_R = (uint32_t)ceil(rpx) + 2;
+            const uint32_t TW = 2 * c.tile_R + 1;
+            lds_bytes = (size_t)kConnectWaves * ((TW * TW + 15u) & ~15u);
+        }
+    }
+
     // ---- sampler jump tables for this grow
     PcgJump jt;
     {
@@ -739,17 +751,6 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     }
     hipLaunchKernelGGL(k_init_root, dim3(1), dim3(1), 0, stream, d_rc.p, start[0], start[1], (unsigned long long)root_reach, root_vid);
 
-    // LDS tile per wave for the raycasts: every neighbour lies within radius <= max_step of the new node
-    size_t lds_bytes = 0;
-    {
-        double rpx = max_step * ppm;
-        if (has_grid && rpx < (double)(kTileRMax - 2)) {
-            c.tile_R = (uint32_t)ceil(rpx) + 2;
-            const uint32_t TW = 2 * c.tile_R + 1;
-            lds_bytes = (size_t)kConnectWaves * ((TW * TW + 15u) & ~15u);
-        }
-    }
-    HIPCHK(hipMemcpyAsync(d_rc.p, &c, sizeof c, hipMemcpyHostToDevice, stream));
 
     // profiling events
     const bool prof = opt_profile;
@@ -1517,8 +1518,9 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             if (r) { if (cs[q] != L) L->set_err(cs[q]->err); return r; }
             if (cs[q]->run_lds_bytes != L->run_lds_bytes) { L->set_err("porrt_grow_batch: the contexts' rasters need different LDS tiles (max_step * ppm differs)"); return PORRT_ERR_INVALID; }
         }
-        for (uint32_t q = 0; q < n; ++q)
-            HIPCHK_CTX(L, hipMemcpyAsync(L->d_rcarr + q, &cs[q]->rc, sizeof(RunConst), hipMemcpyHostToDevice, L->stream));
+        L->rc_staging.resize(n);                 // one upload for all members (the vector outlives the copy: it is a member)
+        for (uint32_t q = 0; q < n; ++q) L->rc_staging[q] = cs[q]->rc;
+        HIPCHK_CTX(L, hipMemcpyAsync(L->d_rcarr, L->rc_staging.data(), (size_t)n * sizeof(RunConst), hipMemcpyHostToDevice, L->stream));
         // the leader: all steps, one hipGraph (or eager), grid rows = contexts
         L->launch_rcp = L->d_rcarr;
         L->launch_Q = n;
