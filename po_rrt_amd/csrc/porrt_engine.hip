@@ -206,6 +206,9 @@ struct porrt_ctx {
     double rad_max_step = -1, rad_search_radius = -1;
     int rad_mode = -1;
     size_t rad_uploaded = 0;
+    bool jump_valid = false;               // the sampler's jump table on the device belongs to jump_inc
+    PcgJump jump_host;
+    u128 jump_inc = 0;
     // ---- run state / results
     RunConst rc;
     int mode = 0;
@@ -333,6 +336,7 @@ int porrt_ctx::layout_buffers() {
     rad_uploaded = 0;
     cls_dirty = true;
     inj_dirty = true;
+    jump_valid = false;
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     return PORRT_OK;
 }
@@ -735,7 +739,12 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     {
         double t0 = now_s();
         HIPCHK(hipMemcpyAsync(d_rc.p, &c, sizeof c, hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(d_jump.p, &jt, sizeof jt, hipMemcpyHostToDevice, stream));
+        if (!jump_valid || jump_inc != crng.inc) {            // the table depends on the stream's increment only: once per seed
+            jump_host = jt;
+            HIPCHK(hipMemcpyAsync(d_jump.p, &jump_host, sizeof jump_host, hipMemcpyHostToDevice, stream));
+            jump_valid = true;
+            jump_inc = crng.inc;
+        }
         // counters, region counts, valid masks, kd hints (0 = the root: depth 0, id 0) and deferred-tie states lie next to
         // each other in the arena: one memset
         {
