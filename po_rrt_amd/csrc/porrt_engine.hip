@@ -772,9 +772,11 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
             ev_pool.push_back(e);
         }
     }
-    hipEvent_t ev_first, ev_last;
-    HIPCHK(hipEventCreate(&ev_first));
-    HIPCHK(hipEventCreate(&ev_last));
+    hipEvent_t ev_first = nullptr, ev_last = nullptr;      // timing of a stand-alone grow (a batch member only prepares)
+    if (stage != 1) {
+        HIPCHK(hipEventCreate(&ev_first));
+        HIPCHK(hipEventCreate(&ev_last));
+    }
 
     std::vector<uint32_t> worlds;
     std::vector<double> hs_x, hs_y;
@@ -840,11 +842,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         if (r) return r;
     }
     run_lds_bytes = lds_bytes;
-    if (stage == 1) {
-        (void)hipEventDestroy(ev_first);
-        (void)hipEventDestroy(ev_last);
-        return PORRT_OK;
-    }
+    if (stage == 1) return PORRT_OK;
     launch_rcp = d_rc.p;
     launch_Q = 1;
     HIPCHK(hipEventRecord(ev_first, stream));
