@@ -234,8 +234,12 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(case, args)
         if not args.no_belief and world == 1:
-            out["config"]["belief_space"] = belief_space(local_rank, not args.no_cpu_baseline)
-            out["config"]["prm_roadmap"] = prm_roadmap(local_rank, not args.no_cpu_baseline)
+            # the rows after the growth are extras of the line: a failure there must not cost the headline measurement
+            for key, fn in (("belief_space", belief_space), ("prm_roadmap", prm_roadmap)):
+                try:
+                    out["config"][key] = fn(local_rank, not args.no_cpu_baseline)
+                except Exception as ex:                      # noqa: BLE001
+                    out["config"][key] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
