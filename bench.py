@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event roofline pass")
     ap.add_argument("--no-single-query", action="store_true", help="skip the single-query (latency mode) reference run")
     ap.add_argument("--no-belief", action="store_true", help="skip the belief-space expansion measurement (SURVEY 8f.1)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option for every context (porrt_set_option), e.g. group_lanes=32")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps run with per-kernel HIP events for `roofline`")
     args = ap.parse_args()
 
@@ -75,6 +76,8 @@ def main():
     eng = engs[0]
     for e in engs:
         e.set_option("profile", 0)
+        for ov in args.opt:
+            e.set_option(ov.split("=")[0], int(ov.split("=")[1]))
     starts = [case.start] * Q
 
     def run_step(s):

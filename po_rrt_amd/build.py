@@ -5,7 +5,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "porrt_engine.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "porrt_device.hpp"), os.path.join(HERE, "csrc", "porrt_belief.hpp"), os.path.join(HERE, "csrc", "porrt_dp.hpp"), os.path.join(HERE, "csrc", "porrt_prm.hpp"), os.path.join(HERE, "csrc", "porrt_edges.hpp"), os.path.join(HERE, "..", "include", "porrt_hip.h")]
+import glob
+DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*"))) + [os.path.join(HERE, "..", "include", "porrt_hip.h")]
 LIB = os.path.join(HERE, "libporrt_hip.so")
 # -ffp-contract=off: the reference (Rust) never fuses a*b+c; parity is bit-exact only without contraction.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
@@ -25,7 +26,7 @@ def needs_build():
 def build(force=False):
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-o", LIB, SRC]
+    cmd = [hipcc()] + FLAGS + os.environ.get("PORRT_CXXFLAGS", "").split() + ["-o", LIB, SRC]
     subprocess.run(cmd, check=True)
     return LIB
 

@@ -77,7 +77,24 @@ struct Counters {
     uint32_t n_deferred, pend_lo;
     uint32_t n_losers;          // k_kd_link -> k_kd_claim
     uint32_t kd_snap;           // step up to whose start the kd structure is complete (release-stored by k_kd_claim)
+    uint32_t clone_n;           // valid samples of the running step steered exactly onto the goal point (k_nn2 -> k_conn2)
+    uint32_t clone_k[64];
+    unsigned long long tim[16]; // developer builds (-DPORRT_TIMING): phase durations summed over waves, 10 ns units, and wave counts
 };
+
+// phase timers of developer builds: T0 at the start of a phase, TACC(slot) adds the time since (one lane per wave)
+#ifdef PORRT_TIMING
+#define PORRT_T0() unsigned long long t__0 = wall_clock64()
+#define PORRT_TACC(rc, slot)                                                                          \
+    do {                                                                                              \
+        const unsigned long long t__1 = wall_clock64();                                               \
+        if ((threadIdx.x & 63u) == 0u) { atomicAdd(&(rc).cnt->tim[slot], t__1 - t__0); atomicAdd(&(rc).cnt->tim[(slot) + 8], 1ull); } \
+        t__0 = t__1;                                                                                  \
+    } while (0)
+#else
+#define PORRT_T0() do {} while (0)
+#define PORRT_TACC(rc, slot) do {} while (0)
+#endif
 
 struct BestCost {
     unsigned long long cost_bits;   // f64 bits of the best cost (+inf bits when there is no final node)
@@ -90,7 +107,7 @@ struct RunConst {
     int *rep;                   // cell -> some node in that cell (3-level pyramid), only ever used for bounds
     double bx0, by0, binv_w, binv_h;   // box the pyramid covers
     // region pages (see scan_disc)
-    uint32_t *rg_cnt;           // nodes per region
+    uint32_t *rg_cnt;           // [2][kRegions] nodes per region, by step parity: step b searches [b & 1] while its new nodes are filed into [(b + 1) & 1]
     uint32_t *rg_dir;           // [region][j]: j-th page of the region, j >= 1
     double *pg_xy;              // [page][slot] (x, y)
     int *pg_id;                 // [page][slot] node id
@@ -175,6 +192,7 @@ struct RunConst {
     double s_low0, s_low1, s_up0, s_up1;
     double max_step;
     int mode;
+    uint16_t *perm;             // [step][part_stride]: the step's sample indices ordered by where the samples lie (k_sort_samples)
     uint32_t tile_R;            // LDS tile half-width in pixels (0 = no tile: read the raster from global)
     uint32_t part_stride;       // sample stride of the arrays double-buffered by step parity
 };
@@ -506,7 +524,7 @@ __device__ __forceinline__ double nn_bound_wave(const RunConst &rc, uint32_t N, 
 // One WAVE serves one sample: lanes <-> the 64 slots of a page (coalesced 1 KiB + 256 B loads, four pages in
 // flight), hits are compacted with a ballot.
 __device__ __forceinline__ uint32_t rank_before(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k);
-__device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k, uint32_t lane);
+__device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k, uint32_t lane, uint32_t stride = 64u);
 constexpr int kRG = 40;
 constexpr uint32_t kRegions = kRG * kRG;
 constexpr uint32_t kPage = 64;
@@ -539,7 +557,7 @@ __device__ __forceinline__ double uni_d(double v) {
 //   sparse   few nodes per region (young tree): lane <-> region, slot by slot
 //   pages    lane <-> slot, region after region (four pages in flight)
 template <class Visit>
-__device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double qy, double rho, uint32_t N, uint32_t lane, Visit visit,
+__device__ __forceinline__ void scan_disc(const RunConst &rc, uint32_t b, double qx, double qy, double rho, uint32_t N, uint32_t lane, Visit visit,
                                           uint32_t skip_region = 0xFFFFFFFFu) {
     int cx0, cy0, cx1, cy1;
     rep_cell(rc, qx - rho, qy - rho, kRG, cx0, cy0);
@@ -562,7 +580,7 @@ __device__ __forceinline__ void scan_disc(const RunConst &rc, double qx, double 
         }
         return;
     }
-    auto gcnt = as_global(rc.rg_cnt);
+    auto gcnt = as_global(rc.rg_cnt) + (b & 1u) * kRegions;
     auto gdir = as_global(rc.rg_dir);
     auto gxy = as_global(reinterpret_cast<const dbl2 *>(rc.pg_xy));
     auto gid = as_global(rc.pg_id);
@@ -694,12 +712,12 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
         // the disc the remaining regions are taken from.  Only when the region holds nothing usable does the bound
         // come from the pyramid.
         const uint32_t own = uni(region_of(rc, sqx, sqy));
-        scan_disc(rc, sqx, sqy, 0.0, N, lane, visit);
+        scan_disc(rc, b, sqx, sqy, 0.0, N, lane, visit);
         wave_best();
         double m2;
         if (best != 0x7FFFFFFF) m2 = thr;                        // d2(best) * (1 + 1e-15)
         else { m2 = nn_bound_wave<PTO>(rc, N, sqx, sqy, world, lane); thr = m2 * (1.0 + 1e-9); }
-        scan_disc(rc, sqx, sqy, disc_radius(m2, sqx, sqy), N, lane, visit, own);
+        scan_disc(rc, b, sqx, sqy, disc_radius(m2, sqx, sqy), N, lane, visit, own);
         wave_best();
     }
     const int nn = best == 0x7FFFFFFF ? 0 : best;   // nothing passed the filter: the root (nearest_neighbor.rs:90)
@@ -740,7 +758,7 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
     const uint32_t cap = rc.cand_cap;
     uint32_t tot = 0;
     bool over = false;
-    scan_disc(rc, tx, ty, disc_radius(T2, tx, ty), N, lane, [&](double x, double y, int id, bool ok) {
+    scan_disc(rc, b, tx, ty, disc_radius(T2, tx, ty), N, lane, [&](double x, double y, int id, bool ok) {
         const bool in = ok && dist2(x, y, tx, ty) <= T2;
         const unsigned long long hm = __ballot(in);
         const uint32_t pos = tot + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
@@ -763,11 +781,16 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
 // Add the step's new nodes to the region pages (run by ONE workgroup, an extra block of the connect kernels:
 // positions and validity are final since k_near, ids follow from the valid mask).  Nothing reads the pages
 // between k_near of this step and k_near of the next.
-__device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords) {
-    __shared__ uint32_t s_add[kRegions];
-    __shared__ uint16_t s_off[4096];
-    __shared__ uint32_t s_np, s_base;
+constexpr uint32_t kInsertLds = kRegions * 4u + 4096u * 2u + 16u;       // bytes of LDS scratch insert_step_pages needs
+__device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords, uint8_t *scratch) {
+    uint32_t *s_add = reinterpret_cast<uint32_t *>(scratch);                            // [kRegions]
+    uint16_t *s_off = reinterpret_cast<uint16_t *>(scratch + kRegions * 4u);            // [4096]
+    uint32_t &s_np = *reinterpret_cast<uint32_t *>(scratch + kRegions * 4u + 4096u * 2u);
+    uint32_t &s_base = *reinterpret_cast<uint32_t *>(scratch + kRegions * 4u + 4096u * 2u + 4u);
     const uint32_t T = blockDim.x;
+    // the step's searches run beside this workgroup: they read the counts of parity b (and only slots below them);
+    // the new counts go to the other parity, for the next step
+    auto rg_old = as_global(rc.rg_cnt) + (b & 1u) * kRegions, rg_new = as_global(rc.rg_cnt) + ((b + 1u) & 1u) * kRegions;
     for (uint32_t r = threadIdx.x; r < kRegions; r += T) s_add[r] = 0;
     if (threadIdx.x == 0) {
         s_np = 0; s_base = kRegions + rc.cnt->n_pages;
@@ -782,7 +805,7 @@ __device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, u
     for (uint32_t r = threadIdx.x; r < kRegions; r += T) {
         const uint32_t add = s_add[r];
         if (!add) continue;
-        const uint32_t old = as_global(rc.rg_cnt)[r];
+        const uint32_t old = rg_old[r];
         const uint32_t p_old = old ? (old + kPage - 1) / kPage : 1u, p_new = (old + add + kPage - 1) / kPage;
         if (p_new > p_old) {
             const uint32_t need = p_new - p_old;
@@ -799,7 +822,7 @@ __device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, u
         if (rc.q_vid[k] < 0) continue;
         const double x = as_global(rc.q_x)[k], y = as_global(rc.q_y)[k];
         const uint32_t r = region_of(rc, x, y);
-        const uint32_t slot = as_global(rc.rg_cnt)[r] + s_off[k], j = slot / kPage;
+        const uint32_t slot = rg_old[r] + s_off[k], j = slot / kPage;
         const uint32_t page = j ? __hip_atomic_load(&rc.rg_dir[(size_t)r * rc.rg_maxp + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : r;
         dbl2 v;
         v.x = x; v.y = y;
@@ -807,8 +830,7 @@ __device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, u
         as_global(rc.pg_id)[(size_t)page * kPage + (slot % kPage)] = (int)(N + rank_before(rc, b, vwords, k));
     }
     __syncthreads();
-    for (uint32_t r = threadIdx.x; r < kRegions; r += T)
-        if (s_add[r]) as_global(rc.rg_cnt)[r] += s_add[r];
+    for (uint32_t r = threadIdx.x; r < kRegions; r += T) rg_new[r] = rg_old[r] + s_add[r];
     if (threadIdx.x == 0) rc.cnt->n_pages += s_np;
 }
 
@@ -900,12 +922,20 @@ __device__ bool kd_preorder_less(const RunConst &rc, int u, int v) {
     return a_from < b_from;
 }
 
-// ---- team reductions: a team is one wave (W = 1) or the W waves of a workgroup sharing `scr`
+// ---- team reductions: a team serves one sample.  Team<W>: one wave (W = 1) or the W waves of a workgroup sharing
+// `scr`; GTeam<GL> (below): GL = 16 / 32 lanes of a wave, several samples per wave.
 template <int W>
 struct Team {
+    static constexpr bool kOneWave = W == 1;
+    static constexpr uint32_t kSize = W * 64u;
     double *scr_d;      // W doubles
     int *scr_i;         // W ints
     uint32_t wave, lane;
+    __device__ __forceinline__ uint32_t tl() const { return wave * 64u + lane; }
+    __device__ __forceinline__ uint32_t sub() const { return lane; }          // lane inside the shuffle domain
+    __device__ __forceinline__ unsigned long long ballot(bool p) const { return __ballot(p); }
+    template <class T>
+    __device__ __forceinline__ T shfl(T v, int src) const { return __shfl(v, src); }
     __device__ __forceinline__ void sync() const { if (W > 1) __syncthreads(); }
     __device__ __forceinline__ uint32_t sum(uint32_t v) const {
         v = wave_sum(v);
@@ -977,20 +1007,106 @@ struct Team {
     }
 };
 
-// RRT*: validated neighbours, best parent, new node, rewire phase 1 for sample k by a team of W waves.
-// A lane keeps its first candidate in registers through all three passes (that is every candidate when the
-// sample has at most 64 * W neighbours, the common case); further candidates go through the scratch lists.
-template <int W, class Grid>
-__device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const Grid &grid, uint32_t b, uint32_t vwords, uint32_t k,
-                                   uint32_t cnt, uint32_t &err) {
-    const uint32_t tl = tm.wave * 64u + tm.lane, TS = W * 64u;
-    const uint32_t N = uni(as_global(rc.n_at)[b]);
-    const uint32_t id = uni(N + rank_before(rc, b, vwords, k));            // k is wave-uniform: scalars
-    const double px = uni_d(as_global(rc.q_x)[k]), py = uni_d(as_global(rc.q_y)[k]);
+// GL consecutive lanes of a wave serving one sample (64 / GL samples per wave).  Control flow around every call is
+// uniform per group; other groups of the wave may be masked off, so nothing here reads a lane outside the group.
+template <int GL>
+struct GTeam {
+    static constexpr bool kOneWave = true;
+    static constexpr uint32_t kSize = GL;
+    uint32_t gl, base;      // lane inside the group, first lane of the group inside the wave
+    __device__ __forceinline__ uint32_t tl() const { return gl; }
+    __device__ __forceinline__ uint32_t sub() const { return gl; }
+    __device__ __forceinline__ unsigned long long ballot(bool p) const {
+        const unsigned long long m = __ballot(p) >> base;
+        return GL == 64 ? m : (m & ((1ull << (GL & 63)) - 1ull));
+    }
+    template <class T>
+    __device__ __forceinline__ T shfl(T v, int src) const { return __shfl(v, (int)base + src); }
+    __device__ __forceinline__ void sync() const {}
+    __device__ __forceinline__ uint32_t sum(uint32_t v) const {
+        for (int off = GL / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        return v;
+    }
+    __device__ __forceinline__ int min_i(int v) const {
+        for (int off = GL / 2; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o < v ? o : v; }
+        return v;
+    }
+    __device__ __forceinline__ int max_i(int v) const { return -min_i(-v); }
+    __device__ __forceinline__ void bcast2(uint32_t &a, uint32_t &b) const {
+        a = (uint32_t)__shfl((int)a, (int)base);
+        b = (uint32_t)__shfl((int)b, (int)base);
+    }
+    __device__ __forceinline__ void argmin(double &t, int &j) const {
+        for (int off = GL / 2; off > 0; off >>= 1) {
+            const double ot = __shfl_xor(t, off);
+            const int oj = __shfl_xor(j, off);
+            if (ot < t || (ot == t && oj < j)) { t = ot; j = oj; }
+        }
+    }
+    __device__ __forceinline__ int first_preorder(const RunConst &rc, int v) const {
+        for (int off = GL / 2; off > 0; off >>= 1) {
+            const int o = __shfl_xor(v, off);
+            if (o != kEmpty && (v == kEmpty || (o != v && kd_preorder_less(rc, o, v)))) v = o;
+        }
+        return v;
+    }
+};
+
+// ---- neighbour lists of one sample, as connect_rrt_sample sees them
+// GlobalList: the lists k_near wrote (ids + coordinates per step parity, values per sample); after the connect pass
+// val[a] holds every neighbour's rewire candidate (or < 0) for the commit pass.
+struct GlobalList {
+    static constexpr bool kCompact = false;
+    GPTR(const int) cid;
+    GPTR(const dbl2) cxy;
+    GPTR(double) cval;
+    GPTR(const double) gdA;
+    __device__ __forceinline__ int id(uint32_t a) const { return cid[a]; }
+    __device__ __forceinline__ void xy(uint32_t a, double &x, double &y) const { const dbl2 v = cxy[a]; x = v.x; y = v.y; }
+    __device__ __forceinline__ double val(uint32_t a) const { return cval[a]; }
+    __device__ __forceinline__ void set_val(uint32_t a, double v) const { cval[a] = v; }
+    __device__ __forceinline__ void set_dA(uint32_t, double) const {}
+    __device__ __forceinline__ double dA(uint32_t, int j) const { return gdA[j]; }
+};
+__device__ __forceinline__ GlobalList global_list(const RunConst &rc, uint32_t b, uint32_t k) {
+    GlobalList L;
+    L.cid = as_global((const int *)rc.cand_id) + cand_off(rc, b, k);
+    L.cxy = as_global(reinterpret_cast<const dbl2 *>(rc.cand_xy)) + cand_off(rc, b, k);
+    L.cval = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
+    L.gdA = as_global((const double *)rc.distA);
+    return L;
+}
+// LdsList: the hits of a radius search held in LDS (x is replaced by the cost, y by dist_root once the raycast is
+// through); only the actual rewire candidates go to memory, compacted, for the commit pass.
+struct LdsList {
+    static constexpr bool kCompact = true;
+    int *hid;
+    double *hx, *hy;
+    GPTR(int) out_id;       // compact (id, candidate dist_root) list of the sample, read by commit_rrt_sample
+    GPTR(double) out_val;
+    GPTR(uint32_t) out_cnt;
+    uint32_t out_cap;
+    __device__ __forceinline__ int id(uint32_t a) const { return hid[a]; }
+    __device__ __forceinline__ void xy(uint32_t a, double &x, double &y) const { x = hx[a]; y = hy[a]; }
+    __device__ __forceinline__ double val(uint32_t a) const { return hx[a]; }
+    __device__ __forceinline__ void set_val(uint32_t a, double v) const { hx[a] = v; }
+    __device__ __forceinline__ void set_dA(uint32_t a, double v) const { hy[a] = v; }
+    __device__ __forceinline__ double dA(uint32_t a, int) const { return hy[a]; }
+};
+
+// RRT*: validated neighbours, best parent, new node, rewire phase 1 for sample k by a team (Team<W> / GTeam<GL>) on a
+// neighbour list (GlobalList / LdsList).  A lane keeps its first candidate in registers through all three passes (that
+// is every candidate when the sample has at most `team size` neighbours, the common case); further candidates go
+// through the list's value slots.
+template <class TeamT, class ListT, class Grid>
+__device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const ListT &L, const Grid &grid, uint32_t b, uint32_t k, uint32_t id,
+                                   double px, double py, uint32_t cnt, uint32_t &err, const uint32_t *clone_ids = nullptr, uint32_t n_clone = 0) {
+    // clone_ids: further new nodes of this step at exactly (px, py), all with ids above `id` (the copies of the goal
+    // point a step adds, rrt.rs:176-181).  The reference would run the same search n_clone + 1 times on the same
+    // snapshot: same neighbours, same costs, same parent, same dist_root; of the rewires only the first copy's are
+    // strict improvements (rrt.rs:157).  They get their nodes (and their own deferred-tie records) from this one pass.
+    const uint32_t tl = tm.tl(), TS = TeamT::kSize;
     const int goal_kind = rc.goal_kind;
-    auto cid = as_global(rc.cand_id) + cand_off(rc, b, k);            // read-only here
-    auto cval = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
-    auto cxy = as_global(reinterpret_cast<const dbl2 *>(rc.cand_xy)) + cand_off(rc, b, k);
     auto gdA = as_global(rc.distA);
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
 
@@ -1001,15 +1117,16 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     int j0 = -1;                // first candidate of this lane, register resident
     double cost0 = -1.0, tot0 = INF, dA0 = 0.0;
     for (uint32_t a = tl; a < cnt; a += TS) {
-        const int j = cid[a];
-        const dbl2 axy = cxy[a];
-        const double ax = axy.x, ay = axy.y, dA = gdA[j];
+        const int j = L.id(a);
+        double ax, ay;
+        L.xy(a, ax, ay);
+        const double dA = gdA[j];
         const double cost = sqrt(dist2(ax, ay, px, py));
         bool ok = true;
         if (rc.has_grid) ok = traversed_class(rc, grid, ax, ay, px, py, &err) == CLS_FREE;
         const double total = dA + cost;
         if (a == tl) { j0 = j; cost0 = ok ? cost : -1.0; tot0 = total; dA0 = dA; }
-        else cval[a] = ok ? cost : -1.0;
+        else { L.set_val(a, ok ? cost : -1.0); L.set_dA(a, dA); }
         if (ok) {
             ++nvalid;
             if (total < bt || (total == bt && j < bj)) { bt = total; bj = j; }
@@ -1022,7 +1139,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     bool deferred = false;
     if (nvalid == 0) {
         // rrt.rs:132-134: fall back to the nearest node, not collision-checked
-        best = rc.q_nn[k];
+        best = as_global(rc.q_nn)[k];
         best_cost = sqrt(dist2(as_global(rc.nx)[best], as_global(rc.ny)[best], px, py));
         dnew = gdA[best] + best_cost;
     } else {
@@ -1034,10 +1151,10 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
         auto each_tie = [&](auto &&f) {
             if (j0 >= 0 && cost0 >= 0.0 && tot0 == bt) f(j0);
             for (uint32_t a = tl + TS; a < cnt; a += TS) {
-                const double cost = cval[a];
+                const double cost = L.val(a);
                 if (cost >= 0.0) {
-                    const int j = cid[a];
-                    if (gdA[j] + cost == bt) f(j);
+                    const int j = L.id(a);
+                    if (L.dA(a, j) + cost == bt) f(j);
                 }
             }
         };
@@ -1095,15 +1212,26 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
                         __threadfence();
                         __hip_atomic_store(&rc.pend_state[rec], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                    // the copies wait for the same tied nodes: records of their own over the same pooled ids
+                    for (uint32_t c = tl; c < n_clone; c += TS) {
+                        const uint32_t rc2 = atomicAdd(&rc.cnt->pend_cnt, 1u);
+                        if (rc2 < rc.pend_cap) {
+                            rc.pend_new[rc2] = (int)clone_ids[c]; rc.pend_off[rc2] = base; rc.pend_n[rc2] = m; rc.pend_cur[rc2] = m;
+                            __threadfence();
+                            __hip_atomic_store(&rc.pend_state[rc2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        } else {
+                            err |= ERR_TIE_POOL;
+                        }
+                    }
                 }
             }
         }
         // cost and dist_root through the chosen parent: the lane that holds it as its first candidate has both
-        const unsigned long long own = W == 1 ? __ballot(j0 == best && cost0 >= 0.0) : 0ull;
+        const unsigned long long own = TeamT::kOneWave ? tm.ballot(j0 == best && cost0 >= 0.0) : 0ull;
         if (own) {
             const int src = (int)__builtin_ctzll(own);
-            best_cost = __shfl(cost0, src);
-            dnew = __shfl(tot0, src);
+            best_cost = tm.shfl(cost0, src);
+            dnew = tm.shfl(tot0, src);
         } else {
             best_cost = sqrt(dist2(as_global(rc.nx)[best], as_global(rc.ny)[best], px, py));
             dnew = gdA[best] + best_cost;
@@ -1115,15 +1243,18 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
     bool fin = false;
     unsigned long long fmask = 0;
     if (goal_kind == 1) {
-        double goal_d = __longlong_as_double(0x7FF0000000000000ll);
-        unsigned long long goal_m = 0;
-        if (tm.lane < rc.G) {
-            goal_d = fabs(rc.gcx[tm.lane] - px);
-            goal_d += fabs(rc.gcy[tm.lane] - py);
-            goal_m = rc.gmask[tm.lane];
+        for (uint32_t g0 = 0; g0 < rc.G && !fin; g0 += TeamT::kOneWave ? TeamT::kSize : 64u) {
+            const uint32_t g = g0 + tm.sub();
+            double goal_d = __longlong_as_double(0x7FF0000000000000ll);
+            unsigned long long goal_m = 0;
+            if (g < rc.G) {
+                goal_d = fabs(rc.gcx[g] - px);
+                goal_d += fabs(rc.gcy[g] - py);
+                goal_m = rc.gmask[g];
+            }
+            const unsigned long long hits = tm.ballot(goal_d < rc.g_l1);      // first listed goal wins
+            if (hits) { fin = true; fmask = tm.shfl(goal_m, (int)__builtin_ctzll(hits)); }
         }
-        const unsigned long long hits = __ballot(goal_d < rc.g_l1);      // first listed goal wins
-        if (hits) { fin = true; fmask = __shfl(goal_m, (int)__builtin_ctzll(hits)); }
     }
     if (tl == 0) {
         // everything that READS memory first (the memory counter is in order: a load's wait behind a store waits for
@@ -1158,8 +1289,54 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
         g_fm[id] = fin ? fmask : 0ull;
         if (fin) atomicAdd(&rc.cnt->n_final, 1u);
     }
+    if (n_clone) {
+        if (goal_kind == 2) {                                            // the team's first lane made that test
+            uint32_t f = fin ? 1u : 0u, unused = 0;
+            tm.bcast2(f, unused);
+            fin = f != 0u;
+        }
+        for (uint32_t c = tl; c < n_clone; c += TS) {
+            const uint32_t ic = clone_ids[c];
+            as_global(rc.nx)[ic] = px;
+            as_global(rc.ny)[ic] = py;
+            as_global(rc.parent)[ic] = deferred ? kParentPending : best;
+            as_global(rc.distA)[ic] = dnew;
+            as_global(rc.distB)[ic] = dnew;
+            as_global(rc.final_flag)[ic] = fin ? 1 : 0;
+            as_global(rc.final_mask)[ic] = fin ? (goal_kind == 2 ? 1ull : fmask) : 0ull;
+            if (fin) atomicAdd(&rc.cnt->n_final, 1u);
+        }
+    }
     // rewire phase 1 (rrt.rs:152-161): dist_root candidates, min wins
     auto gdB = as_global(reinterpret_cast<unsigned long long *>(rc.distB));
+    if constexpr (ListT::kCompact) {
+        // only the actual candidates are kept for the commit pass, compacted (rounds of one candidate per lane)
+        {
+            uint32_t n_out = 0;
+            for (uint32_t a0 = 0; a0 < cnt; a0 += TS) {
+                const uint32_t a = a0 + tl;
+                double via = -1.0;
+                int j = -1;
+                if (a < cnt) {
+                    const double cost = a0 == 0 ? cost0 : L.val(a);
+                    j = a0 == 0 ? j0 : L.id(a);
+                    if (nvalid != 0 && cost >= 0.0 && j != best) {
+                        const double v = dnew + cost;
+                        if (v < (a0 == 0 ? dA0 : L.dA(a, j))) { g_atomic_min(gdB + j, f64_bits(v)); via = v; }
+                    }
+                }
+                const unsigned long long hm = tm.ballot(via >= 0.0);
+                const uint32_t pos = n_out + (uint32_t)__popcll(hm & ((1ull << tm.sub()) - 1ull));
+                if (via >= 0.0) {
+                    if (pos < L.out_cap) { L.out_id[pos] = j; L.out_val[pos] = via; }
+                    else err |= ERR_CAND_OVERFLOW;
+                }
+                n_out += (uint32_t)__popcll(hm);
+            }
+            if (tl == 0) *L.out_cnt = n_out;
+        }
+        return;
+    } else {
     if (j0 >= 0) {
         double out = -1.0;                  // cand_val after this pass: the candidate dist_root of a rewire, or < 0
         if (nvalid != 0 && cost0 >= 0.0 && j0 != best) {
@@ -1169,20 +1346,21 @@ __device__ void connect_rrt_sample(const RunConst &rc, const Team<W> &tm, const 
                 out = via;
             }
         }
-        cval[tl] = out;
+        L.set_val(tl, out);
     }
     for (uint32_t a = tl + TS; a < cnt; a += TS) {
-        const double cost = cval[a];
-        const int j = cid[a];
+        const double cost = L.val(a);
+        const int j = L.id(a);
         double out = -1.0;
         if (nvalid != 0 && cost >= 0.0 && j != best) {
             const double via = dnew + cost;
-            if (via < gdA[j]) {
+            if (via < L.dA(a, j)) {
                 g_atomic_min(gdB + j, f64_bits(via));
                 out = via;
             }
         }
-        cval[a] = out;
+        L.set_val(a, out);
+    }
     }
 }
 
@@ -1198,8 +1376,9 @@ __global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per
     __shared__ double s_d[kConnectWaves];
     __shared__ int s_i[kConnectWaves];
     __shared__ uint32_t s_heavy[kConnectWaves];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ins[kInsertLds];
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
-    if (blockIdx.x == gridDim.x - 1) { insert_step_pages(rc, b, nb, vwords); return; }    // the extra block
+    if (blockIdx.x == gridDim.x - 1) { insert_step_pages(rc, b, nb, vwords, s_ins); return; }    // the extra block
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t k = uni(blockIdx.x * kConnectWaves + wv);
     const bool active = k < nb && as_global(rc.q_vid)[k < nb ? k : 0] >= 0;
@@ -1219,7 +1398,9 @@ __global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per
         }
         Team<1> tm;
         tm.scr_d = nullptr; tm.scr_i = nullptr; tm.wave = 0; tm.lane = lane;
-        connect_rrt_sample<1>(rc, tm, grid, b, vwords, k, cnt, err);
+        const uint32_t id = uni(uni(as_global(rc.n_at)[b]) + rank_before(rc, b, vwords, k));            // k is wave-uniform: scalars
+        const double px = uni_d(as_global(rc.q_x)[k]), py = uni_d(as_global(rc.q_y)[k]);
+        connect_rrt_sample(rc, tm, global_list(rc, b, k), grid, b, k, id, px, py, cnt, err);
     }
     __syncthreads();
     Team<kConnectWaves> tmh;
@@ -1233,14 +1414,16 @@ __global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per
         if (LDSGRID) grid = load_tile(rc, lds_tiles, rc.q_x[kh], rc.q_y[kh], threadIdx.x, kConnectWaves * 64u);
         else { grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0; }
         __syncthreads();
-        connect_rrt_sample<kConnectWaves>(rc, tmh, grid, b, vwords, kh, hc, err);
+        const uint32_t idh = uni(uni(as_global(rc.n_at)[b]) + rank_before(rc, b, vwords, kh));
+        const double pxh = uni_d(as_global(rc.q_x)[kh]), pyh = uni_d(as_global(rc.q_y)[kh]);
+        connect_rrt_sample(rc, tmh, global_list(rc, b, kh), grid, b, kh, idh, pxh, pyh, hc, err);
     }
     if (err) atomicOr(&rc.cnt->err, err);
 }
 
 // RRT*: rewire phase 2 for sample k of step b (one wave).  A pair wins iff its candidate equals the accumulated
 // minimum; among equal candidates the lowest new id wins (sequential order of the reference, strict `<`, rrt.rs:157).
-__device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k, uint32_t lane) {
+__device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k, uint32_t lane, uint32_t stride) {
     if (!((as_global(rc.valid_mask)[(size_t)b * vwords + (k >> 6)] >> (k & 63u)) & 1ull)) return;
     const uint32_t N = as_global(rc.n_at)[b];
     const int id = (int)(N + rank_before(rc, b, vwords, k));
@@ -1248,7 +1431,7 @@ __device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vword
     auto cid = as_global(rc.cand_id) + cand_off(rc, b, k);
     auto cval = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
     auto gdB = as_global(rc.distB);
-    for (uint32_t a = lane; a < cnt; a += 64) {
+    for (uint32_t a = lane; a < cnt; a += stride) {
         const double via = cval[a];
         if (!(via >= 0.0)) continue;
         const int j = cid[a];
@@ -1732,8 +1915,9 @@ template <bool LDSGRID>
 __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
                                                                      uint32_t vwords) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_tiles[];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ins[kInsertLds];
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
-    if (blockIdx.x == gridDim.x - 1) { insert_step_pages(rc, b, nb, vwords); return; }    // the extra block
+    if (blockIdx.x == gridDim.x - 1) { insert_step_pages(rc, b, nb, vwords, s_ins); return; }    // the extra block
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = uni(blockIdx.x * kConnectWaves + (threadIdx.x >> 6));
     if (k >= nb || as_global(rc.q_vid)[k] < 0) return;

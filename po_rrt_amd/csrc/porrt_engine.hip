@@ -11,6 +11,7 @@
 // No CPU fallback exists: without a HIP device porrt_create() fails.
 #include "../../include/porrt_hip.h"
 #include "porrt_device.hpp"
+#include "porrt_group.hpp"
 #include "porrt_belief.hpp"
 #include "porrt_dp.hpp"
 #include "porrt_prm.hpp"
@@ -173,6 +174,8 @@ struct porrt_ctx {
     bool opt_profile = false;
     bool opt_graph = true;
     uint32_t opt_kd_group = 0;     // steps per kd insertion (0 = choose by K)
+    uint32_t opt_group = 16;       // "group_lanes": lanes per sample of the RRT* step kernels (16 / 32 / 64; 0 = one wave per sample, the round-1 kernels)
+    uint32_t opt_lds_tile = 1;     // "lds_tile": raycasts read an LDS tile (1) or the raster in memory (0)
     bool opt_dp_sweeps = false;            // "dp_sweeps": expected costs by whole-graph sweeps instead of layer by layer
     uint32_t opt_cand_cap = 2048;
     // ---- device buffers
@@ -195,6 +198,7 @@ struct porrt_ctx {
     DevBuf<unsigned long long> d_reachA, d_reachB, d_finalmask, d_validmask, d_kdhint;
     DevBuf<uint8_t> d_vid, d_finalflag, d_cls;
     DevBuf<uint32_t> d_nat, d_sworld, d_candcnt, d_efrom, d_eto, d_etv;
+    DevBuf<uint16_t> d_perm;
     DevBuf<Counters> d_cnt;
     DevBuf<RunConst> d_rc;
     DevBuf<PcgJump> d_jump;
@@ -291,7 +295,7 @@ int porrt_ctx::layout_buffers() {
                               &d_kdrec, &d_gx, &d_gy, &d_rgdir, &d_rep, &d_kdbox, &d_locbox, &d_kdlosers, &d_gsnap, &d_pendoff, &d_pendn, &d_pendcur,
                               &d_pendnew, &d_pendpool, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB, &d_finalmask, &d_vid, &d_finalflag, &d_cls,
                               &d_nat, &d_sworld, &d_candcnt, &d_efrom, &d_eto, &d_etv, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags,
-                              &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid, &d_bcscratch, &d_bcout, &d_bccursor};
+                              &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid, &d_bcscratch, &d_bcout, &d_bccursor, &d_perm};
         for (DevBufBase *b2 : list) all_bufs.push_back(b2);
     }
     bool grow_needed = false;
@@ -331,7 +335,7 @@ int porrt_ctx::layout_buffers() {
     d_locflags.p = (uint32_t *)d_locflags.vp; d_kdsurv.p = (uint32_t *)d_kdsurv.vp;
     d_gndx.p = (double *)d_gndx.vp; d_gndy.p = (double *)d_gndy.vp;
     d_kqx.p = (double *)d_kqx.vp; d_kqy.p = (double *)d_kqy.vp; d_kqvid.p = (int *)d_kqvid.vp;
-    d_cnt.p = (Counters *)d_cnt.vp; d_rc.p = (RunConst *)d_rc.vp; d_jump.p = (PcgJump *)d_jump.vp;
+    d_cnt.p = (Counters *)d_cnt.vp; d_rc.p = (RunConst *)d_rc.vp; d_jump.p = (PcgJump *)d_jump.vp; d_perm.p = (uint16_t *)d_perm.vp;
     // cached uploads are gone
     rad_uploaded = 0;
     cls_dirty = true;
@@ -467,8 +471,19 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     };
     const bool rrt = mode == PORRT_MODE_RRT;
     ev();
+    const uint32_t GLn = rrt ? opt_group : 0u;
     if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_near<true>, dim3(wave_blocks, Q), dim3(256), 0, stream, rcp, b, i0, nb, vwords, 0xFFFFFFFFu, 0u);
-    else {
+    else if (GLn) {
+        // GL lanes per sample; the previous step's rewire phase 2 rides along in extra workgroups
+        const uint32_t spb = 256u / GLn, sblocks = (nb + spb - 1) / spb;
+        const uint32_t cblocks = commit_pend_b != 0xFFFFFFFFu ? (commit_pend_nb + spb - 1) / spb : 0;
+        const dim3 g(sblocks + cblocks, Q);
+        const uint32_t cnb = cblocks ? commit_pend_nb : 0u;
+        if (GLn == 16) hipLaunchKernelGGL(k_nn2<16>, g, dim3(256), 0, stream, rcp, b, i0, nb, vwords, commit_pend_b, cnb);
+        else if (GLn == 32) hipLaunchKernelGGL(k_nn2<32>, g, dim3(256), 0, stream, rcp, b, i0, nb, vwords, commit_pend_b, cnb);
+        else hipLaunchKernelGGL(k_nn2<64>, g, dim3(256), 0, stream, rcp, b, i0, nb, vwords, commit_pend_b, cnb);
+        commit_pend_b = 0xFFFFFFFFu;
+    } else {
         // the previous step's rewire phase 2 rides along in extra workgroups
         const uint32_t cblocks = commit_pend_b != 0xFFFFFFFFu ? (commit_pend_nb + 3) / 4 : 0;
         hipLaunchKernelGGL(k_near<false>, dim3(wave_blocks + cblocks, Q), dim3(256), 0, stream, rcp, b, i0, nb, vwords, commit_pend_b, cblocks ? commit_pend_nb : 0u);
@@ -490,7 +505,21 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     // (k_tie_fix).
     (void)hipEventRecord(ev_steered, stream);
     ev();
-    if (lds_bytes) hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
+    if (GLn) {
+        const uint32_t spb = 256u / GLn;
+        const dim3 g2((nb + spb - 1) / spb + 2, Q);       // + the clone workgroup + the page-filing workgroup
+        const bool tile = lds_bytes != 0 && opt_lds_tile;
+        const size_t dyn = conn2_lds_bytes(GLn, tile ? lds_bytes / kConnectWaves : 0);
+#define PORRT_CONN2(GLV)                                                                                               \
+        do {                                                                                                           \
+            if (tile) hipLaunchKernelGGL((k_conn2<GLV, true>), g2, dim3(256), dyn, stream, rcp, b, nb, vwords);       \
+            else hipLaunchKernelGGL((k_conn2<GLV, false>), g2, dim3(256), dyn, stream, rcp, b, nb, vwords);           \
+        } while (0)
+        if (GLn == 16) PORRT_CONN2(16);
+        else if (GLn == 32) PORRT_CONN2(32);
+        else PORRT_CONN2(64);
+#undef PORRT_CONN2
+    } else if (lds_bytes) hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
     else hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
     ev();
     (void)nxt_i0; (void)nxt_nb;
@@ -544,7 +573,9 @@ static uint32_t kd_group_for(uint32_t K, uint32_t opt, uint32_t Q) {
 void porrt_ctx::flush_commit() {
     if (commit_pend_b == 0xFFFFFFFFu) return;
     const uint32_t vwords = (rc.cand_K + 63) / 64;
-    hipLaunchKernelGGL(k_commit_rrt, dim3((commit_pend_nb * 64 + 255) / 256, launch_Q), dim3(256), 0, stream, launch_rcp, commit_pend_b, commit_pend_nb, vwords);
+    if (opt_group == 16) hipLaunchKernelGGL(k_commit2<16>, dim3((commit_pend_nb * 16 + 255) / 256, launch_Q), dim3(256), 0, stream, launch_rcp, commit_pend_b, commit_pend_nb, vwords);
+    else if (opt_group == 32) hipLaunchKernelGGL(k_commit2<32>, dim3((commit_pend_nb * 32 + 255) / 256, launch_Q), dim3(256), 0, stream, launch_rcp, commit_pend_b, commit_pend_nb, vwords);
+    else hipLaunchKernelGGL(k_commit_rrt, dim3((commit_pend_nb * 64 + 255) / 256, launch_Q), dim3(256), 0, stream, launch_rcp, commit_pend_b, commit_pend_nb, vwords);
     commit_pend_b = 0xFFFFFFFFu;
 }
 
@@ -619,7 +650,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(d_qx.reserve(K)); HIPCHK(d_qy.reserve(K)); HIPCHK(d_qnn.reserve(K)); HIPCHK(d_qvid.reserve(K));
         // region pages: one static page per region + a pool that cannot run out (sum of ceil(n_r / 64) <= N / 64 + regions)
         const uint64_t rg_maxp = Nmax / kPage + 2, pg_cap = 2ull * kRegions + Nmax / kPage + 8;
-        HIPCHK(d_rgcnt.reserve(kRegions)); HIPCHK(d_rgdir.reserve((size_t)kRegions * rg_maxp));
+        HIPCHK(d_rgcnt.reserve(2 * kRegions)); HIPCHK(d_rgdir.reserve((size_t)kRegions * rg_maxp));
         HIPCHK(d_pgxy.reserve(2 * (size_t)pg_cap * kPage)); HIPCHK(d_pgid.reserve((size_t)pg_cap * kPage)); 
         HIPCHK(d_candcnt.reserve(2 * (size_t)K)); HIPCHK(d_kdbox.reserve(Nmax)); HIPCHK(d_kdlosers.reserve(kClaimMax)); HIPCHK(d_bcscratch.reserve(8 * Nmax + 4096)); HIPCHK(d_bcout.reserve(1)); HIPCHK(d_bccursor.reserve(1)); HIPCHK(d_locbox.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_kdhint.reserve((size_t)kHG * kHG));
         HIPCHK(d_loccur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locdcur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locgex.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locflags.reserve(2 * (8 * (size_t)K + 4096)));
@@ -627,6 +658,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(d_pendstate.reserve(pend_cap)); HIPCHK(d_pendnew.reserve(pend_cap)); HIPCHK(d_pendpool.reserve(pool_cap)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_gndx.reserve(Nmax)); HIPCHK(d_gndy.reserve(Nmax));
         HIPCHK(d_kqx.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kqy.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kqvid.reserve((steps_max + 2) * Kpad)); HIPCHK(d_candid.reserve(2 * (size_t)K * cand_cap)); HIPCHK(d_candxy.reserve(4 * (size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
         HIPCHK(d_gid.reserve(Nmax));
+        HIPCHK(d_perm.reserve((steps_max + 2) * Kpad));
         HIPCHK(d_rep.reserve(kRepTotal));
         HIPCHK(d_kdrec.reserve(Nmax)); HIPCHK(d_gx.reserve(Nmax + 16)); HIPCHK(d_gy.reserve(Nmax + 16)); HIPCHK(d_kdup.reserve(Nmax)); HIPCHK(d_kddepth.reserve(Nmax)); HIPCHK(d_kdgexit.reserve(Nmax));
         HIPCHK(d_radT2.reserve(Nmax + 8));
@@ -693,6 +725,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.s_low0 = s_low[0]; c.s_low1 = s_low[1]; c.s_up0 = s_up[0]; c.s_up1 = s_up[1];
     c.max_step = max_step; c.mode = mode;
     c.part_stride = Kpad;
+    c.perm = d_perm.p;
 
     // ---- root (rrt.rs:105-106 / pto.rs:61-64)
     uint64_t root_reach = 0;
@@ -782,7 +815,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     std::vector<double> hs_x, hs_y;
     Pcg64 hs_rng = crng0;   // exact host stream (fallback)
     // produce the samples of iterations [it0, it0+n) on the device buffers
-    auto make_samples = [&](uint64_t it0, uint64_t n) -> int {
+    auto make_samples = [&](uint64_t it0, uint64_t n, uint32_t b0) -> int {
         double t0 = now_s();
         if (mode == PORRT_MODE_PTO) {
             worlds.resize(n);
@@ -825,6 +858,9 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
                                (unsigned long long)(uint64_t)crng0.state, (unsigned long long)(uint64_t)(crng0.state >> 64),
                                (unsigned long long)(uint64_t)crng0.inc, (unsigned long long)(uint64_t)(crng0.inc >> 64), 0ull);
         }
+        if (mode == PORRT_MODE_RRT && n > 0)       // the step kernels take a step's samples in spatial order
+            hipLaunchKernelGGL(k_sort_samples, dim3((unsigned)((n + K - 1) / K)), dim3(256), 0, stream, (const RunConst *)d_rc.p, b0,
+                               (unsigned long long)it0, (unsigned long long)n, K);
         t_setup += now_s() - t0;
         return PORRT_OK;
     };
@@ -838,7 +874,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         int r = ensure_radius_table(max_step, search_radius, n_iter_min + 4);
         if (r) return r;
         t_setup += now_s() - t0;
-        r = make_samples(0, n_iter_min);
+        r = make_samples(0, n_iter_min, 0);
         if (r) return r;
     }
     run_lds_bytes = lds_bytes;
@@ -854,7 +890,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     if (opt_graph && !prof && n_iter_min > 0) {
         // all steps up to n_iter_min as one hipGraph (two branches: main pipeline + kd insertion); the graph
         // only depends on the launch geometry, so it is instantiated once and replayed by later grows
-        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)launch_rcp, kd_group | ((uint64_t)launch_Q << 32)};
+        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)launch_rcp, kd_group | ((uint64_t)launch_Q << 32) | ((uint64_t)opt_group << 48) | ((uint64_t)opt_lds_tile << 56)};
         if (!graph_exec || memcmp(key, graph_key, sizeof key)) {
             double t0 = now_s();
             if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -913,7 +949,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         int r = ensure_radius_table(max_step, search_radius, i + nb + 4);
         if (r) return r;
         t_setup += now_s() - t0;
-        r = make_samples(i, nb);
+        r = make_samples(i, nb, b);
         if (r) return r;
         launch_step(b, (uint32_t)i, nb, vwords, lds_bytes, prof, ev_used, 0, 0);
         join_side();
@@ -942,8 +978,11 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     }
     counters = hc;
     if (getenv("PORRT_DEBUG")) {
-        fprintf(stderr, "[porrt] tie fallbacks %u g_len %u\n", hc.tie_fallbacks, hc.g_len);
+        fprintf(stderr, "[porrt] tie fallbacks %u g_len %u; samples served through the lists in memory %u\n", hc.tie_fallbacks, hc.g_len, hc.n_heavy);
         fprintf(stderr, "[porrt] deferred ties: records %u pooled ids %u settled %u\n", hc.pend_cnt, hc.pool_n, hc.n_deferred);
+        for (int t = 0; t < 8; ++t)
+            if (hc.tim[t + 8]) fprintf(stderr, "[porrt] phase %d: %.2f us per wave over %llu waves (total %.1f wave-ms)\n", t, 1e-2 * (double)hc.tim[t] / (double)hc.tim[t + 8],
+                                       (unsigned long long)hc.tim[t + 8], 1e-5 * (double)hc.tim[t]);
     }
     n_iter = i;
     n_steps = b;
@@ -977,6 +1016,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
             scan += a * 1e-3;
             conn += r2 * 1e-3;
             launches += 1;
+            if (getenv("PORRT_DEBUG_STEPS")) fprintf(stderr, "[porrt] step %u N %u near %.1f us connect %.1f us\n", s, nat[s], a * 1e3, r2 * 1e3);
             uint64_t nbq = std::min<uint64_t>(K, (it < n_iter_min ? n_iter_min : n_iter_max) - it);
             it += nbq;
             // what the two searches of the step answer: every (sample, node) pair of the NN and of the radius query
@@ -1462,6 +1502,12 @@ int porrt_ctx::finish_batch_member(uint64_t n_iter_done, uint32_t steps, float d
     if (hc.err & ERR_CAND_OVERFLOW) return -100;
     if (hc.err & ERR_RNG_RETRY) { set_err("a float draw would have been redrawn: grow this context on its own"); return PORRT_ERR_INVALID; }
     counters = hc;
+    if (getenv("PORRT_DEBUG") && batch_slot == 0) {
+        fprintf(stderr, "[porrt] batch member 0: samples served through the lists in memory %u\n", hc.n_heavy);
+        for (int t = 0; t < 8; ++t)
+            if (hc.tim[t + 8]) fprintf(stderr, "[porrt] phase %d: %.2f us per wave over %llu waves (total %.1f wave-ms)\n", t, 1e-2 * (double)hc.tim[t] / (double)hc.tim[t + 8],
+                                       (unsigned long long)hc.tim[t + 8], 1e-5 * (double)hc.tim[t]);
+    }
     n_iter = n_iter_done;
     n_steps = steps;
     n_nodes = n_final_nodes;
@@ -1564,7 +1610,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         };
         uint32_t steps = 0;
         if (L->opt_graph && !prof) {
-            const uint64_t key[6] = {(uint64_t)mode, K, n_iter, L->run_lds_bytes, (uint64_t)(uintptr_t)L->launch_rcp, L->kd_group | ((uint64_t)n << 32)};
+            const uint64_t key[6] = {(uint64_t)mode, K, n_iter, L->run_lds_bytes, (uint64_t)(uintptr_t)L->launch_rcp, L->kd_group | ((uint64_t)n << 32) | ((uint64_t)L->opt_group << 48) | ((uint64_t)L->opt_lds_tile << 56)};
             if (!L->graph_exec || memcmp(key, L->graph_key, sizeof key)) {
                 if (L->graph_exec) { (void)hipGraphExecDestroy(L->graph_exec); L->graph_exec = nullptr; }
                 hipGraph_t g = nullptr;
@@ -1623,6 +1669,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
                 scan += a * 1e-3;
                 conn += r2 * 1e-3;
                 ++launches;
+                if (getenv("PORRT_DEBUG_STEPS")) fprintf(stderr, "[porrt] batch step %u near %.1f us connect %.1f us\n", s, a * 1e3, r2 * 1e3);
             }
             std::vector<uint32_t> nat(steps + 1);
             for (uint32_t q = 0; q < n; ++q) {
@@ -2178,6 +2225,8 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "profile")) c->opt_profile = value != 0;
     else if (!strcmp(name, "cand_cap")) c->opt_cand_cap = (uint32_t)std::max<int64_t>(64, std::min<int64_t>(value, 1 << 26));
     else if (!strcmp(name, "graph")) c->opt_graph = value != 0;
+    else if (!strcmp(name, "group_lanes")) { if (value != 0 && value != 16 && value != 32 && value != 64) { c->set_err("group_lanes: 0, 16, 32 or 64"); return PORRT_ERR_INVALID; } c->opt_group = (uint32_t)value; }
+    else if (!strcmp(name, "lds_tile")) c->opt_lds_tile = value != 0;
     else if (!strcmp(name, "dp_sweeps")) c->opt_dp_sweeps = value != 0;
     else if (!strcmp(name, "kd_group")) c->opt_kd_group = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else { c->set_err(std::string("unknown option ") + name); return PORRT_ERR_INVALID; }

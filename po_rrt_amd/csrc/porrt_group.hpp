@@ -1,0 +1,489 @@
+// porrt_group.hpp -- the RRT* step kernels with several samples per wave (gfx950).
+//
+// A grow step of RRT::grow_tree (src/rrt.rs:109-168) is two kernels:
+//   k_nn2    GL lanes per sample: nearest neighbour (KdTree::nearest_neighbor, nearest_neighbor.rs:48-92, as the exact
+//            minimum of (norm2, id) over the region pages), steer (common.rs:215-225), point validity
+//            (map_shelves_io.rs:158-170).  Extra workgroups run the previous step's rewire phase 2.
+//   k_conn2  GL lanes per sample: radius search around the steered state (nearest_neighbor.rs:94-126) whose hits
+//            never leave the CU -- they are compacted into an LDS list, raycast (map_shelves_io.rs:187-203), reduced to
+//            the best parent (rrt.rs:137-145), and only the handful of actual rewire candidates (rrt.rs:152-161) go to
+//            memory for the commit pass.  A sample with more hits than the LDS list holds (the dense start of a tree,
+//            the copies of the goal point) is served afterwards by the whole workgroup through the global lists, the
+//            way k_connect_rrt does it.  One extra workgroup files the step's new nodes into the region pages.
+// Between the two lies the only global dependency of a step: a new node's id is N + its rank among the step's valid
+// samples.
+//
+// Why groups: with one wave per sample a launch for 128 queries is 131 072 waves of ~1200 vector instructions each, a
+// third of them busy; with 16 lanes per sample it is a quarter of the waves and the index arithmetic is shared by
+// four samples.  The neighbour lists used to make a round trip through HBM (20 B per neighbour written by the search,
+// read by the connect pass, 8 B more written and read again by the commit pass); now 12 B per actual rewire go out.
+#pragma once
+#include "porrt_device.hpp"
+
+namespace porrt {
+
+constexpr uint32_t kLdsHits = 64;                       // hits of one sample held in LDS
+constexpr uint32_t kHitBytes = kLdsHits * (4u + 8u + 8u);   // id, x -> cost, y -> dist_root
+
+// visit(x, y, id, ok) for every node whose region meets the box of the disc (q, rho), called by all lanes of the group
+// together; q, rho, N are uniform over the group.  See scan_disc for the page layout; here a group walks the 64-slot
+// pages of R regions per round (lane <-> region for the counts), 64 / GL coalesced loads per page in flight.
+// (A dense walk -- all regions as one virtual array, slots found by a binary search over the prefix sums held across
+// the group -- was measured: the dependent cross-lane reads cost more than the idle lanes at region ends.)
+template <int GL, int R, class Visit>
+__device__ __forceinline__ void gscan_disc(const RunConst &rc, uint32_t b, const GTeam<GL> &tm, double qx, double qy, double rho, uint32_t N, Visit visit,
+                                           uint32_t skip_region = 0xFFFFFFFFu) {
+    const uint32_t gl = tm.gl;
+    int cx0, cy0, cx1, cy1;
+    rep_cell(rc, qx - rho, qy - rho, kRG, cx0, cy0);
+    rep_cell(rc, qx + rho, qy + rho, kRG, cx1, cy1);
+    const uint32_t x0 = (uint32_t)cx0, y0 = (uint32_t)cy0;
+    const uint32_t w = (uint32_t)(cx1 - cx0 + 1), nreg = w * (uint32_t)(cy1 - cy0 + 1);
+    constexpr int U = (int)kPage / GL;
+    if (nreg * 16u > N) {           // young tree: streaming the id-ordered arrays is cheaper than walking empty regions
+        auto gx = as_global(rc.nx), gy = as_global(rc.ny);
+        for (uint32_t j0 = 0; j0 < N; j0 += (uint32_t)(U * GL)) {
+            double x[U], y[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t j = j0 + (uint32_t)(GL * u) + gl;
+                x[u] = gx[j < N ? j : 0u];
+                y[u] = gy[j < N ? j : 0u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (j0 + (uint32_t)(GL * u) < N) visit(x[u], y[u], (int)(j0 + (uint32_t)(GL * u) + gl), j0 + (uint32_t)(GL * u) + gl < N);
+        }
+        return;
+    }
+    auto gcnt = as_global(rc.rg_cnt) + (b & 1u) * kRegions;
+    auto gdir = as_global(rc.rg_dir);
+    auto gxy = as_global(reinterpret_cast<const dbl2 *>(rc.pg_xy));
+    auto gid = as_global(rc.pg_id);
+    for (uint32_t r0 = 0; r0 < nreg; r0 += (uint32_t)GL) {
+        const uint32_t r = r0 + gl;
+        uint32_t reg = 0, cnt = 0;
+        if (r < nreg) {
+            const uint32_t ry = r / w;
+            reg = (y0 + ry) * kRG + x0 + (r - ry * w);
+            cnt = reg == skip_region ? 0u : gcnt[reg];
+        }
+        uint32_t page = reg;                                     // the first page of a region is static
+        for (uint32_t lvl = 0;; ++lvl) {                         // page level: slots [64 lvl, 64 lvl + 64) of every region
+            const uint32_t have = cnt > lvl * kPage ? cnt - lvl * kPage : 0u;
+            unsigned long long m = tm.ballot(have > 0u);
+            if (!m) break;
+            // the next level's page ids are fetched while this level is walked
+            uint32_t page_next = 0;
+            if (have > kPage) page_next = gdir[(size_t)reg * rc.rg_maxp + lvl + 1u];
+            while (m) {
+                uint32_t pg[R], pc[R];
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+                    pg[q] = 0; pc[q] = 0;
+                    if (m) {
+                        const int l = (int)__builtin_ctzll(m);
+                        m &= m - 1;
+                        pg[q] = tm.shfl(page, l);
+                        const uint32_t h = tm.shfl(have, l);
+                        pc[q] = h < kPage ? h : kPage;
+                    }
+                }
+                dbl2 v[R][U];
+                int id[R][U];
+#pragma unroll
+                for (int q = 0; q < R; ++q)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {                 // only the filled slots are fetched
+                        const uint32_t sl = (uint32_t)(u * GL) + gl;
+                        const bool ld = sl < pc[q];
+                        v[q][u] = ld ? gxy[(size_t)pg[q] * kPage + sl] : dbl2{0.0, 0.0};
+                        id[q][u] = ld ? gid[(size_t)pg[q] * kPage + sl] : -1;
+                    }
+#pragma unroll
+                for (int q = 0; q < R; ++q)
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if ((uint32_t)(u * GL) < pc[q]) visit(v[q][u].x, v[q][u].y, id[q][u], (uint32_t)(u * GL) + gl < pc[q]);
+            }
+            page = page_next;
+        }
+    }
+}
+
+// ---- where a workgroup works
+// Workgroups are dealt to the 8 XCDs round-robin in launch order, and each XCD has its own 4 MiB L2.  A launch serves Q
+// queries (grid rows) whose trees share nothing, so the (x, row) pair a workgroup works on is rearranged: XCD c takes
+// the rows c, c + 8, ... one after the other, all workgroups of a row on one XCD -- a query's pages are fetched into one
+// L2 instead of eight.  (Which XCD gets launch index 0 does not matter; only that i and i + 8 share one.)
+__device__ __forceinline__ void xcd_swizzle(uint32_t &bx, uint32_t &by) {
+    const uint32_t gx = gridDim.x, Q = gridDim.y;
+    if (Q & 7u) return;
+    const uint32_t L = by * gx + bx, slot = L >> 3;
+    by = (slot / gx) * 8u + (L & 7u);
+    bx = slot % gx;
+}
+
+// One workgroup per step: the step's sample indices, ordered by the region grid cell the sample lies in (8 x 8-cell
+// tiles, row-major inside).  Samples served by one workgroup -- and by workgroups that run at the same time -- then
+// read the same few region pages.  Any order is a correct order: results are indexed by the sample.
+__global__ __launch_bounds__(256) void k_sort_samples(const RunConst *__restrict__ rcp, uint32_t b0, unsigned long long it0, unsigned long long n, uint32_t K) {
+    const RunConst &rc = *rcp;
+    __shared__ uint32_t s_bin[kRegions];
+    __shared__ uint32_t s_tot[256];
+    const uint32_t s = blockIdx.x, b = b0 + s;
+    const unsigned long long i0 = it0 + (unsigned long long)s * K;
+    const uint32_t nb = (uint32_t)(n - (unsigned long long)s * K < K ? n - (unsigned long long)s * K : K);
+    auto key_of = [&](uint32_t k) {
+        int cx, cy;
+        rep_cell(rc, rc.sx[i0 + k], rc.sy[i0 + k], kRG, cx, cy);
+        constexpr int TPR = (kRG + 7) / 8;
+        const uint32_t tile = (uint32_t)((cy >> 3) * TPR + (cx >> 3)), in = (uint32_t)((cy & 7) * 8 + (cx & 7));
+        // tiles are 64 keys apart; the last tile row / column of a 40 x 40 grid is only partly used
+        return tile * 64u + in;
+    };
+    constexpr uint32_t NK = ((kRG + 7) / 8) * ((kRG + 7) / 8) * 64u;
+    static_assert(NK <= kRegions, "key space");
+    for (uint32_t r = threadIdx.x; r < NK; r += 256u) s_bin[r] = 0;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nb; k += 256u) atomicAdd(&s_bin[key_of(k)], 1u);
+    __syncthreads();
+    // exclusive scan of the bins: per-thread runs, then the run totals
+    constexpr uint32_t PER = (NK + 255u) / 256u;
+    uint32_t run = 0;
+    for (uint32_t q = 0; q < PER; ++q) { const uint32_t r = threadIdx.x * PER + q; if (r < NK) run += s_bin[r]; }
+    s_tot[threadIdx.x] = run;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t acc = 0; for (uint32_t t = 0; t < 256u; ++t) { const uint32_t v = s_tot[t]; s_tot[t] = acc; acc += v; } }
+    __syncthreads();
+    uint32_t acc = s_tot[threadIdx.x];
+    for (uint32_t q = 0; q < PER; ++q) { const uint32_t r = threadIdx.x * PER + q; if (r < NK) { const uint32_t v = s_bin[r]; s_bin[r] = acc; acc += v; } }
+    __syncthreads();
+    uint16_t *out = rc.perm + (size_t)b * rc.part_stride;
+    for (uint32_t k = threadIdx.x; k < nb; k += 256u) out[atomicAdd(&s_bin[key_of(k)], 1u)] = (uint16_t)k;
+}
+
+// nn_bound_wave for a group (GL >= 16): lanes 0..8 of the group take the 3x3 cells.
+template <int GL>
+__device__ __forceinline__ double nn_bound_group(const RunConst &rc, const GTeam<GL> &tm, uint32_t N, double qx, double qy) {
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    double m = INF;
+    for (int l = 0; l < kRepLevels; ++l) {
+        const int G = rep_dim(l);
+        int cx, cy;
+        rep_cell(rc, qx, qy, G, cx, cy);
+        int r = -1;
+        if (tm.gl < 9u) {
+            const int x = cx + (int)(tm.gl % 3u) - 1, y = cy + (int)(tm.gl / 3u) - 1;
+            if (x >= 0 && y >= 0 && x < G && y < G) r = as_global(rc.rep)[rep_off(l) + y * G + x];
+        }
+        double d2 = INF;
+        if (r >= 0 && (uint32_t)r < N) d2 = dist2(as_global(rc.nx)[r], as_global(rc.ny)[r], qx, qy);
+        for (int off = 8; off > 0; off >>= 1) {           // lanes 0..15 of the group hold everything
+            const double o = __shfl_xor(d2, off);
+            d2 = o < d2 ? o : d2;
+        }
+        m = tm.shfl(d2, 0);
+        if (m < INF) break;
+    }
+    if (m == INF) m = dist2(as_global(rc.nx)[0], as_global(rc.ny)[0], qx, qy);      // the root always exists
+    return m;
+}
+
+// RRT* step, first kernel: GL lanes per sample.  grid.x = ceil(nb / SPB) search workgroups + ceil(cnb / SPB) workgroups
+// running the rewire phase 2 of step cb (commit_rrt_sample), SPB = 256 / GL samples per workgroup.
+template <int GL>
+__global__ __launch_bounds__(256) void k_nn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, uint32_t cb,
+                                             uint32_t cnb) {
+    static_assert(GL == 16 || GL == 32 || GL == 64, "group size");
+    constexpr uint32_t SPB = 256u / GL;
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    xcd_swizzle(bx, by);
+    const RunConst &rc = rcp[by];               // one context per grid row (porrt_grow_batch)
+    GTeam<GL> tm;
+    tm.gl = threadIdx.x % GL;
+    tm.base = (threadIdx.x & 63u) - tm.gl;
+    const uint32_t near_blocks = (nb + SPB - 1u) / SPB;
+    if (bx >= near_blocks) {
+        const uint32_t ck = (bx - near_blocks) * SPB + threadIdx.x / GL;
+        if (ck < cnb) commit_rrt_sample(rc, cb, vwords, ck, tm.gl, GL);
+        return;
+    }
+    const uint32_t slot = bx * SPB + threadIdx.x / GL;
+    if (slot >= nb) return;
+    const uint32_t k = rc.perm[(size_t)b * rc.part_stride + slot];
+    const uint32_t N = as_global(rc.n_at)[b];
+    const double sqx = as_global(rc.sx)[i0 + k], sqy = as_global(rc.sy)[i0 + k];
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    double bestD = INF;
+    int best = 0x7FFFFFFF;
+    {
+        // thr: no node with d2 above it can win or tie (sqrt is monotone; the factor keeps rounded ties in), so the
+        // sqrt -- the expensive part -- is only taken for the few nodes that may improve the lane's best
+        double thr = INF;
+        auto visit = [&](double x, double y, int id, bool ok) {
+            if (!ok) return;
+            const double d2 = dist2(x, y, sqx, sqy);
+            if (d2 > thr) return;
+            const double D = sqrt(d2);                           // the reference compares rounded distances
+            if (D < bestD || (D == bestD && id < best)) { bestD = D; best = id; thr = d2 * (1.0 + 1e-15); }
+        };
+        auto group_best = [&]() {
+            double rd = bestD;
+            int ri = best;
+            tm.argmin(rd, ri);
+            // the lane that holds the winner hands over its threshold
+            const unsigned long long own = tm.ballot(best == ri && bestD == rd);
+            const int src = own ? (int)__builtin_ctzll(own) : 0;
+            thr = tm.shfl(thr, src);
+            bestD = rd; best = ri;
+        };
+        // the sample's own region first: the nearest node is almost always there, and its distance bounds the disc the
+        // remaining regions are taken from; only when the region is empty does the bound come from the pyramid
+        const uint32_t own = region_of(rc, sqx, sqy);
+        gscan_disc<GL, 1>(rc, b, tm, sqx, sqy, 0.0, N, visit);
+        group_best();
+        double m2;
+        if (best != 0x7FFFFFFF) m2 = thr;                        // d2(best) * (1 + 1e-15)
+        else { m2 = nn_bound_group<GL>(rc, tm, N, sqx, sqy); thr = m2 * (1.0 + 1e-9); }
+        gscan_disc<GL, 2>(rc, b, tm, sqx, sqy, disc_radius(m2, sqx, sqy), N, visit, own);
+        group_best();
+    }
+    const int nn = best == 0x7FFFFFFF ? 0 : best;   // (cannot happen without a filter: the root exists)
+    const double fx = as_global(rc.nx)[nn], fy = as_global(rc.ny)[nn];
+    double tx = sqx, ty = sqy;
+    // common.rs:215-225
+    double step = fabs(tx - fx);
+    step += fabs(ty - fy);
+    if (step > rc.max_step) {
+        const double lambda = rc.max_step / step;
+        double ux = (tx - fx) * lambda, uy = (ty - fy) * lambda;
+        tx = fx + ux;
+        ty = fy + uy;
+    }
+    uint32_t err = 0;
+    bool valid = true;
+    if (rc.has_grid) {
+        const int cls = state_class(rc, tx, ty, &err);
+        valid = cls == CLS_FREE && !err;                         // RTTFuncs adapter (tamp_rrt.rs:40-42)
+    }
+    if (tm.gl == 0) {
+        as_global(rc.q_x)[k] = tx;
+        as_global(rc.q_y)[k] = ty;
+        // copy for the kd insertion, which runs beside the following steps (one slice per step)
+        const size_t o2 = (size_t)b * rc.part_stride + k;
+        as_global(rc.kq_x)[o2] = tx; as_global(rc.kq_y)[o2] = ty; as_global(rc.kq_vid)[o2] = valid ? 0 : -1;
+        as_global(rc.q_nn)[k] = nn;
+        // A node exactly on the goal point (every 100th iteration re-adds it once it is reached, rrt.rs:176-181) has every
+        // earlier copy as a neighbour, and a step's copies are identical searches: they are served together, once
+        // (q_vid = 1: the clone workgroup of k_conn2).
+        int qv = valid ? 0 : -1;
+        if (valid && rc.goal_kind != 0 && tx == rc.gp_x && ty == rc.gp_y) {
+            const uint32_t slot = atomicAdd(&rc.cnt->clone_n, 1u);
+            if (slot < 64u) { rc.cnt->clone_k[slot] = k; qv = 1; }
+        }
+        as_global(rc.q_vid)[k] = qv;
+        if (valid) atomicOr(&rc.valid_mask[(size_t)b * vwords + (k >> 6)], 1ull << (k & 63u));
+        if (err) atomicOr(&rc.cnt->err, err);
+    }
+}
+
+// dynamic LDS of k_conn2: per sample the hit list, then per sample a raster tile of `tile_bytes`; the page-filing
+// workgroup uses the same bytes as its scratch
+__host__ __device__ inline size_t conn2_lds_bytes(uint32_t GL, size_t tile_bytes) {
+    const size_t spb = 256u / GL, a = spb * (kHitBytes + tile_bytes);
+    return a > kInsertLds ? a : kInsertLds;
+}
+
+// one wave: radius search around (pxh, pyh) into the global list of sample kh (the form k_near wrote for every sample)
+__device__ __forceinline__ void list_scan_wave(const RunConst &rc, uint32_t b, uint32_t N, double T2, uint32_t kh, double pxh, double pyh, uint32_t lane,
+                                               uint32_t &err) {
+    auto cid = as_global(rc.cand_id) + cand_off(rc, b, kh);
+    auto cxy = as_global(reinterpret_cast<dbl2 *>(rc.cand_xy)) + cand_off(rc, b, kh);
+    const uint32_t cap = rc.cand_cap;
+    uint32_t tot = 0;
+    bool over = false;
+    scan_disc(rc, b, pxh, pyh, disc_radius(T2, pxh, pyh), uni(N), lane, [&](double x, double y, int jd, bool ok) {
+        const bool in = ok && dist2(x, y, pxh, pyh) <= T2;
+        const unsigned long long hm = __ballot(in);
+        const uint32_t pos = tot + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+        if (in) {
+            if (pos < cap) {
+                cid[pos] = jd;
+                dbl2 v;
+                v.x = x; v.y = y;
+                cxy[pos] = v;
+            } else {
+                over = true;
+            }
+        }
+        tot += (uint32_t)__popcll(hm);
+    });
+    if (lane == 0) as_global(rc.cand_cnt)[(b & 1u) * rc.cand_K + kh] = tot;
+    if (over) err |= (uint32_t)ERR_CAND_OVERFLOW;
+}
+
+// The clone workgroup of k_conn2: the step's copies of the goal point, one search for all of them by the 4-wave team.
+// A function of its own (not inlined): its registers are not the step kernel's.
+template <bool LDSGRID>
+__device__ __attribute__((noinline)) void clone_workgroup(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t N, double T2, uint8_t *tiles) {
+    __shared__ double s_d[kConnectWaves];
+    __shared__ int s_i[kConnectWaves];
+    __shared__ uint32_t s_cid[64], s_ck[64];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t err = 0;
+    uint32_t n = rc.cnt->clone_n;
+    n = n < 64u ? n : 64u;
+    if (n == 0) return;
+    if (threadIdx.x < n) {
+        const uint32_t kc = rc.cnt->clone_k[threadIdx.x];
+        s_ck[threadIdx.x] = kc;
+        s_cid[threadIdx.x] = N + rank_before(rc, b, vwords, kc);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                     // the lowest id leads (its rewires are the strict improvements)
+        uint32_t lead = 0;
+        for (uint32_t t = 1; t < n; ++t) if (s_cid[t] < s_cid[lead]) lead = t;
+        const uint32_t ti = s_cid[0], tk = s_ck[0];
+        s_cid[0] = s_cid[lead]; s_ck[0] = s_ck[lead]; s_cid[lead] = ti; s_ck[lead] = tk;
+        rc.cnt->clone_n = 0;                    // for the next step
+    }
+    __syncthreads();
+    const uint32_t kh = uni(s_ck[0]), idh = uni(s_cid[0]);
+    if (threadIdx.x >= 1 && threadIdx.x < n) as_global(rc.cand_cnt)[(b & 1u) * rc.cand_K + s_ck[threadIdx.x]] = 0u;     // no rewire candidates of their own
+    const double pxh = uni_d(as_global(rc.q_x)[kh]), pyh = uni_d(as_global(rc.q_y)[kh]);
+    if (wv == 0) {
+        list_scan_wave(rc, b, N, T2, kh, pxh, pyh, lane, err);
+        __threadfence();
+    }
+    __syncthreads();
+    const uint32_t hc = cand_count(rc, b, kh);
+    TileGrid grid;
+    if (LDSGRID) grid = load_tile(rc, tiles, pxh, pyh, threadIdx.x, kConnectWaves * 64u);
+    else { grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0; }
+    __syncthreads();
+    Team<kConnectWaves> tmh;
+    tmh.scr_d = s_d; tmh.scr_i = s_i; tmh.wave = wv; tmh.lane = lane;
+    connect_rrt_sample(rc, tmh, global_list(rc, b, kh), grid, b, kh, idh, pxh, pyh, hc, err, s_cid + 1, n - 1u);
+    if (err) atomicOr(&rc.cnt->err, err);
+}
+
+template <int GL, bool LDSGRID>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_conn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
+    static_assert(GL == 16 || GL == 32 || GL == 64, "group size");
+    constexpr uint32_t SPB = 256u / GL;
+    constexpr uint32_t GPW = 64u / GL;             // groups (samples) per wave
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];
+    __shared__ uint32_t s_over[SPB];
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    xcd_swizzle(bx, by);
+    const RunConst &rc = rcp[by];               // one context per grid row (porrt_grow_batch)
+    // the two single workgroups of a row come first: they take longest
+    if (bx == 0) { insert_step_pages(rc, b, nb, vwords, lds_dyn); return; }    // the page-filing workgroup
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, si = threadIdx.x / GL;
+    const uint32_t TWmax = 2u * rc.tile_R + 1u;
+    const uint32_t tile_bytes = LDSGRID ? ((TWmax * TWmax + 15u) & ~15u) : 0u;
+    uint8_t *tiles = lds_dyn + SPB * kHitBytes;
+    const uint32_t N = as_global(rc.n_at)[b];
+    const double T2 = as_global(rc.rad_T2)[N];             // rrt.rs:121: the size before insertion
+    uint32_t err = 0;
+    auto list_scan = [&](uint32_t kh, double pxh, double pyh) { list_scan_wave(rc, b, N, T2, kh, pxh, pyh, lane, err); };
+    if (bx == 1) { clone_workgroup<LDSGRID>(rc, b, vwords, N, T2, tiles); return; }
+    bx -= 2u;
+    GTeam<GL> tm;
+    tm.gl = threadIdx.x % GL;
+    tm.base = lane - tm.gl;
+    if (lane < GPW) s_over[wv * GPW + lane] = 0u;          // every wave keeps to its own entries: no workgroup barrier in here
+    __builtin_amdgcn_wave_barrier();
+    // s_k[]: the sample each group of the workgroup serves
+    __shared__ uint16_t s_k[SPB];
+    const uint32_t slot = bx * SPB + si;
+    const uint32_t k = slot < nb ? rc.perm[(size_t)b * rc.part_stride + slot] : 0xFFFFFFFFu;
+    if (tm.gl == 0) s_k[si] = (uint16_t)k;
+    const bool active = slot < nb && as_global(rc.q_vid)[slot < nb ? k : 0u] == 0;
+    PORRT_T0();
+    if (active) {
+        const uint32_t id = N + rank_before(rc, b, vwords, k);
+        const double px = as_global(rc.q_x)[k], py = as_global(rc.q_y)[k];
+        TileGrid grid;
+        grid.glob = rc.cls; grid.W = rc.W;
+        if (LDSGRID) {
+            // every neighbour lies within sqrt(T2) of the new node: the window the rays can touch
+            uint32_t R = (uint32_t)ceil(sqrt(T2) * rc.ppm) + 2u;
+            R = R < rc.tile_R ? R : rc.tile_R;
+            uint8_t *tile = tiles + si * tile_bytes;
+            grid.lds = tile; grid.TW = 2u * R + 1u;
+            uint32_t ci, cj;
+            to_pixel(rc, px, py, ci, cj);
+            grid.oi = (int)ci - (int)R;
+            grid.oj = (int)cj - (int)R;
+            for (uint32_t ri = 0; ri < grid.TW; ++ri) {
+                const int i = grid.oi + (int)ri;
+                for (uint32_t rj = tm.gl; rj < grid.TW; rj += (uint32_t)GL) {
+                    const int j = grid.oj + (int)rj;
+                    uint8_t c = CLS_BAD;
+                    if (i >= 0 && j >= 0 && (uint32_t)i < rc.H && (uint32_t)j < rc.W) c = as_global(rc.cls)[(uint32_t)i * rc.W + (uint32_t)j];
+                    tile[ri * grid.TW + rj] = c;
+                }
+            }
+        } else {
+            grid.lds = nullptr; grid.TW = 0; grid.oi = 0; grid.oj = 0;
+        }
+        LdsList L;
+        uint8_t *hb = lds_dyn + si * kHitBytes;
+        L.hx = reinterpret_cast<double *>(hb);
+        L.hy = L.hx + kLdsHits;
+        L.hid = reinterpret_cast<int *>(L.hy + kLdsHits);
+        L.out_id = as_global(rc.cand_id) + cand_off(rc, b, k);
+        L.out_val = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
+        L.out_cnt = as_global(rc.cand_cnt) + (b & 1u) * rc.cand_K + k;
+        L.out_cap = rc.cand_cap;
+        uint32_t tot = 0;
+        PORRT_TACC(rc, 0);
+        gscan_disc<GL, 1>(rc, b, tm, px, py, disc_radius(T2, px, py), N, [&](double x, double y, int jd, bool ok) {
+            const bool in = ok && dist2(x, y, px, py) <= T2;
+            const unsigned long long hm = tm.ballot(in);
+            const uint32_t pos = tot + (uint32_t)__popcll(hm & ((1ull << tm.gl) - 1ull));
+            if (in && pos < kLdsHits) { L.hid[pos] = jd; L.hx[pos] = x; L.hy[pos] = y; }
+            tot += (uint32_t)__popcll(hm);
+        });
+        __builtin_amdgcn_wave_barrier();
+        PORRT_TACC(rc, 1);
+        if (tot <= kLdsHits) connect_rrt_sample(rc, tm, L, grid, b, k, id, px, py, tot, err);
+        else if (tm.gl == 0) { s_over[si] = tot; atomicAdd(&rc.cnt->n_heavy, 1u); }
+    }
+    // A sample whose hits did not fit goes through the lists in memory, the way k_near / k_connect_rrt served every
+    // sample: searched again and connected by its own wave, 64 lanes.
+    __builtin_amdgcn_wave_barrier();
+    PORRT_TACC(rc, 2);
+    for (uint32_t g = 0; g < GPW; ++g) {
+        const uint32_t sw = wv * GPW + g;
+        const uint32_t hits = uni(s_over[sw]);     // written by this wave
+        if (hits == 0u) continue;
+        const uint32_t kh = uni((uint32_t)s_k[sw]);
+        const uint32_t idh = uni(N + rank_before(rc, b, vwords, kh));
+        const double pxh = uni_d(as_global(rc.q_x)[kh]), pyh = uni_d(as_global(rc.q_y)[kh]);
+        list_scan(kh, pxh, pyh);
+        TileGrid grid;
+        if (LDSGRID) {
+            grid = load_tile(rc, tiles + sw * tile_bytes, pxh, pyh, lane, 64u);
+            __builtin_amdgcn_wave_barrier();
+        } else { grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0; }
+        Team<1> tw;
+        tw.scr_d = nullptr; tw.scr_i = nullptr; tw.wave = 0; tw.lane = lane;
+        // the list was written by this wave: its own loads see its own stores once they are counted down
+        __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
+        connect_rrt_sample(rc, tw, global_list(rc, b, kh), grid, b, kh, idh, pxh, pyh, hits < rc.cand_cap ? hits : rc.cand_cap, err);
+    }
+    PORRT_TACC(rc, 3);
+    if (err) atomicOr(&rc.cnt->err, err);
+}
+
+// stand-alone rewire phase 2 for the last step of a launch sequence, GL lanes per sample
+template <int GL>
+__global__ __launch_bounds__(256) void k_commit2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
+    const uint32_t k = (blockIdx.x * 256u + threadIdx.x) / GL;
+    if (k < nb) commit_rrt_sample(rcp[blockIdx.y], b, vwords, k, threadIdx.x % GL, GL);
+}
+
+} // namespace porrt

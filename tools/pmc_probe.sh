@@ -2,18 +2,21 @@
 # GPU box: a few SQ counters per kernel for one batch step (diagnostics, not evidence)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 Q=${1:-8}
+OPTS=${2:-}
 cd /tmp && export TMPDIR=/tmp
 for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES" "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64"; do
   rm -rf $R/gpurun_out/pmcp
-  rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmcp -o p -- python3 $R/bench.py --steps 1 --warmup 0 --queries $Q --no-cpu-baseline --no-profile > /dev/null 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmcp -o p -- python3 $R/bench.py --steps 1 --warmup 0 --queries $Q --no-cpu-baseline --no-profile --no-single-query --no-belief $OPTS > /dev/null 2>&1
   python3 - "$(find $R/gpurun_out/pmcp -name '*counter_collection.csv' | head -1)" <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"].split("(")[0].split("::")[-1].replace("void ", "")
+    if agg.get(k) is None: pass
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     n[(k, r["Counter_Name"])] += 1
-for k in ("k_near<false>", "k_connect_rrt<true>", "k_kd_locate<1>"):
+for k in sorted(agg):
+    if not any(t in k for t in ("k_near", "k_connect", "k_nn2", "k_conn2", "k_kd_", "k_tie")): continue
     print(k, {c: "%.3g" % (v / max(n[(k, c)], 1)) for c, v in agg[k].items()})
 PY
 done
