@@ -121,6 +121,17 @@ def main():
     else:
         total_nodes = float(agg["nodes"])
 
+    # SURVEY 8(d) counts the D2H copy of every tree; the headline keeps the trees on the device (a caller downloads the
+    # winner).  Measured here: all Q trees of the last step fetched (coordinates, parents, dist_root), per step.
+    t1 = time.perf_counter()
+    for e in engs:
+        e.tree()
+    t_download_step = time.perf_counter() - t1
+    if world > 1:
+        t_dl = torch.tensor([t_download_step], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t_dl, op=dist.ReduceOp.MAX)
+        t_download_step = float(t_dl.item())
+
     # latency mode for reference: the same query alone (porrt_grow, one context), outside the timed region
     single = None
     if rank == 0 and not args.no_single_query:
@@ -162,6 +173,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "value_with_tree_download": total_nodes / (elapsed + args.steps * t_download_step),
+            "single_query": single,
             "config": {
                 "workload": "map_benchmark-like 200x200 synthetic map (reference raster is a Git-LFS pointer), 2D RRT* "
                             "(rrt.rs grow_tree), batch K=%d samples/step, %d iterations -> ~%d-node tree per query, "
@@ -183,32 +196,46 @@ def main():
         }
         if prof["scan_s"] > 0:
             L = max(prof["scan_launches"], 1)
-            # SURVEY 8d, per step ("batch"): the searches stream node x,y (16 B/node per query kind) + samples and
-            # nn/state writes (36 B/sample); connect reads dist_root (8 B/node), the 40 kB grid, and writes the
-            # committed nodes (28 B each).  N_b averaged over the run's steps.
+            # SURVEY 8(d), per step and query: B_alg = 16 N_b (node x, y) + 8 N_b (dist_root, read by the connect phase)
+            # + 36 K (samples in; nn id / distance / new state out) + 28 K_valid (committed nodes) + W H (the raster).
+            # A step is two kernels: k_nn2 (nearest neighbour, steer, validity) takes the 16 N_b + 36 K, k_conn2 (radius search,
+            # raycasts, best parent, commit) the 8 N_b + W H + 28 K_valid -- it reads the coordinates a second time (the radius
+            # search runs around the steered state), which is real traffic, not algorithmic bytes.  All figures per launch =
+            # summed over the Q queries of the step, N_b averaged over the run's steps.
             grid_bytes = 200.0 * 200.0
-            nb_avg = prof["scan_pairs"] / (2.0 * args.batch * L)        # summed over the Q queries of a launch
-            near_bytes = prof["scan_bytes"] / L
-            conn_bytes = 8.0 * nb_avg + Q * grid_bytes + 28.0 * prof["nodes"] / L
-            near_us, conn_us = 1e6 * prof["scan_s"] / L, 1e6 * prof["connect_s"] / L
-            pm = {}
-            try:    # HBM traffic per launch from the committed rocprofv3 --pmc passes
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            except Exception:
-                pass
+            n_sum = prof["scan_pairs"] / (2.0 * args.batch * L)          # sum over the Q queries of N_b
+            nn_bytes = 16.0 * n_sum + 36.0 * args.batch * Q
+            conn_bytes = 8.0 * n_sum + Q * grid_bytes + 28.0 * prof["nodes"] / L
+            nn_us, conn_us = 1e6 * prof["scan_s"] / L, 1e6 * prof["connect_s"] / L
+            pm, pm_src = {}, None
+            for cand in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):      # HBM traffic per launch from the committed rocprofv3 --pmc passes
+                try:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                    pm_src = "profiles/" + cand
+                    break
+                except Exception:
+                    pass
 
             def traffic_of(prefix):
-                exact = {"k_near": "k_near<false>", "k_connect_rrt": "k_connect_rrt<true>"}.get(prefix)      # the RRT* instantiations
-                ks = [pm[exact]] if exact in pm else [pm[k] for k in pm if k.startswith(prefix)]
+                ks = [pm[k] for k in pm if k.startswith(prefix + "<16") or k == prefix] or [pm[k] for k in pm if k.startswith(prefix)]
                 if not ks:
                     return None
                 return sum(2.0 * k["fetch_bytes_per_launch_raw"] + k["write_bytes_per_launch"] for k in ks) / len(ks)
 
-            # the two step kernels take about the same time; the searches carry the algorithmic bytes of SURVEY 8d, so they are
-            # the kernel reported unless the connect kernel is clearly (> 10 %) the longer one; both are under "kernels"
-            dom = "k_connect_rrt" if conn_us > 1.10 * near_us else "k_near"
-            dom_bytes, dom_us = (conn_bytes, conn_us) if dom == "k_connect_rrt" else (near_bytes, near_us)
+            dom = "k_conn2" if conn_us >= nn_us else "k_nn2"
+            dom_bytes, dom_us = (conn_bytes, conn_us) if dom == "k_conn2" else (nn_bytes, nn_us)
             achieved = dom_bytes / (dom_us * 1e-6) / 1e9
+            step_bytes, step_us = nn_bytes + conn_bytes, nn_us + conn_us
+            # FP64 work of SURVEY 8(d): 6 flop per (sample, node) pair and search kind, 12 K N_b per step; peak = the measured
+            # v_fma_f64 issue rate of tools/valu_peak.hip on this GPU (profiles/r2_valu_peak.txt), 2 flop per lane-instruction
+            flops = 6.0 * prof["scan_pairs"] / L
+            valu_peak = None
+            try:
+                for ln in open(os.path.join(ROOT, "profiles", "r2_valu_peak.txt")):
+                    if "fma_f64" in ln and "blocks 4096" in ln:
+                        valu_peak = 2.0 * float(ln.split("fma_f64")[1].split()[0])
+            except Exception:
+                pass
             out["roofline"] = {
                 "bound": "hbm",
                 "kernel": dom,
@@ -217,21 +244,27 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic_of(dom),
-                "traffic_note": "HBM bytes per launch = 2 x FETCH_SIZE (gfx950 under-reports streaming reads; these kernels gather, "
-                                "so the raw figure may be the truer one) + WRITE_SIZE, separate --pmc passes (profiles/r1_pmc_traffic.json)",
+                "traffic_source": pm_src,
+                "traffic_note": "HBM bytes per launch = 2 x FETCH_SIZE (gfx950 counts a 128-B request as 64 B for wide streaming reads; for gathers "
+                                "the raw figure may be the truer one) + WRITE_SIZE, separate --pmc passes of the same command; not measured in this run",
                 "avg_launch_us": dom_us,
                 "launches": L,
                 "algorithmic_bytes_per_launch": dom_bytes,
-                "note": "One launch serves the Q queries of the step.  The step chain is latency bound, not bandwidth bound: ~110 dependent steps per query, each a "
-                        "chain of dependent loads (0.5-1 us each).  The searches touch only the region pages a query disc "
-                        "meets, so real traffic is far below the brute-force figure used for `achieved` (SURVEY 8d).",
+                "formula": "SURVEY 8(d): k_nn2 16 N_b + 36 K, k_conn2 8 N_b + W H + 28 K_valid, per query, summed over the Q queries of a launch",
+                "note": "One launch serves the Q queries of the step.  The step kernels are bound by dependent-load latency at the occupancy their "
+                        "registers and LDS allow, not by bandwidth: the searches touch only the region pages a query disc meets.",
                 "kernels": {
-                    "k_near": {"avg_launch_us": near_us, "algorithmic_bytes_per_launch": near_bytes,
-                               "achieved_GBs": near_bytes / (near_us * 1e-6) / 1e9, "traffic": traffic_of("k_near"),
-                               "pairs_answered_per_s": prof["scan_pairs"] / prof["scan_s"]},
-                    "k_connect_rrt": {"avg_launch_us": conn_us, "algorithmic_bytes_per_launch": conn_bytes,
-                                      "achieved_GBs": conn_bytes / (conn_us * 1e-6) / 1e9, "traffic": traffic_of("k_connect_rrt")},
+                    "k_nn2": {"avg_launch_us": nn_us, "algorithmic_bytes_per_launch": nn_bytes, "achieved_GBs": nn_bytes / (nn_us * 1e-6) / 1e9,
+                              "traffic": traffic_of("k_nn2")},
+                    "k_conn2": {"avg_launch_us": conn_us, "algorithmic_bytes_per_launch": conn_bytes, "achieved_GBs": conn_bytes / (conn_us * 1e-6) / 1e9,
+                                "reread_of_coordinates_bytes": 16.0 * n_sum, "traffic": traffic_of("k_conn2")},
                 },
+                "step": {"algorithmic_bytes": step_bytes, "us": step_us, "achieved_GBs": step_bytes / (step_us * 1e-6) / 1e9,
+                         "frac": step_bytes / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                "fp64_valu": {"algorithmic_flops_per_launch_pair": flops, "achieved_TFLOPs": flops / (step_us * 1e-6) / 1e12,
+                              "peak_TFLOPs": valu_peak, "frac": (flops / (step_us * 1e-6) / 1e12 / valu_peak) if valu_peak else None,
+                              "note": "6 flop per (sample, node) pair and search (brute-force definition of the two searches, SURVEY 8d) over the time of both "
+                                      "step kernels; peak = measured v_fma_f64 rate (tools/valu_peak.hip)"},
                 "share_of_device_time": (prof["scan_s"] + prof["connect_s"]) / max(prof["device_s"], 1e-12),
             }
         if not args.no_cpu_baseline and world == 1:

@@ -761,8 +761,9 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
     c.N = (uint32_t)N; c.B = 0; c.nz = (uint32_t)in.n_zones; c.n_validities = (uint32_t)in.n_validities;
     c.nx = in.d_nx; c.ny = in.d_ny; c.vid = in.d_vid; c.visibility = in.visibility;
     hipStream_t s = in.stream;
-    hipEvent_t ev0, ev1, ev2, ev3;
-    BG_HIP(hipEventCreate(&ev0)); BG_HIP(hipEventCreate(&ev1)); BG_HIP(hipEventCreate(&ev2)); BG_HIP(hipEventCreate(&ev3));
+    ScopedEvents<4> evs;
+    BG_HIP(evs.create());
+    hipEvent_t ev0 = evs.e[0], ev1 = evs.e[1], ev2 = evs.e[2], ev3 = evs.e[3];
 
     // 1. visible zones per node
     std::vector<double> zxy(2 * std::max(in.n_zones, 1));
@@ -957,7 +958,6 @@ static int belief_graph_build(BeliefGraphState &g, const BeliefInputs &in, const
     float ms_a = 0, ms_b = 0;
     BG_HIP(hipEventElapsedTime(&ms_a, ev0, ev1));
     BG_HIP(hipEventElapsedTime(&ms_b, ev2, ev3));
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(ev2); (void)hipEventDestroy(ev3);
     g.n_edges = n_edges;
     g.last = c;
     g.d_types = c.types; g.d_child_off = c.child_off; g.d_par_off = c.par_off; g.d_child_id = c.child_id; g.d_par_id = c.par_id;

@@ -24,6 +24,20 @@
 
 namespace porrt {
 
+// timing events of one call: destroyed on every way out of it (an early error return used to leak them)
+template <int NEV>
+struct ScopedEvents {
+    hipEvent_t e[NEV];
+    ScopedEvents() { for (int i = 0; i < NEV; ++i) e[i] = nullptr; }
+    hipError_t create() {
+        for (int i = 0; i < NEV; ++i) { const hipError_t r = hipEventCreate(&e[i]); if (r != hipSuccess) return r; }
+        return hipSuccess;
+    }
+    ~ScopedEvents() { for (int i = 0; i < NEV; ++i) if (e[i]) (void)hipEventDestroy(e[i]); }
+    ScopedEvents(const ScopedEvents &) = delete;
+    ScopedEvents &operator=(const ScopedEvents &) = delete;
+};
+
 constexpr int kConnectWaves = 4;     // samples per connect workgroup (one wave each)
 constexpr uint32_t kTileRMax = 31;             // LDS tile half-width limit (pixels); above it rays read global
 constexpr int kEmpty = 0x7FFFFFFF;       // empty kd child slot (atomicMin claims it)
@@ -95,6 +109,17 @@ struct Counters {
 #define PORRT_T0() do {} while (0)
 #define PORRT_TACC(rc, slot) do {} while (0)
 #endif
+// -DPORRT_TIMING=1: the timers of k_nn2, =2: those of k_conn2 (they share the slots)
+#if defined(PORRT_TIMING) && PORRT_TIMING == 1
+#define PORRT_TACC_A(rc, slot) PORRT_TACC(rc, slot)
+#define PORRT_TACC_B(rc, slot) do { (void)t__0; } while (0)
+#elif defined(PORRT_TIMING)
+#define PORRT_TACC_A(rc, slot) do { (void)t__0; } while (0)
+#define PORRT_TACC_B(rc, slot) PORRT_TACC(rc, slot)
+#else
+#define PORRT_TACC_A(rc, slot) do {} while (0)
+#define PORRT_TACC_B(rc, slot) do {} while (0)
+#endif
 
 struct BestCost {
     unsigned long long cost_bits;   // f64 bits of the best cost (+inf bits when there is no final node)
@@ -111,6 +136,8 @@ struct RunConst {
     uint32_t *rg_dir;           // [region][j]: j-th page of the region, j >= 1
     double *pg_xy;              // [page][slot] (x, y)
     int *pg_id;                 // [page][slot] node id
+    double *pg_d;               // [page][slot] dist_root as of the step's start (RRT*): the radius search gets it with the coordinates
+    uint32_t *slot_of;          // node -> page * 64 + slot (the rewire commit keeps pg_d in step with distA)
     uint32_t rg_maxp, pg_cap;   // directory stride, pages in the pool
     double *distA, *distB;      // dist_root: A = snapshot read by the step, B = rewire accumulator
     int *parent;
@@ -174,6 +201,8 @@ struct RunConst {
     double gp_x, gp_y;
     // grid
     const uint8_t *cls;
+    const uint8_t *clr;         // per pixel: Chebyshev distance to the nearest pixel that is not CLS_FREE or lies outside (0 on such a
+                                // pixel, capped at 255): a segment whose end pixels are closer than that crosses free pixels only
     uint32_t W, H;
     double low0, low1, ppm;
     int domain, has_grid;
@@ -193,6 +222,10 @@ struct RunConst {
     double max_step;
     int mode;
     uint16_t *perm;             // [step][part_stride]: the step's sample indices ordered by where the samples lie (k_sort_samples)
+    double *ssx, *ssy;          // [step][part_stride]: the samples in that order (one coalesced load instead of perm -> sx, sy)
+    double *bq_x, *bq_y;        // [part_stride] steered states in slot order and the sample they belong to (0xFFFF: nothing for
+    uint16_t *bq_k;             //   the connect groups to do), written by k_nn2 for k_conn2
+    double *t2_at;              // t2_at[b] = rad_T2[n_at[b]] (RRT*: the step's radius threshold, written with n_at)
     uint32_t tile_R;            // LDS tile half-width in pixels (0 = no tile: read the raster from global)
     uint32_t part_stride;       // sample stride of the arrays double-buffered by step parity
 };
@@ -291,13 +324,10 @@ struct TileGrid {
     }
 };
 
-// Traversed-space class of the segment a -> b (map_shelves_io.rs:187-203, map_io.rs:216-241).
-// Returns CLS_FREE / CLS_LOW / CLS_HIGH / CLS_ZONE+z.  Raster faults set *err and read as CLS_HIGH.
+// Traversed-space class of the segment a -> b (map_shelves_io.rs:187-203, map_io.rs:216-241), end points given as pixels
+// (to_pixel).  Returns CLS_FREE / CLS_LOW / CLS_HIGH / CLS_ZONE+z.  Raster faults set *err and read as CLS_HIGH.
 template <class Grid>
-__device__ int traversed_class(const RunConst &rc, const Grid &grid, double ax, double ay, double bx, double by, uint32_t *err) {
-    uint32_t ai, aj, bi, bj;
-    to_pixel(rc, ax, ay, ai, aj);
-    to_pixel(rc, bx, by, bi, bj);
+__device__ int traversed_class_px(const RunConst &rc, const Grid &grid, uint32_t ai, uint32_t aj, uint32_t bi, uint32_t bj, uint32_t *err) {
     if (ai >= rc.H || bi >= rc.H || aj >= rc.W || bj >= rc.W) {
         *err |= ERR_RASTER;
         return CLS_HIGH;
@@ -339,6 +369,20 @@ __device__ int traversed_class(const RunConst &rc, const Grid &grid, double ax, 
         e += ddy;
     }
     return worst;
+}
+template <class Grid>
+__device__ __forceinline__ int traversed_class(const RunConst &rc, const Grid &grid, double ax, double ay, double bx, double by, uint32_t *err) {
+    uint32_t ai, aj, bi, bj;
+    to_pixel(rc, ax, ay, ai, aj);
+    to_pixel(rc, bx, by, bi, bj);
+    return traversed_class_px(rc, grid, ai, aj, bi, bj, err);
+}
+
+// Is the segment between two pixels free without looking at it?  The Bresenham walk stays inside the bounding box of its
+// end pixels, so it is when that box lies inside the all-free window around one of them (clr of that end).
+__device__ __forceinline__ bool segment_in_clearance(uint32_t ai, uint32_t aj, uint32_t bi, uint32_t bj, uint32_t clr_b) {
+    const uint32_t di = ai > bi ? ai - bi : bi - ai, dj = aj > bj ? aj - bj : bj - aj;
+    return (di > dj ? di : dj) < clr_b;
 }
 
 // class of one state (map_shelves_io.rs:158-163, map_io.rs:165-174); global raster
@@ -796,7 +840,9 @@ __device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, u
         s_np = 0; s_base = kRegions + rc.cnt->n_pages;
         uint32_t add = 0;
         for (uint32_t w = 0; w < vwords; ++w) add += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
-        as_global(rc.n_at)[b + 1] = as_global(rc.n_at)[b] + add;        // tree size at the start of the next step
+        const uint32_t n_next = as_global(rc.n_at)[b] + add;
+        as_global(rc.n_at)[b + 1] = n_next;                              // tree size at the start of the next step
+        as_global(rc.t2_at)[b + 1] = as_global(rc.rad_T2)[n_next];
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < nb; k += T)
@@ -827,7 +873,9 @@ __device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, u
         dbl2 v;
         v.x = x; v.y = y;
         pxy[(size_t)page * kPage + (slot % kPage)] = v;
-        as_global(rc.pg_id)[(size_t)page * kPage + (slot % kPage)] = (int)(N + rank_before(rc, b, vwords, k));
+        const uint32_t nid = N + rank_before(rc, b, vwords, k);
+        as_global(rc.pg_id)[(size_t)page * kPage + (slot % kPage)] = (int)nid;
+        as_global(rc.slot_of)[nid] = page * kPage + (slot % kPage);          // pg_d of the slot: the step's commit pass
     }
     __syncthreads();
     for (uint32_t r = threadIdx.x; r < kRegions; r += T) rg_new[r] = rg_old[r] + s_add[r];
@@ -1076,12 +1124,18 @@ __device__ __forceinline__ GlobalList global_list(const RunConst &rc, uint32_t b
     L.gdA = as_global((const double *)rc.distA);
     return L;
 }
-// LdsList: the hits of a radius search held in LDS (x is replaced by the cost, y by dist_root once the raycast is
-// through); only the actual rewire candidates go to memory, compacted, for the commit pass.
-struct LdsList {
+// The hits of a radius search as k_conn2 keeps them: id, coordinates (x is replaced by the cost once the ray is through,
+// then by nothing: the rewire candidates leave through out_*) and dist_root, which came with the coordinates from the
+// region page.  LdsHits: a sample with at most kLdsHits hits, everything in LDS.  MemHits: more hits (dense starts of a
+// tree, neighbourhoods of the goal point), everything in the sample's slice of the global list arrays.  Either way only
+// the actual rewire candidates are left in memory for the commit pass, compacted -- for MemHits in place: a candidate's
+// position is at most its entry index, and an entry is read before anything is written in its round.
+constexpr uint32_t kLdsHits = 64;
+constexpr uint32_t kHitBytes = kLdsHits * (4u + 8u + 8u + 8u);
+struct LdsHits {
     static constexpr bool kCompact = true;
     int *hid;
-    double *hx, *hy;
+    double *hx, *hy, *hd;
     GPTR(int) out_id;       // compact (id, candidate dist_root) list of the sample, read by commit_rrt_sample
     GPTR(double) out_val;
     GPTR(uint32_t) out_cnt;
@@ -1090,17 +1144,35 @@ struct LdsList {
     __device__ __forceinline__ void xy(uint32_t a, double &x, double &y) const { x = hx[a]; y = hy[a]; }
     __device__ __forceinline__ double val(uint32_t a) const { return hx[a]; }
     __device__ __forceinline__ void set_val(uint32_t a, double v) const { hx[a] = v; }
-    __device__ __forceinline__ void set_dA(uint32_t a, double v) const { hy[a] = v; }
-    __device__ __forceinline__ double dA(uint32_t a, int) const { return hy[a]; }
+    __device__ __forceinline__ void set_dA(uint32_t, double) const {}
+    __device__ __forceinline__ double dA(uint32_t a, int) const { return hd[a]; }
+};
+struct MemHits {
+    static constexpr bool kCompact = true;
+    GPTR(int) sid;
+    GPTR(dbl2) sxy;
+    GPTR(double) sd;
+    GPTR(int) out_id;
+    GPTR(double) out_val;
+    GPTR(uint32_t) out_cnt;
+    uint32_t out_cap;
+    __device__ __forceinline__ int id(uint32_t a) const { return sid[a]; }
+    __device__ __forceinline__ void xy(uint32_t a, double &x, double &y) const { const dbl2 v = sxy[a]; x = v.x; y = v.y; }
+    __device__ __forceinline__ double val(uint32_t a) const { return sxy[a].x; }
+    __device__ __forceinline__ void set_val(uint32_t a, double v) const { sxy[a].x = v; }
+    __device__ __forceinline__ void set_dA(uint32_t, double) const {}
+    __device__ __forceinline__ double dA(uint32_t a, int) const { return sd[a]; }
 };
 
 // RRT*: validated neighbours, best parent, new node, rewire phase 1 for sample k by a team (Team<W> / GTeam<GL>) on a
-// neighbour list (GlobalList / LdsList).  A lane keeps its first candidate in registers through all three passes (that
+// neighbour list (GlobalList / HitList).  A lane keeps its first candidate in registers through all three passes (that
 // is every candidate when the sample has at most `team size` neighbours, the common case); further candidates go
 // through the list's value slots.
-template <class TeamT, class ListT, class Grid>
+struct NoNearestSearch { __device__ int operator()() const { return 0; } };      // k_near always names the nearest node
+template <class TeamT, class ListT, class Grid, class NNF = NoNearestSearch>
 __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const ListT &L, const Grid &grid, uint32_t b, uint32_t k, uint32_t id,
-                                   double px, double py, uint32_t cnt, uint32_t &err, const uint32_t *clone_ids = nullptr, uint32_t n_clone = 0) {
+                                   double px, double py, uint32_t cnt, uint32_t &err, const uint32_t *clone_ids = nullptr, uint32_t n_clone = 0,
+                                   int clr_known = -1, NNF nearest_search = NNF()) {
     // clone_ids: further new nodes of this step at exactly (px, py), all with ids above `id` (the copies of the goal
     // point a step adds, rrt.rs:176-181).  The reference would run the same search n_clone + 1 times on the same
     // snapshot: same neighbours, same costs, same parent, same dist_root; of the rewires only the first copy's are
@@ -1110,20 +1182,29 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
     auto gdA = as_global(rc.distA);
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
 
-    // pass 1: raycast every neighbour, total cost through it (rrt.rs:124, 137-140)
+    // pass 1: raycast every neighbour, total cost through it (rrt.rs:124, 137-140).  A ray whose end pixels lie inside
+    // the all-free window around the new node's pixel (clr) crosses free pixels only and is not walked.
     double bt = INF;
     int bj = 0x7FFFFFFF;
     uint32_t nvalid = 0;
     int j0 = -1;                // first candidate of this lane, register resident
     double cost0 = -1.0, tot0 = INF, dA0 = 0.0;
+    uint32_t bi = 0, bjx = 0, clr_b = 0;
+    if (rc.has_grid) {
+        to_pixel(rc, px, py, bi, bjx);
+        if (clr_known >= 0) clr_b = (uint32_t)clr_known;         // the caller fetched it beside its other loads
+        else if (bi < rc.H && bjx < rc.W) clr_b = as_global(rc.clr)[bi * rc.W + bjx];
+    }
     for (uint32_t a = tl; a < cnt; a += TS) {
         const int j = L.id(a);
         double ax, ay;
         L.xy(a, ax, ay);
-        const double dA = gdA[j];
+        const double dA = L.dA(a, j);
         const double cost = sqrt(dist2(ax, ay, px, py));
+        uint32_t ai = 0, aj = 0;
+        if (rc.has_grid) to_pixel(rc, ax, ay, ai, aj);
         bool ok = true;
-        if (rc.has_grid) ok = traversed_class(rc, grid, ax, ay, px, py, &err) == CLS_FREE;
+        if (rc.has_grid) ok = segment_in_clearance(ai, aj, bi, bjx, clr_b) || traversed_class_px(rc, grid, ai, aj, bi, bjx, &err) == CLS_FREE;
         const double total = dA + cost;
         if (a == tl) { j0 = j; cost0 = ok ? cost : -1.0; tot0 = total; dA0 = dA; }
         else { L.set_val(a, ok ? cost : -1.0); L.set_dA(a, dA); }
@@ -1132,14 +1213,17 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
             if (total < bt || (total == bt && j < bj)) { bt = total; bj = j; }
         }
     }
+    PORRT_T0();
     nvalid = tm.sum(nvalid);
     tm.argmin(bt, bj);
+    PORRT_TACC_B(rc, 4);
     int best;
     double best_cost, dnew;
     bool deferred = false;
     if (nvalid == 0) {
         // rrt.rs:132-134: fall back to the nearest node, not collision-checked
         best = as_global(rc.q_nn)[k];
+        if (best < 0) best = nearest_search();      // k_nn2 did not need it (the sample was not steered): searched now, by the whole team
         best_cost = sqrt(dist2(as_global(rc.nx)[best], as_global(rc.ny)[best], px, py));
         dnew = gdA[best] + best_cost;
     } else {
@@ -1238,6 +1322,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
         }
     }
 
+    PORRT_TACC_B(rc, 5);
     // new node (rrt.rs:148, 30-37) and goal test (rrt.rs:165-167)
     // SquareGoal test (common.rs:336-345), lane g <-> goal g; the goal table sits in the run constants (scalar cache)
     bool fin = false;
@@ -1307,6 +1392,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
             if (fin) atomicAdd(&rc.cnt->n_final, 1u);
         }
     }
+    PORRT_TACC_B(rc, 6);
     // rewire phase 1 (rrt.rs:152-161): dist_root candidates, min wins
     auto gdB = as_global(reinterpret_cast<unsigned long long *>(rc.distB));
     if constexpr (ListT::kCompact) {
@@ -1335,6 +1421,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
             }
             if (tl == 0) *L.out_cnt = n_out;
         }
+        PORRT_TACC_B(rc, 7);
         return;
     } else {
     if (j0 >= 0) {
@@ -1431,6 +1518,10 @@ __device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vword
     auto cid = as_global(rc.cand_id) + cand_off(rc, b, k);
     auto cval = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
     auto gdB = as_global(rc.distB);
+    auto gpd = as_global(rc.pg_d);
+    auto gso = as_global(rc.slot_of);
+    // the new node's own dist_root goes to its page slot (filed by insert_step_pages beside the connect pass)
+    if (lane == 0) gpd[gso[id]] = as_global(rc.distA)[id];
     for (uint32_t a = lane; a < cnt; a += stride) {
         const double via = cval[a];
         if (!(via >= 0.0)) continue;
@@ -1444,6 +1535,7 @@ __device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vword
             old = expect;
         }
         as_global(rc.distA)[j] = via;
+        gpd[gso[j]] = via;
     }
 }
 

@@ -367,8 +367,9 @@ static int dp_run(DpState &st, DpConst c, bool implicit, const std::vector<unsig
     }
     c.dist = st.d_dist;
     c.flags = st.d_flags;
-    hipEvent_t ev0, ev1;
-    DP_HIP(hipEventCreate(&ev0)); DP_HIP(hipEventCreate(&ev1));
+    ScopedEvents<2> evs;
+    DP_HIP(evs.create());
+    hipEvent_t ev0 = evs.e[0], ev1 = evs.e[1];
     DP_HIP(hipEventRecord(ev0, s));
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     hipLaunchKernelGGL(k_dp_fill, grid, block, 0, s, st.d_dist, (unsigned long long)n, __builtin_huge_val());
@@ -401,7 +402,6 @@ static int dp_run(DpState &st, DpConst c, bool implicit, const std::vector<unsig
     DP_HIP(hipGetLastError());
     float ms = 0;
     DP_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
     if (h_flags[0] & DP_ERR_UNKNOWN_TYPE) { err = "node type should be know at this stage! (belief_graph.rs:138)"; return PORRT_ERR_INVALID; }
     if (h_flags[0] & DP_ERR_ZERO_PROBABILITY) { err = "assert!(p > 0.0) failed (belief_graph.rs:128)"; return PORRT_ERR_INVALID; }
     st.n = n;
@@ -467,8 +467,9 @@ static int dp_run_layered(DpState &st, BeliefGraphState &bg, DpConst c, const st
     }
     double *d_w = (double *)st.d_aux;
     uint32_t *d_rank = (uint32_t *)(d_w + n_adj), *d_belief_at = d_rank + B;
-    hipEvent_t ev0, ev1;
-    DP_HIP(hipEventCreate(&ev0)); DP_HIP(hipEventCreate(&ev1));
+    ScopedEvents<2> evs;
+    DP_HIP(evs.create());
+    hipEvent_t ev0 = evs.e[0], ev1 = evs.e[1];
     DP_HIP(hipEventRecord(ev0, s));
     DP_HIP(hipMemcpyAsync(d_rank, rank.data(), B * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     DP_HIP(hipMemcpyAsync(d_belief_at, belief_at.data(), B * sizeof(uint32_t), hipMemcpyHostToDevice, s));
@@ -510,7 +511,6 @@ static int dp_run_layered(DpState &st, BeliefGraphState &bg, DpConst c, const st
     DP_HIP(hipGetLastError());
     float ms = 0;
     DP_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
     c.dist = st.d_dist;
     c.flags = st.d_flags;
     st.n = n;

@@ -174,12 +174,16 @@ struct porrt_ctx {
     bool opt_profile = false;
     bool opt_graph = true;
     uint32_t opt_kd_group = 0;     // steps per kd insertion (0 = choose by K)
-    uint32_t opt_group = 16;       // "group_lanes": lanes per sample of the RRT* step kernels (16 / 32 / 64; 0 = one wave per sample, the round-1 kernels)
-    uint32_t opt_lds_tile = 1;     // "lds_tile": raycasts read an LDS tile (1) or the raster in memory (0)
+    // "group_lanes": lanes per sample of the RRT* step kernels.  16 / 32 / 64: k_nn2 + k_conn2 (several samples per wave: fewer
+    // waves, hits kept in LDS -- throughput); 0: k_near + k_connect_rrt (one wave per sample: the shortest dependent chain per
+    // step -- latency).  -1 (default): by the number of queries advanced together, 16 from 8 queries on, else 0.
+    int opt_group_req = -1;
+    uint32_t opt_group = 0;        // the choice in force for the running launch sequence
     bool opt_dp_sweeps = false;            // "dp_sweeps": expected costs by whole-graph sweeps instead of layer by layer
     uint32_t opt_cand_cap = 2048;
+    uint64_t edge_per_node = 256, tie_pool_mult = 16;      // pool sizes: grown and the run replayed when one overflows (as the neighbour lists)
     // ---- device buffers
-    DevBuf<double> d_nx, d_ny, d_distA, d_distB, d_sx, d_sy, d_qx, d_qy, d_pgxy, d_candxy, d_candval, d_radT2, d_inj;
+    DevBuf<double> d_nx, d_ny, d_distA, d_distB, d_sx, d_sy, d_qx, d_qy, d_pgxy, d_pgd, d_candxy, d_candval, d_radT2, d_inj, d_ssx, d_ssy, d_bqx, d_bqy, d_t2at;
     DevBuf<int> d_parent, d_qnn, d_qvid, d_pgid, d_candid, d_gid, d_kdup;
     DevBuf<KdRec> d_kdrec;
     DevBuf<KdBox> d_kdbox, d_locbox;
@@ -198,7 +202,8 @@ struct porrt_ctx {
     DevBuf<unsigned long long> d_reachA, d_reachB, d_finalmask, d_validmask, d_kdhint;
     DevBuf<uint8_t> d_vid, d_finalflag, d_cls;
     DevBuf<uint32_t> d_nat, d_sworld, d_candcnt, d_efrom, d_eto, d_etv;
-    DevBuf<uint16_t> d_perm;
+    DevBuf<uint16_t> d_perm, d_bqk;
+    DevBuf<uint32_t> d_slotof;
     DevBuf<Counters> d_cnt;
     DevBuf<RunConst> d_rc;
     DevBuf<PcgJump> d_jump;
@@ -240,6 +245,7 @@ struct porrt_ctx {
     uint32_t batch_nodes = 0;
     BatchOut *d_batch_out = nullptr;       // leader of a batch: gathered counters of the members
     std::vector<RunConst> rc_staging;      // leader of a batch: the members' RunConst, uploaded in one copy
+    std::vector<uint32_t> worlds_staging;  // sampled worlds of the last upload (PTO)
     size_t batch_out_cap = 0;
     size_t run_lds_bytes = 0;
     int best_cost_device(double *cost, uint64_t *final_id);
@@ -257,6 +263,9 @@ struct porrt_ctx {
     int64_t prm_plan_path(const double start[2], const double goal[2], double *path_xy, uint64_t cap);
     int read_best_cost(double *cost, uint64_t *final_id);
     porrt_ctx *batch_leader = nullptr;     // set by porrt_grow_batch: the context whose RunConst array holds this one
+    uint64_t batch_gen = 0, batch_gen_counter = 0;     // which of the leader's batches this context belongs to / the leader's count
+    std::vector<porrt_ctx *> batch_members;            // leader: the members of its last batch (their back pointers are cleared when it goes)
+    uint64_t bg_graph_tag = 0;             // results_tag the belief graph (and the costs on it) were built from
     uint32_t batch_slot = 0, batch_size = 0;
     RunConst *d_rcarr = nullptr;      // leader of a porrt_grow_batch: the members' RunConst, one per grid row
     size_t rcarr_cap = 0;
@@ -295,7 +304,7 @@ int porrt_ctx::layout_buffers() {
                               &d_kdrec, &d_gx, &d_gy, &d_rgdir, &d_rep, &d_kdbox, &d_locbox, &d_kdlosers, &d_gsnap, &d_pendoff, &d_pendn, &d_pendcur,
                               &d_pendnew, &d_pendpool, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB, &d_finalmask, &d_vid, &d_finalflag, &d_cls,
                               &d_nat, &d_sworld, &d_candcnt, &d_efrom, &d_eto, &d_etv, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags,
-                              &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid, &d_bcscratch, &d_bcout, &d_bccursor, &d_perm};
+                              &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid, &d_bcscratch, &d_bcout, &d_bccursor, &d_perm, &d_pgd, &d_slotof, &d_ssx, &d_ssy, &d_bqx, &d_bqy, &d_t2at, &d_bqk};
         for (DevBufBase *b2 : list) all_bufs.push_back(b2);
     }
     bool grow_needed = false;
@@ -335,7 +344,7 @@ int porrt_ctx::layout_buffers() {
     d_locflags.p = (uint32_t *)d_locflags.vp; d_kdsurv.p = (uint32_t *)d_kdsurv.vp;
     d_gndx.p = (double *)d_gndx.vp; d_gndy.p = (double *)d_gndy.vp;
     d_kqx.p = (double *)d_kqx.vp; d_kqy.p = (double *)d_kqy.vp; d_kqvid.p = (int *)d_kqvid.vp;
-    d_cnt.p = (Counters *)d_cnt.vp; d_rc.p = (RunConst *)d_rc.vp; d_jump.p = (PcgJump *)d_jump.vp; d_perm.p = (uint16_t *)d_perm.vp;
+    d_cnt.p = (Counters *)d_cnt.vp; d_rc.p = (RunConst *)d_rc.vp; d_jump.p = (PcgJump *)d_jump.vp; d_perm.p = (uint16_t *)d_perm.vp; d_pgd.p = (double *)d_pgd.vp; d_slotof.p = (uint32_t *)d_slotof.vp; d_ssx.p = (double *)d_ssx.vp; d_ssy.p = (double *)d_ssy.vp; d_bqx.p = (double *)d_bqx.vp; d_bqy.p = (double *)d_bqy.vp; d_t2at.p = (double *)d_t2at.vp; d_bqk.p = (uint16_t *)d_bqk.vp;
     // cached uploads are gone
     rad_uploaded = 0;
     cls_dirty = true;
@@ -363,7 +372,26 @@ int porrt_ctx::build_cls() {
         }
         cls[p] = c;
     }
-    HIPCHK(hipMemcpyAsync(d_cls.p, cls.data(), n, hipMemcpyHostToDevice, stream));
+    // clearance plane behind the classes: Chebyshev distance to the nearest pixel that is not free or lies outside the
+    // raster (two chamfer passes are exact for that metric), capped at 255
+    cls.resize(2 * n);
+    {
+        uint8_t *d = cls.data() + n;
+        auto at = [&](long i, long j) -> int { return (i < 0 || j < 0 || i >= (long)H || j >= (long)W) ? 0 : d[(size_t)i * W + j]; };
+        for (long i = 0; i < (long)H; ++i)
+            for (long j = 0; j < (long)W; ++j) {
+                int v = cls[(size_t)i * W + j] == CLS_FREE ? 255 : 0;
+                if (v) v = std::min(v, 1 + std::min(std::min(at(i - 1, j - 1), at(i - 1, j)), std::min(at(i - 1, j + 1), at(i, j - 1))));
+                d[(size_t)i * W + j] = (uint8_t)v;
+            }
+        for (long i = (long)H - 1; i >= 0; --i)
+            for (long j = (long)W - 1; j >= 0; --j) {
+                int v = d[(size_t)i * W + j];
+                if (v) v = std::min(v, 1 + std::min(std::min(at(i + 1, j + 1), at(i + 1, j)), std::min(at(i + 1, j - 1), at(i, j + 1))));
+                d[(size_t)i * W + j] = (uint8_t)v;
+            }
+    }
+    HIPCHK(hipMemcpyAsync(d_cls.p, cls.data(), 2 * n, hipMemcpyHostToDevice, stream));
     cls_dirty = false;
     return PORRT_OK;
 }
@@ -426,11 +454,14 @@ __global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y
     rc.final_flag[0] = 0;
     rc.final_mask[0] = 0;
     rc.n_at[0] = 1;
+    rc.t2_at[0] = 0.0;          // heuristic_radius(1) = 0 (common.rs:357-369: ln 1 = 0), whatever the parameters
     rep_insert(rc, x, y, 0);
     {   // region pages
         const uint32_t r = region_of(rc, x, y);
         rc.pg_xy[2 * ((size_t)r * kPage)] = x; rc.pg_xy[2 * ((size_t)r * kPage) + 1] = y;
         rc.pg_id[(size_t)r * kPage] = 0;
+        rc.pg_d[(size_t)r * kPage] = 0.0;
+        rc.slot_of[0] = r * kPage;
         rc.rg_cnt[r] = 1;
     }
     rc.g_id[0] = 0;          // the root is on every kd descent path
@@ -508,17 +539,10 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     if (GLn) {
         const uint32_t spb = 256u / GLn;
         const dim3 g2((nb + spb - 1) / spb + 2, Q);       // + the clone workgroup + the page-filing workgroup
-        const bool tile = lds_bytes != 0 && opt_lds_tile;
-        const size_t dyn = conn2_lds_bytes(GLn, tile ? lds_bytes / kConnectWaves : 0);
-#define PORRT_CONN2(GLV)                                                                                               \
-        do {                                                                                                           \
-            if (tile) hipLaunchKernelGGL((k_conn2<GLV, true>), g2, dim3(256), dyn, stream, rcp, b, nb, vwords);       \
-            else hipLaunchKernelGGL((k_conn2<GLV, false>), g2, dim3(256), dyn, stream, rcp, b, nb, vwords);           \
-        } while (0)
-        if (GLn == 16) PORRT_CONN2(16);
-        else if (GLn == 32) PORRT_CONN2(32);
-        else PORRT_CONN2(64);
-#undef PORRT_CONN2
+        const size_t dyn = conn2_lds_bytes(GLn);
+        if (GLn == 16) hipLaunchKernelGGL(k_conn2<16>, g2, dim3(256), dyn, stream, rcp, b, nb, vwords);
+        else if (GLn == 32) hipLaunchKernelGGL(k_conn2<32>, g2, dim3(256), dyn, stream, rcp, b, nb, vwords);
+        else hipLaunchKernelGGL(k_conn2<64>, g2, dim3(256), dyn, stream, rcp, b, nb, vwords);
     } else if (lds_bytes) hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
     else hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
     ev();
@@ -613,6 +637,10 @@ int porrt_ctx::grow(const double start[2], double max_step, double search_radius
             opt_cand_cap = (uint32_t)std::min<uint64_t>((uint64_t)opt_cand_cap * 4, n_iter_max + 2);
         } else if (rc_ == -101) {   // a float draw would have retried: replay with the exact host stream
             host_samples = true;
+        } else if (rc_ == -102) {   // edge pool (PTO: the reference's parameters reach ~240 neighbours per node): regrow and replay
+            edge_per_node *= 4;
+        } else if (rc_ == -103) {   // deferred-tie pool
+            tie_pool_mult *= 4;
         } else {
             return rc_;
         }
@@ -639,7 +667,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     const uint32_t Kpad = vwords * 64;       // sample stride of the per-chunk arrays (multiple of the wave size)
     const uint32_t cand_cap = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(opt_cand_cap, 64), Nmax);
     // deferred equal-cost parents: at most one record per iteration; the pooled ids are bounded by experience
-    const uint64_t pend_cap = n_iter_max + 2, pool_cap = std::max<uint64_t>(1u << 20, 16 * n_iter_max);
+    const uint64_t pend_cap = n_iter_max + 2, pool_cap = std::max<uint64_t>(1u << 20, tie_pool_mult * n_iter_max);
     {
         double t0 = now_s();
         HIPCHK(d_nx.reserve(Nmax)); HIPCHK(d_ny.reserve(Nmax)); HIPCHK(d_distA.reserve(Nmax)); HIPCHK(d_distB.reserve(Nmax));
@@ -651,23 +679,24 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         // region pages: one static page per region + a pool that cannot run out (sum of ceil(n_r / 64) <= N / 64 + regions)
         const uint64_t rg_maxp = Nmax / kPage + 2, pg_cap = 2ull * kRegions + Nmax / kPage + 8;
         HIPCHK(d_rgcnt.reserve(2 * kRegions)); HIPCHK(d_rgdir.reserve((size_t)kRegions * rg_maxp));
-        HIPCHK(d_pgxy.reserve(2 * (size_t)pg_cap * kPage)); HIPCHK(d_pgid.reserve((size_t)pg_cap * kPage)); 
+        HIPCHK(d_pgxy.reserve(2 * (size_t)pg_cap * kPage)); HIPCHK(d_pgid.reserve((size_t)pg_cap * kPage)); HIPCHK(d_pgd.reserve((size_t)pg_cap * kPage)); HIPCHK(d_slotof.reserve(Nmax));
         HIPCHK(d_candcnt.reserve(2 * (size_t)K)); HIPCHK(d_kdbox.reserve(Nmax)); HIPCHK(d_kdlosers.reserve(kClaimMax)); HIPCHK(d_bcscratch.reserve(8 * Nmax + 4096)); HIPCHK(d_bcout.reserve(1)); HIPCHK(d_bccursor.reserve(1)); HIPCHK(d_locbox.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_kdhint.reserve((size_t)kHG * kHG));
         HIPCHK(d_loccur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locdcur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locgex.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locflags.reserve(2 * (8 * (size_t)K + 4096)));
         HIPCHK(d_gsnap.reserve((steps_max + 4) * 4)); HIPCHK(d_pendoff.reserve(pend_cap)); HIPCHK(d_pendn.reserve(pend_cap)); HIPCHK(d_pendcur.reserve(pend_cap));
         HIPCHK(d_pendstate.reserve(pend_cap)); HIPCHK(d_pendnew.reserve(pend_cap)); HIPCHK(d_pendpool.reserve(pool_cap)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_gndx.reserve(Nmax)); HIPCHK(d_gndy.reserve(Nmax));
         HIPCHK(d_kqx.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kqy.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kqvid.reserve((steps_max + 2) * Kpad)); HIPCHK(d_candid.reserve(2 * (size_t)K * cand_cap)); HIPCHK(d_candxy.reserve(4 * (size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
         HIPCHK(d_gid.reserve(Nmax));
-        HIPCHK(d_perm.reserve((steps_max + 2) * Kpad));
+        HIPCHK(d_perm.reserve((steps_max + 2) * Kpad)); HIPCHK(d_ssx.reserve((steps_max + 2) * Kpad)); HIPCHK(d_ssy.reserve((steps_max + 2) * Kpad));
+        HIPCHK(d_bqx.reserve(Kpad)); HIPCHK(d_bqy.reserve(Kpad)); HIPCHK(d_bqk.reserve(Kpad)); HIPCHK(d_t2at.reserve(steps_max + 4));
         HIPCHK(d_rep.reserve(kRepTotal));
         HIPCHK(d_kdrec.reserve(Nmax)); HIPCHK(d_gx.reserve(Nmax + 16)); HIPCHK(d_gy.reserve(Nmax + 16)); HIPCHK(d_kdup.reserve(Nmax)); HIPCHK(d_kddepth.reserve(Nmax)); HIPCHK(d_kdgexit.reserve(Nmax));
         HIPCHK(d_radT2.reserve(Nmax + 8));
         HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_jump.reserve(1));
         if (mode == PORRT_MODE_PTO) {
-            const uint64_t ecap = std::min<uint64_t>(Nmax * 256 + 4096, 1ull << 28);
+            const uint64_t ecap = std::min<uint64_t>(Nmax * edge_per_node + 4096, 1ull << 31);
             HIPCHK(d_efrom.reserve(ecap)); HIPCHK(d_eto.reserve(ecap)); HIPCHK(d_etv.reserve(ecap));
         }
-        if (has_grid) HIPCHK(d_cls.reserve((size_t)W * H + 16));
+        if (has_grid) HIPCHK(d_cls.reserve(2 * (size_t)W * H + 16));
         if (has_inj) HIPCHK(d_inj.reserve(inj_xy.size() + 2));
         int r = layout_buffers();
         if (r) return r;
@@ -690,7 +719,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.inj_xy = (has_inj && !host_samples) ? d_inj.p : nullptr;
     c.inj_base = inj_pos; c.inj_n = inj_xy.size() / 2;
     c.q_x = d_qx.p; c.q_y = d_qy.p; c.q_nn = d_qnn.p; c.q_vid = d_qvid.p;
-    c.rg_cnt = d_rgcnt.p; c.rg_dir = d_rgdir.p; c.pg_xy = d_pgxy.p; c.pg_id = d_pgid.p;
+    c.rg_cnt = d_rgcnt.p; c.rg_dir = d_rgdir.p; c.pg_xy = d_pgxy.p; c.pg_id = d_pgid.p; c.pg_d = d_pgd.p; c.slot_of = d_slotof.p;
     c.rg_maxp = (uint32_t)(Nmax / kPage + 2); c.pg_cap = (uint32_t)(2ull * kRegions + Nmax / kPage + 8);
     c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p; c.kd_box = d_kdbox.p; c.loc_box = d_locbox.p; c.kd_losers = d_kdlosers.p; c.bc_scratch = d_bcscratch.p; c.bc_cap = (uint32_t)std::min<size_t>(d_bcscratch.n, 0xFFFFFFFFu); c.bc_cursor = d_bccursor.p; c.bc_out = d_bcout.p; c.kd_hint = d_kdhint.p; c.g_snap = d_gsnap.p; c.loc_stride = 8 * K + 4096;
     c.pend_new = d_pendnew.p; c.pend_pool = d_pendpool.p; c.pend_off = d_pendoff.p; c.pend_n = d_pendn.p; c.pend_cur = d_pendcur.p; c.pend_state = d_pendstate.p;
@@ -710,7 +739,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     }
     c.kd_rec = d_kdrec.p; c.g_x = d_gx.p; c.g_y = d_gy.p; c.kd_up = d_kdup.p; c.kd_depth = d_kddepth.p; c.kd_gexit = d_kdgexit.p;
     c.g_id = d_gid.p; c.g_cap = (uint32_t)std::min<uint64_t>(d_gid.n, 0xFFFFFFFFull);
-    c.cls = d_cls.p; c.W = W; c.H = H; c.low0 = low[0]; c.low1 = low[1]; c.ppm = ppm; c.domain = domain; c.has_grid = has_grid;
+    c.cls = d_cls.p; c.clr = d_cls.p + (size_t)W * H; c.W = W; c.H = H; c.low0 = low[0]; c.low1 = low[1]; c.ppm = ppm; c.domain = domain; c.has_grid = has_grid;
     c.n_validities = n_validities;
     for (int i = 0; i < n_validities; ++i) c.validities[i] = validities[i];
     c.all_worlds = ones(n_worlds);
@@ -725,7 +754,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.s_low0 = s_low[0]; c.s_low1 = s_low[1]; c.s_up0 = s_up[0]; c.s_up1 = s_up[1];
     c.max_step = max_step; c.mode = mode;
     c.part_stride = Kpad;
-    c.perm = d_perm.p;
+    c.perm = d_perm.p; c.ssx = d_ssx.p; c.ssy = d_ssy.p; c.bq_x = d_bqx.p; c.bq_y = d_bqy.p; c.bq_k = d_bqk.p; c.t2_at = d_t2at.p;
 
     // ---- root (rrt.rs:105-106 / pto.rs:61-64)
     uint64_t root_reach = 0;
@@ -805,13 +834,11 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
             ev_pool.push_back(e);
         }
     }
-    hipEvent_t ev_first = nullptr, ev_last = nullptr;      // timing of a stand-alone grow (a batch member only prepares)
-    if (stage != 1) {
-        HIPCHK(hipEventCreate(&ev_first));
-        HIPCHK(hipEventCreate(&ev_last));
-    }
+    ScopedEvents<2> run_evs;                                // timing of a stand-alone grow (a batch member only prepares)
+    if (stage != 1) HIPCHK(run_evs.create());
+    hipEvent_t ev_first = run_evs.e[0], ev_last = run_evs.e[1];
 
-    std::vector<uint32_t> worlds;
+    std::vector<uint32_t> &worlds = worlds_staging;      // outlives the asynchronous upload (a batch member returns without a sync)
     std::vector<double> hs_x, hs_y;
     Pcg64 hs_rng = crng0;   // exact host stream (fallback)
     // produce the samples of iterations [it0, it0+n) on the device buffers
@@ -881,6 +908,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     if (stage == 1) return PORRT_OK;
     launch_rcp = d_rc.p;
     launch_Q = 1;
+    opt_group = opt_group_req < 0 ? 0u : (uint32_t)opt_group_req;
     HIPCHK(hipEventRecord(ev_first, stream));
     side_active = false;
     commit_pend_b = 0xFFFFFFFFu;
@@ -890,7 +918,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     if (opt_graph && !prof && n_iter_min > 0) {
         // all steps up to n_iter_min as one hipGraph (two branches: main pipeline + kd insertion); the graph
         // only depends on the launch geometry, so it is instantiated once and replayed by later grows
-        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)launch_rcp, kd_group | ((uint64_t)launch_Q << 32) | ((uint64_t)opt_group << 48) | ((uint64_t)opt_lds_tile << 56)};
+        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)launch_rcp, kd_group | ((uint64_t)launch_Q << 32) | ((uint64_t)opt_group << 48)};
         if (!graph_exec || memcmp(key, graph_key, sizeof key)) {
             double t0 = now_s();
             if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -968,14 +996,14 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     }
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ev_first, ev_last));
-    (void)hipEventDestroy(ev_first);
-    (void)hipEventDestroy(ev_last);
 
     if (hc.err & ERR_CAND_OVERFLOW) return -100;
     if (hc.err & ERR_RNG_RETRY) {
         if (has_inj) { set_err("injected sample stream exhausted"); return PORRT_ERR_INVALID; }
         return -101;
     }
+    if ((hc.err & ERR_EDGE_OVERFLOW) && (Nmax * edge_per_node + 4096 < (1ull << 31))) return -102;
+    if ((hc.err & ERR_TIE_POOL) && tie_pool_mult < (1ull << 12)) return -103;
     counters = hc;
     if (getenv("PORRT_DEBUG")) {
         fprintf(stderr, "[porrt] tie fallbacks %u g_len %u; samples served through the lists in memory %u\n", hc.tie_fallbacks, hc.g_len, hc.n_heavy);
@@ -1021,8 +1049,8 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
             it += nbq;
             // what the two searches of the step answer: every (sample, node) pair of the NN and of the radius query
             pairs += 2.0 * (double)nbq * (double)nat[s];
-            // algorithmic bytes of the searches: node x,y once per query kind, the samples, nn / state writes
-            bytes += 2.0 * 16.0 * (double)nat[s] + (16.0 + 20.0) * (double)nbq;
+            // algorithmic bytes of the searches: node x,y, the samples, nn / state writes
+            bytes += 16.0 * (double)nat[s] + (16.0 + 20.0) * (double)nbq;
         }
         metrics.scan_s = scan;
         metrics.connect_s = conn;
@@ -1195,6 +1223,7 @@ int porrt_ctx::build_belief_graph(const double *start_belief, uint32_t n_worlds_
     in.d_nx = d_nx.p; in.d_ny = d_ny.p; in.d_vid = d_vid.p; in.h_vid = h_vid.data();
     in.d_adj_off = eo.d_adj_off; in.d_adj_id = eo.d_adj_id; in.d_adj_val = eo.d_adj_val; in.d_radj_id = eo.d_radj_id; in.d_radj_val = eo.d_radj_val;
     in.graph_tag = results_tag;
+    bg_graph_tag = results_tag;
     in.stream = stream;
     std::string e;
     r = belief_graph_build(bg, in, start_belief, e);
@@ -1205,7 +1234,7 @@ int porrt_ctx::build_belief_graph(const double *start_belief, uint32_t n_worlds_
 
 // PTO::compute_expected_costs_to_goals (pto.rs:261-275): the final belief nodes, then conditional_dijkstra on the device.
 int porrt_ctx::compute_expected_costs() {
-    if (!bg.valid) { set_err("compute_expected_costs: build the belief graph first (porrt_build_belief_graph)"); return PORRT_ERR_INVALID; }
+    if (!bg.valid || bg_graph_tag != results_tag) { set_err("compute_expected_costs: build the belief graph first (porrt_build_belief_graph)"); return PORRT_ERR_INVALID; }
     HIPCHK(hipSetDevice(device));
     int r = download(DL_TREE | DL_MASKS);
     if (r) return r;
@@ -1236,7 +1265,7 @@ int porrt_ctx::compute_expected_costs() {
 
 // PTO::extract_policy (pto.rs:277-283, belief_graph.rs:177-263) on the expected costs of the last compute_expected_costs.
 int porrt_ctx::extract_policy() {
-    if (!bg.valid || !dp.valid) { set_err("extract_policy: compute the expected costs first (porrt_bg_compute_expected_costs)"); return PORRT_ERR_INVALID; }
+    if (!bg.valid || !dp.valid || bg_graph_tag != results_tag) { set_err("extract_policy: compute the expected costs first (porrt_bg_compute_expected_costs)"); return PORRT_ERR_INVALID; }
     HIPCHK(hipSetDevice(device));
     const BeliefSpace &bs = bg.cache.space;
     const size_t B = bg.B;
@@ -1346,8 +1375,9 @@ int porrt_ctx::grow_prm(const double start[2], double max_step, double search_ra
     p.x0 = x0; p.y0 = y0; p.inv_cell = 1.0 / cell;
     p.cell_cnt = prm.d_cell_cnt; p.cell_off = prm.d_cell_off; p.cell_ids = prm.d_cell_ids;
     p.efrom = d_efrom.p; p.eto = d_eto.p; p.ev = d_etv.p; p.deg = prm.d_deg; p.edge_off = prm.d_edge_off; p.err = prm.d_err;
-    hipEvent_t ev0, ev1;
-    HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
+    ScopedEvents<2> evs;
+    HIPCHK(evs.create());
+    hipEvent_t ev0 = evs.e[0], ev1 = evs.e[1];
     HIPCHK(hipEventRecord(ev0, stream));
     HIPCHK(hipMemsetAsync(prm.d_cell_cnt, 0, cells * sizeof(uint32_t), stream));
     HIPCHK(hipMemsetAsync(prm.d_deg, 0, N * sizeof(uint32_t), stream));
@@ -1373,7 +1403,6 @@ int porrt_ctx::grow_prm(const double start[2], double max_step, double search_ra
     HIPCHK(hipGetLastError());
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
     if (h_err & ERR_RASTER) { set_err("raster access the reference would panic on (image::get_pixel out of range, door pixel without zone, two zones on one segment)"); return PORRT_ERR_RASTER; }
     memset(&counters, 0, sizeof counters);
     counters.n_edges = (uint32_t)n_edges;
@@ -1548,8 +1577,16 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         if (mode == PORRT_MODE_PTO && !cs[q]->has_grid) { cs[q]->set_err("PTO mode needs a grid"); return PORRT_ERR_INVALID; }
         cs[q]->have_results = false;
         ++cs[q]->results_tag;
+        // what was derived from the previous graph goes with it, as in porrt_grow (the belief graph's CSR and the costs are
+        // sized for the old node count)
+        cs[q]->bg.release();
+        cs[q]->dp.release();
+        cs[q]->batch_leader = nullptr;
     }
     HIPCHK_CTX(L, hipSetDevice(L->device));
+    for (porrt_ctx *m : L->batch_members) if (m && m->batch_leader == L) m->batch_leader = nullptr;      // the previous batch is over
+    L->batch_members.clear();
+    const uint64_t batch_gen = ++L->batch_gen_counter;
     std::vector<Pcg64> c0(n), d0(n);
     std::vector<size_t> ip0(n), iw0(n);
     for (uint32_t q = 0; q < n; ++q) { c0[q] = cs[q]->crng; d0[q] = cs[q]->drng; ip0[q] = cs[q]->inj_pos; iw0[q] = cs[q]->inj_wpos; }
@@ -1577,14 +1614,15 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         // the leader: all steps, one hipGraph (or eager), grid rows = contexts
         L->launch_rcp = L->d_rcarr;
         L->launch_Q = n;
+        L->opt_group = L->opt_group_req < 0 ? (n >= 8 ? 16u : 0u) : (uint32_t)L->opt_group_req;
         L->side_active = false;
         L->commit_pend_b = 0xFFFFFFFFu;
         L->kd_b0 = 0; L->kd_last_b = 0; L->kd_last_nb = 0; L->kd_gidx = 0;
         L->kd_pend[0] = L->kd_pend[1] = false;
         L->kd_group = kd_group_for(K, L->opt_kd_group, n);
-        hipEvent_t e0, e1;
-        HIPCHK_CTX(L, hipEventCreate(&e0));
-        HIPCHK_CTX(L, hipEventCreate(&e1));
+        ScopedEvents<2> bevs;
+        HIPCHK_CTX(L, bevs.create());
+        hipEvent_t e0 = bevs.e[0], e1 = bevs.e[1];
         HIPCHK_CTX(L, hipEventRecord(e0, L->stream));
         size_t ev_used = 0;
         const bool prof = L->opt_profile;
@@ -1610,7 +1648,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         };
         uint32_t steps = 0;
         if (L->opt_graph && !prof) {
-            const uint64_t key[6] = {(uint64_t)mode, K, n_iter, L->run_lds_bytes, (uint64_t)(uintptr_t)L->launch_rcp, L->kd_group | ((uint64_t)n << 32) | ((uint64_t)L->opt_group << 48) | ((uint64_t)L->opt_lds_tile << 56)};
+            const uint64_t key[6] = {(uint64_t)mode, K, n_iter, L->run_lds_bytes, (uint64_t)(uintptr_t)L->launch_rcp, L->kd_group | ((uint64_t)n << 32) | ((uint64_t)L->opt_group << 48)};
             if (!L->graph_exec || memcmp(key, L->graph_key, sizeof key)) {
                 if (L->graph_exec) { (void)hipGraphExecDestroy(L->graph_exec); L->graph_exec = nullptr; }
                 hipGraph_t g = nullptr;
@@ -1645,8 +1683,6 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         }
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
         L->launch_rcp = L->d_rc.p;
         L->launch_Q = 1;
         bool retry = false;
@@ -1679,14 +1715,15 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
                     const uint64_t nbq = std::min<uint64_t>(K, n_iter - it);
                     it += nbq;
                     pairs += 2.0 * (double)nbq * (double)nat[s];
-                    bytes += 2.0 * 16.0 * (double)nat[s] + (16.0 + 20.0) * (double)nbq;
+                    bytes += 16.0 * (double)nat[s] + (16.0 + 20.0) * (double)nbq;      // 16 N_b + 36 K
                 }
             }
             L->metrics.scan_s = scan; L->metrics.connect_s = conn; L->metrics.scan_launches = launches;
             L->metrics.scan_pairs = pairs; L->metrics.scan_bytes = bytes;
         }
         if (!retry) {
-            for (uint32_t q = 0; q < n; ++q) { cs[q]->batch_leader = L; cs[q]->batch_slot = q; cs[q]->batch_size = n; }
+            for (uint32_t q = 0; q < n; ++q) { cs[q]->batch_leader = L; cs[q]->batch_slot = q; cs[q]->batch_size = n; cs[q]->batch_gen = batch_gen; }
+            L->batch_members.assign(cs, cs + n);
             return worst;
         }
         for (uint32_t q = 0; q < n; ++q) {          // neighbour lists overflowed somewhere: regrow them everywhere and replay
@@ -1725,6 +1762,10 @@ porrt_ctx *porrt_create(int device) {
 
 void porrt_destroy(porrt_ctx *c) {
     if (!c) return;
+    // a batch leader going away takes its RunConst array with it: its members must not look for it any more
+    for (porrt_ctx *m : c->batch_members) if (m && m != c && m->batch_leader == c) m->batch_leader = nullptr;
+    if (c->batch_leader && c->batch_leader != c)
+        for (porrt_ctx *&m : c->batch_leader->batch_members) if (m == c) m = nullptr;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->arena.base) (void)hipFree(c->arena.base);
@@ -2015,7 +2056,8 @@ int porrt_best_cost_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, double *costs)
     porrt_ctx *L = ctxs[0] ? ctxs[0]->batch_leader : nullptr;
     bool together = L != nullptr && L->batch_size == n_ctx;
     for (uint32_t q = 0; q < n_ctx && together; ++q)
-        together = ctxs[q] && ctxs[q]->have_results && ctxs[q]->batch_leader == L && ctxs[q]->batch_slot == q && ctxs[q]->n_steps == L->n_steps;
+        together = ctxs[q] && ctxs[q]->have_results && ctxs[q]->batch_leader == L && ctxs[q]->batch_slot == q && ctxs[q]->n_steps == L->n_steps &&
+                   ctxs[q]->batch_gen == L->batch_gen_counter;        // the leader's LAST batch: its RunConst array holds these members
     const double inf = std::numeric_limits<double>::infinity();
     if (together) {
         if (hipSetDevice(L->device) != hipSuccess) return PORRT_ERR_DEVICE;
@@ -2225,8 +2267,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "profile")) c->opt_profile = value != 0;
     else if (!strcmp(name, "cand_cap")) c->opt_cand_cap = (uint32_t)std::max<int64_t>(64, std::min<int64_t>(value, 1 << 26));
     else if (!strcmp(name, "graph")) c->opt_graph = value != 0;
-    else if (!strcmp(name, "group_lanes")) { if (value != 0 && value != 16 && value != 32 && value != 64) { c->set_err("group_lanes: 0, 16, 32 or 64"); return PORRT_ERR_INVALID; } c->opt_group = (uint32_t)value; }
-    else if (!strcmp(name, "lds_tile")) c->opt_lds_tile = value != 0;
+    else if (!strcmp(name, "group_lanes")) { if (value != -1 && value != 0 && value != 16 && value != 32 && value != 64) { c->set_err("group_lanes: -1 (auto), 0, 16, 32 or 64"); return PORRT_ERR_INVALID; } c->opt_group_req = (int)value; }
     else if (!strcmp(name, "dp_sweeps")) c->opt_dp_sweeps = value != 0;
     else if (!strcmp(name, "kd_group")) c->opt_kd_group = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else { c->set_err(std::string("unknown option ") + name); return PORRT_ERR_INVALID; }

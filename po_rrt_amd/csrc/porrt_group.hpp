@@ -22,15 +22,13 @@
 
 namespace porrt {
 
-constexpr uint32_t kLdsHits = 64;                       // hits of one sample held in LDS
-constexpr uint32_t kHitBytes = kLdsHits * (4u + 8u + 8u);   // id, x -> cost, y -> dist_root
 
 // visit(x, y, id, ok) for every node whose region meets the box of the disc (q, rho), called by all lanes of the group
 // together; q, rho, N are uniform over the group.  See scan_disc for the page layout; here a group walks the 64-slot
 // pages of R regions per round (lane <-> region for the counts), 64 / GL coalesced loads per page in flight.
 // (A dense walk -- all regions as one virtual array, slots found by a binary search over the prefix sums held across
 // the group -- was measured: the dependent cross-lane reads cost more than the idle lanes at region ends.)
-template <int GL, int R, class Visit>
+template <int GL, int R, bool WITHD, class Visit>
 __device__ __forceinline__ void gscan_disc(const RunConst &rc, uint32_t b, const GTeam<GL> &tm, double qx, double qy, double rho, uint32_t N, Visit visit,
                                            uint32_t skip_region = 0xFFFFFFFFu) {
     const uint32_t gl = tm.gl;
@@ -41,18 +39,19 @@ __device__ __forceinline__ void gscan_disc(const RunConst &rc, uint32_t b, const
     const uint32_t w = (uint32_t)(cx1 - cx0 + 1), nreg = w * (uint32_t)(cy1 - cy0 + 1);
     constexpr int U = (int)kPage / GL;
     if (nreg * 16u > N) {           // young tree: streaming the id-ordered arrays is cheaper than walking empty regions
-        auto gx = as_global(rc.nx), gy = as_global(rc.ny);
+        auto gx = as_global(rc.nx), gy = as_global(rc.ny), gdA = as_global(rc.distA);
         for (uint32_t j0 = 0; j0 < N; j0 += (uint32_t)(U * GL)) {
-            double x[U], y[U];
+            double x[U], y[U], d[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t j = j0 + (uint32_t)(GL * u) + gl;
                 x[u] = gx[j < N ? j : 0u];
                 y[u] = gy[j < N ? j : 0u];
+                d[u] = WITHD ? gdA[j < N ? j : 0u] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (j0 + (uint32_t)(GL * u) < N) visit(x[u], y[u], (int)(j0 + (uint32_t)(GL * u) + gl), j0 + (uint32_t)(GL * u) + gl < N);
+                if (j0 + (uint32_t)(GL * u) < N) visit(x[u], y[u], d[u], (int)(j0 + (uint32_t)(GL * u) + gl), j0 + (uint32_t)(GL * u) + gl < N);
         }
         return;
     }
@@ -60,6 +59,7 @@ __device__ __forceinline__ void gscan_disc(const RunConst &rc, uint32_t b, const
     auto gdir = as_global(rc.rg_dir);
     auto gxy = as_global(reinterpret_cast<const dbl2 *>(rc.pg_xy));
     auto gid = as_global(rc.pg_id);
+    auto gpd = as_global(rc.pg_d);
     for (uint32_t r0 = 0; r0 < nreg; r0 += (uint32_t)GL) {
         const uint32_t r = r0 + gl;
         uint32_t reg = 0, cnt = 0;
@@ -90,6 +90,7 @@ __device__ __forceinline__ void gscan_disc(const RunConst &rc, uint32_t b, const
                     }
                 }
                 dbl2 v[R][U];
+                double d[R][U];
                 int id[R][U];
 #pragma unroll
                 for (int q = 0; q < R; ++q)
@@ -99,12 +100,13 @@ __device__ __forceinline__ void gscan_disc(const RunConst &rc, uint32_t b, const
                         const bool ld = sl < pc[q];
                         v[q][u] = ld ? gxy[(size_t)pg[q] * kPage + sl] : dbl2{0.0, 0.0};
                         id[q][u] = ld ? gid[(size_t)pg[q] * kPage + sl] : -1;
+                        d[q][u] = (WITHD && ld) ? gpd[(size_t)pg[q] * kPage + sl] : 0.0;
                     }
 #pragma unroll
                 for (int q = 0; q < R; ++q)
 #pragma unroll
                     for (int u = 0; u < U; ++u)
-                        if ((uint32_t)(u * GL) < pc[q]) visit(v[q][u].x, v[q][u].y, id[q][u], (uint32_t)(u * GL) + gl < pc[q]);
+                        if ((uint32_t)(u * GL) < pc[q]) visit(v[q][u].x, v[q][u].y, d[q][u], id[q][u], (uint32_t)(u * GL) + gl < pc[q]);
             }
             page = page_next;
         }
@@ -122,6 +124,20 @@ __device__ __forceinline__ void xcd_swizzle(uint32_t &bx, uint32_t &by) {
     const uint32_t L = by * gx + bx, slot = L >> 3;
     by = (slot / gx) * 8u + (L & 7u);
     bx = slot % gx;
+}
+// The same with `ns` single workgroups per row (page filing, clone) taken out first: launch indices 0 .. ns Q - 1 are
+// row i / ns, role i % ns -- they take longest and start before everything else -- the rest are the rows' gx - ns
+// ordinary workgroups.  Returns the role (< ns) or ns for an ordinary workgroup, whose index is left in bx.
+__device__ __forceinline__ uint32_t xcd_swizzle_roles(uint32_t &bx, uint32_t &by, uint32_t ns) {
+    const uint32_t gx = gridDim.x, Q = gridDim.y;
+    const uint32_t L = by * gx + bx;
+    if (L < ns * Q) { by = L / ns; bx = 0; return L % ns; }
+    const uint32_t t = L - ns * Q, g2 = gx - ns;
+    if (Q & 7u) { by = t / g2; bx = t % g2; return ns; }
+    const uint32_t slot = t >> 3;                      // ns Q is a multiple of 8: t and L agree on the XCD
+    by = (slot / g2) * 8u + (t & 7u);
+    bx = slot % g2;
+    return ns;
 }
 
 // One workgroup per step: the step's sample indices, ordered by the region grid cell the sample lies in (8 x 8-cell
@@ -160,7 +176,13 @@ __global__ __launch_bounds__(256) void k_sort_samples(const RunConst *__restrict
     for (uint32_t q = 0; q < PER; ++q) { const uint32_t r = threadIdx.x * PER + q; if (r < NK) { const uint32_t v = s_bin[r]; s_bin[r] = acc; acc += v; } }
     __syncthreads();
     uint16_t *out = rc.perm + (size_t)b * rc.part_stride;
-    for (uint32_t k = threadIdx.x; k < nb; k += 256u) out[atomicAdd(&s_bin[key_of(k)], 1u)] = (uint16_t)k;
+    double *ox = rc.ssx + (size_t)b * rc.part_stride, *oy = rc.ssy + (size_t)b * rc.part_stride;
+    for (uint32_t k = threadIdx.x; k < nb; k += 256u) {
+        const uint32_t pos = atomicAdd(&s_bin[key_of(k)], 1u);
+        out[pos] = (uint16_t)k;
+        ox[pos] = rc.sx[i0 + k];
+        oy[pos] = rc.sy[i0 + k];
+    }
 }
 
 // nn_bound_wave for a group (GL >= 16): lanes 0..8 of the group take the 3x3 cells.
@@ -190,10 +212,52 @@ __device__ __forceinline__ double nn_bound_group(const RunConst &rc, const GTeam
     return m;
 }
 
+// KdTree::nearest_neighbor (nearest_neighbor.rs:48-92) for a group: the exact minimum of (norm2, id) over the region pages.
+template <int GL>
+__device__ __forceinline__ void group_nn(const RunConst &rc, uint32_t b, const GTeam<GL> &tm, uint32_t N, double sqx, double sqy, int &nn, double &fx,
+                                         double &fy) {
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    double bestD = INF, bestx = 0.0, besty = 0.0;
+    int best = 0x7FFFFFFF;
+    // thr: no node with d2 above it can win or tie (sqrt is monotone; the factor keeps rounded ties in), so the
+    // sqrt -- the expensive part -- is only taken for the few nodes that may improve the lane's best
+    double thr = INF;
+    auto visit = [&](double x, double y, double, int id, bool ok) {
+        if (!ok) return;
+        const double d2 = dist2(x, y, sqx, sqy);
+        if (d2 > thr) return;
+        const double D = sqrt(d2);                           // the reference compares rounded distances
+        if (D < bestD || (D == bestD && id < best)) { bestD = D; best = id; bestx = x; besty = y; thr = d2 * (1.0 + 1e-15); }
+    };
+    auto group_best = [&]() {
+        double rd = bestD;
+        int ri = best;
+        tm.argmin(rd, ri);
+        // the lane that holds the winner hands over its threshold and the node's coordinates
+        const unsigned long long own = tm.ballot(best == ri && bestD == rd);
+        const int src = own ? (int)__builtin_ctzll(own) : 0;
+        thr = tm.shfl(thr, src);
+        bestx = tm.shfl(bestx, src); besty = tm.shfl(besty, src);
+        bestD = rd; best = ri;
+    };
+    // the sample's own region first: the nearest node is almost always there, and its distance bounds the disc the
+    // remaining regions are taken from; only when the region is empty does the bound come from the pyramid
+    const uint32_t own = region_of(rc, sqx, sqy);
+    gscan_disc<GL, 1, false>(rc, b, tm, sqx, sqy, 0.0, N, visit);
+    group_best();
+    double m2;
+    if (best != 0x7FFFFFFF) m2 = thr;                        // d2(best) * (1 + 1e-15)
+    else { m2 = nn_bound_group<GL>(rc, tm, N, sqx, sqy); thr = m2 * (1.0 + 1e-9); }
+    gscan_disc<GL, 2, false>(rc, b, tm, sqx, sqy, disc_radius(m2, sqx, sqy), N, visit, own);
+    group_best();
+    nn = best; fx = bestx; fy = besty;
+    if (best == 0x7FFFFFFF) { nn = 0; fx = as_global(rc.nx)[0]; fy = as_global(rc.ny)[0]; }   // (cannot happen without a filter: the root exists)
+}
+
 // RRT* step, first kernel: GL lanes per sample.  grid.x = ceil(nb / SPB) search workgroups + ceil(cnb / SPB) workgroups
 // running the rewire phase 2 of step cb (commit_rrt_sample), SPB = 256 / GL samples per workgroup.
 template <int GL>
-__global__ __launch_bounds__(256) void k_nn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, uint32_t cb,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_nn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, uint32_t cb,
                                              uint32_t cnb) {
     static_assert(GL == 16 || GL == 32 || GL == 64, "group size");
     constexpr uint32_t SPB = 256u / GL;
@@ -206,60 +270,55 @@ __global__ __launch_bounds__(256) void k_nn2(const RunConst *__restrict__ rcp, u
     const uint32_t near_blocks = (nb + SPB - 1u) / SPB;
     if (bx >= near_blocks) {
         const uint32_t ck = (bx - near_blocks) * SPB + threadIdx.x / GL;
+        PORRT_T0();
         if (ck < cnb) commit_rrt_sample(rc, cb, vwords, ck, tm.gl, GL);
+        PORRT_TACC_A(rc, 4);
         return;
     }
     const uint32_t slot = bx * SPB + threadIdx.x / GL;
     if (slot >= nb) return;
-    const uint32_t k = rc.perm[(size_t)b * rc.part_stride + slot];
+    PORRT_T0();
+    const size_t so = (size_t)b * rc.part_stride + slot;
+    const uint32_t k = as_global(rc.perm)[so];
     const uint32_t N = as_global(rc.n_at)[b];
-    const double sqx = as_global(rc.sx)[i0 + k], sqy = as_global(rc.sy)[i0 + k];
-    const double INF = __longlong_as_double(0x7FF0000000000000ll);
-    double bestD = INF;
-    int best = 0x7FFFFFFF;
+    const double sqx = as_global(rc.ssx)[so], sqy = as_global(rc.ssy)[so];
+    (void)i0;
+    // Most samples of a grown tree are not steered: steer() (common.rs:215-225) moves the sample only if the L1 distance to
+    // its nearest node (by L2) exceeds max_step, and L1 <= sqrt(2) L2 <= sqrt(2) * (L2 distance to ANY node).  So a node
+    // within 0.7 max_step (< max_step / sqrt(2), margin for the roundings) proves that the new state is the sample itself,
+    // whichever node is nearest -- and that node is only needed if no neighbour turns out to be connectable (rrt.rs:132-134;
+    // k_conn2 searches it then).  The bound pyramid names a node in the 3x3 finest cells around the sample, if there is one.
+    int nn = -1;
+    double fx = 0.0, fy = 0.0;
+    bool easy = false;
     {
-        // thr: no node with d2 above it can win or tie (sqrt is monotone; the factor keeps rounded ties in), so the
-        // sqrt -- the expensive part -- is only taken for the few nodes that may improve the lane's best
-        double thr = INF;
-        auto visit = [&](double x, double y, int id, bool ok) {
-            if (!ok) return;
-            const double d2 = dist2(x, y, sqx, sqy);
-            if (d2 > thr) return;
-            const double D = sqrt(d2);                           // the reference compares rounded distances
-            if (D < bestD || (D == bestD && id < best)) { bestD = D; best = id; thr = d2 * (1.0 + 1e-15); }
-        };
-        auto group_best = [&]() {
-            double rd = bestD;
-            int ri = best;
-            tm.argmin(rd, ri);
-            // the lane that holds the winner hands over its threshold
-            const unsigned long long own = tm.ballot(best == ri && bestD == rd);
-            const int src = own ? (int)__builtin_ctzll(own) : 0;
-            thr = tm.shfl(thr, src);
-            bestD = rd; best = ri;
-        };
-        // the sample's own region first: the nearest node is almost always there, and its distance bounds the disc the
-        // remaining regions are taken from; only when the region is empty does the bound come from the pyramid
-        const uint32_t own = region_of(rc, sqx, sqy);
-        gscan_disc<GL, 1>(rc, b, tm, sqx, sqy, 0.0, N, visit);
-        group_best();
-        double m2;
-        if (best != 0x7FFFFFFF) m2 = thr;                        // d2(best) * (1 + 1e-15)
-        else { m2 = nn_bound_group<GL>(rc, tm, N, sqx, sqy); thr = m2 * (1.0 + 1e-9); }
-        gscan_disc<GL, 2>(rc, b, tm, sqx, sqy, disc_radius(m2, sqx, sqy), N, visit, own);
-        group_best();
+        int cx, cy;
+        const int G = rep_dim(0);
+        rep_cell(rc, sqx, sqy, G, cx, cy);
+        int r = -1;
+        if (tm.gl < 9u) {
+            const int x = cx + (int)(tm.gl % 3u) - 1, y = cy + (int)(tm.gl / 3u) - 1;
+            if (x >= 0 && y >= 0 && x < G && y < G) r = as_global(rc.rep)[rep_off(0) + y * G + x];
+        }
+        const double lim = 0.7 * rc.max_step;
+        bool near = false;
+        if (r >= 0 && (uint32_t)r < N) near = dist2(as_global(rc.nx)[r], as_global(rc.ny)[r], sqx, sqy) <= lim * lim;
+        easy = tm.ballot(near) != 0ull;
     }
-    const int nn = best == 0x7FFFFFFF ? 0 : best;   // (cannot happen without a filter: the root exists)
-    const double fx = as_global(rc.nx)[nn], fy = as_global(rc.ny)[nn];
+    PORRT_TACC_A(rc, 0);
+    if (!easy) group_nn<GL>(rc, b, tm, N, sqx, sqy, nn, fx, fy);
+    PORRT_TACC_A(rc, 1);
     double tx = sqx, ty = sqy;
-    // common.rs:215-225
-    double step = fabs(tx - fx);
-    step += fabs(ty - fy);
-    if (step > rc.max_step) {
-        const double lambda = rc.max_step / step;
-        double ux = (tx - fx) * lambda, uy = (ty - fy) * lambda;
-        tx = fx + ux;
-        ty = fy + uy;
+    if (!easy) {
+        // common.rs:215-225
+        double step = fabs(tx - fx);
+        step += fabs(ty - fy);
+        if (step > rc.max_step) {
+            const double lambda = rc.max_step / step;
+            double ux = (tx - fx) * lambda, uy = (ty - fy) * lambda;
+            tx = fx + ux;
+            ty = fy + uy;
+        }
     }
     uint32_t err = 0;
     bool valid = true;
@@ -267,6 +326,7 @@ __global__ __launch_bounds__(256) void k_nn2(const RunConst *__restrict__ rcp, u
         const int cls = state_class(rc, tx, ty, &err);
         valid = cls == CLS_FREE && !err;                         // RTTFuncs adapter (tamp_rrt.rs:40-42)
     }
+    PORRT_TACC_A(rc, 2);
     if (tm.gl == 0) {
         as_global(rc.q_x)[k] = tx;
         as_global(rc.q_y)[k] = ty;
@@ -283,16 +343,39 @@ __global__ __launch_bounds__(256) void k_nn2(const RunConst *__restrict__ rcp, u
             if (slot < 64u) { rc.cnt->clone_k[slot] = k; qv = 1; }
         }
         as_global(rc.q_vid)[k] = qv;
+        // what the connect groups read, in slot order
+        as_global(rc.bq_x)[slot] = tx; as_global(rc.bq_y)[slot] = ty; as_global(rc.bq_k)[slot] = qv == 0 ? (uint16_t)k : (uint16_t)0xFFFFu;
         if (valid) atomicOr(&rc.valid_mask[(size_t)b * vwords + (k >> 6)], 1ull << (k & 63u));
         if (err) atomicOr(&rc.cnt->err, err);
     }
 }
 
-// dynamic LDS of k_conn2: per sample the hit list, then per sample a raster tile of `tile_bytes`; the page-filing
-// workgroup uses the same bytes as its scratch
-__host__ __device__ inline size_t conn2_lds_bytes(uint32_t GL, size_t tile_bytes) {
-    const size_t spb = 256u / GL, a = spb * (kHitBytes + tile_bytes);
+// dynamic LDS of k_conn2: per sample the LDS part of its hit list; the page-filing workgroup uses the same bytes as its
+// scratch
+__host__ __device__ inline size_t conn2_lds_bytes(uint32_t GL) {
+    const size_t spb = 256u / GL, a = spb * kHitBytes;
     return a > kInsertLds ? a : kInsertLds;
+}
+
+// (the connect pass needs these rarely: functions of their own, so that their registers are not the step kernel's)
+template <int GL>
+__device__ __attribute__((noinline)) int group_nn_call(const RunConst &rc, uint32_t b, uint32_t gl, uint32_t base, uint32_t N, double px, double py) {
+    GTeam<GL> tm;
+    tm.gl = gl; tm.base = base;
+    int nn;
+    double fx, fy;
+    group_nn<GL>(rc, b, tm, N, px, py, nn, fx, fy);
+    return nn;
+}
+// nearest node of (px, py) by all 64 lanes of the calling wave (px, py wave-uniform)
+__device__ __attribute__((noinline)) int wave_nn(const RunConst &rc, uint32_t b, uint32_t N, double px, double py) {
+    GTeam<64> t64;
+    t64.gl = threadIdx.x & 63u;
+    t64.base = 0;
+    int nn;
+    double fx, fy;
+    group_nn<64>(rc, b, t64, N, px, py, nn, fx, fy);
+    return nn;
 }
 
 // one wave: radius search around (pxh, pyh) into the global list of sample kh (the form k_near wrote for every sample)
@@ -325,8 +408,7 @@ __device__ __forceinline__ void list_scan_wave(const RunConst &rc, uint32_t b, u
 
 // The clone workgroup of k_conn2: the step's copies of the goal point, one search for all of them by the 4-wave team.
 // A function of its own (not inlined): its registers are not the step kernel's.
-template <bool LDSGRID>
-__device__ __attribute__((noinline)) void clone_workgroup(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t N, double T2, uint8_t *tiles) {
+__device__ __attribute__((noinline)) void clone_workgroup(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t N, double T2) {
     __shared__ double s_d[kConnectWaves];
     __shared__ int s_i[kConnectWaves];
     __shared__ uint32_t s_cid[64], s_ck[64];
@@ -358,124 +440,123 @@ __device__ __attribute__((noinline)) void clone_workgroup(const RunConst &rc, ui
     }
     __syncthreads();
     const uint32_t hc = cand_count(rc, b, kh);
-    TileGrid grid;
-    if (LDSGRID) grid = load_tile(rc, tiles, pxh, pyh, threadIdx.x, kConnectWaves * 64u);
-    else { grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0; }
-    __syncthreads();
+    GlobalGrid grid;            // the few rays outside the clearance window read the raster in memory
+    grid.p = rc.cls; grid.W = rc.W;
     Team<kConnectWaves> tmh;
     tmh.scr_d = s_d; tmh.scr_i = s_i; tmh.wave = wv; tmh.lane = lane;
-    connect_rrt_sample(rc, tmh, global_list(rc, b, kh), grid, b, kh, idh, pxh, pyh, hc, err, s_cid + 1, n - 1u);
+    connect_rrt_sample(rc, tmh, global_list(rc, b, kh), grid, b, kh, idh, pxh, pyh, hc, err, s_cid + 1, n - 1u, -1,
+                       [&]() { return wave_nn(rc, b, N, pxh, pyh); });       // (every wave of the team finds the same node)
     if (err) atomicOr(&rc.cnt->err, err);
 }
 
-template <int GL, bool LDSGRID>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_conn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
+__device__ __forceinline__ MemHits mem_hits(const RunConst &rc, uint32_t b, uint32_t k) {
+    MemHits M;
+    M.sid = as_global(rc.cand_id) + cand_off(rc, b, k);
+    M.sxy = as_global(reinterpret_cast<dbl2 *>(rc.cand_xy)) + cand_off(rc, b, k);
+    M.sd = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
+    M.out_id = M.sid;
+    M.out_val = M.sd;
+    M.out_cnt = as_global(rc.cand_cnt) + (b & 1u) * rc.cand_K + k;
+    M.out_cap = rc.cand_cap;
+    return M;
+}
+
+template <int GL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_conn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
     static_assert(GL == 16 || GL == 32 || GL == 64, "group size");
     constexpr uint32_t SPB = 256u / GL;
-    constexpr uint32_t GPW = 64u / GL;             // groups (samples) per wave
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];
-    __shared__ uint32_t s_over[SPB];
     uint32_t bx = blockIdx.x, by = blockIdx.y;
-    xcd_swizzle(bx, by);
+    const uint32_t role = xcd_swizzle_roles(bx, by, 2u);
     const RunConst &rc = rcp[by];               // one context per grid row (porrt_grow_batch)
-    // the two single workgroups of a row come first: they take longest
-    if (bx == 0) { insert_step_pages(rc, b, nb, vwords, lds_dyn); return; }    // the page-filing workgroup
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, si = threadIdx.x / GL;
-    const uint32_t TWmax = 2u * rc.tile_R + 1u;
-    const uint32_t tile_bytes = LDSGRID ? ((TWmax * TWmax + 15u) & ~15u) : 0u;
-    uint8_t *tiles = lds_dyn + SPB * kHitBytes;
+    if (role == 0) { insert_step_pages(rc, b, nb, vwords, lds_dyn); return; }    // the page-filing workgroup
+    const uint32_t lane = threadIdx.x & 63u, si = threadIdx.x / GL;
+    const uint32_t slot = bx * SPB + si;
+    // first round trip: everything that depends on nothing
     const uint32_t N = as_global(rc.n_at)[b];
-    const double T2 = as_global(rc.rad_T2)[N];             // rrt.rs:121: the size before insertion
-    uint32_t err = 0;
-    auto list_scan = [&](uint32_t kh, double pxh, double pyh) { list_scan_wave(rc, b, N, T2, kh, pxh, pyh, lane, err); };
-    if (bx == 1) { clone_workgroup<LDSGRID>(rc, b, vwords, N, T2, tiles); return; }
-    bx -= 2u;
+    const double T2 = as_global(rc.t2_at)[b];              // rad_T2[N], rrt.rs:121: the size before insertion
+    uint32_t k = 0xFFFFu;
+    double px = 0.0, py = 0.0;
+    if (role == 2u && slot < nb) { k = as_global(rc.bq_k)[slot]; px = as_global(rc.bq_x)[slot]; py = as_global(rc.bq_y)[slot]; }
+    if (role == 1) { clone_workgroup(rc, b, vwords, N, T2); return; }
     GTeam<GL> tm;
     tm.gl = threadIdx.x % GL;
     tm.base = lane - tm.gl;
-    if (lane < GPW) s_over[wv * GPW + lane] = 0u;          // every wave keeps to its own entries: no workgroup barrier in here
-    __builtin_amdgcn_wave_barrier();
-    // s_k[]: the sample each group of the workgroup serves
-    __shared__ uint16_t s_k[SPB];
-    const uint32_t slot = bx * SPB + si;
-    const uint32_t k = slot < nb ? rc.perm[(size_t)b * rc.part_stride + slot] : 0xFFFFFFFFu;
-    if (tm.gl == 0) s_k[si] = (uint16_t)k;
-    const bool active = slot < nb && as_global(rc.q_vid)[slot < nb ? k : 0u] == 0;
+    const bool act = k != 0xFFFFu;                         // else: no sample, an invalid one, or a copy of the goal point (clone workgroup)
+    uint32_t err = 0;
     PORRT_T0();
-    if (active) {
-        const uint32_t id = N + rank_before(rc, b, vwords, k);
-        const double px = as_global(rc.q_x)[k], py = as_global(rc.q_y)[k];
-        TileGrid grid;
-        grid.glob = rc.cls; grid.W = rc.W;
-        if (LDSGRID) {
-            // every neighbour lies within sqrt(T2) of the new node: the window the rays can touch
-            uint32_t R = (uint32_t)ceil(sqrt(T2) * rc.ppm) + 2u;
-            R = R < rc.tile_R ? R : rc.tile_R;
-            uint8_t *tile = tiles + si * tile_bytes;
-            grid.lds = tile; grid.TW = 2u * R + 1u;
-            uint32_t ci, cj;
-            to_pixel(rc, px, py, ci, cj);
-            grid.oi = (int)ci - (int)R;
-            grid.oj = (int)cj - (int)R;
-            for (uint32_t ri = 0; ri < grid.TW; ++ri) {
-                const int i = grid.oi + (int)ri;
-                for (uint32_t rj = tm.gl; rj < grid.TW; rj += (uint32_t)GL) {
-                    const int j = grid.oj + (int)rj;
-                    uint8_t c = CLS_BAD;
-                    if (i >= 0 && j >= 0 && (uint32_t)i < rc.H && (uint32_t)j < rc.W) c = as_global(rc.cls)[(uint32_t)i * rc.W + (uint32_t)j];
-                    tile[ri * grid.TW + rj] = c;
-                }
-            }
-        } else {
-            grid.lds = nullptr; grid.TW = 0; grid.oi = 0; grid.oj = 0;
+    uint32_t id = 0, tot = 0;
+    int clr_b = 0;
+    bool heavy = false;
+    const uint32_t cap = rc.cand_cap;
+    GlobalGrid grid;            // the few rays outside the clearance window read the raster in memory
+    grid.p = rc.cls; grid.W = rc.W;
+    if (act) {
+        // second round trip: the new node's id and the clearance around its pixel, beside the region counts of the search
+        id = N + rank_before(rc, b, vwords, k);
+        if (rc.has_grid) {
+            uint32_t bi, bj;
+            to_pixel(rc, px, py, bi, bj);
+            if (bi < rc.H && bj < rc.W) clr_b = as_global(rc.clr)[bi * rc.W + bj];
         }
-        LdsList L;
         uint8_t *hb = lds_dyn + si * kHitBytes;
+        LdsHits L;
         L.hx = reinterpret_cast<double *>(hb);
         L.hy = L.hx + kLdsHits;
-        L.hid = reinterpret_cast<int *>(L.hy + kLdsHits);
-        L.out_id = as_global(rc.cand_id) + cand_off(rc, b, k);
-        L.out_val = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
-        L.out_cnt = as_global(rc.cand_cnt) + (b & 1u) * rc.cand_K + k;
-        L.out_cap = rc.cand_cap;
-        uint32_t tot = 0;
-        PORRT_TACC(rc, 0);
-        gscan_disc<GL, 1>(rc, b, tm, px, py, disc_radius(T2, px, py), N, [&](double x, double y, int jd, bool ok) {
+        L.hd = L.hy + kLdsHits;
+        L.hid = reinterpret_cast<int *>(L.hd + kLdsHits);
+        const MemHits M = mem_hits(rc, b, k);
+        L.out_id = M.out_id; L.out_val = M.out_val; L.out_cnt = M.out_cnt; L.out_cap = M.out_cap;
+        PORRT_TACC_B(rc, 0);
+        gscan_disc<GL, 1, true>(rc, b, tm, px, py, disc_radius(T2, px, py), N, [&](double x, double y, double dA, int jd, bool ok) {
             const bool in = ok && dist2(x, y, px, py) <= T2;
             const unsigned long long hm = tm.ballot(in);
             const uint32_t pos = tot + (uint32_t)__popcll(hm & ((1ull << tm.gl) - 1ull));
-            if (in && pos < kLdsHits) { L.hid[pos] = jd; L.hx[pos] = x; L.hy[pos] = y; }
+            if (in) {
+                if (pos < kLdsHits) { L.hid[pos] = jd; L.hx[pos] = x; L.hy[pos] = y; L.hd[pos] = dA; }
+                else if (pos < cap) { M.sid[pos] = jd; dbl2 v; v.x = x; v.y = y; M.sxy[pos] = v; M.sd[pos] = dA; }
+                else err |= (uint32_t)ERR_CAND_OVERFLOW;
+            }
             tot += (uint32_t)__popcll(hm);
         });
         __builtin_amdgcn_wave_barrier();
-        PORRT_TACC(rc, 1);
-        if (tot <= kLdsHits) connect_rrt_sample(rc, tm, L, grid, b, k, id, px, py, tot, err);
-        else if (tm.gl == 0) { s_over[si] = tot; atomicAdd(&rc.cnt->n_heavy, 1u); }
+        PORRT_TACC_B(rc, 1);
+        if (tot <= kLdsHits) {
+            connect_rrt_sample(rc, tm, L, grid, b, k, id, px, py, tot, err, nullptr, 0, clr_b,
+                               [&]() { return group_nn_call<GL>(rc, b, tm.gl, tm.base, N, px, py); });
+            PORRT_TACC_B(rc, 2);
+        } else {
+            // more hits than LDS holds (the dense start of a tree, the neighbourhood of the goal point): the first ones
+            // join the rest in memory, and the whole wave serves the sample below
+            heavy = true;
+            if (tm.gl == 0) atomicAdd(&rc.cnt->n_heavy, 1u);
+            for (uint32_t a = tm.gl; a < kLdsHits; a += (uint32_t)GL) {
+                M.sid[a] = L.hid[a];
+                dbl2 v;
+                v.x = L.hx[a]; v.y = L.hy[a];
+                M.sxy[a] = v;
+                M.sd[a] = L.hd[a];
+            }
+        }
     }
-    // A sample whose hits did not fit goes through the lists in memory, the way k_near / k_connect_rrt served every
-    // sample: searched again and connected by its own wave, 64 lanes.
-    __builtin_amdgcn_wave_barrier();
-    PORRT_TACC(rc, 2);
-    for (uint32_t g = 0; g < GPW; ++g) {
-        const uint32_t sw = wv * GPW + g;
-        const uint32_t hits = uni(s_over[sw]);     // written by this wave
-        if (hits == 0u) continue;
-        const uint32_t kh = uni((uint32_t)s_k[sw]);
-        const uint32_t idh = uni(N + rank_before(rc, b, vwords, kh));
-        const double pxh = uni_d(as_global(rc.q_x)[kh]), pyh = uni_d(as_global(rc.q_y)[kh]);
-        list_scan(kh, pxh, pyh);
-        TileGrid grid;
-        if (LDSGRID) {
-            grid = load_tile(rc, tiles + sw * tile_bytes, pxh, pyh, lane, 64u);
-            __builtin_amdgcn_wave_barrier();
-        } else { grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0; }
+    unsigned long long hv = __ballot(heavy && tm.gl == 0);
+    if (hv) {
+        // written by this wave: its own loads see the entries once its stores are counted down
+        __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
+        __builtin_amdgcn_wave_barrier();
         Team<1> tw;
         tw.scr_d = nullptr; tw.scr_i = nullptr; tw.wave = 0; tw.lane = lane;
-        // the list was written by this wave: its own loads see its own stores once they are counted down
-        __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
-        connect_rrt_sample(rc, tw, global_list(rc, b, kh), grid, b, kh, idh, pxh, pyh, hits < rc.cand_cap ? hits : rc.cand_cap, err);
+        while (hv) {
+            const int l = (int)__builtin_ctzll(hv);
+            hv &= hv - 1;
+            const uint32_t kh = uni((uint32_t)__shfl((int)k, l)), idh = uni((uint32_t)__shfl((int)id, l)), toth = uni((uint32_t)__shfl((int)tot, l));
+            const int clrh = (int)uni((uint32_t)__shfl(clr_b, l));
+            const double pxh = uni_d(__shfl(px, l)), pyh = uni_d(__shfl(py, l));
+            connect_rrt_sample(rc, tw, mem_hits(rc, b, kh), grid, b, kh, idh, pxh, pyh, toth < cap ? toth : cap, err, nullptr, 0, clrh,
+                               [&]() { return wave_nn(rc, b, N, pxh, pyh); });
+        }
+        PORRT_TACC_B(rc, 3);
     }
-    PORRT_TACC(rc, 3);
     if (err) atomicOr(&rc.cnt->err, err);
 }
 

@@ -130,6 +130,27 @@ def test_recompute_after_rebuild(eng_mod):
     assert np.array_equal(e.expected_costs().view(np.uint64), d2.view(np.uint64))
 
 
+def test_batch_regrow_invalidates_the_belief_graph(eng_mod):
+    """a context regrown through porrt_grow_batch loses its belief graph and costs, as after porrt_grow: the old CSR was
+    sized for the old node count (round-1 advisor finding: out-of-bounds writes in the cost kernels)"""
+    case = cases.cfg3_near(1500)
+    es = [cases.configure(eng_mod.Engine(), cases.Case(case, seed=q)) for q in range(2)]
+    for e in es:
+        cases.grow(e, case, K=64)
+        e.build_belief_graph([0.5, 0.5])
+        e.compute_expected_costs()
+    eng_mod.Engine.grow_batch(es, [case.start] * 2, case.max_step, case.search_radius, 2500, 64, mode=cases.PTO)
+    for e in es:
+        with pytest.raises(RuntimeError):
+            e.compute_expected_costs()
+        with pytest.raises(RuntimeError):
+            e.extract_policy()
+        assert e.bg_num_edges() == 0
+        e.build_belief_graph([0.5, 0.5])                     # and a fresh build on the new graph works
+        e.compute_expected_costs()
+        assert np.isfinite(e.expected_costs()[0])
+
+
 def test_layered_and_swept_evaluations_agree(eng_mod):
     """the context path solves the layers one after the other; option dp_sweeps = the general whole-graph sweeps"""
     case = cases.cfg_door(paper=True)

@@ -101,6 +101,31 @@ def test_rrt_matches_oracle(eng_mod, case, K):
         assert np.array_equal(be[0], bo[0]) and be[1] == bo[1]
 
 
+@pytest.mark.parametrize("gl", [16, 32, 64])
+@pytest.mark.parametrize("K", [64, 1024])
+@pytest.mark.parametrize("case", RRT_SMALL, ids=lambda c: c.name)
+def test_rrt_group_kernels_match_oracle(eng_mod, case, K, gl):
+    """the step kernels with several samples per wave (k_nn2 / k_conn2: what porrt_grow_batch uses from 8 queries on), forced
+    for a single query, at every group size"""
+    e, _ = run_gpu(eng_mod, case, K, group_lanes=gl)
+    o, _ = run_orc(case, K)
+    assert e.num_nodes() > 50
+    assert_same(e, o)
+
+
+def test_rrt_group_kernels_full_size_and_eager(eng_mod):
+    """configs[1] at full size through k_nn2 / k_conn2 (hipGraph replay), and a shorter run launched eagerly"""
+    case = cases.cfg2(125000)
+    e, _ = run_gpu(eng_mod, case, 1024, group_lanes=16)
+    o, _ = run_orc(case, 1024)
+    assert e.num_nodes() > 90000
+    assert_same(e, o)
+    case = cases.cfg2(30000, seed=5)
+    e, _ = run_gpu(eng_mod, case, 1024, group_lanes=16, graph=0)
+    o, _ = run_orc(case, 1024)
+    assert_same(e, o)
+
+
 def test_rrt_k1_is_the_reference_loop(eng_mod):
     """K = 1 against the literal sequential restatement (kd-tree and all)."""
     case = cases.cfg2(1500)
@@ -195,6 +220,18 @@ def test_grow_batch_equals_separate_grows(eng_mod, graph):
                 cases.grow(o, c, K=1024, algo=orc.ALGO_BATCHED_KD)
                 cases.grow(o, c, K=1024, algo=orc.ALGO_BATCHED_KD)          # the oracle's sampler moves on the same way
                 assert_same(e, o)
+
+
+def test_grow_batch_of_eight_uses_the_group_kernels(eng_mod):
+    """from 8 contexts on porrt_grow_batch picks k_nn2 / k_conn2 by itself (XCD-aware rows need a multiple of 8; 9 do not have one)"""
+    for n in (8, 9):
+        cs = [cases.cfg2(12000, seed=s, grid="map_benchmark_like_%s" % "abcdefghi"[s]) for s in range(n)]
+        engs = [cases.configure(eng_mod.Engine(), c) for c in cs]
+        eng_mod.Engine.grow_batch(engs, [c.start for c in cs], cs[0].max_step, cs[0].search_radius, cs[0].n_iter_min, 1024)
+        for e, c in zip(engs, cs):
+            o = cases.configure(orc.Oracle(), c)
+            cases.grow(o, c, K=1024, algo=orc.ALGO_BATCHED_KD)
+            assert_same(e, o)
 
 
 def test_grow_batch_pto(eng_mod):

@@ -10,8 +10,8 @@ for opts in "$@"; do
 import json
 d=json.loads(open("gpurun_out/${tag}_$i.json").read().strip().splitlines()[-1])
 r=d.get("roofline",{}).get("kernels",{})
-print("$opts", "value %.1f M/s" % (d["value"]/1e6), "ms/step %.1f" % d["ms_per_step"], "single", d["config"].get("single_query"),
-      "near us %.0f conn us %.0f" % (r.get("k_near",{}).get("avg_launch_us",0), r.get("k_connect_rrt",{}).get("avg_launch_us",0)))
+print("$opts", "value %.1f M/s" % (d["value"]/1e6), "ms/step %.1f" % d["ms_per_step"], "single", (d.get("single_query") or {}).get("ms_per_query"),
+      "near us %.0f conn us %.0f" % (r.get("k_nn2",{}).get("avg_launch_us",0), r.get("k_conn2",{}).get("avg_launch_us",0)))
 PY
   i=$((i+1))
 done
