@@ -12,8 +12,9 @@ HBM before the timed region; the trees stay on the device (results are downloade
 
   python bench.py --gpus N --steps K --warmup W
 For N > 1 it is launched by torch.distributed.run, one rank per GPU: every rank plans its own independent
-queries (different RNG seeds, no data-path collective: weak scaling) and the job ends with ONE RCCL exchange:
-all_gather of the best path costs + broadcast of the winning tree.
+queries (different RNG seeds, at N > 1 spread over the nine maps map_benchmark_like_{a..i}; no data-path collective:
+weak scaling) and the job ends with ONE exchange behind the C ABI (porrt_exchange_best: ncclAllGather of the best path
+cost per map and rank, ncclBroadcast of the winning trees).
 Rank 0 prints one JSON line.  `roofline` is measured live with HIP events around the search and connect kernels;
 `cpu_baseline` times the single-thread C restatement of the reference loop (oracle/) on the host.
 """
@@ -72,8 +73,19 @@ def main():
 
     case = cases.cfg2(args.n_iter)
     Q = max(1, args.queries)
-    engs = [cases.configure(po_rrt_amd.Engine(local_rank), case) for _ in range(Q)]
+    # N = 1: every query plans on the map_benchmark stand-in (configs[1], the configuration the metric is quoted on).
+    # N > 1 (configs[4]): the queries of a rank are spread over the nine maps map_benchmark_like_{a..i}; same tree size,
+    # same parameters, so the work per GPU stays what it is at N = 1 (weak scaling); the exchange picks a winner per map.
+    if world > 1:
+        n_maps = 9
+        map_ids = [j % n_maps for j in range(Q)]
+        engs = [cases.configure(po_rrt_amd.Engine(local_rank), cases.cfg2(args.n_iter, grid="map_benchmark_like_%s" % "abcdefghi"[m])) for m in map_ids]
+    else:
+        n_maps, map_ids = 1, [0] * Q
+        engs = [cases.configure(po_rrt_amd.Engine(local_rank), case) for _ in range(Q)]
     eng = engs[0]
+    from po_rrt_amd import sharding
+    comm = sharding.make_comm(local_rank, dist if world > 1 else None)      # RCCL communicator of the job's one exchange (outside the timed region)
     for e in engs:
         e.set_option("profile", 0)
         for ov in args.opt:
@@ -97,15 +109,14 @@ def main():
         agg["nodes"] += run_step(s)
         agg["device_s"] += eng.metrics()["device_s"]
     t_loop = time.perf_counter() - t0
-    # the one exchange of the job: who holds the best tree?  (download happens here, once per rank)
-    # (each context's best path cost is evaluated on the device; only the winner's tree is fetched)
-    costs = po_rrt_amd.Engine.best_cost_batch(engs)
-    qbest = int(np.argmin(costs))          # first minimum, as get_best_solution picks among final nodes
-    my_cost, best_e = float(costs[qbest]), engs[qbest]
-    xy, parent, dist_root = best_e.tree()
-    from po_rrt_amd import sharding
-    winner, win_cost, _, wparent, _ = sharding.exchange_best_tree(my_cost, xy, parent, dist_root,
-                                                                    dist=dist if world > 1 else None, device="cuda")
+    # the one exchange of the job (porrt_exchange_best, behind the C ABI): per map, who holds the best tree?  Path costs are
+    # evaluated on the device, 16 bytes per map and rank are all-gathered, the winning trees are broadcast device to device
+    # (RCCL) and stay on the device; one of them -- the best of all maps -- is fetched to the host here.
+    win = sharding.exchange_best_per_map(comm, engs, map_ids, n_maps)
+    solved = [m for m in range(n_maps) if win[m]["rank"] >= 0]
+    mbest = min(solved, key=lambda m: (win[m]["cost"], m)) if solved else 0
+    winner, win_cost = int(win[mbest]["rank"]), float(win[mbest]["cost"])
+    _, wparent, _ = comm.tree(mbest)
     win_nodes = len(wparent)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -187,9 +198,13 @@ def main():
                 "nodes_per_query": agg["nodes"] / max(args.steps * Q, 1),
                 "ms_per_query": 1e3 * elapsed / max(args.steps * Q, 1),
                 "single_query": single,
-                "parallelism": "independent queries: %d per GPU advanced together x %d GPU(s), one RCCL all_gather+broadcast at the end" % (Q, world),
+                "parallelism": "independent queries: %d per GPU advanced together x %d GPU(s); one exchange at the end behind the C ABI "
+                               "(porrt_exchange_best: ncclAllGather of 16 B per map and rank + ncclBroadcast of the winning trees, device to device)" % (Q, world),
+                "maps": "map_benchmark_like" if world == 1 else "map_benchmark_like_{a..i}, queries of a rank spread over the nine (configs[4])",
+                "exchange_winners": [{"map": m, "rank": int(win[m]["rank"]), "cost": float(win[m]["cost"]), "nodes": int(win[m]["n_nodes"])} for m in range(n_maps)],
                 "best_path_cost": win_cost,
                 "winner_rank": winner,
+                "winner_nodes": win_nodes,
                 "loop_s_rank0": t_loop,
                 "launch": "hipGraph replay of all steps (main stream: search, connect; side stream: kd tie-order structure, never waited for)",
             },
@@ -277,6 +292,7 @@ def main():
                 except Exception as ex:                      # noqa: BLE001
                     out["config"][key] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         print(json.dumps(out))
+    comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -227,13 +227,49 @@ typedef struct {
 int porrt_get_metrics(const porrt_ctx *ctx, porrt_metrics *out);
 /* options: "profile" (0/1 per-kernel HIP events), "cand_cap" (initial neighbour-list
  * capacity per sample), "graph" (0/1 replay the growth loop as a hipGraph), "kd_group" (steps whose
- * new nodes enter the tie-order structure together; 0 = chosen from batch_K).  None of them changes
- * a result. */
+ * new nodes enter the tie-order structure together; 0 = chosen from batch_K), "group_lanes" (RRT*
+ * step kernels: 16 / 32 / 64 lanes per sample, 0 = one wave per sample, -1 = chosen from the number
+ * of contexts advanced together), "dp_sweeps".  None of them changes a result. */
 int porrt_set_option(porrt_ctx *ctx, const char *name, int64_t value);
 
 /* Device arithmetic self-test: sqrt and divide of n doubles on the GPU versus the host's correctly
  * rounded results; both mismatch counts must be 0 for bit-exact parity (rrt.rs costs, common.rs:218). */
 int porrt_selftest(porrt_ctx *ctx, uint64_t n, uint64_t *sqrt_mismatch, uint64_t *div_mismatch);
+
+/* ---- the one exchange of a query-sharded job (the reference is one process and has no
+ * counterpart).  Queries are independent: query q runs on rank q mod world, nothing is communicated
+ * while trees grow.  At the end, per map: ncclAllGather of one 16-byte entry per rank, the first minimum of
+ * (cost, rank) wins, and the winner's node arrays are broadcast device to device (RCCL over xGMI) into
+ * buffers the communicator owns on every rank.  Rendezvous is the caller's: rank 0 makes the id, its 128
+ * bytes travel by whatever channel the host program has (MPI, a file, torch.distributed ...). */
+#define PORRT_UNIQUE_ID_BYTES 128
+typedef struct porrt_comm porrt_comm;
+typedef struct {
+    double  cost;            /* best path cost (RRT::get_best_solution, rrt.rs:183-193); +inf = no solution */
+    int32_t rank;            /* owner; -1 in a result = nobody solved this map */
+    int32_t n_nodes;         /* size of that tree */
+} porrt_best_entry;
+int         porrt_comm_unique_id(uint8_t id[PORRT_UNIQUE_ID_BYTES]);
+porrt_comm *porrt_comm_create(int device, int rank, int world, const uint8_t id[PORRT_UNIQUE_ID_BYTES]);   /* NULL on failure */
+void        porrt_comm_destroy(porrt_comm *comm);
+const char *porrt_comm_last_error(const porrt_comm *comm);
+/* ctxs[q] planned on map map_ids[q] (< n_maps); every rank passes the same n_maps.  winners[m] is the same
+ * on every rank afterwards.  Collective: all ranks of the communicator must call it. */
+int      porrt_exchange_best(porrt_comm *comm, porrt_ctx *const *ctxs, uint32_t n_ctx, const uint32_t *map_ids,
+                             uint32_t n_maps, porrt_best_entry *winners);
+uint64_t porrt_exchange_num_nodes(const porrt_comm *comm, uint32_t map);
+int      porrt_exchange_get_tree(const porrt_comm *comm, uint32_t map, double *xy, int64_t *parent, double *dist_root);
+/* step 2 of the exchange on its own (pure host code): all[r * n_maps + m] -> win_rank[m] */
+int      porrt_exchange_decide(const porrt_best_entry *all, uint32_t world, uint32_t n_maps, int32_t *win_rank);
+
+/* The grown tree where it lives: device pointers into the context's arena (valid until the context's
+ * next grow or its destruction).  n_nodes = 0 when there are no results. */
+typedef struct {
+    const double *nx, *ny, *dist_root;
+    const int32_t *parent;       /* -1 = root */
+    uint64_t n_nodes;
+} porrt_tree_device_view;
+porrt_tree_device_view porrt_tree_device(const porrt_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,8 @@ DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*"))) + [os.path.join(HERE, 
 LIB = os.path.join(HERE, "libporrt_hip.so")
 # -ffp-contract=off: the reference (Rust) never fuses a*b+c; parity is bit-exact only without contraction.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+# RCCL: the one exchange of a query-sharded job (csrc/porrt_exchange.hpp)
+LIBS = ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
 
 
 def hipcc():
@@ -26,7 +28,7 @@ def needs_build():
 def build(force=False):
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + FLAGS + os.environ.get("PORRT_CXXFLAGS", "").split() + ["-o", LIB, SRC]
+    cmd = [hipcc()] + FLAGS + os.environ.get("PORRT_CXXFLAGS", "").split() + ["-o", LIB, SRC] + LIBS
     subprocess.run(cmd, check=True)
     return LIB
 

@@ -2262,6 +2262,14 @@ int porrt_selftest(porrt_ctx *c, uint64_t n, uint64_t *sqrt_mismatch, uint64_t *
     return PORRT_OK;
 }
 
+porrt_tree_device_view porrt_tree_device(const porrt_ctx *c) {
+    porrt_tree_device_view v;
+    memset(&v, 0, sizeof v);
+    if (!c || !c->have_results || c->mode != PORRT_MODE_RRT) return v;
+    v.nx = c->d_nx.p; v.ny = c->d_ny.p; v.dist_root = c->d_distA.p; v.parent = c->d_parent.p; v.n_nodes = c->n_nodes;
+    return v;
+}
+
 int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return PORRT_ERR_INVALID;
     if (!strcmp(name, "profile")) c->opt_profile = value != 0;
@@ -2275,3 +2283,5 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
 }
 
 } // extern "C"
+
+#include "porrt_exchange.hpp"

@@ -32,6 +32,8 @@ SYMBOLS = [
     "porrt_build_belief_graph", "porrt_bg_num_beliefs", "porrt_bg_num_nodes", "porrt_bg_num_edges", "porrt_bg_get_beliefs",
     "porrt_bg_get_observable_zones", "porrt_bg_get_node_types", "porrt_bg_get_children", "porrt_bg_get_parents", "porrt_bg_get_seconds",
     "porrt_bg_compute_expected_costs", "porrt_bg_get_expected_costs", "porrt_bg_expected_cost_of", "porrt_bg_get_dp_info", "porrt_bg_extract_policy", "porrt_conditional_dijkstra",
+    "porrt_comm_unique_id", "porrt_comm_create", "porrt_comm_destroy", "porrt_comm_last_error", "porrt_exchange_best", "porrt_exchange_num_nodes",
+    "porrt_exchange_get_tree", "porrt_exchange_decide", "porrt_tree_device",
 ]
 
 
@@ -40,6 +42,14 @@ class Metrics(C.Structure):
                 ("n_tie_fallbacks", C.c_uint64), ("total_s", C.c_double), ("setup_s", C.c_double),
                 ("device_s", C.c_double), ("scan_s", C.c_double), ("scan_launches", C.c_uint64),
                 ("scan_pairs", C.c_double), ("scan_bytes", C.c_double), ("connect_s", C.c_double)]
+
+
+class TreeDeviceView(C.Structure):
+    _fields_ = [("nx", C.c_void_p), ("ny", C.c_void_p), ("dist_root", C.c_void_p), ("parent", C.c_void_p), ("n_nodes", C.c_uint64)]
+
+
+BEST_ENTRY = np.dtype([("cost", np.float64), ("rank", np.int32), ("n_nodes", np.int32)])      # porrt_best_entry, 16 bytes
+UNIQUE_ID_BYTES = 128
 
 
 class PorrtError(RuntimeError):
@@ -119,6 +129,15 @@ def load_library():
     sig("porrt_get_metrics", C.c_int, vp, C.POINTER(Metrics))
     sig("porrt_set_option", C.c_int, vp, C.c_char_p, C.c_int64)
     sig("porrt_selftest", C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+    sig("porrt_comm_unique_id", C.c_int, C.c_void_p)
+    sig("porrt_comm_create", vp, C.c_int, C.c_int, C.c_int, C.c_void_p)
+    sig("porrt_comm_destroy", None, vp)
+    sig("porrt_comm_last_error", C.c_char_p, vp)
+    sig("porrt_exchange_best", C.c_int, vp, C.POINTER(C.c_void_p), C.c_uint32, _u32p, C.c_uint32, C.c_void_p)
+    sig("porrt_exchange_num_nodes", C.c_uint64, vp, C.c_uint32)
+    sig("porrt_exchange_get_tree", C.c_int, vp, C.c_uint32, _f64p, _i64p, _f64p)
+    sig("porrt_exchange_decide", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)
+    sig("porrt_tree_device", TreeDeviceView, vp)
     _LIB = L
     return L
 
@@ -395,3 +414,65 @@ def conditional_dijkstra(xy, belief_row, beliefs, types, children, parents, fina
     if rc < 0:
         raise RuntimeError("porrt_conditional_dijkstra failed (%d)" % rc)
     return dist
+
+
+def exchange_decide(entries):
+    """porrt_exchange_decide: entries[rank, map] (BEST_ENTRY) -> winning rank per map (-1 = nobody solved it); host code only"""
+    L = load_library()
+    e = np.ascontiguousarray(entries, dtype=BEST_ENTRY)
+    world, n_maps = e.shape
+    win = np.zeros(n_maps, dtype=np.int32)
+    rc = L.porrt_exchange_decide(e.ctypes.data_as(C.c_void_p), world, n_maps, win.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise PorrtError(rc, "porrt_exchange_decide")
+    return win
+
+
+class Comm:
+    """The one exchange of a query-sharded job (porrt_comm_*, porrt_exchange_*): RCCL over xGMI, device to device."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES)()
+        rc = load_library().porrt_comm_unique_id(buf)
+        if rc:
+            raise PorrtError(rc, "porrt_comm_unique_id (RCCL)")
+        return bytes(buf)
+
+    def __init__(self, device, rank, world, unique_id):
+        self._l = load_library()
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        self._c = self._l.porrt_comm_create(device, rank, world, buf)
+        if not self._c:
+            raise PorrtError(-4, "porrt_comm_create failed (device %d, rank %d of %d)" % (device, rank, world))
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if getattr(self, "_c", None):
+            self._l.porrt_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def exchange_best(self, engines, map_ids, n_maps):
+        """collective: winners[m] (BEST_ENTRY) identical on every rank; the winning trees stay on the device (tree(m))"""
+        n = len(engines)
+        arr = (C.c_void_p * max(n, 1))(*[e._c for e in engines])
+        ids = np.ascontiguousarray(map_ids, dtype=np.uint32)
+        win = np.zeros(n_maps, dtype=BEST_ENTRY)
+        rc = self._l.porrt_exchange_best(self._c, arr, n, ids, n_maps, win.ctypes.data_as(C.c_void_p))
+        if rc:
+            raise PorrtError(rc, self._l.porrt_comm_last_error(self._c).decode())
+        return win
+
+    def tree(self, m):
+        n = self._l.porrt_exchange_num_nodes(self._c, m)
+        xy, parent, dist = np.zeros((n, 2)), np.zeros(n, dtype=np.int64), np.zeros(n)
+        rc = self._l.porrt_exchange_get_tree(self._c, m, xy, parent, dist)
+        if rc:
+            raise PorrtError(rc, self._l.porrt_comm_last_error(self._c).decode())
+        return xy, parent, dist
