@@ -46,7 +46,8 @@ enum {
                                        (image get_pixel; map_io.rs:233) */
     PORRT_ERR_DEVICE = -4,          /* HIP runtime error */
     PORRT_ERR_CAPACITY = -5,        /* a neighbour list outgrew its capacity even after regrowth */
-    PORRT_ERR_NO_DEVICE = -6
+    PORRT_ERR_NO_DEVICE = -6,
+    PORRT_ERR_IO = -7               /* a file could not be opened / written (the reference panics: "Impossible to open image") */
 };
 
 enum { PORRT_DOMAIN_SHELF = 0, PORRT_DOMAIN_DOOR = 1 };   /* MapShelfDomain / Map */
@@ -235,6 +236,34 @@ int porrt_set_option(porrt_ctx *ctx, const char *name, int64_t value);
 /* Device arithmetic self-test: sqrt and divide of n doubles on the GPU versus the host's correctly
  * rounded results; both mismatch counts must be 0 for bit-exact parity (rrt.rs costs, common.rs:218). */
 int porrt_selftest(porrt_ctx *ctx, uint64_t n, uint64_t *sqrt_mismatch, uint64_t *div_mismatch);
+
+/* ---- on-disk formats either side of the path (host code; no GPU needed).
+ * porrt_read_pgm: the raster MapShelfDomain::open / Map::open load (image::open -> ImageLuma8,
+ * map_shelves_io.rs:88-103, map_io.rs:90-105): P2 / P5 (P1 / P4 as 0 / 255), '#' comments in the header, samples as
+ * stored (no rescaling by maxval), row-major from the top -- what porrt_set_grid / porrt_set_zones take.  Files the
+ * reference rejects with "Wrong image format!" (maxval > 255 -> 16-bit gray, colour) give PORRT_ERR_INVALID.  Call with
+ * out = NULL for the size. */
+int porrt_read_pgm(const char *path, uint8_t *out /* W*H or NULL */, uint32_t *W, uint32_t *H);
+int porrt_read_pgm_mem(const uint8_t *bytes, size_t n, uint8_t *out, uint32_t *W, uint32_t *H);
+/* PTOGraph JSON (pto_graph.rs:22-118 save / load): {"nodes": [{"state", "validity_id", "parents": [{"id",
+ * "validity_id"}], "children": [..]}], "validities": [[bool]]} in serde_json's pretty form.  The writer takes CSR
+ * adjacency; porrt_graph_save_json writes the graph of the context's last PTO grow / PRM roadmap with the lists as the
+ * reference holds them.  The reader hands the file back as the same arrays (query the sizes, then porrt_graph_file_get
+ * with caller buffers; any pointer may be NULL). */
+typedef struct porrt_graph_file porrt_graph_file;
+int porrt_graph_write_json(const char *path, uint64_t n_nodes, const double *xy, const uint64_t *node_validity, const uint64_t *child_off,
+                           const uint64_t *child_id, const uint64_t *child_validity, const uint64_t *parent_off, const uint64_t *parent_id,
+                           const uint64_t *parent_validity, uint64_t n_validities, uint64_t n_worlds, const uint8_t *validities /* [n_validities][n_worlds] 0/1 */);
+int porrt_graph_save_json(const porrt_ctx *ctx, const char *path);
+porrt_graph_file *porrt_graph_load_json(const char *path, char *err /* may be NULL */, size_t err_cap);   /* NULL on failure */
+void     porrt_graph_file_free(porrt_graph_file *g);
+uint64_t porrt_graph_file_num_nodes(const porrt_graph_file *g);
+uint64_t porrt_graph_file_num_children(const porrt_graph_file *g);
+uint64_t porrt_graph_file_num_parents(const porrt_graph_file *g);
+uint64_t porrt_graph_file_num_validities(const porrt_graph_file *g);
+uint64_t porrt_graph_file_num_worlds(const porrt_graph_file *g);
+int      porrt_graph_file_get(const porrt_graph_file *g, double *xy, uint64_t *node_validity, uint64_t *child_off, uint64_t *child_id,
+                              uint64_t *child_validity, uint64_t *parent_off, uint64_t *parent_id, uint64_t *parent_validity, uint8_t *validities);
 
 /* ---- the one exchange of a query-sharded job (the reference is one process and has no
  * counterpart).  Queries are independent: query q runs on rank q mod world, nothing is communicated

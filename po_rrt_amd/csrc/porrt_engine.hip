@@ -2285,3 +2285,4 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
 } // extern "C"
 
 #include "porrt_exchange.hpp"
+#include "porrt_formats.hpp"

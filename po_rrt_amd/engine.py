@@ -34,6 +34,9 @@ SYMBOLS = [
     "porrt_bg_compute_expected_costs", "porrt_bg_get_expected_costs", "porrt_bg_expected_cost_of", "porrt_bg_get_dp_info", "porrt_bg_extract_policy", "porrt_conditional_dijkstra",
     "porrt_comm_unique_id", "porrt_comm_create", "porrt_comm_destroy", "porrt_comm_last_error", "porrt_exchange_best", "porrt_exchange_num_nodes",
     "porrt_exchange_get_tree", "porrt_exchange_decide", "porrt_tree_device",
+    "porrt_read_pgm", "porrt_read_pgm_mem", "porrt_graph_write_json", "porrt_graph_save_json", "porrt_graph_load_json", "porrt_graph_file_free",
+    "porrt_graph_file_num_nodes", "porrt_graph_file_num_children", "porrt_graph_file_num_parents", "porrt_graph_file_num_validities",
+    "porrt_graph_file_num_worlds", "porrt_graph_file_get",
 ]
 
 
@@ -138,6 +141,15 @@ def load_library():
     sig("porrt_exchange_get_tree", C.c_int, vp, C.c_uint32, _f64p, _i64p, _f64p)
     sig("porrt_exchange_decide", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)
     sig("porrt_tree_device", TreeDeviceView, vp)
+    sig("porrt_read_pgm", C.c_int, C.c_char_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+    sig("porrt_read_pgm_mem", C.c_int, C.c_char_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+    sig("porrt_graph_write_json", C.c_int, C.c_char_p, C.c_uint64, _f64p, _u64p, _u64p, _u64p, _u64p, _u64p, _u64p, _u64p, C.c_uint64, C.c_uint64, _u8p)
+    sig("porrt_graph_save_json", C.c_int, vp, C.c_char_p)
+    sig("porrt_graph_load_json", vp, C.c_char_p, C.c_char_p, C.c_size_t)
+    sig("porrt_graph_file_free", None, vp)
+    for nm in ("nodes", "children", "parents", "validities", "worlds"):
+        sig("porrt_graph_file_num_" + nm, C.c_uint64, vp)
+    sig("porrt_graph_file_get", C.c_int, vp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
     _LIB = L
     return L
 
@@ -388,6 +400,10 @@ class Engine:
         self._chk(self._l.porrt_selftest(self._c, n, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def save_graph_json(self, path):
+        """the PTO graph / PRM roadmap of the last grow as the reference's PTOGraph JSON (pto_graph.rs:22-118)"""
+        self._chk(self._l.porrt_graph_save_json(self._c, os.fsencode(path)))
+
     def metrics(self):
         m = Metrics()
         self._chk(self._l.porrt_get_metrics(self._c, C.byref(m)))
@@ -476,3 +492,61 @@ class Comm:
         if rc:
             raise PorrtError(rc, self._l.porrt_comm_last_error(self._c).decode())
         return xy, parent, dist
+
+
+# ---- on-disk formats (host code of the library: no GPU needed)
+def read_pgm(path=None, data=None):
+    """porrt_read_pgm / porrt_read_pgm_mem: the gray raster the reference's domains open (uint8 [H, W])"""
+    L = load_library()
+    W, H = C.c_uint32(0), C.c_uint32(0)
+    if data is not None:
+        call = lambda out: L.porrt_read_pgm_mem(data, len(data), out, C.byref(W), C.byref(H))
+    else:
+        call = lambda out: L.porrt_read_pgm(os.fsencode(path), out, C.byref(W), C.byref(H))
+    rc = call(None)
+    if rc:
+        raise PorrtError(rc, "porrt_read_pgm: %s" % ("cannot open the file" if rc == -7 else "not an 8-bit gray PNM (the reference: \"Wrong image format!\")"))
+    out = np.zeros((H.value, W.value), dtype=np.uint8)
+    rc = call(out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise PorrtError(rc, "porrt_read_pgm")
+    return out
+
+
+def _u64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
+
+
+def graph_write_json(path, xy, node_validity, children, parents, validities):
+    """porrt_graph_write_json; children / parents = (offsets, ids, validity ids); validities = bool [n_validities, n_worlds]"""
+    L = load_library()
+    xy = _f64(xy).reshape(-1, 2)
+    v = np.ascontiguousarray(np.asarray(validities, dtype=np.uint8).reshape(len(validities), -1))
+    (co, ci, cv), (po, pi, pv) = children, parents
+    rc = L.porrt_graph_write_json(os.fsencode(path), len(xy), xy, _u64(node_validity), _u64(co), _u64(ci), _u64(cv), _u64(po), _u64(pi), _u64(pv),
+                                  v.shape[0], v.shape[1] if v.size else 0, v)
+    if rc:
+        raise PorrtError(rc, "porrt_graph_write_json")
+
+
+def graph_load_json(path):
+    """porrt_graph_load_json: dict(xy, node_validity, children=(off, ids, validity), parents=(...), validities bool [n, n_worlds])"""
+    L = load_library()
+    err = C.create_string_buffer(256)
+    g = L.porrt_graph_load_json(os.fsencode(path), err, 256)
+    if not g:
+        raise PorrtError(-1, "porrt_graph_load_json: " + err.value.decode())
+    try:
+        n, nc, npar = L.porrt_graph_file_num_nodes(g), L.porrt_graph_file_num_children(g), L.porrt_graph_file_num_parents(g)
+        nv, nw = L.porrt_graph_file_num_validities(g), L.porrt_graph_file_num_worlds(g)
+        xy, val = np.zeros((n, 2)), np.zeros(n, dtype=np.uint64)
+        co, ci, cv = np.zeros(n + 1, dtype=np.uint64), np.zeros(nc, dtype=np.uint64), np.zeros(nc, dtype=np.uint64)
+        po, pi, pv = np.zeros(n + 1, dtype=np.uint64), np.zeros(npar, dtype=np.uint64), np.zeros(npar, dtype=np.uint64)
+        vb = np.zeros((nv, nw), dtype=np.uint8)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = L.porrt_graph_file_get(g, p(xy), p(val), p(co), p(ci), p(cv), p(po), p(pi), p(pv), p(vb))
+        if rc:
+            raise PorrtError(rc, "porrt_graph_file_get")
+    finally:
+        L.porrt_graph_file_free(g)
+    return dict(xy=xy, node_validity=val, children=(co, ci, cv), parents=(po, pi, pv), validities=vb.astype(bool))
