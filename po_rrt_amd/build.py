@@ -25,11 +25,18 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
+SHIM_SRC = os.path.join(HERE, "csrc", "pto_c_shim.cpp")
+SHIM_LIB = os.path.join(HERE, "libpo_rrt.so")
+
+
 def build(force=False):
-    if not force and not needs_build():
-        return LIB
-    cmd = [hipcc()] + FLAGS + os.environ.get("PORRT_CXXFLAGS", "").split() + ["-o", LIB, SRC] + LIBS
-    subprocess.run(cmd, check=True)
+    if force or needs_build():
+        cmd = [hipcc()] + FLAGS + os.environ.get("PORRT_CXXFLAGS", "").split() + ["-o", LIB, SRC] + LIBS
+        subprocess.run(cmd, check=True)
+    # libpo_rrt.so: the reference's own C symbols (src/pto_c.rs) on top of the C ABI above -- plain C++, no HIP
+    deps = [SHIM_SRC, LIB, os.path.join(HERE, "..", "include", "po_rrt_c.h"), os.path.join(HERE, "..", "include", "porrt_hip.h")]
+    if force or not os.path.exists(SHIM_LIB) or any(os.path.getmtime(d) > os.path.getmtime(SHIM_LIB) for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", SHIM_LIB, SHIM_SRC, "-L" + HERE, "-lporrt_hip", "-Wl,-rpath,$ORIGIN"], check=True)
     return LIB
 
 
