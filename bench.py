@@ -286,7 +286,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(case, args)
         if not args.no_belief and world == 1:
             # the rows after the growth are extras of the line: a failure there must not cost the headline measurement
-            for key, fn in (("belief_space", belief_space), ("prm_roadmap", prm_roadmap)):
+            for key, fn in (("belief_space", belief_space), ("prm_roadmap", prm_roadmap), ("mm_prm", mm_prm)):
                 try:
                     out["config"][key] = fn(local_rank, not args.no_cpu_baseline)
                 except Exception as ex:                      # noqa: BLE001
@@ -418,6 +418,43 @@ def prm_roadmap(device, with_cpu):
         out["cpu_baseline"] = {"value": n / dt, "unit": "nodes/s", "cores": 1, "kind": "port",
                                "sample": "the full workload, %.2f s (plan_path: %.2f s, %d states); C restatement of prm.rs:33-123 with the "
                                          "reference's kd-tree" % (dt, dt2, len(po))}
+    return out
+
+
+def mm_prm(device, with_cpu):
+    """SURVEY 8f.3, second half, outside the timed region: MapShelfDomainTampPRM::grow_mm_prm (map_shelves_tamp_prm.rs:328-393) on the
+    12-shelf problem (main.rs:386-408 map and prior): one PRM* roadmap per mode (belief), grown on the GPU from the point lists the
+    reference's loop assigns to the modes."""
+    import cases
+    import po_rrt_amd
+    case = cases.cfg4(1000, 1000)
+    prior, n_iter = [1.0 / 12] * 12, 100
+    e = cases.configure(po_rrt_amd.Engine(device), case)
+    ts = []
+    for rep in range(3):
+        e.set_discrete_seed(rep)
+        t0 = time.perf_counter()
+        g = e.grow_mm_prm(case.start, prior, 0.1, 2.0, n_iter)
+        ts.append((time.perf_counter() - t0, e.mm_seconds()))
+    wall, sec = sorted(ts, key=lambda r: r[0])[1]
+    nodes = sum(len(m["xy"]) for m in g["modes"])
+    edges = sum(len(m["edges"][0]) for m in g["modes"])
+    out = {"what": "grow_mm_prm: 12 shelves, uniform prior (%d reachable beliefs), %d samples per belief -> %d modes, %d transitions, %d roadmap nodes, "
+                   "%d forward edges" % (g["n_beliefs"], n_iter, len(g["modes"]), len(g["transitions"]), nodes, edges),
+           "ms_wall": 1e3 * wall, "ms_host_mode_tree": 1e3 * sec["host_s"], "ms_roadmaps": 1e3 * sec["roadmap_s"], "ms_device": 1e3 * sec["device_s"],
+           "nodes_per_s": nodes / wall,
+           "note": "one launch sequence per mode (thousands of small roadmaps): bound by launches and copies, not by the kernels; the wall time "
+                   "includes fetching every mode's edges"}
+    if with_cpu:
+        from oracle import orc
+        o = cases.configure(orc.Oracle(), case)
+        o.set_discrete_seed(2)
+        t0 = time.perf_counter()
+        go = o.grow_mm_prm(case.start, prior, 0.1, 2.0, n_iter)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": sum(len(m["xy"]) for m in go["modes"]) / dt, "unit": "nodes/s", "cores": 1, "kind": "port",
+                               "sample": "the full workload, %.2f s; C restatement of map_shelves_tamp_prm.rs:135-393 with one kd-tree PRM per mode "
+                                         "(oracle/mmprm.c)" % dt}
     return out
 
 

@@ -237,6 +237,27 @@ int porrt_set_option(porrt_ctx *ctx, const char *name, int64_t value);
  * rounded results; both mismatch counts must be 0 for bit-exact parity (rrt.rs costs, common.rs:218). */
 int porrt_selftest(porrt_ctx *ctx, uint64_t n, uint64_t *sqrt_mismatch, uint64_t *div_mismatch);
 
+/* ---- multi-modal PRM growth: MapShelfDomainTampPRM::grow_mm_prm (src/map_shelves_tamp_prm.rs:328-393; ModeTree :135-283,
+ * sample_observation_of_zone :482-493) on a shelf domain with zones.  One PRM* roadmap per mode (belief); the reference's loop
+ * decides on the host which point goes to which mode in which order (the context's discrete sampler moves on; every mode
+ * clones the continuous sampler's current state, which is NOT advanced -- the reference's behaviour; the zone sampler is a
+ * fresh seed-0 stream per call), then each mode's roadmap is built at once on the GPU from its ordered points.  Results:
+ * per mode its belief, reaching probability, nodes (add_sample order), forward edges (neighbour -> new node, the reference's
+ * adjacency order; the reverse edge is implied, prm.rs:96-103) and final node ids; per transition the observed zone, the two
+ * modes, the observation flag as the reference stores it and the [node in from-mode, node in to-mode] pairs.  After this
+ * call the single-graph getters (porrt_get_tree ...) have no results. */
+int      porrt_grow_mm_prm(porrt_ctx *ctx, const double start[2], const double *initial_belief, uint32_t n_worlds, double max_step,
+                           double search_radius, uint64_t n_iter_per_belief);
+uint64_t porrt_mm_num_modes(const porrt_ctx *ctx);
+uint64_t porrt_mm_num_transitions(const porrt_ctx *ctx);
+uint64_t porrt_mm_num_beliefs(const porrt_ctx *ctx);          /* reachable belief states of the prior (the sample budget's factor) */
+int      porrt_mm_get_mode(const porrt_ctx *ctx, uint64_t mode, double *belief /* n_worlds */, double *reaching_probability, uint64_t *n_nodes,
+                           uint64_t *n_edges, uint64_t *n_final);
+int      porrt_mm_get_mode_graph(const porrt_ctx *ctx, uint64_t mode, double *xy, uint32_t *edge_from, uint32_t *edge_to, uint64_t *final_ids);
+int      porrt_mm_get_transition(const porrt_ctx *ctx, uint64_t t, uint32_t *zone, uint32_t *from_mode, uint32_t *to_mode, int *observation, uint64_t *n_pairs);
+int      porrt_mm_get_transition_pairs(const porrt_ctx *ctx, uint64_t t, uint64_t *pairs /* 2 * n_pairs */);
+int      porrt_mm_get_seconds(const porrt_ctx *ctx, double *host_s, double *roadmap_s, double *device_s);
+
 /* ---- on-disk formats either side of the path (host code; no GPU needed).
  * porrt_read_pgm: the raster MapShelfDomain::open / Map::open load (image::open -> ImageLuma8,
  * map_shelves_io.rs:88-103, map_io.rs:90-105): P2 / P5 (P1 / P4 as 0 / 255), '#' comments in the header, samples as

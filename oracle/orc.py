@@ -60,6 +60,14 @@ def lib():
     sig("orc_state_class", C.c_int, vp, _f64p)
     sig("orc_prm_grow", C.c_int, vp, _f64p, C.c_double, C.c_double, C.c_uint64)
     sig("orc_prm_plan_path", C.c_int64, vp, _f64p, _f64p, _f64p, C.c_uint64)
+    sig("orc_mm_prm_grow", vp, vp, _f64p, _f64p, C.c_double, C.c_double, C.c_uint64)
+    sig("orc_mm_free", None, vp)
+    for nm in ("modes", "transitions", "beliefs"):
+        sig("orc_mm_num_" + nm, C.c_uint64, vp)
+    sig("orc_mm_mode_info", None, vp, C.c_uint64, _f64p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+    sig("orc_mm_mode_graph", None, vp, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+    sig("orc_mm_transition", None, vp, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_uint64))
+    sig("orc_mm_transition_pairs", None, vp, C.c_uint64, C.c_void_p)
     sig("orc_belief_hash", C.c_uint64, _f64p, C.c_uint32)
     sig("orc_belief_successors", C.c_int, vp, _f64p, C.c_uint32, _f64p)
     sig("orc_zone_observable", C.c_int, vp, _f64p, C.c_uint32)
@@ -337,6 +345,35 @@ class Oracle:
     def grow_prm(self, start, max_step, search_radius, n_iter):
         """PRM::init + PRM::grow_graph (prm.rs:33-109)"""
         return self._chk(self._l.orc_prm_grow(self._c, _f64(start), max_step, search_radius, n_iter))
+
+    def grow_mm_prm(self, start, belief, max_step, search_radius, n_iter_per_belief):
+        """MapShelfDomainTampPRM::grow_mm_prm (map_shelves_tamp_prm.rs:328-393): dict(n_beliefs, modes=[dict(belief, reaching_probability,
+        xy, edges=(from, to), finals)], transitions=[dict(zone, from_mode, to_mode, observation, pairs)])"""
+        L = self._l
+        g = L.orc_mm_prm_grow(self._c, _f64(start), _f64(belief), max_step, search_radius, n_iter_per_belief)
+        if not g:
+            raise RuntimeError(L.orc_last_error(self._c).decode())
+        try:
+            nw = self.n_worlds()
+            modes, trs = [], []
+            for m in range(L.orc_mm_num_modes(g)):
+                b, rp = np.zeros(nw), C.c_double(0)
+                nn, ne, nf = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+                L.orc_mm_mode_info(g, m, b, C.byref(rp), C.byref(nn), C.byref(ne), C.byref(nf))
+                xy = np.zeros((nn.value, 2))
+                ef, et, fin = np.zeros(ne.value, dtype=np.uint64), np.zeros(ne.value, dtype=np.uint64), np.zeros(nf.value, dtype=np.uint64)
+                p = lambda a: a.ctypes.data_as(C.c_void_p)
+                L.orc_mm_mode_graph(g, m, p(xy), p(ef), p(et), p(fin))
+                modes.append(dict(belief=b, reaching_probability=rp.value, xy=xy, edges=(ef, et), finals=fin))
+            for t in range(L.orc_mm_num_transitions(g)):
+                z, f, to, ob, n = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_int(0), C.c_uint64(0)
+                L.orc_mm_transition(g, t, C.byref(z), C.byref(f), C.byref(to), C.byref(ob), C.byref(n))
+                pairs = np.zeros((n.value, 2), dtype=np.uint64)
+                L.orc_mm_transition_pairs(g, t, pairs.ctypes.data_as(C.c_void_p))
+                trs.append(dict(zone=z.value, from_mode=f.value, to_mode=to.value, observation=ob.value, pairs=pairs))
+            return dict(n_beliefs=L.orc_mm_num_beliefs(g), modes=modes, transitions=trs)
+        finally:
+            L.orc_mm_free(g)
 
     def prm_plan_path(self, start, goal):
         """PRM::plan_path (prm.rs:111-123): list of states, empty when the goal is not connected"""

@@ -195,4 +195,17 @@ int64_t  orc_bg_extract_policy(const orc_ctx *c, const double *dist, uint64_t *o
 #ifdef __cplusplus
 }
 #endif
+/* ---- multi-modal PRM growth (mmprm.c): MapShelfDomainTampPRM::grow_mm_prm, src/map_shelves_tamp_prm.rs:328-393.  Uses the
+ * context's continuous sampler state (cloned into every mode, not advanced) and advances its discrete sampler. */
+typedef struct orc_mm orc_mm;
+orc_mm  *orc_mm_prm_grow(orc_ctx *c, const double start[2], const double *initial_belief, double max_step, double search_radius, uint64_t n_iter_per_belief);
+void     orc_mm_free(orc_mm *g);
+uint64_t orc_mm_num_modes(const orc_mm *g);
+uint64_t orc_mm_num_transitions(const orc_mm *g);
+uint64_t orc_mm_num_beliefs(const orc_mm *g);
+void     orc_mm_mode_info(const orc_mm *g, uint64_t m, double *belief, double *reach_p, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *n_final);
+void     orc_mm_mode_graph(const orc_mm *g, uint64_t m, double *xy, uint64_t *efrom, uint64_t *eto, uint64_t *finals);
+void     orc_mm_transition(const orc_mm *g, uint64_t t, uint32_t *zone, uint32_t *from, uint32_t *to, int *observation, uint64_t *n_pairs);
+void     orc_mm_transition_pairs(const orc_mm *g, uint64_t t, uint64_t *pairs);
+
 #endif

@@ -137,6 +137,8 @@ uint64_t ones(int n) { return n >= 64 ? ~0ULL : ((1ULL << n) - 1); }
 
 } // namespace
 
+#include "porrt_mmprm.hpp"
+
 struct porrt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -260,6 +262,9 @@ struct porrt_ctx {
     uint64_t host_kd_tag = ~0ull;
     int ensure_edge_order();
     int grow_prm(const double start[2], double max_step, double search_radius, uint64_t n_iter);
+    MmState mm;                            // porrt_grow_mm_prm: the mode tree and the modes' roadmaps
+    int grow_mm_prm(const double start[2], const double *initial_belief, uint32_t n_worlds_in, double max_step, double search_radius, uint64_t n_iter_per_belief);
+    int roadmap_of_points(const std::vector<double> &xy, double max_step, double search_radius, std::vector<uint32_t> &efrom, std::vector<uint32_t> &eto, double &dev_s);
     int64_t prm_plan_path(const double start[2], const double goal[2], double *path_xy, uint64_t cap);
     int read_best_cost(double *cost, uint64_t *final_id);
     porrt_ctx *batch_leader = nullptr;     // set by porrt_grow_batch: the context whose RunConst array holds this one
@@ -1315,7 +1320,7 @@ int porrt_ctx::grow_prm(const double start[2], double max_step, double search_ra
     const uint64_t ecap = std::min<uint64_t>((uint64_t)N * 256 + 4096, 1ull << 30);
     HIPCHK(d_nx.reserve(N)); HIPCHK(d_ny.reserve(N)); HIPCHK(d_distA.reserve(N)); HIPCHK(d_parent.reserve(N)); HIPCHK(d_reachA.reserve(N));
     HIPCHK(d_vid.reserve(N)); HIPCHK(d_finalflag.reserve(N)); HIPCHK(d_finalmask.reserve(N)); HIPCHK(d_radT2.reserve(N + 8));
-    HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_cls.reserve((size_t)W * H + 16));
+    HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_cls.reserve(2 * (size_t)W * H + 16));       // classes + clearance plane (build_cls)
     HIPCHK(d_efrom.reserve(ecap)); HIPCHK(d_eto.reserve(ecap)); HIPCHK(d_etv.reserve(ecap));
     int r = layout_buffers();
     if (r) return r;
@@ -1333,7 +1338,7 @@ int porrt_ctx::grow_prm(const double start[2], double max_step, double search_ra
     HIPCHK(hipMemsetAsync(d_finalflag.p, 0, N, stream));
     memset(&rc, 0, sizeof rc);
     rc.nx = d_nx.p; rc.ny = d_ny.p; rc.vid = d_vid.p;
-    rc.cls = d_cls.p; rc.W = W; rc.H = H; rc.low0 = low[0]; rc.low1 = low[1]; rc.ppm = ppm; rc.domain = domain; rc.has_grid = has_grid;
+    rc.cls = d_cls.p; rc.clr = d_cls.p + (size_t)W * H; rc.W = W; rc.H = H; rc.low0 = low[0]; rc.low1 = low[1]; rc.ppm = ppm; rc.domain = domain; rc.has_grid = has_grid;
     rc.n_validities = n_validities;
     for (int i = 0; i < n_validities; ++i) rc.validities[i] = validities[i];
     rc.all_worlds = ones(n_worlds);
@@ -1419,6 +1424,172 @@ int porrt_ctx::grow_prm(const double start[2], double max_step, double search_ra
 
 // PRM::plan_path (prm.rs:111-123): dijkstra from the goal's nearest node (pto_graph.rs:275-303 == conditional_dijkstra
 // without observation nodes: the device sweeps), extract_path on the host (pto_graph.rs:305-326).
+
+// One mode's roadmap from its ordered nodes: the kernels of porrt_grow_prm on an injected point list (node 0 = the first
+// point, prm.rs:54-58), forward edges back in the reference's adjacency order.  The context's own sampler state and
+// injected stream are put back afterwards.
+int porrt_ctx::roadmap_of_points(const std::vector<double> &xy, double max_step, double search_radius, std::vector<uint32_t> &efrom, std::vector<uint32_t> &eto,
+                                 double &dev_s) {
+    efrom.clear(); eto.clear();
+    const size_t n = xy.size() / 2;
+    if (n < 2) return PORRT_OK;
+    std::vector<double> keep_inj;
+    keep_inj.swap(inj_xy);
+    const size_t keep_pos = inj_pos;
+    const bool keep_has = has_inj;
+    const Pcg64 keep_rng = crng;
+    inj_xy.assign(xy.begin() + 2, xy.end());
+    inj_pos = 0; has_inj = true;
+    const double start[2] = {xy[0], xy[1]};
+    int r = grow_prm(start, max_step, search_radius, n - 1);
+    if (!r) r = download(DL_EDGES);
+    if (!r) { efrom = h_efrom; eto = h_eto; dev_s += prm.t_device; }
+    inj_xy.swap(keep_inj); inj_pos = keep_pos; has_inj = keep_has; inj_dirty = true; crng = keep_rng;
+    return r;
+}
+
+int porrt_ctx::grow_mm_prm(const double start[2], const double *initial_belief, uint32_t n_worlds_in, double max_step, double search_radius,
+                           uint64_t n_iter_per_belief) {
+    using namespace mmprm;
+    mm.clear();
+    if (!has_grid || domain != PORRT_DOMAIN_SHELF || n_zones == 0) { set_err("multi-modal PRM: a shelf domain with zones (porrt_set_grid + porrt_set_zones)"); return PORRT_ERR_INVALID; }
+    if (!start || !initial_belief || n_worlds_in != (uint32_t)n_worlds) { set_err("multi-modal PRM: start / belief of n_worlds entries"); return PORRT_ERR_INVALID; }
+    if (!(max_step > 0.0) || !(search_radius > 0.0)) { set_err("bad PRM parameters"); return PORRT_ERR_INVALID; }
+    {
+        double sum = 0.0;
+        for (uint32_t w = 0; w < n_worlds_in; ++w) sum += initial_belief[w];
+        if (std::fabs(sum - 1.0) > 1e-6) { set_err("belief state does not sum to 1 (check_belief_state)"); return PORRT_ERR_INVALID; }
+    }
+    const double t0 = now_s();
+    const uint32_t nw = n_worlds_in;
+    mm.nw = nw;
+    // reachable_belief_states (:331): only their number enters the growth (the sample budget)
+    {
+        BeliefSpace bs;
+        bs.domain = domain; bs.nz = n_zones; bs.nw = nw; bs.validities = validities;
+        std::string e;
+        const int r = bs.reach_from(initial_belief, e);
+        if (r) { set_err(e); return r; }
+        mm.n_beliefs = bs.size();
+    }
+    const Pcg64 planner_sampler = crng;          // never advanced by the planner: every mode clones this state
+    Pcg64 zone_sampler;                          // ContinuousSampler::new([0, 0], [visibility, 2 pi]) (:302)
+    zone_sampler.seed_from_u64(0);
+    auto add_mode = [&](const std::vector<int> &remaining, double reach_p, const std::vector<double> &belief) {      // :135-164
+        MmMode m;
+        m.belief = belief; m.reaching_probability = reach_p; m.remaining = remaining;
+        m.there.assign(64, -1); m.not_there.assign(64, -1);
+        m.sampler = planner_sampler;
+        mm.modes.push_back(std::move(m));
+        return mm.modes.size() - 1;
+    };
+    auto mode_of_hash = [&](uint64_t h) -> int64_t {             // mode_hash_map: the last mode inserted with that hash
+        for (size_t m = mm.modes.size(); m-- > 0;) if (BeliefSpace::hash_of(mm.modes[m].belief.data(), nw) == h) return (int64_t)m;
+        return -1;
+    };
+    auto add_sample = [&](size_t mode, double x, double y) -> uint64_t {      // PRM::add_sample: the node; its edges come later, on the GPU
+        mm.modes[mode].xy.push_back(x); mm.modes[mode].xy.push_back(y);
+        return mm.modes[mode].xy.size() / 2 - 1;
+    };
+    auto get_transitions = [&](size_t mode_id, int zone, size_t out[2]) -> int {      // :183-282
+        int n_out = 0;
+        if (is_final(mm.modes[mode_id].belief)) return 0;
+        for (int pass = 0; pass < 2; ++pass) {                   // object there, then object not there
+            std::vector<int64_t> &map = pass == 0 ? mm.modes[mode_id].there : mm.modes[mode_id].not_there;
+            if (map[zone] >= 0) { out[n_out++] = (size_t)map[zone]; continue; }
+            const MmMode &mode = mm.modes[mode_id];
+            std::vector<double> sb;
+            double reach_p;
+            if (pass == 0) {
+                sb.assign(nw, 0.0);
+                sb[zone] = 1.0;
+                normalize(sb);
+                reach_p = mode.reaching_probability * transition_probability(mode.belief, sb);
+            } else {
+                sb = mode.belief;
+                sb[zone] = 0.0;
+                reach_p = mode.reaching_probability * transition_probability(mode.belief, sb);
+                double sum = 0.0;
+                for (double v : sb) sum = sum + v;
+                if (!(sum > 0.0)) return -1;                     // the reference asserts
+                normalize(sb);
+            }
+            int64_t succ = mode_of_hash(BeliefSpace::hash_of(sb.data(), nw));
+            if (succ < 0) {
+                std::vector<int> remaining;
+                for (int z : mode.remaining) if (z != zone) remaining.push_back(z);
+                succ = (int64_t)add_mode(remaining, reach_p, sb);
+                int goal_zone = -1;
+                if (pass == 0) goal_zone = zone;
+                else for (uint32_t w = 0; w < nw; ++w) if (sb[w] == 1.0) { goal_zone = (int)w; break; }
+                if (goal_zone >= 0) mm.modes[succ].finals.push_back(add_sample((size_t)succ, zone_pos[goal_zone][0], zone_pos[goal_zone][1]));     // initial goal state
+            }
+            MmTransition t;
+            t.zone = (uint32_t)zone; t.from = (uint32_t)mode_id; t.to = (uint32_t)succ; t.observation = 1;      // sic: `true` in both branches
+            mm.tr.push_back(std::move(t));
+            (pass == 0 ? mm.modes[mode_id].there : mm.modes[mode_id].not_there)[zone] = (int64_t)mm.tr.size() - 1;
+            out[n_out++] = mm.tr.size() - 1;
+        }
+        return n_out;
+    };
+    {
+        std::vector<int> remaining(n_zones);
+        for (int z = 0; z < n_zones; ++z) remaining[z] = z;
+        add_mode(remaining, 1.0, std::vector<double>(initial_belief, initial_belief + nw));
+        add_sample(0, start[0], start[1]);                       // :339 planning start
+    }
+    const uint64_t total = n_iter_per_belief * mm.n_beliefs;
+    const uint64_t n_outer = (uint64_t)((double)total / 200.0);
+    const double two_pi = 2.0 * 3.14159265358979323846;          // 2.0 * PI as f64
+    for (uint64_t i = 0; i < n_outer; ++i) {
+        const size_t mode_id = (size_t)drng.gen_range_usize(mm.modes.size());          // :351
+        for (int s = 0; s < 190; ++s) {                                                // :357 grow_graph(.., 190)
+            MmMode &m = mm.modes[mode_id];
+            const double x = m.sampler.gen_range_f64(s_low[0], s_up[0]);
+            const double y = m.sampler.gen_range_f64(s_low[1], s_up[1]);
+            add_sample(mode_id, x, y);
+        }
+        for (int j = 0; j < 10; ++j) {                                                 // :360-389
+            if (mm.modes[mode_id].remaining.empty()) continue;
+            const size_t zi = (size_t)drng.gen_range_usize(mm.modes[mode_id].remaining.size());
+            const int zone = mm.modes[mode_id].remaining[zi];
+            size_t tids[2];
+            const int nt = get_transitions(mode_id, zone, tids);
+            if (nt < 0) { set_err("belief without mass (the reference asserts)"); mm.clear(); return PORRT_ERR_INVALID; }
+            // sample_observation_of_zone (:482-493): the radius draw is made and discarded; libm as Rust's f64::cos / sin
+            (void)zone_sampler.gen_range_f64(0.0, visibility);
+            const double angle = zone_sampler.gen_range_f64(0.0, two_pi);
+            // (cos and sin of one operand: LLVM -- rustc as well as this compiler -- merges them into one sincos call on glibc; said explicitly)
+            double sn, cs;
+            ::sincos(angle, &sn, &cs);
+            double ts[2] = {zone_pos[zone][0] + visibility * cs, zone_pos[zone][1] + visibility * sn};
+            for (int d = 0; d < 2; ++d) {                                              // f64::clamp(low, up - 0.0001)
+                const double lo = s_low[d], hi = s_up[d] - 0.0001;
+                if (ts[d] < lo) ts[d] = lo;
+                if (ts[d] > hi) ts[d] = hi;
+            }
+            const uint64_t obs = add_sample(mode_id, ts[0], ts[1]);
+            for (int k = 0; k < nt; ++k) {
+                MmTransition &t = mm.tr[tids[k]];
+                const uint64_t dst = add_sample(t.to, ts[0], ts[1]);
+                t.pairs.push_back(obs); t.pairs.push_back(dst);
+            }
+        }
+    }
+    mm.host_s = now_s() - t0;
+    // the modes' roadmaps, one after the other on the GPU
+    const double t1 = now_s();
+    mm.device_s = 0;
+    for (MmMode &m : mm.modes) {
+        const int r = roadmap_of_points(m.xy, max_step, search_radius, m.efrom, m.eto, mm.device_s);
+        if (r) { mm.clear(); return r; }
+    }
+    mm.roadmap_s = now_s() - t1;
+    have_results = false;                        // the context's single-graph getters do not describe a mode tree
+    mm.valid = true;
+    return PORRT_OK;
+}
+
 int64_t porrt_ctx::prm_plan_path(const double start[2], const double goal[2], double *path_xy, uint64_t cap) {
     if (!have_results || mode != PORRT_MODE_PRM) { set_err("plan_path: grow a roadmap first (porrt_grow_prm)"); return PORRT_ERR_INVALID; }
     if (!start || !goal) { set_err("plan_path: start and goal"); return PORRT_ERR_INVALID; }
@@ -2078,6 +2249,55 @@ int porrt_best_cost_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, double *costs)
 
 int porrt_grow_prm(porrt_ctx *c, const double start[2], double max_step, double search_radius, uint64_t n_iter) {
     return c ? c->grow_prm(start, max_step, search_radius, n_iter) : PORRT_ERR_INVALID;
+}
+
+int porrt_grow_mm_prm(porrt_ctx *c, const double start[2], const double *initial_belief, uint32_t n_worlds, double max_step, double search_radius,
+                      uint64_t n_iter_per_belief) {
+    return c ? c->grow_mm_prm(start, initial_belief, n_worlds, max_step, search_radius, n_iter_per_belief) : PORRT_ERR_INVALID;
+}
+uint64_t porrt_mm_num_modes(const porrt_ctx *c) { return c && c->mm.valid ? c->mm.modes.size() : 0; }
+uint64_t porrt_mm_num_transitions(const porrt_ctx *c) { return c && c->mm.valid ? c->mm.tr.size() : 0; }
+uint64_t porrt_mm_num_beliefs(const porrt_ctx *c) { return c && c->mm.valid ? c->mm.n_beliefs : 0; }
+int porrt_mm_get_mode(const porrt_ctx *c, uint64_t m, double *belief, double *reaching_probability, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *n_final) {
+    if (!c || !c->mm.valid || m >= c->mm.modes.size()) return PORRT_ERR_INVALID;
+    const MmMode &md = c->mm.modes[m];
+    if (belief) memcpy(belief, md.belief.data(), md.belief.size() * sizeof(double));
+    if (reaching_probability) *reaching_probability = md.reaching_probability;
+    if (n_nodes) *n_nodes = md.xy.size() / 2;
+    if (n_edges) *n_edges = md.efrom.size();
+    if (n_final) *n_final = md.finals.size();
+    return PORRT_OK;
+}
+int porrt_mm_get_mode_graph(const porrt_ctx *c, uint64_t m, double *xy, uint32_t *efrom, uint32_t *eto, uint64_t *final_ids) {
+    if (!c || !c->mm.valid || m >= c->mm.modes.size()) return PORRT_ERR_INVALID;
+    const MmMode &md = c->mm.modes[m];
+    if (xy && !md.xy.empty()) memcpy(xy, md.xy.data(), md.xy.size() * sizeof(double));
+    if (efrom && !md.efrom.empty()) memcpy(efrom, md.efrom.data(), md.efrom.size() * sizeof(uint32_t));
+    if (eto && !md.eto.empty()) memcpy(eto, md.eto.data(), md.eto.size() * sizeof(uint32_t));
+    if (final_ids && !md.finals.empty()) memcpy(final_ids, md.finals.data(), md.finals.size() * sizeof(uint64_t));
+    return PORRT_OK;
+}
+int porrt_mm_get_transition(const porrt_ctx *c, uint64_t t, uint32_t *zone, uint32_t *from_mode, uint32_t *to_mode, int *observation, uint64_t *n_pairs) {
+    if (!c || !c->mm.valid || t >= c->mm.tr.size()) return PORRT_ERR_INVALID;
+    const MmTransition &tr = c->mm.tr[t];
+    if (zone) *zone = tr.zone;
+    if (from_mode) *from_mode = tr.from;
+    if (to_mode) *to_mode = tr.to;
+    if (observation) *observation = tr.observation;
+    if (n_pairs) *n_pairs = tr.pairs.size() / 2;
+    return PORRT_OK;
+}
+int porrt_mm_get_transition_pairs(const porrt_ctx *c, uint64_t t, uint64_t *pairs) {
+    if (!c || !c->mm.valid || t >= c->mm.tr.size() || !pairs) return PORRT_ERR_INVALID;
+    if (!c->mm.tr[t].pairs.empty()) memcpy(pairs, c->mm.tr[t].pairs.data(), c->mm.tr[t].pairs.size() * sizeof(uint64_t));
+    return PORRT_OK;
+}
+int porrt_mm_get_seconds(const porrt_ctx *c, double *host_s, double *roadmap_s, double *device_s) {
+    if (!c || !c->mm.valid) return PORRT_ERR_INVALID;
+    if (host_s) *host_s = c->mm.host_s;
+    if (roadmap_s) *roadmap_s = c->mm.roadmap_s;
+    if (device_s) *device_s = c->mm.device_s;
+    return PORRT_OK;
 }
 
 int64_t porrt_prm_plan_path(porrt_ctx *c, const double start[2], const double goal[2], double *path_xy, uint64_t cap) {

@@ -34,6 +34,8 @@ SYMBOLS = [
     "porrt_bg_compute_expected_costs", "porrt_bg_get_expected_costs", "porrt_bg_expected_cost_of", "porrt_bg_get_dp_info", "porrt_bg_extract_policy", "porrt_conditional_dijkstra",
     "porrt_comm_unique_id", "porrt_comm_create", "porrt_comm_destroy", "porrt_comm_last_error", "porrt_exchange_best", "porrt_exchange_num_nodes",
     "porrt_exchange_get_tree", "porrt_exchange_decide", "porrt_tree_device",
+    "porrt_grow_mm_prm", "porrt_mm_num_modes", "porrt_mm_num_transitions", "porrt_mm_num_beliefs", "porrt_mm_get_mode", "porrt_mm_get_mode_graph",
+    "porrt_mm_get_transition", "porrt_mm_get_transition_pairs", "porrt_mm_get_seconds",
     "porrt_read_pgm", "porrt_read_pgm_mem", "porrt_graph_write_json", "porrt_graph_save_json", "porrt_graph_load_json", "porrt_graph_file_free",
     "porrt_graph_file_num_nodes", "porrt_graph_file_num_children", "porrt_graph_file_num_parents", "porrt_graph_file_num_validities",
     "porrt_graph_file_num_worlds", "porrt_graph_file_get",
@@ -141,6 +143,14 @@ def load_library():
     sig("porrt_exchange_get_tree", C.c_int, vp, C.c_uint32, _f64p, _i64p, _f64p)
     sig("porrt_exchange_decide", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)
     sig("porrt_tree_device", TreeDeviceView, vp)
+    sig("porrt_grow_mm_prm", C.c_int, vp, _f64p, _f64p, C.c_uint32, C.c_double, C.c_double, C.c_uint64)
+    for nm in ("modes", "transitions", "beliefs"):
+        sig("porrt_mm_num_" + nm, C.c_uint64, vp)
+    sig("porrt_mm_get_mode", C.c_int, vp, C.c_uint64, _f64p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+    sig("porrt_mm_get_mode_graph", C.c_int, vp, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+    sig("porrt_mm_get_transition", C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_uint64))
+    sig("porrt_mm_get_transition_pairs", C.c_int, vp, C.c_uint64, C.c_void_p)
+    sig("porrt_mm_get_seconds", C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
     sig("porrt_read_pgm", C.c_int, C.c_char_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
     sig("porrt_read_pgm_mem", C.c_int, C.c_char_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
     sig("porrt_graph_write_json", C.c_int, C.c_char_p, C.c_uint64, _f64p, _u64p, _u64p, _u64p, _u64p, _u64p, _u64p, _u64p, C.c_uint64, C.c_uint64, _u8p)
@@ -399,6 +409,35 @@ class Engine:
         a, b = C.c_uint64(0), C.c_uint64(0)
         self._chk(self._l.porrt_selftest(self._c, n, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def grow_mm_prm(self, start, belief, max_step, search_radius, n_iter_per_belief):
+        """MapShelfDomainTampPRM::grow_mm_prm (map_shelves_tamp_prm.rs:328-393); same dict as the oracle's"""
+        L = self._l
+        b = _f64(belief)
+        self._chk(L.porrt_grow_mm_prm(self._c, _f64(start), b, len(b), max_step, search_radius, n_iter_per_belief))
+        nw = len(b)
+        modes, trs = [], []
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        for m in range(L.porrt_mm_num_modes(self._c)):
+            bb, rp = np.zeros(nw), C.c_double(0)
+            nn, ne, nf = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+            self._chk(L.porrt_mm_get_mode(self._c, m, bb, C.byref(rp), C.byref(nn), C.byref(ne), C.byref(nf)))
+            xy = np.zeros((nn.value, 2))
+            ef, et, fin = np.zeros(ne.value, dtype=np.uint32), np.zeros(ne.value, dtype=np.uint32), np.zeros(nf.value, dtype=np.uint64)
+            self._chk(L.porrt_mm_get_mode_graph(self._c, m, p(xy), p(ef), p(et), p(fin)))
+            modes.append(dict(belief=bb, reaching_probability=rp.value, xy=xy, edges=(ef.astype(np.uint64), et.astype(np.uint64)), finals=fin))
+        for t in range(L.porrt_mm_num_transitions(self._c)):
+            z, f, to, ob, n = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_int(0), C.c_uint64(0)
+            self._chk(L.porrt_mm_get_transition(self._c, t, C.byref(z), C.byref(f), C.byref(to), C.byref(ob), C.byref(n)))
+            pairs = np.zeros((n.value, 2), dtype=np.uint64)
+            self._chk(L.porrt_mm_get_transition_pairs(self._c, t, p(pairs)))
+            trs.append(dict(zone=z.value, from_mode=f.value, to_mode=to.value, observation=ob.value, pairs=pairs))
+        return dict(n_beliefs=L.porrt_mm_num_beliefs(self._c), modes=modes, transitions=trs)
+
+    def mm_seconds(self):
+        h, r, d = C.c_double(0), C.c_double(0), C.c_double(0)
+        self._chk(self._l.porrt_mm_get_seconds(self._c, C.byref(h), C.byref(r), C.byref(d)))
+        return dict(host_s=h.value, roadmap_s=r.value, device_s=d.value)
 
     def save_graph_json(self, path):
         """the PTO graph / PRM roadmap of the last grow as the reference's PTOGraph JSON (pto_graph.rs:22-118)"""

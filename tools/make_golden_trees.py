@@ -32,12 +32,28 @@ def specs():
     yield "rrt_batched1024_benchmark_seed0", cases.cfg2(6000, seed=0), 1024, orc.ALGO_BATCHED_KD
     yield "pto_seq_2_goals_seed0", cases.cfg3(1500, 1500, seed=0), 1, orc.ALGO_SEQ
     yield "pto_batched256_near_goals_seed0", cases.cfg3_near(1500), 64, orc.ALGO_BATCHED_KD
+    # BASELINE.json configs[3] at the size bench.py measures it (main.rs:386-408: map5-like, 12 shelves, visibility 0.2, start
+    # (0, -0.8), max_step 0.05, search_radius 5; 20 000 iterations): digests only, and a prior with 8 of the 12 worlds possible
+    # (255 beliefs: the CPU oracle builds that belief graph in ~20 s; the uniform prior's 4095 beliefs are out of its reach)
+    yield "pto_cfg4_20000_it_255_beliefs", cases.cfg4(20000, 20000), 256, orc.ALGO_BATCHED_KD
+
+
+CFG4_PRIOR = [0.125] * 8 + [0.0] * 4
 
 
 def build(name, case, K, algo):
     o = cases.configure(orc.Oracle(), case)
     cases.grow(o, case, K=K, algo=algo)
     xy, parent, dist = o.tree()
+    if name.startswith("pto_cfg4"):
+        o.build_belief_graph(CFG4_PRIOR)
+        beliefs, types, (coff, cid), (poff, pid) = o.belief_graph()
+        d = o.expected_costs()
+        oid, par, leaf = o.extract_policy(d)
+        return dict(n_nodes=np.int64(len(xy)), node_digest=np.array(digest(xy, o.reach(), o.node_validity(), o.final_ids().astype(np.uint64))),
+                    n_belief_edges=np.int64(len(cid)), belief_digest=np.array(digest(beliefs, types, coff, cid, poff, pid)),
+                    cost_digest=np.array(digest(d)), root_cost_bits=np.array([d[0]]).view(np.uint64), policy_ids=oid, policy_parents=par,
+                    policy_leaf=leaf.astype(np.uint8), K=np.int64(K), algo=np.int64(algo))
     rec = dict(xy_bits=xy.view(np.uint64), parent=parent.astype(np.int32), dist_bits=dist.view(np.uint64),
                final_ids=o.final_ids().astype(np.uint64), K=np.int64(K), algo=np.int64(algo))
     if case.mode == cases.PTO:
@@ -55,6 +71,9 @@ def build(name, case, K, algo):
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]
     for name, case, K, algo in specs():
+        if only and name not in only:
+            continue
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **build(name, case, K, algo))
         print(name)
