@@ -276,10 +276,13 @@ def main():
                 },
                 "step": {"algorithmic_bytes": step_bytes, "us": step_us, "achieved_GBs": step_bytes / (step_us * 1e-6) / 1e9,
                          "frac": step_bytes / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
-                "fp64_valu": {"algorithmic_flops_per_launch_pair": flops, "achieved_TFLOPs": flops / (step_us * 1e-6) / 1e12,
-                              "peak_TFLOPs": valu_peak, "frac": (flops / (step_us * 1e-6) / 1e12 / valu_peak) if valu_peak else None,
-                              "note": "6 flop per (sample, node) pair and search (brute-force definition of the two searches, SURVEY 8d) over the time of both "
-                                      "step kernels; peak = measured v_fma_f64 rate (tools/valu_peak.hip)"},
+                "fp64_valu": {"brute_force_flops_per_step": flops, "brute_force_equivalent_TFLOPs": flops / (step_us * 1e-6) / 1e12,
+                              "peak_TFLOPs": valu_peak, "ratio_to_peak": (flops / (step_us * 1e-6) / 1e12 / valu_peak) if valu_peak else None,
+                              "note": "SURVEY 8(d)'s FP64 figure: 6 flop per (sample, node) pair and search kind, 12 K N_b per step -- the work of the brute-force "
+                                      "DEFINITION of the two searches -- over the time of both step kernels; peak = measured v_fma_f64 rate "
+                                      "(tools/valu_peak.hip, profiles/r2_valu_peak.txt).  The searches are exact but only visit the region pages a query disc "
+                                      "meets (about 0.3 % of the pairs), so a ratio above 1 says how much of that work is avoided, not how busy the VALUs are "
+                                      "(they are not the bound: DESIGN.md section 6)"},
                 "share_of_device_time": (prof["scan_s"] + prof["connect_s"]) / max(prof["device_s"], 1e-12),
             }
         if not args.no_cpu_baseline and world == 1:

@@ -23,6 +23,12 @@
  * thread-safe (it mirrors `&mut self` of RRT::plan, rrt.rs:88); sampler state
  * persists across porrt_grow calls on one context (the reference reuses one RRT
  * object for many plans, src/map_shelves_tamp_rrt.rs:196-232).
+ *
+ * Limits: states are 2-D (every grid-backed domain of the reference is); at most 64 worlds (one
+ * u64 mask per node; the reference's largest case has 16) and 64 goals; batch_K in 1..4096; rasters
+ * up to 2^32 pixels; iteration counts below 2^31.  Capacities inside (neighbour lists, edge and
+ * deferred-tie pools) grow on demand: the run is replayed from the saved sampler state, results do
+ * not depend on it.
  */
 #ifndef PORRT_HIP_H
 #define PORRT_HIP_H
@@ -119,8 +125,9 @@ int      porrt_get_final_masks(const porrt_ctx *ctx, uint64_t *masks);
  * ascending, and for one new node its neighbours in the order KdTree::nearest_neighbors lists
  * them (kd pre-order, nearest_neighbor.rs:101-117) -- so that adjacency lists rebuilt from it
  * equal the reference's element for element.  The reference also stores each reverse edge with
- * the same validity id (pto.rs:117-120).  The order is restored on the host when the edges are
- * first asked for (a kd-tree over the node coordinates); the growth itself does not need it. */
+ * the same validity id (pto.rs:117-120).  The order is restored on the device when the edges are
+ * first asked for (three sorts by the nodes' kd pre-order ranks, which the host supplies from a
+ * kd-tree over the node coordinates); the growth itself does not need it. */
 int      porrt_get_reach(const porrt_ctx *ctx, uint64_t *masks /* N */);
 int      porrt_get_node_validity(const porrt_ctx *ctx, uint32_t *validity_ids /* N */);
 uint64_t porrt_num_edges(const porrt_ctx *ctx);
