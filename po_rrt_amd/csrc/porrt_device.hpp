@@ -1522,20 +1522,33 @@ __device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vword
     auto gso = as_global(rc.slot_of);
     // the new node's own dist_root goes to its page slot (filed by insert_step_pages beside the connect pass)
     if (lane == 0) gpd[gso[id]] = as_global(rc.distA)[id];
-    for (uint32_t a = lane; a < cnt; a += stride) {
-        const double via = cval[a];
-        if (!(via >= 0.0)) continue;
-        const int j = cid[a];
-        if (f64_bits(via) != f64_bits(gdB[j])) continue;
-        auto gpar = as_global(rc.parent) + j;
-        int old = *gpar;
-        while (old < (int)N || id < old) {      // parents from before this step are always < N
-            int expect = old;
-            if (__hip_atomic_compare_exchange_strong(gpar, &expect, id, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-            old = expect;
+    // four candidates per lane in flight: the list of a sample in a dense neighbourhood has hundreds, and each is a chain of
+    // dependent loads (candidate -> distB[j] -> parent[j])
+    constexpr int U = 4;
+    for (uint32_t a0 = lane; a0 < cnt; a0 += stride * U) {
+        double via[U], dB[U];
+        int j[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t a = a0 + (uint32_t)u * stride;
+            via[u] = a < cnt ? cval[a] : -1.0;
+            j[u] = a < cnt ? cid[a] : 0;
         }
-        as_global(rc.distA)[j] = via;
-        gpd[gso[j]] = via;
+#pragma unroll
+        for (int u = 0; u < U; ++u) dB[u] = via[u] >= 0.0 ? gdB[j[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!(via[u] >= 0.0) || f64_bits(via[u]) != f64_bits(dB[u])) continue;
+            auto gpar = as_global(rc.parent) + j[u];
+            int old = *gpar;
+            while (old < (int)N || id < old) {      // parents from before this step are always < N
+                int expect = old;
+                if (__hip_atomic_compare_exchange_strong(gpar, &expect, id, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                old = expect;
+            }
+            as_global(rc.distA)[j[u]] = via[u];
+            gpd[gso[j[u]]] = via[u];
+        }
     }
 }
 

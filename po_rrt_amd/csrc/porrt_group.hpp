@@ -291,18 +291,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     int nn = -1;
     double fx = 0.0, fy = 0.0;
     bool easy = false;
-    {
+    // ... and within the step's search radius, so that the radius search of k_conn2 finds it too (a sample without any neighbour
+    // needs the nearest node after all)
+    const double lim = 0.7 * rc.max_step, t2b = as_global(rc.t2_at)[b];
+    const double lim2 = lim * lim < t2b ? lim * lim : t2b;
+    for (int l = 0; l < 2 && !easy; ++l) {           // the finest cells; then, for a thin tree, the 3x3 cells of the next level
         int cx, cy;
-        const int G = rep_dim(0);
+        const int G = rep_dim(l);
         rep_cell(rc, sqx, sqy, G, cx, cy);
         int r = -1;
         if (tm.gl < 9u) {
             const int x = cx + (int)(tm.gl % 3u) - 1, y = cy + (int)(tm.gl / 3u) - 1;
-            if (x >= 0 && y >= 0 && x < G && y < G) r = as_global(rc.rep)[rep_off(0) + y * G + x];
+            if (x >= 0 && y >= 0 && x < G && y < G) r = as_global(rc.rep)[rep_off(l) + y * G + x];
         }
-        const double lim = 0.7 * rc.max_step;
         bool near = false;
-        if (r >= 0 && (uint32_t)r < N) near = dist2(as_global(rc.nx)[r], as_global(rc.ny)[r], sqx, sqy) <= lim * lim;
+        if (r >= 0 && (uint32_t)r < N) near = dist2(as_global(rc.nx)[r], as_global(rc.ny)[r], sqx, sqy) <= lim2;
         easy = tm.ballot(near) != 0ull;
     }
     PORRT_TACC_A(rc, 0);

@@ -7,8 +7,9 @@ os.environ["PORRT_DEBUG_STEPS"] = "1"
 os.environ["PORRT_DEBUG"] = "1"
 import cases, po_rrt_amd
 Q = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-opts = [a.split("=") for a in sys.argv[2:]]
-case = cases.cfg2(111500)
+opts = [a.split("=") for a in sys.argv[2:] if not a.startswith("n_iter=")]
+n_iter = [int(a.split("=")[1]) for a in sys.argv[2:] if a.startswith("n_iter=")]
+case = cases.cfg2(n_iter[0] if n_iter else 111500)
 engs = [cases.configure(po_rrt_amd.Engine(0), case) for _ in range(Q)]
 for e in engs:
     for k, v in opts:
