@@ -91,6 +91,7 @@ struct Counters {
     uint32_t n_deferred, pend_lo;
     uint32_t n_losers;          // k_kd_link -> k_kd_claim
     uint32_t kd_snap;           // step up to whose start the kd structure is complete (release-stored by k_kd_claim)
+    uint32_t dbg[4];            // developer statistics (kd claim: max / sum of losers, launches; non-duplicate levels of G)
     uint32_t clone_n;           // valid samples of the running step steered exactly onto the goal point (k_nn2 -> k_conn2)
     uint32_t clone_k[64];
     unsigned long long tim[16]; // developer builds (-DPORRT_TIMING): phase durations summed over waves, 10 ns units, and wave counts
@@ -133,6 +134,8 @@ struct RunConst {
     double bx0, by0, binv_w, binv_h;   // box the pyramid covers
     // region pages (see scan_disc)
     uint32_t *rg_cnt;           // [2][kRegions] nodes per region, by step parity: step b searches [b & 1] while its new nodes are filed into [(b + 1) & 1]
+    unsigned long long *rg_occ; // [2][kOccWords] bit r = region r holds a node (same parity as rg_cnt): the nearest-neighbour search of
+                                // k_nn2 finds the occupied regions of a thin tree without walking the empty ones
     uint32_t *rg_dir;           // [region][j]: j-th page of the region, j >= 1
     double *pg_xy;              // [page][slot] (x, y)
     int *pg_id;                 // [page][slot] node id
@@ -572,6 +575,7 @@ __device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vword
 constexpr int kRG = 40;
 constexpr uint32_t kRegions = kRG * kRG;
 constexpr uint32_t kPage = 64;
+constexpr uint32_t kOccWords = (kRegions + 63u) / 64u;
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t region_of(const RunConst &rc, double x, double y) {
@@ -879,6 +883,14 @@ __device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, u
     }
     __syncthreads();
     for (uint32_t r = threadIdx.x; r < kRegions; r += T) rg_new[r] = rg_old[r] + s_add[r];
+    if (threadIdx.x < kOccWords) {          // (rg_old and s_add are final; a region never empties)
+        unsigned long long w = 0;
+        for (uint32_t i = 0; i < 64u; ++i) {
+            const uint32_t r = threadIdx.x * 64u + i;
+            if (r < kRegions && rg_old[r] + s_add[r] > 0u) w |= 1ull << i;
+        }
+        as_global(rc.rg_occ)[((b + 1u) & 1u) * kOccWords + threadIdx.x] = w;
+    }
     if (threadIdx.x == 0) rc.cnt->n_pages += s_np;
 }
 
@@ -1825,6 +1837,11 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
             mv[r] = rc.kd_losers[todo[r] ? q : 0u];
         }
         __syncthreads();
+        // Losers are few next to the 1024 threads (a few hundred of a group's 2048 nodes): a wave none of whose lanes holds one
+        // has nothing to do in any round and leaves now -- the barriers below count the waves that are still there -- so that
+        // the step kernels running beside this workgroup get its wave slots and registers back.  (Wave 0 holds the first
+        // losers and does the closing part.)
+        if (threadIdx.x >= 64u && !__ballot(todo[0])) return;
         auto settle = [&](KdMove &m, bool &td) {            // after the bids of a round
             const int w = s_ch[m.cur][m.side];
             if (w == (int)m.t) { kd_publish(rc, N, m, (int)(N + (uint32_t)m.cur)); td = false; }
@@ -1973,7 +1990,8 @@ __global__ __launch_bounds__(256) void k_kd_hint(const RunConst *__restrict__ rc
 // wave per record, starting at the first record not yet settled; runs on the kd stream after each k_kd_claim and
 // once more at the end of a run.  The parent is only installed if no rewire replaced the placeholder in the
 // meantime (a rewire is final, rrt.rs:152-161).
-__global__ __launch_bounds__(1024) void k_tie_fix(const RunConst *__restrict__ rcp) {
+template <int T>
+__global__ __launch_bounds__(T) void k_tie_fix(const RunConst *__restrict__ rcp) {
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     uint32_t n = __hip_atomic_load(&rc.cnt->pend_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1982,7 +2000,7 @@ __global__ __launch_bounds__(1024) void k_tie_fix(const RunConst *__restrict__ r
     const uint32_t kd_done = __hip_atomic_load(&rc.cnt->kd_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     Team<1> tm;
     tm.scr_d = nullptr; tm.scr_i = nullptr; tm.wave = 0; tm.lane = lane;
-    for (uint32_t p = lo + wv; p < n; p += 16u) {
+    for (uint32_t p = lo + wv; p < n; p += (uint32_t)(T / 64)) {
         if (__hip_atomic_load(&rc.pend_state[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1u) continue;
         const uint32_t base = as_global(rc.pend_off)[p], m = as_global(rc.pend_n)[p];
         int mx = -1;

@@ -201,7 +201,7 @@ struct porrt_ctx {
     DevBuf<int> d_pendnew, d_pendpool;
     DevBuf<int> d_rep;
     DevBuf<uint32_t> d_kddepth, d_kdgexit;
-    DevBuf<unsigned long long> d_reachA, d_reachB, d_finalmask, d_validmask, d_kdhint;
+    DevBuf<unsigned long long> d_reachA, d_reachB, d_finalmask, d_validmask, d_kdhint, d_rgocc;
     DevBuf<uint8_t> d_vid, d_finalflag, d_cls;
     DevBuf<uint32_t> d_nat, d_sworld, d_candcnt, d_efrom, d_eto, d_etv;
     DevBuf<uint16_t> d_perm, d_bqk;
@@ -309,7 +309,7 @@ int porrt_ctx::layout_buffers() {
                               &d_kdrec, &d_gx, &d_gy, &d_rgdir, &d_rep, &d_kdbox, &d_locbox, &d_kdlosers, &d_gsnap, &d_pendoff, &d_pendn, &d_pendcur,
                               &d_pendnew, &d_pendpool, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB, &d_finalmask, &d_vid, &d_finalflag, &d_cls,
                               &d_nat, &d_sworld, &d_candcnt, &d_efrom, &d_eto, &d_etv, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags,
-                              &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid, &d_bcscratch, &d_bcout, &d_bccursor, &d_perm, &d_pgd, &d_slotof, &d_ssx, &d_ssy, &d_bqx, &d_bqy, &d_t2at, &d_bqk};
+                              &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid, &d_bcscratch, &d_bcout, &d_bccursor, &d_perm, &d_pgd, &d_slotof, &d_ssx, &d_ssy, &d_bqx, &d_bqy, &d_t2at, &d_bqk, &d_rgocc};
         for (DevBufBase *b2 : list) all_bufs.push_back(b2);
     }
     bool grow_needed = false;
@@ -349,7 +349,7 @@ int porrt_ctx::layout_buffers() {
     d_locflags.p = (uint32_t *)d_locflags.vp; d_kdsurv.p = (uint32_t *)d_kdsurv.vp;
     d_gndx.p = (double *)d_gndx.vp; d_gndy.p = (double *)d_gndy.vp;
     d_kqx.p = (double *)d_kqx.vp; d_kqy.p = (double *)d_kqy.vp; d_kqvid.p = (int *)d_kqvid.vp;
-    d_cnt.p = (Counters *)d_cnt.vp; d_rc.p = (RunConst *)d_rc.vp; d_jump.p = (PcgJump *)d_jump.vp; d_perm.p = (uint16_t *)d_perm.vp; d_pgd.p = (double *)d_pgd.vp; d_slotof.p = (uint32_t *)d_slotof.vp; d_ssx.p = (double *)d_ssx.vp; d_ssy.p = (double *)d_ssy.vp; d_bqx.p = (double *)d_bqx.vp; d_bqy.p = (double *)d_bqy.vp; d_t2at.p = (double *)d_t2at.vp; d_bqk.p = (uint16_t *)d_bqk.vp;
+    d_cnt.p = (Counters *)d_cnt.vp; d_rc.p = (RunConst *)d_rc.vp; d_jump.p = (PcgJump *)d_jump.vp; d_perm.p = (uint16_t *)d_perm.vp; d_pgd.p = (double *)d_pgd.vp; d_slotof.p = (uint32_t *)d_slotof.vp; d_ssx.p = (double *)d_ssx.vp; d_ssy.p = (double *)d_ssy.vp; d_bqx.p = (double *)d_bqx.vp; d_bqy.p = (double *)d_bqy.vp; d_t2at.p = (double *)d_t2at.vp; d_bqk.p = (uint16_t *)d_bqk.vp; d_rgocc.p = (unsigned long long *)d_rgocc.vp;
     // cached uploads are gone
     rad_uploaded = 0;
     cls_dirty = true;
@@ -468,6 +468,7 @@ __global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y
         rc.pg_d[(size_t)r * kPage] = 0.0;
         rc.slot_of[0] = r * kPage;
         rc.rg_cnt[r] = 1;
+        for (uint32_t w = 0; w < kOccWords; ++w) rc.rg_occ[w] = w == r / 64u ? 1ull << (r % 64u) : 0ull;
     }
     rc.g_id[0] = 0;          // the root is on every kd descent path
     rc.cnt->g_len = 1;
@@ -574,7 +575,8 @@ void porrt_ctx::launch_kd_group() {
     hipLaunchKernelGGL(k_kd_hint, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords);
     (void)hipEventRecord(ev_step_done, stream);
     (void)hipStreamWaitEvent(stream2, ev_step_done, 0);
-    hipLaunchKernelGGL(k_tie_fix, dim3(1, Q), dim3(1024), 0, stream2, rcp);
+    if (Q > 1) hipLaunchKernelGGL(k_tie_fix<256>, dim3(1, Q), dim3(256), 0, stream2, rcp);
+    else hipLaunchKernelGGL(k_tie_fix<1024>, dim3(1, Q), dim3(1024), 0, stream2, rcp);
     // A lagging join: the main stream waits for the group BEFORE this one, which had a whole group of steps to finish.
     // It bounds how far the kd structure may fall behind and keeps a replayed hipGraph from running the side branch last.
     const uint32_t par = kd_gidx & 1u;
@@ -615,7 +617,8 @@ void porrt_ctx::join_side() {
     (void)hipEventRecord(ev_join, stream2);
     (void)hipStreamWaitEvent(stream, ev_join, 0);
     kd_pend[0] = kd_pend[1] = false;
-    hipLaunchKernelGGL(k_tie_fix, dim3(1, launch_Q), dim3(1024), 0, stream, launch_rcp);
+    if (launch_Q > 1) hipLaunchKernelGGL(k_tie_fix<256>, dim3(1, launch_Q), dim3(256), 0, stream, launch_rcp);
+    else hipLaunchKernelGGL(k_tie_fix<1024>, dim3(1, launch_Q), dim3(1024), 0, stream, launch_rcp);
     side_active = false;
 }
 
@@ -683,7 +686,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(d_qx.reserve(K)); HIPCHK(d_qy.reserve(K)); HIPCHK(d_qnn.reserve(K)); HIPCHK(d_qvid.reserve(K));
         // region pages: one static page per region + a pool that cannot run out (sum of ceil(n_r / 64) <= N / 64 + regions)
         const uint64_t rg_maxp = Nmax / kPage + 2, pg_cap = 2ull * kRegions + Nmax / kPage + 8;
-        HIPCHK(d_rgcnt.reserve(2 * kRegions)); HIPCHK(d_rgdir.reserve((size_t)kRegions * rg_maxp));
+        HIPCHK(d_rgcnt.reserve(2 * kRegions)); HIPCHK(d_rgocc.reserve(2 * kOccWords)); HIPCHK(d_rgdir.reserve((size_t)kRegions * rg_maxp));
         HIPCHK(d_pgxy.reserve(2 * (size_t)pg_cap * kPage)); HIPCHK(d_pgid.reserve((size_t)pg_cap * kPage)); HIPCHK(d_pgd.reserve((size_t)pg_cap * kPage)); HIPCHK(d_slotof.reserve(Nmax));
         HIPCHK(d_candcnt.reserve(2 * (size_t)K)); HIPCHK(d_kdbox.reserve(Nmax)); HIPCHK(d_kdlosers.reserve(kClaimMax)); HIPCHK(d_bcscratch.reserve(8 * Nmax + 4096)); HIPCHK(d_bcout.reserve(1)); HIPCHK(d_bccursor.reserve(1)); HIPCHK(d_locbox.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_kdhint.reserve((size_t)kHG * kHG));
         HIPCHK(d_loccur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locdcur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locgex.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locflags.reserve(2 * (8 * (size_t)K + 4096)));
@@ -724,7 +727,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.inj_xy = (has_inj && !host_samples) ? d_inj.p : nullptr;
     c.inj_base = inj_pos; c.inj_n = inj_xy.size() / 2;
     c.q_x = d_qx.p; c.q_y = d_qy.p; c.q_nn = d_qnn.p; c.q_vid = d_qvid.p;
-    c.rg_cnt = d_rgcnt.p; c.rg_dir = d_rgdir.p; c.pg_xy = d_pgxy.p; c.pg_id = d_pgid.p; c.pg_d = d_pgd.p; c.slot_of = d_slotof.p;
+    c.rg_cnt = d_rgcnt.p; c.rg_occ = d_rgocc.p; c.rg_dir = d_rgdir.p; c.pg_xy = d_pgxy.p; c.pg_id = d_pgid.p; c.pg_d = d_pgd.p; c.slot_of = d_slotof.p;
     c.rg_maxp = (uint32_t)(Nmax / kPage + 2); c.pg_cap = (uint32_t)(2ull * kRegions + Nmax / kPage + 8);
     c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p; c.kd_box = d_kdbox.p; c.loc_box = d_locbox.p; c.kd_losers = d_kdlosers.p; c.bc_scratch = d_bcscratch.p; c.bc_cap = (uint32_t)std::min<size_t>(d_bcscratch.n, 0xFFFFFFFFu); c.bc_cursor = d_bccursor.p; c.bc_out = d_bcout.p; c.kd_hint = d_kdhint.p; c.g_snap = d_gsnap.p; c.loc_stride = 8 * K + 4096;
     c.pend_new = d_pendnew.p; c.pend_pool = d_pendpool.p; c.pend_off = d_pendoff.p; c.pend_n = d_pendn.p; c.pend_cur = d_pendcur.p; c.pend_state = d_pendstate.p;
@@ -1703,7 +1706,8 @@ int porrt_ctx::finish_batch_member(uint64_t n_iter_done, uint32_t steps, float d
     if (hc.err & ERR_RNG_RETRY) { set_err("a float draw would have been redrawn: grow this context on its own"); return PORRT_ERR_INVALID; }
     counters = hc;
     if (getenv("PORRT_DEBUG") && batch_slot == 0) {
-        fprintf(stderr, "[porrt] batch member 0: samples served through the lists in memory %u\n", hc.n_heavy);
+        fprintf(stderr, "[porrt] batch member 0: samples served through the lists in memory %u; kd claim losers max %u mean %.1f over %u launches; g_nd %u; deferred ties %u (pooled ids %u)\n",
+                hc.n_heavy, hc.dbg[0], hc.dbg[2] ? (double)hc.dbg[1] / hc.dbg[2] : 0.0, hc.dbg[2], hc.dbg[3], hc.pend_cnt, hc.pool_n);
         for (int t = 0; t < 8; ++t)
             if (hc.tim[t + 8]) fprintf(stderr, "[porrt] phase %d: %.2f us per wave over %llu waves (total %.1f wave-ms)\n", t, 1e-2 * (double)hc.tim[t] / (double)hc.tim[t + 8],
                                        (unsigned long long)hc.tim[t + 8], 1e-5 * (double)hc.tim[t]);

@@ -212,17 +212,65 @@ __device__ __forceinline__ double nn_bound_group(const RunConst &rc, const GTeam
     return m;
 }
 
+// one region's pages for a group: visit(x, y, id, ok) for its `cnt` nodes
+template <int GL, class Visit>
+__device__ __forceinline__ void gscan_region(const RunConst &rc, const GTeam<GL> &tm, uint32_t reg, uint32_t cnt, Visit visit) {
+    auto gdir = as_global(rc.rg_dir);
+    auto gxy = as_global(reinterpret_cast<const dbl2 *>(rc.pg_xy));
+    auto gid = as_global(rc.pg_id);
+    constexpr int U = (int)kPage / GL;
+    uint32_t page = reg;
+    for (uint32_t s0 = 0; s0 < cnt; s0 += kPage) {
+        const uint32_t pc = cnt - s0 < kPage ? cnt - s0 : kPage;
+        uint32_t page_next = 0;
+        if (cnt - s0 > kPage) page_next = gdir[(size_t)reg * rc.rg_maxp + s0 / kPage + 1u];      // fetched beside the slots of this page
+        dbl2 v[U];
+        int id[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t sl = (uint32_t)(u * GL) + tm.gl;
+            const bool ld = sl < pc;
+            v[u] = ld ? gxy[(size_t)page * kPage + sl] : dbl2{0.0, 0.0};
+            id[u] = ld ? gid[(size_t)page * kPage + sl] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if ((uint32_t)(u * GL) < pc) visit(v[u].x, v[u].y, id[u], (uint32_t)(u * GL) + tm.gl < pc);
+        page = page_next;
+    }
+}
+
+// squared distance from q to the part of the plane region (cx, cy) takes its nodes from (rep_cell: border regions reach to
+// infinity), shrunk by a margin that covers the roundings of the cell function: a lower bound for every node of the region
+__device__ __forceinline__ double region_gap2(const RunConst &rc, double qx, double qy, int cx, int cy) {
+    const double wx = 1.0 / (rc.binv_w * (double)kRG), wy = 1.0 / (rc.binv_h * (double)kRG);
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    const double xlo = cx == 0 ? -INF : rc.bx0 + (double)cx * wx, xhi = cx == kRG - 1 ? INF : rc.bx0 + (double)(cx + 1) * wx;
+    const double ylo = cy == 0 ? -INF : rc.by0 + (double)cy * wy, yhi = cy == kRG - 1 ? INF : rc.by0 + (double)(cy + 1) * wy;
+    double gx = qx < xlo ? xlo - qx : (qx > xhi ? qx - xhi : 0.0), gy = qy < ylo ? ylo - qy : (qy > yhi ? qy - yhi : 0.0);
+    const double eps = 1e-9 * (1.0 + fabs(qx) + fabs(qy));
+    gx = gx > eps ? gx - eps : 0.0;
+    gy = gy > eps ? gy - eps : 0.0;
+    return gx * gx + gy * gy;
+}
+
 // KdTree::nearest_neighbor (nearest_neighbor.rs:48-92) for a group: the exact minimum of (norm2, id) over the region pages.
+// Regions are taken nearest first (by the distance from the sample to the region's rectangle) and the walk ends when the
+// next one cannot hold a node as near as the best so far.  Stage A: the 4 x 4 block of regions around the sample, one
+// lane each (their counts are one load); it settles the search whenever the best node is nearer than the block's border --
+// always, once the tree covers the map.  Stage B (a thin tree, or a sample far from it): the occupied regions of the whole
+// grid from the occupancy bitmap, 128 regions per lane.
 template <int GL>
 __device__ __forceinline__ void group_nn(const RunConst &rc, uint32_t b, const GTeam<GL> &tm, uint32_t N, double sqx, double sqy, int &nn, double &fx,
                                          double &fy) {
+    static_assert(GL >= 16, "a 4 x 4 block of regions, one lane each");
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
     double bestD = INF, bestx = 0.0, besty = 0.0;
     int best = 0x7FFFFFFF;
     // thr: no node with d2 above it can win or tie (sqrt is monotone; the factor keeps rounded ties in), so the
     // sqrt -- the expensive part -- is only taken for the few nodes that may improve the lane's best
     double thr = INF;
-    auto visit = [&](double x, double y, double, int id, bool ok) {
+    auto visit = [&](double x, double y, int id, bool ok) {
         if (!ok) return;
         const double d2 = dist2(x, y, sqx, sqy);
         if (d2 > thr) return;
@@ -240,16 +288,85 @@ __device__ __forceinline__ void group_nn(const RunConst &rc, uint32_t b, const G
         bestx = tm.shfl(bestx, src); besty = tm.shfl(besty, src);
         bestD = rd; best = ri;
     };
-    // the sample's own region first: the nearest node is almost always there, and its distance bounds the disc the
-    // remaining regions are taken from; only when the region is empty does the bound come from the pyramid
-    const uint32_t own = region_of(rc, sqx, sqy);
-    gscan_disc<GL, 1, false>(rc, b, tm, sqx, sqy, 0.0, N, visit);
-    group_best();
-    double m2;
-    if (best != 0x7FFFFFFF) m2 = thr;                        // d2(best) * (1 + 1e-15)
-    else { m2 = nn_bound_group<GL>(rc, tm, N, sqx, sqy); thr = m2 * (1.0 + 1e-9); }
-    gscan_disc<GL, 2, false>(rc, b, tm, sqx, sqy, disc_radius(m2, sqx, sqy), N, visit, own);
-    group_best();
+    auto gcnt = as_global(rc.rg_cnt) + (b & 1u) * kRegions;
+    int rx, ry;
+    rep_cell(rc, sqx, sqy, kRG, rx, ry);
+    // ---- stage A: the block [bx0, bx0 + 4) x [by0, by0 + 4) with the sample's region in its middle half
+    const double fcx = (sqx - rc.bx0) * rc.binv_w * (double)kRG - (double)rx, fcy = (sqy - rc.by0) * rc.binv_h * (double)kRG - (double)ry;
+    int ax0 = rx - (fcx < 0.5 ? 2 : 1), ay0 = ry - (fcy < 0.5 ? 2 : 1);
+    ax0 = ax0 < 0 ? 0 : (ax0 > kRG - 4 ? kRG - 4 : ax0);
+    ay0 = ay0 < 0 ? 0 : (ay0 > kRG - 4 ? kRG - 4 : ay0);
+    {
+        const int cx = ax0 + (int)(tm.gl & 3u), cy = ay0 + (int)((tm.gl >> 2) & 3u);
+        const uint32_t reg = (uint32_t)(cy * kRG + cx);
+        uint32_t cnt = tm.gl < 16u ? gcnt[reg] : 0u;
+        double gap = cnt ? region_gap2(rc, sqx, sqy, cx, cy) : INF;
+        for (;;) {
+            double g = gap;
+            int who = (int)tm.gl;
+            tm.argmin(g, who);
+            if (!(g <= thr) || g == INF) break;              // nothing left in the block that could hold a node as near
+            gscan_region<GL>(rc, tm, tm.shfl(reg, who), tm.shfl(cnt, who), visit);
+            group_best();
+            if ((int)tm.gl == who) gap = INF;
+        }
+    }
+    // settled if no node outside the block can be as near: the gap to the block's complement (border regions reach to infinity)
+    {
+        const double wx = 1.0 / (rc.binv_w * (double)kRG), wy = 1.0 / (rc.binv_h * (double)kRG);
+        const double eps = 1e-9 * (1.0 + fabs(sqx) + fabs(sqy));
+        double out = INF;
+        if (ax0 > 0) { const double d = sqx - (rc.bx0 + (double)ax0 * wx) - eps; out = d < out ? d : out; }
+        if (ax0 + 4 < kRG) { const double d = (rc.bx0 + (double)(ax0 + 4) * wx) - sqx - eps; out = d < out ? d : out; }
+        if (ay0 > 0) { const double d = sqy - (rc.by0 + (double)ay0 * wy) - eps; out = d < out ? d : out; }
+        if (ay0 + 4 < kRG) { const double d = (rc.by0 + (double)(ay0 + 4) * wy) - sqy - eps; out = d < out ? d : out; }
+        out = out > 0.0 ? out : 0.0;
+        if (out * out > thr) { nn = best; fx = bestx; fy = besty; return; }
+    }
+    // ---- stage B: every occupied region outside the block, from the bitmap (lane l: words l and l + GL)
+    auto gocc = as_global(rc.rg_occ) + (b & 1u) * kOccWords;
+    unsigned long long w[(kOccWords + GL - 1) / GL];
+#pragma unroll
+    for (uint32_t q = 0; q < (kOccWords + GL - 1) / GL; ++q) {
+        const uint32_t wi = tm.gl + q * (uint32_t)GL;
+        w[q] = wi < kOccWords ? gocc[wi] : 0ull;
+        // (the block's regions are done)
+        for (unsigned long long m = w[q]; m;) {
+            const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            const int r = (int)(wi * 64u + bit), cx = r % kRG, cy = r / kRG;
+            if (cx >= ax0 && cx < ax0 + 4 && cy >= ay0 && cy < ay0 + 4) w[q] &= ~(1ull << bit);
+        }
+    }
+    for (;;) {
+        // this lane's nearest pending region
+        double gap = INF;
+        int mine = -1;
+#pragma unroll
+        for (uint32_t q = 0; q < (kOccWords + GL - 1) / GL; ++q) {
+            const uint32_t wi = tm.gl + q * (uint32_t)GL;
+            for (unsigned long long m = w[q]; m;) {
+                const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                const int r = (int)(wi * 64u + bit);
+                const double g = region_gap2(rc, sqx, sqy, r % kRG, r / kRG);
+                if (!(g <= thr)) { w[q] &= ~(1ull << bit); continue; }       // can never matter again: thr only shrinks
+                if (g < gap) { gap = g; mine = r; }
+            }
+        }
+        double g = gap;
+        int who = (int)tm.gl;
+        tm.argmin(g, who);
+        if (!(g <= thr) || g == INF) break;
+        const uint32_t reg = (uint32_t)tm.shfl(mine, who);
+        gscan_region<GL>(rc, tm, reg, gcnt[reg], visit);
+        group_best();
+        if ((int)tm.gl == who) {
+            const uint32_t wi = reg / 64u, q = (wi - tm.gl) / (uint32_t)GL;
+#pragma unroll
+            for (uint32_t qq = 0; qq < (kOccWords + GL - 1) / GL; ++qq) if (qq == q) w[qq] &= ~(1ull << (reg % 64u));
+        }
+    }
     nn = best; fx = bestx; fy = besty;
     if (best == 0x7FFFFFFF) { nn = 0; fx = as_global(rc.nx)[0]; fy = as_global(rc.ny)[0]; }   // (cannot happen without a filter: the root exists)
 }
@@ -257,7 +374,7 @@ __device__ __forceinline__ void group_nn(const RunConst &rc, uint32_t b, const G
 // RRT* step, first kernel: GL lanes per sample.  grid.x = ceil(nb / SPB) search workgroups + ceil(cnb / SPB) workgroups
 // running the rewire phase 2 of step cb (commit_rrt_sample), SPB = 256 / GL samples per workgroup.
 template <int GL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_nn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, uint32_t cb,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_nn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, uint32_t cb,
                                              uint32_t cnb) {
     static_assert(GL == 16 || GL == 32 || GL == 64, "group size");
     constexpr uint32_t SPB = 256u / GL;
