@@ -91,6 +91,14 @@ def main():
         for ov in args.opt:
             e.set_option(ov.split("=")[0], int(ov.split("=")[1]))
     starts = [case.start] * Q
+    # porrt_grow_batch advances the Q queries as G launch sequences side by side (option batch_streams: 2 from 32 queries on);
+    # one kernel launch serves the Q_launch queries of one of them
+    G = 0
+    for ov in args.opt:
+        if ov.split("=")[0] == "batch_streams":
+            G = int(ov.split("=")[1])
+    G = min(G if G else (2 if Q >= 32 else 1), Q)
+    Q_launch = Q // G
 
     def run_step(s):
         """one step = Q queries; query ids (= RNG seeds) are unique over steps, ranks and slots"""
@@ -163,7 +171,8 @@ def main():
     if rank == 0 and not args.no_profile:
         eng.set_option("profile", 1)
         for s in range(args.profile_steps):
-            prof["nodes"] += run_step(s)
+            run_step(s)
+            prof["nodes"] += sum(e.num_nodes() - 1 for e in engs[:Q_launch])      # eng leads the first launch sequence: its metrics cover these
             m = eng.metrics()
             for k in ("scan_s", "scan_pairs", "scan_bytes", "device_s", "connect_s"):
                 prof[k] += m[k]
@@ -206,6 +215,7 @@ def main():
                 "winner_rank": winner,
                 "winner_nodes": win_nodes,
                 "loop_s_rank0": t_loop,
+                "launch_sequences": G,
                 "launch": "hipGraph replay of all steps (main stream: search, connect; side stream: kd tie-order structure, never waited for)",
             },
         }
@@ -216,11 +226,11 @@ def main():
             # A step is two kernels: k_nn2 (nearest neighbour, steer, validity) takes the 16 N_b + 36 K, k_conn2 (radius search,
             # raycasts, best parent, commit) the 8 N_b + W H + 28 K_valid -- it reads the coordinates a second time (the radius
             # search runs around the steered state), which is real traffic, not algorithmic bytes.  All figures per launch =
-            # summed over the Q queries of the step, N_b averaged over the run's steps.
+            # summed over the Q_launch queries of a launch, N_b averaged over the run's steps.
             grid_bytes = 200.0 * 200.0
-            n_sum = prof["scan_pairs"] / (2.0 * args.batch * L)          # sum over the Q queries of N_b
-            nn_bytes = 16.0 * n_sum + 36.0 * args.batch * Q
-            conn_bytes = 8.0 * n_sum + Q * grid_bytes + 28.0 * prof["nodes"] / L
+            n_sum = prof["scan_pairs"] / (2.0 * args.batch * L)          # sum over the launch's queries of N_b
+            nn_bytes = 16.0 * n_sum + 36.0 * args.batch * Q_launch
+            conn_bytes = 8.0 * n_sum + Q_launch * grid_bytes + 28.0 * prof["nodes"] / L
             nn_us, conn_us = 1e6 * prof["scan_s"] / L, 1e6 * prof["connect_s"] / L
             pm, pm_src = {}, None
             for cand in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):      # HBM traffic per launch from the committed rocprofv3 --pmc passes
@@ -264,9 +274,11 @@ def main():
                                 "the raw figure may be the truer one) + WRITE_SIZE, separate --pmc passes of the same command; not measured in this run",
                 "avg_launch_us": dom_us,
                 "launches": L,
+                "queries_per_launch": Q_launch,
+                "launch_sequences_side_by_side": G,
                 "algorithmic_bytes_per_launch": dom_bytes,
-                "formula": "SURVEY 8(d): k_nn2 16 N_b + 36 K, k_conn2 8 N_b + W H + 28 K_valid, per query, summed over the Q queries of a launch",
-                "note": "One launch serves the Q queries of the step.  The step kernels are bound by dependent-load latency at the occupancy their "
+                "formula": "SURVEY 8(d): k_nn2 16 N_b + 36 K, k_conn2 8 N_b + W H + 28 K_valid, per query, summed over the queries of a launch",
+                "note": "One launch serves Q / G queries of the step; the G launch sequences run side by side (avg_launch_us is measured under that overlap, on the first one's stream).  The step kernels are bound by dependent-load latency at the occupancy their "
                         "registers and LDS allow, not by bandwidth: the searches touch only the region pages a query disc meets.",
                 "kernels": {
                     "k_nn2": {"avg_launch_us": nn_us, "algorithmic_bytes_per_launch": nn_bytes, "achieved_GBs": nn_bytes / (nn_us * 1e-6) / 1e9,

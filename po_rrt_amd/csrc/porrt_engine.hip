@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <limits>
 #include <memory>
 #include <vector>
@@ -181,6 +182,10 @@ struct porrt_ctx {
     // step -- latency).  -1 (default): by the number of queries advanced together, 16 from 8 queries on, else 0.
     int opt_group_req = -1;
     uint32_t opt_group = 0;        // the choice in force for the running launch sequence
+    // "batch_streams": porrt_grow_batch advances its contexts as this many sub-batches side by side, each a launch sequence
+    // (hipGraph) of its own on its own streams, so that one sub-batch's kernel tails and its kd side chain are filled by the
+    // other's kernels.  0 (default): 2 from 32 contexts on, else 1.
+    uint32_t opt_batch_streams = 0;
     bool opt_dp_sweeps = false;            // "dp_sweeps": expected costs by whole-graph sweeps instead of layer by layer
     uint32_t opt_cand_cap = 2048;
     uint64_t edge_per_node = 256, tie_pool_mult = 16;      // pool sizes: grown and the run replayed when one overflows (as the neighbour lists)
@@ -2092,7 +2097,30 @@ int porrt_grow(porrt_ctx *c, const double start[2], double max_step, double sear
 int porrt_grow_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, const double *starts, double max_step, double search_radius, uint64_t n_iter,
                      uint32_t batch_K, int mode) {
     if (!ctxs || !n_ctx || !starts || !ctxs[0]) return PORRT_ERR_INVALID;
-    return grow_batch(ctxs, n_ctx, starts, max_step, search_radius, n_iter, batch_K, mode);
+    for (uint32_t q = 0; q < n_ctx; ++q) if (!ctxs[q]) return PORRT_ERR_INVALID;
+    uint32_t G = ctxs[0]->opt_batch_streams ? ctxs[0]->opt_batch_streams : (n_ctx >= 32 ? 2u : 1u);
+    G = std::min(G, n_ctx);
+    if (G <= 1) return grow_batch(ctxs, n_ctx, starts, max_step, search_radius, n_iter, batch_K, mode);
+    for (uint32_t q = 0; q < n_ctx; ++q)          // checked here for the whole call: the sub-batches only see their own members
+        for (uint32_t r = 0; r < q; ++r) if (ctxs[r] == ctxs[q]) { ctxs[0]->set_err("porrt_grow_batch: a context appears twice"); return PORRT_ERR_INVALID; }
+    // contiguous runs of the argument, led by their first member; every run is a complete porrt_grow_batch of its own (its own
+    // streams, hipGraph, results), driven from a host thread of its own so that the launch sequences are fed side by side
+    std::vector<int> rcs(G, PORRT_OK);
+    std::vector<uint32_t> lo(G + 1);
+    for (uint32_t g = 0; g <= G; ++g) lo[g] = (uint32_t)((uint64_t)n_ctx * g / G);
+    auto part = [&](uint32_t g) { rcs[g] = grow_batch(ctxs + lo[g], lo[g + 1] - lo[g], starts + 2 * (size_t)lo[g], max_step, search_radius, n_iter, batch_K, mode); };
+    {
+        std::vector<std::thread> th;
+        for (uint32_t g = 1; g < G; ++g) th.emplace_back(part, g);
+        part(0);
+        for (auto &t : th) t.join();
+    }
+    int worst = PORRT_OK;
+    for (uint32_t g = 0; g < G; ++g) {
+        if (rcs[g] < 0) { if (g) ctxs[0]->set_err(ctxs[lo[g]]->err); return rcs[g]; }
+        worst = std::max(worst, rcs[g]);
+    }
+    return worst;
 }
 
 uint64_t porrt_num_nodes(const porrt_ctx *c) { return c && c->have_results ? c->n_nodes : 0; }
@@ -2228,22 +2256,33 @@ int porrt_best_cost(const porrt_ctx *cc, double *cost, uint64_t *final_id) {
 // costs[q] = +inf where a member has no solution.  Members of different batches (or none) are evaluated one by one.
 int porrt_best_cost_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, double *costs) {
     if (!ctxs || !n_ctx || !costs) return PORRT_ERR_INVALID;
-    porrt_ctx *L = ctxs[0] ? ctxs[0]->batch_leader : nullptr;
-    bool together = L != nullptr && L->batch_size == n_ctx;
-    for (uint32_t q = 0; q < n_ctx && together; ++q)
-        together = ctxs[q] && ctxs[q]->have_results && ctxs[q]->batch_leader == L && ctxs[q]->batch_slot == q && ctxs[q]->n_steps == L->n_steps &&
-                   ctxs[q]->batch_gen == L->batch_gen_counter;        // the leader's LAST batch: its RunConst array holds these members
+    for (uint32_t q = 0; q < n_ctx; ++q) if (!ctxs[q]) return PORRT_ERR_INVALID;
     const double inf = std::numeric_limits<double>::infinity();
-    if (together) {
+    // runs of the argument that are exactly some leader's last batch, in its order (porrt_grow_batch leaves one such run per
+    // sub-batch): one launch per run, all of them in flight before the first wait
+    std::vector<char> together(n_ctx, 0);
+    std::vector<porrt_ctx *> launched;
+    for (uint32_t q0 = 0; q0 < n_ctx;) {
+        porrt_ctx *L = ctxs[q0]->batch_leader;
+        const uint32_t m = L ? L->batch_size : 0;
+        bool run = L != nullptr && m > 0 && q0 + m <= n_ctx;
+        for (uint32_t r = 0; r < m && run; ++r) {
+            const porrt_ctx *c = ctxs[q0 + r];
+            run = c->have_results && c->batch_leader == L && c->batch_slot == r && c->n_steps == L->n_steps &&
+                  c->batch_gen == L->batch_gen_counter;        // the leader's LAST batch: its RunConst array holds these members
+        }
+        if (!run) { ++q0; continue; }
         if (hipSetDevice(L->device) != hipSuccess) return PORRT_ERR_DEVICE;
-        for (uint32_t q = 0; q < n_ctx; ++q) (void)hipMemsetAsync(ctxs[q]->d_bccursor.p, 0, sizeof(uint32_t), L->stream);
-        hipLaunchKernelGGL(k_best_cost, dim3(1, n_ctx), dim3(1024), 0, L->stream, (const RunConst *)L->d_rcarr, (uint32_t)L->n_steps);
-        if (hipStreamSynchronize(L->stream) != hipSuccess) return PORRT_ERR_DEVICE;
+        for (uint32_t r = 0; r < m; ++r) (void)hipMemsetAsync(ctxs[q0 + r]->d_bccursor.p, 0, sizeof(uint32_t), L->stream);
+        hipLaunchKernelGGL(k_best_cost, dim3(1, m), dim3(1024), 0, L->stream, (const RunConst *)L->d_rcarr, (uint32_t)L->n_steps);
+        launched.push_back(L);
+        for (uint32_t r = 0; r < m; ++r) together[q0 + r] = 1;
+        q0 += m;
     }
+    for (porrt_ctx *L : launched) if (hipStreamSynchronize(L->stream) != hipSuccess) return PORRT_ERR_DEVICE;
     for (uint32_t q = 0; q < n_ctx; ++q) {
-        if (!ctxs[q]) return PORRT_ERR_INVALID;
         double c = inf;
-        int r = together ? ctxs[q]->read_best_cost(&c, nullptr) : -1;
+        int r = together[q] ? ctxs[q]->read_best_cost(&c, nullptr) : -1;
         if (r == -1) r = porrt_best_cost(ctxs[q], &c, nullptr);
         if (r < 0) return r;
         costs[q] = r ? c : inf;
@@ -2501,6 +2540,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "graph")) c->opt_graph = value != 0;
     else if (!strcmp(name, "group_lanes")) { if (value != -1 && value != 0 && value != 16 && value != 32 && value != 64) { c->set_err("group_lanes: -1 (auto), 0, 16, 32 or 64"); return PORRT_ERR_INVALID; } c->opt_group_req = (int)value; }
     else if (!strcmp(name, "dp_sweeps")) c->opt_dp_sweeps = value != 0;
+    else if (!strcmp(name, "batch_streams")) c->opt_batch_streams = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else if (!strcmp(name, "kd_group")) c->opt_kd_group = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else { c->set_err(std::string("unknown option ") + name); return PORRT_ERR_INVALID; }
     return PORRT_OK;

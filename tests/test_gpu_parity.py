@@ -234,6 +234,30 @@ def test_grow_batch_of_eight_uses_the_group_kernels(eng_mod):
             assert_same(e, o)
 
 
+def test_grow_batch_in_sub_batches(eng_mod):
+    """batch_streams: the contexts advance as several launch sequences side by side (host thread, streams and hipGraph per
+    sub-batch); nothing in a tree may depend on it, and porrt_best_cost_batch serves the sub-batches' members run by run."""
+    cs = [cases.cfg2(9000, seed=s, grid="map_benchmark_like_%s" % "abcdefghi"[s % 9]) for s in range(7)]
+    ref = []
+    for c in cs:
+        o = cases.configure(orc.Oracle(), c)
+        cases.grow(o, c, K=1024, algo=orc.ALGO_BATCHED_KD)
+        ref.append(o)
+    for streams in (2, 3, 8):
+        engs = [cases.configure(eng_mod.Engine(), c) for c in cs]
+        engs[0].set_option("batch_streams", streams)
+        engs[0].set_option("group_lanes", 16)
+        for rep in range(2):
+            for j, e in enumerate(engs):
+                e.set_sampler((-1.0, -1.0), (1.0, 1.0), cs[j].seed)
+            eng_mod.Engine.grow_batch(engs, [c.start for c in cs], cs[0].max_step, cs[0].search_radius, cs[0].n_iter_min, 1024)
+            costs = eng_mod.Engine.best_cost_batch(engs)
+            for e, o, c in zip(engs, ref, costs):
+                assert_same(e, o)
+                sol = o.best_solution()
+                assert (sol is None and np.isinf(c)) or (sol is not None and c == sol[1])
+
+
 def test_grow_batch_pto(eng_mod):
     cs = [cases.cfg3(6000, 6000, seed=s) for s in (0, 1)]
     engs = [cases.configure(eng_mod.Engine(), c) for c in cs]
