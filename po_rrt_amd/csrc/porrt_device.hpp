@@ -1635,15 +1635,20 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     const uint32_t lane = LPN == 64 ? (threadIdx.x & 63u) : 0u;
     const uint32_t wid = LPN == 64 ? blockIdx.x * 4u + (threadIdx.x >> 6) : blockIdx.x * 256u + threadIdx.x;
-    const uint32_t st = wid / K, k = wid - st * K;
-    bool active = st < nsteps && k < (st + 1 == nsteps ? nb_last : K);
+    const uint32_t st = wid / K, ks = wid - st * K;
+    bool active = st < nsteps && ks < (st + 1 == nsteps ? nb_last : K);
     const uint32_t b = b0 + (active ? st : 0u);
+    // the step's samples in the spatial order of k_sort_samples: neighbouring threads descend through the same nodes, so a
+    // wave's loads of a level fall into a few cache lines instead of 64
+    const uint32_t k = active ? (uint32_t)as_global(rc.perm)[(size_t)b * rc.part_stride + ks] : 0u;
     // The new nodes are the valid samples (positions known since k_near), id = n_at[b] + rank in their step.
     const size_t o2 = (size_t)b * rc.part_stride + (active ? k : 0u);
     if (active && as_global(rc.kq_vid)[o2] < 0) active = false;
     const uint32_t bsnap = __hip_atomic_load(&rc.cnt->kd_snap, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t glen0 = as_global(rc.g_snap)[4 * bsnap + 0], n_nd = as_global(rc.g_snap)[4 * bsnap + 1];
-    constexpr uint32_t kNdLds = 1024;
+    // (a goal path has a few dozen non-duplicate levels; the LDS of a side-stream workgroup is LDS the step kernels beside it
+    // cannot have, and their occupancy hangs on it)
+    constexpr uint32_t kNdLds = 128;
     __shared__ double s_ndx[LPN == 1 ? kNdLds : 1], s_ndy[LPN == 1 ? kNdLds : 1];
     __shared__ uint32_t s_ndi[LPN == 1 ? kNdLds : 1];
     if (LPN == 1) {
@@ -1815,19 +1820,23 @@ __global__ __launch_bounds__(256) void k_kd_link(const RunConst *__restrict__ rc
     rc.kd_losers[atomicAdd(&rc.cnt->n_losers, 1u)] = m;
 }
 
+// CAP: the most nodes a launch may hold (the slots in LDS, the losers in registers); the engine takes the smaller form when the
+// group's steps cannot hold more -- beside the step kernels every KB of LDS counts.
+template <uint32_t CAP>
 __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords) {
+    static_assert(CAP % 1024u == 0 && CAP <= kClaimMax, "k_kd_claim: CAP");
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
-    __shared__ int s_ch[kClaimMax][2];
+    __shared__ int s_ch[CAP][2];
     __shared__ uint32_t s_nact;
     __shared__ KdMove s_tail[64];
     const uint32_t N = as_global(rc.n_at)[b0], b = b0 + nsteps - 1u;
     const uint32_t n_new = kd_group_size(rc, b0, nsteps, vwords);
-    if (n_new > kClaimMax) { if (threadIdx.x == 0) atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW); return; }
+    if (n_new > CAP) { if (threadIdx.x == 0) atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW); return; }
     const uint32_t n_l = rc.cnt->n_losers;
     auto grec = as_global(rc.kd_rec);
     if (n_l) {
         for (uint32_t t = threadIdx.x; t < n_new; t += 1024u) { s_ch[t][0] = kEmpty; s_ch[t][1] = kEmpty; }
-        constexpr int kPer = kClaimMax / 1024;
+        constexpr int kPer = CAP / 1024;
         bool todo[kPer];
         KdMove mv[kPer];
 #pragma unroll

@@ -186,6 +186,8 @@ struct porrt_ctx {
     // (hipGraph) of its own on its own streams, so that one sub-batch's kernel tails and its kd side chain are filled by the
     // other's kernels.  0 (default): 2 from 32 contexts on, else 1.
     uint32_t opt_batch_streams = 0;
+    bool sub_eager = false;                        // leader of a sub-batch on measured streams: launch step by step (see porrt_grow_batch)
+    std::vector<hipStream_t> sub_streams;          // first context of such a call: the sub-batches' main streams (see porrt_grow_batch)
     bool opt_dp_sweeps = false;            // "dp_sweeps": expected costs by whole-graph sweeps instead of layer by layer
     uint32_t opt_cand_cap = 2048;
     uint64_t edge_per_node = 256, tie_pool_mult = 16;      // pool sizes: grown and the run replayed when one overflows (as the neighbour lists)
@@ -576,7 +578,8 @@ void porrt_ctx::launch_kd_group() {
     if ((uint64_t)nsteps * K * Q >= 4096u) hipLaunchKernelGGL(k_kd_locate<1>, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u);
     else hipLaunchKernelGGL(k_kd_locate<64>, dim3((nsteps * K * 64 + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u);
     hipLaunchKernelGGL(k_kd_link, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords, 0u);
-    hipLaunchKernelGGL(k_kd_claim, dim3(1, Q), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
+    if ((uint64_t)nsteps * K <= 2048u) hipLaunchKernelGGL(k_kd_claim<2048>, dim3(1, Q), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
+    else hipLaunchKernelGGL(k_kd_claim<kClaimMax>, dim3(1, Q), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
     hipLaunchKernelGGL(k_kd_hint, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords);
     (void)hipEventRecord(ev_step_done, stream);
     (void)hipStreamWaitEvent(stream2, ev_step_done, 0);
@@ -1741,6 +1744,40 @@ int porrt_ctx::finish_batch_member(uint64_t n_iter_done, uint32_t steps, float d
     return PORRT_OK;
 }
 
+// `want` streams of the current device of which any two run their kernels side by side, found by trying: a pair of single-wave
+// kernels that each wait 150 us takes 150 us on two hardware queues and 300 on one.  Fewer than `want` (the caller then keeps
+// its own streams) if 4 * want candidates do not hold such a set.
+__global__ void k_wait_us(uint32_t us) {
+    const unsigned long long t0 = wall_clock64();          // 100 MHz
+    while (wall_clock64() - t0 < 100ull * us) __builtin_amdgcn_s_sleep(8);
+}
+static std::vector<hipStream_t> pick_parallel_streams(uint32_t want) {
+    std::vector<hipStream_t> chosen, rejected;
+    auto pair_s = [](hipStream_t a, hipStream_t b) {
+        (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+        const double t0 = now_s();
+        hipLaunchKernelGGL(k_wait_us, dim3(1), dim3(64), 0, a, 150u);
+        hipLaunchKernelGGL(k_wait_us, dim3(1), dim3(64), 0, b, 150u);
+        (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+        return now_s() - t0;
+    };
+    for (uint32_t tries = 0; chosen.size() < want && tries < 4u * want; ++tries) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+        hipLaunchKernelGGL(k_wait_us, dim3(1), dim3(64), 0, st, 1u);          // first use: the stream gets its queue
+        bool ok = true;
+        for (hipStream_t c : chosen) {
+            const double t = std::min(pair_s(c, st), pair_s(c, st));
+            if (t > 240e-6) { ok = false; break; }
+        }
+        (ok ? chosen : rejected).push_back(st);
+    }
+    for (hipStream_t st : rejected) (void)hipStreamDestroy(st);
+    if (getenv("PORRT_DEBUG")) fprintf(stderr, "[porrt] sub-batch streams: %zu of %u found side by side (%zu candidates shared a queue)\n", chosen.size(), want, rejected.size());
+    if (chosen.size() < want) { for (hipStream_t st : chosen) (void)hipStreamDestroy(st); chosen.clear(); }
+    return chosen;
+}
+
 // porrt_grow_batch: the same growth, with a fixed iteration budget, for several contexts of one device at once.
 // Context 0 leads: every step kernel is launched once with one grid row per context, so the contexts' dependent
 // load chains overlap inside each kernel instead of queueing behind each other.
@@ -1827,7 +1864,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             return cb;
         };
         uint32_t steps = 0;
-        if (L->opt_graph && !prof) {
+        if (L->opt_graph && !prof && !L->sub_eager) {
             const uint64_t key[6] = {(uint64_t)mode, K, n_iter, L->run_lds_bytes, (uint64_t)(uintptr_t)L->launch_rcp, L->kd_group | ((uint64_t)n << 32) | ((uint64_t)L->opt_group << 48)};
             if (!L->graph_exec || memcmp(key, L->graph_key, sizeof key)) {
                 if (L->graph_exec) { (void)hipGraphExecDestroy(L->graph_exec); L->graph_exec = nullptr; }
@@ -1943,6 +1980,7 @@ porrt_ctx *porrt_create(int device) {
 void porrt_destroy(porrt_ctx *c) {
     if (!c) return;
     // a batch leader going away takes its RunConst array with it: its members must not look for it any more
+    for (hipStream_t st : c->sub_streams) (void)hipStreamDestroy(st);
     for (porrt_ctx *m : c->batch_members) if (m && m != c && m->batch_leader == c) m->batch_leader = nullptr;
     if (c->batch_leader && c->batch_leader != c)
         for (porrt_ctx *&m : c->batch_leader->batch_members) if (m == c) m = nullptr;
@@ -2108,7 +2146,27 @@ int porrt_grow_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, const double *start
     std::vector<int> rcs(G, PORRT_OK);
     std::vector<uint32_t> lo(G + 1);
     for (uint32_t g = 0; g <= G; ++g) lo[g] = (uint32_t)((uint64_t)n_ctx * g / G);
-    auto part = [&](uint32_t g) { rcs[g] = grow_batch(ctxs + lo[g], lo[g + 1] - lo[g], starts + 2 * (size_t)lo[g], max_step, search_radius, n_iter, batch_K, mode); };
+    // Each sub-batch needs a main and a side stream that run side by side with the other sub-batches' -- and the runtime spreads
+    // streams over a handful of hardware queues by rules of its own: two streams on one queue take turns (the contexts' own
+    // streams do about every other time: 140 instead of 160 M expansions/s on the bench).  So the streams are chosen by
+    // measurement, once per leading context: pick_parallel_streams.
+    porrt_ctx *top = ctxs[0];
+    if (hipSetDevice(top->device) != hipSuccess) { top->set_err("hipSetDevice"); return PORRT_ERR_DEVICE; }
+    if (top->sub_streams.size() < 2u * G) {
+        for (hipStream_t st : top->sub_streams) (void)hipStreamDestroy(st);
+        top->sub_streams = pick_parallel_streams(2u * G);
+    }
+    const bool have_streams = top->sub_streams.size() >= 2u * G;
+    auto part = [&](uint32_t g) {
+        porrt_ctx *Lg = ctxs[lo[g]];
+        hipStream_t own = Lg->stream, own2 = Lg->stream2;
+        // On these streams the steps are launched one by one: a replayed hipGraph puts its branches on streams of the runtime's
+        // choosing, and two replays side by side then share a queue more often than not (135-141 against 160 M expansions/s);
+        // the launches (~900 per sub-batch) stay ahead of the GPU from a host thread each.
+        if (have_streams) { Lg->stream = top->sub_streams[g]; Lg->stream2 = top->sub_streams[G + g]; Lg->sub_eager = true; }
+        rcs[g] = grow_batch(ctxs + lo[g], lo[g + 1] - lo[g], starts + 2 * (size_t)lo[g], max_step, search_radius, n_iter, batch_K, mode);
+        Lg->stream = own; Lg->stream2 = own2; Lg->sub_eager = false;
+    };
     {
         std::vector<std::thread> th;
         for (uint32_t g = 1; g < G; ++g) th.emplace_back(part, g);
