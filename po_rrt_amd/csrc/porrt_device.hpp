@@ -231,6 +231,16 @@ struct RunConst {
     double *t2_at;              // t2_at[b] = rad_T2[n_at[b]] (RRT*: the step's radius threshold, written with n_at)
     uint32_t tile_R;            // LDS tile half-width in pixels (0 = no tile: read the raster from global)
     uint32_t part_stride;       // sample stride of the arrays double-buffered by step parity
+    // what the preparation of a grow needs, for the kernels that prepare all members of a porrt_grow_batch at once (k_batch_prep,
+    // and k_init_root / k_gen_samples / k_sort_samples with one grid row per member)
+    double start_x, start_y;
+    unsigned long long root_reach;
+    int root_vid;
+    unsigned long long rng_st_lo, rng_st_hi, rng_inc_lo, rng_inc_hi;      // the continuous sampler at the start of the grow
+    struct PcgJump *jump;       // its jump table
+    RunConst *self;             // the context's own copy on the device (kernels launched for it alone read that one)
+    uint32_t *zero0;            // [zero0, zero0 + zero_words): counters, region counts, valid masks, kd hints, deferred-tie states
+    unsigned long long zero_words;
 };
 
 // Pointers read out of RunConst have no known address space, so hipcc emits flat_* accesses and drains both
@@ -455,7 +465,8 @@ __device__ __forceinline__ double gen_range_once(unsigned long long r, double lo
 __global__ void k_gen_samples(const RunConst *__restrict__ rcp, const PcgJump *__restrict__ jt, unsigned long long it0,
                               unsigned long long n, unsigned long long st_lo, unsigned long long st_hi,
                               unsigned long long inc_lo, unsigned long long inc_hi, unsigned long long draws_before) {
-    const RunConst &rc = *rcp;
+    const RunConst &rc = rcp[blockIdx.y];      // one context per grid row; jt == nullptr: table and sampler state from the run constants
+    if (!jt) { jt = rc.jump; st_lo = rc.rng_st_lo; st_hi = rc.rng_st_hi; inc_lo = rc.rng_inc_lo; inc_hi = rc.rng_inc_hi; }
     unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     unsigned long long idx = it0 + t;     // 0-based iteration of this grow call

@@ -453,8 +453,41 @@ __global__ void k_selftest(const double *__restrict__ a, const double *__restric
     out_div[t] = a[t] / b[t];
 }
 
-__global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y, unsigned long long reach, int vid) {
-    const RunConst &rc = *rcp;
+// Members of a porrt_grow_batch are prepared together: one grid row per context, everything taken from the run constants.
+// k_batch_prep clears what a grow starts from (the host's two memsets) and derives the sampler's jump table from its increment
+// (entry i advances the LCG 2^i steps: 64 squarings, one thread); k_init_root / k_gen_samples / k_sort_samples follow with the
+// same rows.  Seven small operations per member become four launches per batch.
+__global__ __launch_bounds__(256) void k_batch_prep(const RunConst *__restrict__ rcp) {
+    const RunConst &rc = rcp[blockIdx.y];
+    const unsigned long long tid = (unsigned long long)blockIdx.x * 256u + threadIdx.x, nth = (unsigned long long)gridDim.x * 256u;
+    {
+        const unsigned long long n4 = rc.zero_words / 4ull;            // zero0 is 16-byte aligned (arena granules)
+        uint4 *z = reinterpret_cast<uint4 *>(rc.zero0);
+        for (unsigned long long i = tid; i < n4; i += nth) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (unsigned long long i = 4ull * n4 + tid; i < rc.zero_words; i += nth) rc.zero0[i] = 0u;
+    }
+    for (unsigned long long i = tid; i < (unsigned long long)kRepTotal; i += nth) rc.rep[i] = -1;
+    if (blockIdx.x == 1u || gridDim.x == 1u) {          // the context's own copy of its run constants (porrt_best_cost and the like)
+        static_assert(sizeof(RunConst) % 8 == 0, "RunConst is copied in 8-byte words");
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&rc);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(rc.self);
+        for (uint32_t i = threadIdx.x; i < sizeof(RunConst) / 8; i += 256u) dst[i] = src[i];
+    }
+    if (tid == 0) {
+        u128 cm = mk128(0x4385DF649FCCF645ull, 0x2360ED051FC65DA4ull), cp = mk128(rc.rng_inc_lo, rc.rng_inc_hi);
+        for (int b = 0; b < 64; ++b) {
+            rc.jump->mult_lo[b] = (unsigned long long)cm; rc.jump->mult_hi[b] = (unsigned long long)(cm >> 64);
+            rc.jump->plus_lo[b] = (unsigned long long)cp; rc.jump->plus_hi[b] = (unsigned long long)(cp >> 64);
+            cp = (cm + 1) * cp;
+            cm *= cm;
+        }
+    }
+}
+
+// from_rc: start and root validity from the run constants of the row (batch) instead of the arguments
+__global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y, unsigned long long reach, int vid, int from_rc) {
+    const RunConst &rc = rcp[blockIdx.y];
+    if (from_rc) { x = rc.start_x; y = rc.start_y; reach = rc.root_reach; vid = rc.root_vid; }
     rc.nx[0] = x;
     rc.ny[0] = y;
     rc.parent[0] = -1;
@@ -814,7 +847,23 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         }
     }
     const Pcg64 crng0 = crng;
-    {
+    // a member of a porrt_grow_batch (RRT*): the leader prepares all members at once on the device (k_batch_prep ...)
+    const bool batch_prep = stage == 1 && mode == PORRT_MODE_RRT && !host_samples;
+    c.start_x = start[0]; c.start_y = start[1]; c.root_reach = root_reach; c.root_vid = root_vid;
+    c.rng_st_lo = (uint64_t)crng0.state; c.rng_st_hi = (uint64_t)(crng0.state >> 64); c.rng_inc_lo = (uint64_t)crng0.inc; c.rng_inc_hi = (uint64_t)(crng0.inc >> 64);
+    c.jump = d_jump.p;
+    c.self = d_rc.p;
+    c.zero0 = (uint32_t *)d_cnt.p;
+    c.zero_words = (uint64_t)(((char *)d_pendstate.p + pend_cap * sizeof(uint32_t)) - (char *)d_cnt.p) / 4;
+    if (batch_prep) {
+        char *z0 = (char *)d_cnt.p;
+        if (!((char *)d_rgcnt.p > z0 && (char *)d_validmask.p > (char *)d_rgcnt.p && (char *)d_kdhint.p > (char *)d_validmask.p &&
+              (char *)d_pendstate.p > (char *)d_kdhint.p) || ((uintptr_t)z0 & 15u)) {
+            set_err("arena layout"); return PORRT_ERR_DEVICE;
+        }
+        jump_valid = true;           // the table the device derives is the one of this increment
+        jump_inc = crng.inc;
+    } else {
         double t0 = now_s();
         HIPCHK(hipMemcpyAsync(d_rc.p, &c, sizeof c, hipMemcpyHostToDevice, stream));
         if (!jump_valid || jump_inc != crng.inc) {            // the table depends on the stream's increment only: once per seed
@@ -836,7 +885,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(hipMemsetAsync(d_rep.p, 0xFF, kRepTotal * sizeof(int), stream));
         t_setup += now_s() - t0;
     }
-    hipLaunchKernelGGL(k_init_root, dim3(1), dim3(1), 0, stream, d_rc.p, start[0], start[1], (unsigned long long)root_reach, root_vid);
+    if (!batch_prep) hipLaunchKernelGGL(k_init_root, dim3(1), dim3(1), 0, stream, d_rc.p, start[0], start[1], (unsigned long long)root_reach, root_vid, 0);
 
 
     // profiling events
@@ -895,13 +944,13 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
             HIPCHK(hipMemcpyAsync(d_sx.p + it0, hs_x.data(), n * sizeof(double), hipMemcpyHostToDevice, stream));
             HIPCHK(hipMemcpyAsync(d_sy.p + it0, hs_y.data(), n * sizeof(double), hipMemcpyHostToDevice, stream));
             HIPCHK(hipStreamSynchronize(stream));
-        } else {
+        } else if (!batch_prep) {
             hipLaunchKernelGGL(k_gen_samples, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const RunConst *)d_rc.p,
                                (const PcgJump *)d_jump.p, (unsigned long long)it0, (unsigned long long)n,
                                (unsigned long long)(uint64_t)crng0.state, (unsigned long long)(uint64_t)(crng0.state >> 64),
                                (unsigned long long)(uint64_t)crng0.inc, (unsigned long long)(uint64_t)(crng0.inc >> 64), 0ull);
         }
-        if (mode == PORRT_MODE_RRT && n > 0)       // the step kernels take a step's samples in spatial order
+        if (mode == PORRT_MODE_RRT && n > 0 && !batch_prep)       // the step kernels take a step's samples in spatial order
             hipLaunchKernelGGL(k_sort_samples, dim3((unsigned)((n + K - 1) / K)), dim3(256), 0, stream, (const RunConst *)d_rc.p, b0,
                                (unsigned long long)it0, (unsigned long long)n, K);
         t_setup += now_s() - t0;
@@ -1828,6 +1877,14 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         L->rc_staging.resize(n);                 // one upload for all members (the vector outlives the copy: it is a member)
         for (uint32_t q = 0; q < n; ++q) L->rc_staging[q] = cs[q]->rc;
         HIPCHK_CTX(L, hipMemcpyAsync(L->d_rcarr, L->rc_staging.data(), (size_t)n * sizeof(RunConst), hipMemcpyHostToDevice, L->stream));
+        if (mode == PORRT_MODE_RRT) {            // the members' preparation, all at once (k_batch_prep)
+            const RunConst *rows = L->d_rcarr;
+            hipLaunchKernelGGL(k_batch_prep, dim3(32, n), dim3(256), 0, L->stream, rows);
+            hipLaunchKernelGGL(k_init_root, dim3(1, n), dim3(1), 0, L->stream, rows, 0.0, 0.0, 0ull, 0, 1);
+            hipLaunchKernelGGL(k_gen_samples, dim3((unsigned)((n_iter + 255) / 256), n), dim3(256), 0, L->stream, rows, (const PcgJump *)nullptr, 0ull,
+                               (unsigned long long)n_iter, 0ull, 0ull, 0ull, 0ull, 0ull);
+            hipLaunchKernelGGL(k_sort_samples, dim3((unsigned)((n_iter + K - 1) / K), n), dim3(256), 0, L->stream, rows, 0u, 0ull, (unsigned long long)n_iter, K);
+        }
         // the leader: all steps, one hipGraph (or eager), grid rows = contexts
         L->launch_rcp = L->d_rcarr;
         L->launch_Q = n;

@@ -144,7 +144,7 @@ __device__ __forceinline__ uint32_t xcd_swizzle_roles(uint32_t &bx, uint32_t &by
 // tiles, row-major inside).  Samples served by one workgroup -- and by workgroups that run at the same time -- then
 // read the same few region pages.  Any order is a correct order: results are indexed by the sample.
 __global__ __launch_bounds__(256) void k_sort_samples(const RunConst *__restrict__ rcp, uint32_t b0, unsigned long long it0, unsigned long long n, uint32_t K) {
-    const RunConst &rc = *rcp;
+    const RunConst &rc = rcp[blockIdx.y];      // one context per grid row
     __shared__ uint32_t s_bin[kRegions];
     __shared__ uint32_t s_tot[256];
     const uint32_t s = blockIdx.x, b = b0 + s;
