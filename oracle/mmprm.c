@@ -21,6 +21,7 @@ static void u64_push(u64vec *a, uint64_t x) {
 typedef struct {
     double belief[64];
     double reaching_probability;
+    uint64_t hash;                  /* of the belief (the key of mode_hash_map) */
     int remaining[64], n_remaining;
     int64_t there[64], not_there[64];          /* zone -> transition index (the two hash maps), -1 = none */
     orc_pcg64 sampler;                         /* PRM::continuous_sampler */
@@ -98,6 +99,7 @@ static size_t mm_add_mode(orc_mm *g, const int *remaining, int n_remaining, doub
     memset(m, 0, sizeof *m);
     memcpy(m->belief, belief, (size_t)g->nw * sizeof(double));
     m->reaching_probability = reach_p;
+    m->hash = mm_hash(m->belief, g->nw);
     memcpy(m->remaining, remaining, (size_t)n_remaining * sizeof(int));
     m->n_remaining = n_remaining;
     for (int z = 0; z < 64; ++z) m->there[z] = m->not_there[z] = -1;
@@ -105,7 +107,7 @@ static size_t mm_add_mode(orc_mm *g, const int *remaining, int n_remaining, doub
     return g->n_modes++;
 }
 static int64_t mm_mode_of_hash(const orc_mm *g, uint64_t h) {    /* mode_hash_map: the last mode inserted with that hash */
-    for (size_t m = g->n_modes; m-- > 0;) if (mm_hash(g->modes[m].belief, g->nw) == h) return (int64_t)m;
+    for (size_t m = g->n_modes; m-- > 0;) if (g->modes[m].hash == h) return (int64_t)m;
     return -1;
 }
 static size_t mm_add_transition(orc_mm *g, uint32_t zone, uint32_t from, uint32_t to, int observation) {     /* :166-181 */

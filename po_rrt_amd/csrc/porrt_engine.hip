@@ -24,6 +24,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <limits>
 #include <memory>
 #include <vector>
@@ -271,6 +272,7 @@ struct porrt_ctx {
     int grow_prm(const double start[2], double max_step, double search_radius, uint64_t n_iter);
     MmState mm;                            // porrt_grow_mm_prm: the mode tree and the modes' roadmaps
     int grow_mm_prm(const double start[2], const double *initial_belief, uint32_t n_worlds_in, double max_step, double search_radius, uint64_t n_iter_per_belief);
+    int roadmaps_of_modes(double max_step, double search_radius);
     int roadmap_of_points(const std::vector<double> &xy, double max_step, double search_radius, std::vector<uint32_t> &efrom, std::vector<uint32_t> &eto, double &dev_s);
     int64_t prm_plan_path(const double start[2], const double goal[2], double *path_xy, uint64_t cap);
     int read_best_cost(double *cost, uint64_t *final_id);
@@ -1508,6 +1510,121 @@ int porrt_ctx::roadmap_of_points(const std::vector<double> &xy, double max_step,
     return r;
 }
 
+struct DeviceScratch {
+    std::vector<void *> ps;
+    ~DeviceScratch() { for (void *q : ps) if (q) (void)hipFree(q); }
+    template <class T> hipError_t get(T *&p, size_t n) {
+        void *q = nullptr;
+        const hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) { ps.push_back(q); p = (T *)q; }
+        return e;
+    }
+};
+
+// All modes' roadmaps at once (k_mm_connect / k_mm_order, porrt_prm.hpp): nodes end to end, the kd pre-order rank of every node
+// from a host kd-tree per mode, one count / scan / fill / order sequence, one download.
+int porrt_ctx::roadmaps_of_modes(double max_step, double search_radius) {
+    HIPCHK(hipSetDevice(device));
+    size_t NT = 0, max_n = 0;
+    for (const MmMode &m : mm.modes) { NT += m.xy.size() / 2; max_n = std::max(max_n, m.xy.size() / 2); }
+    for (MmMode &m : mm.modes) { m.efrom.clear(); m.eto.clear(); }
+    if (NT == 0) return PORRT_OK;
+    if (NT + 1 >= 0x7FFFFFFFull) { set_err("too many roadmap nodes"); return PORRT_ERR_INVALID; }
+    std::vector<double> hx(NT), hy(NT);
+    std::vector<uint32_t> base(NT), rank(NT);
+    std::vector<size_t> off(mm.modes.size() + 1, 0);
+    {
+        std::vector<double> mx, my;
+        std::vector<int> stack;
+        size_t at = 0;
+        for (size_t mi = 0; mi < mm.modes.size(); ++mi) {
+            const MmMode &m = mm.modes[mi];
+            const size_t n = m.xy.size() / 2;
+            off[mi] = at;
+            mx.resize(n); my.resize(n);
+            for (size_t t = 0; t < n; ++t) { mx[t] = m.xy[2 * t]; my[t] = m.xy[2 * t + 1]; hx[at + t] = mx[t]; hy[at + t] = my[t]; base[at + t] = (uint32_t)at; }
+            if (n) {
+                const HostKd kd(mx, my);                         // KdTree::add in node order (nearest_neighbor.rs:29-46)
+                uint32_t next = 0;
+                stack.assign(1, 0);
+                while (!stack.empty()) {                         // pre-order: node, left subtree, right subtree (:101-117)
+                    const int nd = stack.back();
+                    stack.pop_back();
+                    rank[at + (size_t)nd] = next++;
+                    if (kd.right[nd] >= 0) stack.push_back(kd.right[nd]);
+                    if (kd.left[nd] >= 0) stack.push_back(kd.left[nd]);
+                }
+            }
+            at += n;
+        }
+        off[mm.modes.size()] = at;
+    }
+    HIPCHK(d_radT2.reserve(max_n + 8)); HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_cls.reserve(2 * (size_t)W * H + 16));
+    int r = layout_buffers();
+    if (r) return r;
+    cls_dirty = true;                                   // a re-layout loses the raster
+    if ((r = build_cls())) return r;
+    rad_uploaded = 0;
+    if ((r = ensure_radius_table(max_step, search_radius, max_n + 2))) return r;
+    memset(&rc, 0, sizeof rc);
+    rc.cls = d_cls.p; rc.clr = d_cls.p + (size_t)W * H; rc.W = W; rc.H = H; rc.low0 = low[0]; rc.low1 = low[1]; rc.ppm = ppm; rc.domain = domain; rc.has_grid = has_grid;
+    rc.n_validities = n_validities;
+    for (int i = 0; i < n_validities; ++i) rc.validities[i] = validities[i];
+    rc.all_worlds = ones(n_worlds);
+    rc.visibility = visibility;
+    rc.rad_T2 = d_radT2.p;
+    HIPCHK(hipMemcpyAsync(d_rc.p, &rc, sizeof rc, hipMemcpyHostToDevice, stream));
+    DeviceScratch sc;                                    // freed on every way out
+    double *dx = nullptr, *dy = nullptr;
+    uint32_t *dbase = nullptr, *drank = nullptr, *ddeg = nullptr, *derr = nullptr, *dtmp = nullptr, *dfrom = nullptr, *dto = nullptr;
+    unsigned long long *doff = nullptr, *dtot = nullptr;
+    HIPCHK(sc.get(dx, NT)); HIPCHK(sc.get(dy, NT)); HIPCHK(sc.get(dbase, NT)); HIPCHK(sc.get(drank, NT)); HIPCHK(sc.get(ddeg, NT)); HIPCHK(sc.get(derr, 1));
+    HIPCHK(sc.get(doff, NT + 1)); HIPCHK(sc.get(dtot, (NT + kScanTile - 1) / kScanTile + 2));
+    HIPCHK(hipMemcpyAsync(dx, hx.data(), NT * 8, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(dy, hy.data(), NT * 8, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(dbase, base.data(), NT * 4, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(drank, rank.data(), NT * 4, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemsetAsync(derr, 0, sizeof(uint32_t), stream));
+    MmConst p{};
+    p.NT = (uint32_t)NT; p.x = dx; p.y = dy; p.base = dbase; p.rank = drank; p.rad_T2 = d_radT2.p; p.deg = ddeg; p.edge_off = doff; p.err = derr;
+    ScopedEvents<2> evs;
+    HIPCHK(evs.create());
+    HIPCHK(hipEventRecord(evs.e[0], stream));
+    const dim3 wgrid((unsigned)((NT + 3) / 4)), block(256);
+    hipLaunchKernelGGL(k_mm_connect<false>, wgrid, block, 0, stream, (const RunConst *)d_rc.p, p);
+    bg_scan(ddeg, NT, dtot, doff, stream);
+    unsigned long long E = 0;
+    HIPCHK(hipMemcpyAsync(&E, doff + NT, sizeof E, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (E >= 0xFFFFFFFFull) { set_err("multi-modal PRM: edge list too long"); return PORRT_ERR_CAPACITY; }
+    HIPCHK(sc.get(dtmp, E)); HIPCHK(sc.get(dfrom, E)); HIPCHK(sc.get(dto, E));
+    p.tmp = dtmp; p.efrom = dfrom; p.eto = dto;
+    hipLaunchKernelGGL(k_mm_connect<true>, wgrid, block, 0, stream, (const RunConst *)d_rc.p, p);
+    hipLaunchKernelGGL(k_mm_order, wgrid, block, 0, stream, p);
+    HIPCHK(hipEventRecord(evs.e[1], stream));
+    std::vector<uint32_t> hfrom(E), hto(E);
+    std::vector<unsigned long long> hoff(NT + 1);
+    uint32_t h_err = 0;
+    if (E) {
+        HIPCHK(hipMemcpyAsync(hfrom.data(), dfrom, E * 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(hto.data(), dto, E * 4, hipMemcpyDeviceToHost, stream));
+    }
+    HIPCHK(hipMemcpyAsync(hoff.data(), doff, (NT + 1) * 8, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(&h_err, derr, sizeof h_err, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipGetLastError());
+    if (h_err & ERR_RASTER) { set_err("raster access the reference would panic on (image::get_pixel out of range, door pixel without zone, two zones on one segment)"); return PORRT_ERR_RASTER; }
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, evs.e[0], evs.e[1]));
+    mm.device_s += 1e-3 * (double)ms;
+    for (size_t mi = 0; mi < mm.modes.size(); ++mi) {
+        const size_t e0 = (size_t)hoff[off[mi]], e1 = (size_t)hoff[off[mi + 1]];
+        mm.modes[mi].efrom.assign(hfrom.begin() + e0, hfrom.begin() + e1);
+        mm.modes[mi].eto.assign(hto.begin() + e0, hto.begin() + e1);
+    }
+    return PORRT_OK;
+}
+
 int porrt_ctx::grow_mm_prm(const double start[2], const double *initial_belief, uint32_t n_worlds_in, double max_step, double search_radius,
                            uint64_t n_iter_per_belief) {
     using namespace mmprm;
@@ -1535,17 +1652,19 @@ int porrt_ctx::grow_mm_prm(const double start[2], const double *initial_belief, 
     const Pcg64 planner_sampler = crng;          // never advanced by the planner: every mode clones this state
     Pcg64 zone_sampler;                          // ContinuousSampler::new([0, 0], [visibility, 2 pi]) (:302)
     zone_sampler.seed_from_u64(0);
+    std::unordered_map<uint64_t, size_t> mode_hash_map;          // hash -> the last mode inserted with it (:160)
     auto add_mode = [&](const std::vector<int> &remaining, double reach_p, const std::vector<double> &belief) {      // :135-164
         MmMode m;
+        mode_hash_map[BeliefSpace::hash_of(belief.data(), nw)] = mm.modes.size();
         m.belief = belief; m.reaching_probability = reach_p; m.remaining = remaining;
         m.there.assign(64, -1); m.not_there.assign(64, -1);
         m.sampler = planner_sampler;
         mm.modes.push_back(std::move(m));
         return mm.modes.size() - 1;
     };
-    auto mode_of_hash = [&](uint64_t h) -> int64_t {             // mode_hash_map: the last mode inserted with that hash
-        for (size_t m = mm.modes.size(); m-- > 0;) if (BeliefSpace::hash_of(mm.modes[m].belief.data(), nw) == h) return (int64_t)m;
-        return -1;
+    auto mode_of_hash = [&](uint64_t h) -> int64_t {
+        const auto it = mode_hash_map.find(h);
+        return it == mode_hash_map.end() ? -1 : (int64_t)it->second;
     };
     auto add_sample = [&](size_t mode, double x, double y) -> uint64_t {      // PRM::add_sample: the node; its edges come later, on the GPU
         mm.modes[mode].xy.push_back(x); mm.modes[mode].xy.push_back(y);
@@ -1637,11 +1756,16 @@ int porrt_ctx::grow_mm_prm(const double start[2], const double *initial_belief, 
         }
     }
     mm.host_s = now_s() - t0;
-    // the modes' roadmaps, one after the other on the GPU
+    // the modes' roadmaps, all at once on the GPU
     const double t1 = now_s();
     mm.device_s = 0;
-    for (MmMode &m : mm.modes) {
-        const int r = roadmap_of_points(m.xy, max_step, search_radius, m.efrom, m.eto, mm.device_s);
+    if (getenv("PORRT_MM_ONE_BY_ONE")) {           // developer switch: one launch sequence per mode (the first version; same result)
+        for (MmMode &m : mm.modes) {
+            const int r = roadmap_of_points(m.xy, max_step, search_radius, m.efrom, m.eto, mm.device_s);
+            if (r) { mm.clear(); return r; }
+        }
+    } else {
+        const int r = roadmaps_of_modes(max_step, search_radius);
         if (r) { mm.clear(); return r; }
     }
     mm.roadmap_s = now_s() - t1;

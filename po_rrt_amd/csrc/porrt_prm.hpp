@@ -95,6 +95,70 @@ __global__ __launch_bounds__(256) void k_prm_connect(const RunConst *__restrict_
     if (err) atomicOr(p.err, err);
 }
 
+// ---- the roadmaps of ALL modes of a multi-modal PRM in one pass (MapShelfDomainTampPRM::grow_mm_prm, porrt_mmprm.hpp): thousands of
+// small roadmaps (~130 nodes each, the first modes a few thousand), their nodes laid end to end.  A node's candidates are the
+// earlier nodes of its own mode -- few enough that one wave tests them all (no grid), with the threshold of the node's position
+// IN ITS MODE; count, scan, fill as k_prm_connect, then every node's neighbours are put into the reference's order (kd pre-order
+// of the mode's kd-tree: the rank comes from the host).  Four launches for all modes instead of ~120 API calls per mode.
+struct MmConst {
+    uint32_t NT;                      // nodes of all modes
+    const double *x, *y;
+    const uint32_t *base;             // [NT] first node of the node's mode
+    const uint32_t *rank;             // [NT] kd pre-order rank within the mode
+    const double *rad_T2;
+    uint32_t *deg;                    // [NT]
+    const unsigned long long *edge_off;   // [NT + 1]
+    uint32_t *tmp;                    // [E] neighbours (global index) in index order
+    uint32_t *efrom, *eto;            // [E] neighbour -> new node, indices within the mode, the reference's order
+    uint32_t *err;
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_mm_connect(const RunConst *__restrict__ rcp, MmConst p) {
+    const RunConst &rc = *rcp;
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / 64u, lane = threadIdx.x & 63u;
+    if (i >= p.NT) return;
+    const uint32_t b = as_global(p.base)[i], li = i - b;
+    uint32_t err = 0, total = 0;
+    if (li > 0) {
+        const double px = as_global(p.x)[i], py = as_global(p.y)[i];
+        const double T2 = as_global(p.rad_T2)[li + 1];                      // heuristic_radius(self.graph.nodes.len()) with the new node in
+        GlobalGrid grid{rc.cls, rc.W};
+        const unsigned long long out0 = FILL ? as_global(p.edge_off)[i] : 0ull;
+        for (uint32_t j0 = b; j0 < i; j0 += 64u) {
+            const uint32_t j = j0 + lane;
+            bool hit = false;
+            if (j < i) {
+                const double ax = as_global(p.x)[j], ay = as_global(p.y)[j];
+                if (dist2(ax, ay, px, py) <= T2) {                           // norm2(node, new_state) <= radius
+                    const int cls = traversed_class(rc, grid, ax, ay, px, py, &err);    // transition_validator(node, new_node)
+                    hit = class_to_validity(rc, cls) >= 0;
+                }
+            }
+            const unsigned long long ballot = __ballot(hit);
+            if (FILL && hit) as_global(p.tmp)[out0 + total + (unsigned long long)__popcll(ballot & ((1ull << lane) - 1ull))] = j;
+            total += (uint32_t)__popcll(ballot);
+        }
+    }
+    if (!FILL && lane == 0) as_global(p.deg)[i] = total;
+    if (err) atomicOr(p.err, err);
+}
+
+// a node's neighbours by ascending pre-order rank (ranks are distinct): position = number of smaller ranks in the list
+__global__ __launch_bounds__(256) void k_mm_order(MmConst p) {
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / 64u, lane = threadIdx.x & 63u;
+    if (i >= p.NT) return;
+    const unsigned long long o0 = as_global(p.edge_off)[i], o1 = as_global(p.edge_off)[i + 1];
+    const uint32_t d = (uint32_t)(o1 - o0), b = as_global(p.base)[i];
+    for (uint32_t e = lane; e < d; e += 64u) {
+        const uint32_t j = as_global(p.tmp)[o0 + e], r = as_global(p.rank)[j];
+        uint32_t pos = 0;
+        for (uint32_t f = 0; f < d; ++f) pos += as_global(p.rank)[as_global(p.tmp)[o0 + f]] < r ? 1u : 0u;
+        as_global(p.efrom)[o0 + pos] = j - b;
+        as_global(p.eto)[o0 + pos] = i - b;
+    }
+}
+
 // ---- PRM::plan_path: dijkstra from the goal's node (pto_graph.rs:275-303) as sweeps over the roadmap's device adjacency
 // (the same monotone relaxation as the expected costs, porrt_dp.hpp: any order ends in the same fixpoint).
 __global__ __launch_bounds__(256) void k_prm_weights(uint32_t N, const unsigned long long *__restrict__ adj_off, const uint32_t *__restrict__ adj_id,

@@ -51,6 +51,22 @@ def test_twelve_shelves_mode_tree():
     assert_same(ge, go)
 
 
+def test_all_modes_at_once_equals_one_by_one(monkeypatch):
+    """the batched roadmap pass (k_mm_connect / k_mm_order: every mode's nodes end to end, one launch sequence) against the first
+    version, one porrt_grow_prm launch sequence per mode with the grid-binned kernels (developer switch PORRT_MM_ONE_BY_ONE)"""
+    import po_rrt_amd
+    case = cases.cfg3(1500, 1500)
+    res = []
+    for one_by_one in (False, True):
+        if one_by_one:
+            monkeypatch.setenv("PORRT_MM_ONE_BY_ONE", "1")
+        e = cases.configure(po_rrt_amd.Engine(), cases.Case(case, seed=1))
+        e.set_discrete_seed(5)
+        res.append(e.grow_mm_prm(case.start, [0.3, 0.7], 0.1, 2.0, 3000))
+    assert sum(len(m["edges"][0]) for m in res[0]["modes"]) > 20000
+    assert_same(res[0], res[1])
+
+
 def test_errors():
     import po_rrt_amd
     case = cases.cfg3(1500, 1500)
