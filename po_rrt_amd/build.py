@@ -9,7 +9,10 @@ import glob
 DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*"))) + [os.path.join(HERE, "..", "include", "porrt_hip.h")]
 LIB = os.path.join(HERE, "libporrt_hip.so")
 # -ffp-contract=off: the reference (Rust) never fuses a*b+c; parity is bit-exact only without contraction.
-FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+# -disable-promote-alloca-to-lds: the compiler moved k_kd_claim's per-thread moves (a small array) into LDS -- 77 KB per
+# workgroup instead of 22 -- and a side-stream workgroup's LDS is LDS the step kernels beside it cannot have (two k_conn2
+# workgroups on that CU instead of five); no other kernel is changed by it.
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-mllvm", "-disable-promote-alloca-to-lds"]
 # RCCL: the one exchange of a query-sharded job (csrc/porrt_exchange.hpp)
 LIBS = ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
 

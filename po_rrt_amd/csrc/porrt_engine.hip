@@ -537,6 +537,10 @@ __global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y
     rc.g_snap[0] = 1; rc.g_snap[1] = rc.cnt->g_nd_len; rc.g_snap[2] = rc.cnt->g_first_dup[0]; rc.g_snap[3] = rc.cnt->g_first_dup[1];
 }
 
+__global__ void k_wait_us(uint32_t us) {
+    const unsigned long long t0 = wall_clock64();          // 100 MHz
+    while (wall_clock64() - t0 < 100ull * us) __builtin_amdgcn_s_sleep(8);
+}
 // One step.  Main stream: near (NN + steer + radius search), connect, commit (which also bounds the next step's
 // samples).  Side stream (RRT*): order-exact kd insertion of this step's nodes, started as soon as their positions
 // are final and needed only by the NEXT step's connect -- two cross-stream edges per step.
@@ -1920,10 +1924,6 @@ int porrt_ctx::finish_batch_member(uint64_t n_iter_done, uint32_t steps, float d
 // `want` streams of the current device of which any two run their kernels side by side, found by trying: a pair of single-wave
 // kernels that each wait 150 us takes 150 us on two hardware queues and 300 on one.  Fewer than `want` (the caller then keeps
 // its own streams) if 4 * want candidates do not hold such a set.
-__global__ void k_wait_us(uint32_t us) {
-    const unsigned long long t0 = wall_clock64();          // 100 MHz
-    while (wall_clock64() - t0 < 100ull * us) __builtin_amdgcn_s_sleep(8);
-}
 static std::vector<hipStream_t> pick_parallel_streams(uint32_t want) {
     std::vector<hipStream_t> chosen, rejected;
     auto pair_s = [](hipStream_t a, hipStream_t b) {
