@@ -216,7 +216,9 @@ def main():
                 "winner_nodes": win_nodes,
                 "loop_s_rank0": t_loop,
                 "launch_sequences": G,
-                "launch": "hipGraph replay of all steps (main stream: search, connect; side stream: kd tie-order structure, never waited for)",
+                "launch": ("%d launch sequences side by side (porrt_grow_batch, option batch_streams), each on a main and a side stream chosen by "
+                           "measurement to sit on different hardware queues, launched step by step from a host thread each" % G) if G > 1 else
+                          "hipGraph replay of all steps (main stream: search, connect; side stream: kd tie-order structure, never waited for)",
             },
         }
         if prof["scan_s"] > 0:
