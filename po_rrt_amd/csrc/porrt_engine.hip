@@ -187,6 +187,10 @@ struct porrt_ctx {
     // (hipGraph) of its own on its own streams, so that one sub-batch's kernel tails and its kd side chain are filled by the
     // other's kernels.  0 (default): 2 from 32 contexts on, else 1.
     uint32_t opt_batch_streams = 0;
+    // porrt_get_trees (first context of the call): pinned staging slots and copy streams, one per worker thread
+    std::vector<void *> dl_pin;
+    std::vector<hipStream_t> dl_streams;
+    size_t dl_pin_bytes = 0;
     bool sub_eager = false;                        // leader of a sub-batch on measured streams: launch step by step (see porrt_grow_batch)
     std::vector<hipStream_t> sub_streams;          // first context of such a call: the sub-batches' main streams (see porrt_grow_batch)
     bool opt_dp_sweeps = false;            // "dp_sweeps": expected costs by whole-graph sweeps instead of layer by layer
@@ -2162,6 +2166,8 @@ void porrt_destroy(porrt_ctx *c) {
     if (!c) return;
     // a batch leader going away takes its RunConst array with it: its members must not look for it any more
     for (hipStream_t st : c->sub_streams) (void)hipStreamDestroy(st);
+    for (hipStream_t st : c->dl_streams) (void)hipStreamDestroy(st);
+    for (void *q : c->dl_pin) if (q) (void)hipHostFree(q);
     for (porrt_ctx *m : c->batch_members) if (m && m != c && m->batch_leader == c) m->batch_leader = nullptr;
     if (c->batch_leader && c->batch_leader != c)
         for (porrt_ctx *&m : c->batch_leader->batch_members) if (m == c) m = nullptr;
@@ -2375,6 +2381,69 @@ int porrt_get_tree(const porrt_ctx *cc, double *xy, int64_t *parent, double *dis
         if (parent) parent[j] = c->h_parent[j];
         if (dist_root) dist_root[j] = c->h_dist[j];
     }
+    return PORRT_OK;
+}
+
+// porrt_get_tree for many contexts of one device at once (the trees of a porrt_grow_batch): a few worker threads, each with a
+// pinned staging slot and a copy stream of its own, fetch the trees straight from the device arrays (four asynchronous copies
+// per tree at the link's speed) and lay them out in the caller's arrays while the other workers' copies are in flight.  The
+// contexts' cached host copies are not touched.  xy / parent / dist_root: n pointers each (an entry or a whole array may be NULL).
+int porrt_get_trees(porrt_ctx *const *ctxs, uint32_t n_ctx, double *const *xy, int64_t *const *parent, double *const *dist_root) {
+    if (!ctxs || !n_ctx || !ctxs[0]) return PORRT_ERR_INVALID;
+    porrt_ctx *top = ctxs[0];
+    size_t maxN = 0;
+    for (uint32_t q = 0; q < n_ctx; ++q) {
+        if (!ctxs[q] || ctxs[q]->device != top->device) { top->set_err("porrt_get_trees: contexts of one device"); return PORRT_ERR_INVALID; }
+        if (!ctxs[q]->have_results || ctxs[q]->mm.valid) { top->set_err("porrt_get_trees: a context without a grown tree"); return PORRT_ERR_INVALID; }
+        maxN = std::max<size_t>(maxN, ctxs[q]->n_nodes);
+    }
+    if (hipSetDevice(top->device) != hipSuccess) { top->set_err("hipSetDevice"); return PORRT_ERR_DEVICE; }
+    const uint32_t W = std::min<uint32_t>(8u, n_ctx);
+    const size_t slot = (maxN * 28u + 4095u) & ~(size_t)4095u;          // nx, ny, dist_root (f64) and parent (i32) of one tree
+    if (top->dl_pin_bytes < slot) {
+        for (void *q : top->dl_pin) if (q) (void)hipHostFree(q);
+        top->dl_pin.clear(); top->dl_pin_bytes = 0;
+    }
+    while (top->dl_pin.size() < W) {
+        void *q = nullptr;
+        if (hipHostMalloc(&q, slot + slot / 8, hipHostMallocDefault) != hipSuccess) { top->set_err("hipHostMalloc (tree staging)"); return PORRT_ERR_DEVICE; }
+        top->dl_pin.push_back(q);
+        top->dl_pin_bytes = slot + slot / 8;
+    }
+    while (top->dl_streams.size() < W) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { top->set_err("hipStreamCreate"); return PORRT_ERR_DEVICE; }
+        top->dl_streams.push_back(st);
+    }
+    std::vector<int> rcs(W, PORRT_OK);
+    auto work = [&](uint32_t w) {
+        if (hipSetDevice(top->device) != hipSuccess) { rcs[w] = PORRT_ERR_DEVICE; return; }
+        hipStream_t st = top->dl_streams[w];
+        for (uint32_t q = w; q < n_ctx; q += W) {
+            const porrt_ctx *c = ctxs[q];
+            const size_t N = c->n_nodes;
+            double *px = (double *)top->dl_pin[w], *py = px + N, *pd = py + N;
+            int *pp = (int *)(pd + N);
+            double *oxy = xy ? xy[q] : nullptr, *od = dist_root ? dist_root[q] : nullptr;
+            int64_t *op = parent ? parent[q] : nullptr;
+            hipError_t e = hipSuccess;
+            if (oxy) { e = hipMemcpyAsync(px, c->d_nx.p, N * 8, hipMemcpyDeviceToHost, st); if (e == hipSuccess) e = hipMemcpyAsync(py, c->d_ny.p, N * 8, hipMemcpyDeviceToHost, st); }
+            if (od && e == hipSuccess) e = hipMemcpyAsync(pd, c->d_distA.p, N * 8, hipMemcpyDeviceToHost, st);
+            if (op && e == hipSuccess) e = hipMemcpyAsync(pp, c->d_parent.p, N * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { rcs[w] = PORRT_ERR_DEVICE; return; }
+            if (oxy) for (size_t j = 0; j < N; ++j) { oxy[2 * j] = px[j]; oxy[2 * j + 1] = py[j]; }
+            if (od) memcpy(od, pd, N * 8);
+            if (op) for (size_t j = 0; j < N; ++j) op[j] = pp[j];
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint32_t w = 1; w < W; ++w) th.emplace_back(work, w);
+        work(0);
+        for (auto &t : th) t.join();
+    }
+    for (uint32_t w = 0; w < W; ++w) if (rcs[w]) { top->set_err("porrt_get_trees: device copy failed"); return rcs[w]; }
     return PORRT_OK;
 }
 

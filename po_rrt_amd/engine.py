@@ -25,7 +25,7 @@ _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 SYMBOLS = [
     "porrt_create", "porrt_destroy", "porrt_last_error", "porrt_set_grid", "porrt_set_zones", "porrt_set_sampler",
     "porrt_set_discrete_seed", "porrt_set_samples", "porrt_set_worlds", "porrt_set_square_goal",
-    "porrt_set_observation_goal", "porrt_grow", "porrt_grow_batch", "porrt_grow_prm", "porrt_prm_plan_path", "porrt_num_nodes", "porrt_num_iterations", "porrt_get_tree",
+    "porrt_set_observation_goal", "porrt_grow", "porrt_grow_batch", "porrt_grow_prm", "porrt_prm_plan_path", "porrt_num_nodes", "porrt_num_iterations", "porrt_get_tree", "porrt_get_trees",
     "porrt_num_final", "porrt_get_final_ids", "porrt_get_final_masks", "porrt_get_reach", "porrt_get_node_validity",
     "porrt_num_edges", "porrt_get_edges", "porrt_is_final_set_complete", "porrt_n_worlds", "porrt_get_validities",
     "porrt_get_zone_positions", "porrt_best_solution", "porrt_best_cost", "porrt_best_cost_batch", "porrt_get_metrics", "porrt_set_option", "porrt_selftest",
@@ -98,6 +98,7 @@ def load_library():
     sig("porrt_num_nodes", C.c_uint64, vp)
     sig("porrt_num_iterations", C.c_uint64, vp)
     sig("porrt_get_tree", C.c_int, vp, _f64p, _i64p, _f64p)
+    sig("porrt_get_trees", C.c_int, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p))
     sig("porrt_num_final", C.c_uint64, vp)
     sig("porrt_get_final_ids", C.c_int, vp, _u64p)
     sig("porrt_get_final_masks", C.c_int, vp, _u64p)
@@ -266,6 +267,27 @@ class Engine:
         dist = np.zeros(n)
         self._chk(self._l.porrt_get_tree(self._c, xy, parent, dist))
         return xy, parent, dist
+
+    @staticmethod
+    def trees(engines, buffers=None):
+        """porrt_get_trees: the trees of several contexts of one device in one call -> [(xy, parent, dist_root), ...].
+        buffers: per engine (xy [cap, 2] f64, parent [cap] i64, dist [cap] f64) to fill instead of new arrays (a caller that
+        fetches trees again and again keeps its memory mapped: fresh pages cost more than the copies); views of them come back."""
+        n = len(engines)
+        sizes = [e.num_nodes() for e in engines]
+        if buffers is None:
+            out = [(np.empty((m, 2)), np.empty(m, dtype=np.int64), np.empty(m)) for m in sizes]
+        else:
+            out = []
+            for m, (bxy, bp, bd) in zip(sizes, buffers):
+                if len(bxy) < m or len(bp) < m or len(bd) < m or bxy.dtype != np.float64 or bp.dtype != np.int64 or bd.dtype != np.float64:
+                    raise ValueError("trees: a buffer is too small or of the wrong type")
+                out.append((bxy[:m], bp[:m], bd[:m]))
+        arr = (C.c_void_p * n)(*[e._c for e in engines])
+        ptrs = [(C.c_void_p * n)(*[o[k].ctypes.data for o in out]) for k in range(3)]
+        rc = engines[0]._l.porrt_get_trees(arr, n, ptrs[0], ptrs[1], ptrs[2])
+        engines[0]._chk(rc)
+        return out
 
     def final_ids(self):
         n = self._l.porrt_num_final(self._c)

@@ -258,6 +258,26 @@ def test_grow_batch_in_sub_batches(eng_mod):
                 assert (sol is None and np.isinf(c)) or (sol is not None and c == sol[1])
 
 
+def test_get_trees_equals_get_tree(eng_mod):
+    """porrt_get_trees (worker threads, pinned staging, more contexts than workers) == porrt_get_tree per context"""
+    cs = [cases.cfg2(3000 + 700 * s, seed=s) for s in range(11)]
+    engs = []
+    for c in cs:
+        e, _ = run_gpu(eng_mod, c, 256)
+        engs.append(e)
+    for rep in range(2):                       # the second call reuses the staging
+        got = eng_mod.Engine.trees(engs)
+        for e, (xy, parent, dist) in zip(engs, got):
+            rxy, rparent, rdist = e.tree()
+            assert np.array_equal(xy.view(np.uint64), rxy.view(np.uint64)) and np.array_equal(parent, rparent)
+            assert np.array_equal(dist.view(np.uint64), rdist.view(np.uint64))
+    assert len(eng_mod.Engine.trees(engs[:1])[0][1]) == engs[0].num_nodes()
+    bufs = [(np.zeros((12000, 2)), np.zeros(12000, dtype=np.int64), np.zeros(12000)) for _ in engs]       # the caller's own memory
+    for e, (xy, parent, dist) in zip(engs, eng_mod.Engine.trees(engs, bufs)):
+        rxy, rparent, rdist = e.tree()
+        assert np.array_equal(xy, rxy) and np.array_equal(parent, rparent) and np.array_equal(dist, rdist) and xy.base is not None
+
+
 def test_grow_batch_pto(eng_mod):
     cs = [cases.cfg3(6000, 6000, seed=s) for s in (0, 1)]
     engs = [cases.configure(eng_mod.Engine(), c) for c in cs]
