@@ -231,6 +231,8 @@ struct RunConst {
     double *t2_at;              // t2_at[b] = rad_T2[n_at[b]] (RRT*: the step's radius threshold, written with n_at)
     uint32_t tile_R;            // LDS tile half-width in pixels (0 = no tile: read the raster from global)
     uint32_t part_stride;       // sample stride of the arrays double-buffered by step parity
+    uint32_t q_stride;          // q_x / q_y / q_nn / q_vid of step b start at (b & 1) * q_stride: part_stride when the steps are
+                                // pipelined (k_step_rrt: step b + 1 is searched while step b is connected), else 0
     // what the preparation of a grow needs, for the kernels that prepare all members of a porrt_grow_batch at once (k_batch_prep,
     // and k_init_root / k_gen_samples / k_sort_samples with one grid row per member)
     double start_x, start_y;
@@ -261,6 +263,7 @@ __device__ __forceinline__ T g_atomic_min(GPTR(T) p, T v) { return __hip_atomic_
 // ------------------------------------------------------------------ small helpers
 
 // neighbour list of sample k in step b (parity buffers)
+__device__ __forceinline__ uint32_t q_off(const RunConst &rc, uint32_t b) { return (b & 1u) * rc.q_stride; }
 __device__ __forceinline__ size_t cand_off(const RunConst &rc, uint32_t b, uint32_t k) { return ((size_t)(b & 1u) * rc.cand_K + k) * rc.cand_cap; }
 __device__ __forceinline__ uint32_t cand_count(const RunConst &rc, uint32_t b, uint32_t k) {
     const uint32_t c = as_global(rc.cand_cnt)[(b & 1u) * rc.cand_K + k];
@@ -716,19 +719,9 @@ __device__ __forceinline__ void scan_disc(const RunConst &rc, uint32_t b, double
 // norm2 <= radius  <=>  d2 <= T2 with T2 from the host table) into the sample's neighbour list.
 // The launch may carry the PREVIOUS step's rewire phase 2 in extra workgroups (cb = that step, cnb its samples):
 // the two touch disjoint data, and the step chain loses a kernel.
+// (the search of one sample by one wave; k is wave-uniform)
 template <bool PTO>
-__global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, uint32_t cb,
-                                              uint32_t cnb) {
-    const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t near_blocks = (nb + 3u) / 4u;
-    if (blockIdx.x >= near_blocks) {
-        const uint32_t ck = uni((blockIdx.x - near_blocks) * 4u + (threadIdx.x >> 6));     // wave-uniform: addresses in SGPRs
-        if (!PTO && ck < cnb) commit_rrt_sample(rc, cb, vwords, ck, lane);
-        return;
-    }
-    const uint32_t k = uni(blockIdx.x * 4u + (threadIdx.x >> 6));       // wave-uniform: addresses in SGPRs
-    if (k >= nb) return;
+__device__ __forceinline__ void near_sample(const RunConst &rc, uint32_t b, uint32_t i0, uint32_t vwords, uint32_t k, uint32_t lane) {
     const uint32_t N = uni(as_global(rc.n_at)[b]);
     const double sqx = uni_d(as_global(rc.sx)[i0 + k]), sqy = uni_d(as_global(rc.sy)[i0 + k]);
     uint32_t world = 0;
@@ -801,13 +794,14 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
         if (err) valid = false;
     }
     if (lane == 0) {
-        as_global(rc.q_x)[k] = tx;
-        as_global(rc.q_y)[k] = ty;
+        const uint32_t qo = q_off(rc, b);
+        as_global(rc.q_x)[qo + k] = tx;
+        as_global(rc.q_y)[qo + k] = ty;
         // copy for the kd insertion, which runs beside the following steps (one slice per step)
         const size_t o2 = (size_t)b * rc.part_stride + k;
         as_global(rc.kq_x)[o2] = tx; as_global(rc.kq_y)[o2] = ty; as_global(rc.kq_vid)[o2] = valid ? vid : -1;
-        as_global(rc.q_nn)[k] = nn;
-        as_global(rc.q_vid)[k] = valid ? vid : -1;
+        as_global(rc.q_nn)[qo + k] = nn;
+        as_global(rc.q_vid)[qo + k] = valid ? vid : -1;
         if (valid) atomicOr(&rc.valid_mask[(size_t)b * vwords + (k >> 6)], 1ull << (k & 63u));
         if (err) atomicOr(&rc.cnt->err, err);
     }
@@ -837,6 +831,22 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
     if (over) atomicOr(&rc.cnt->err, (uint32_t)ERR_CAND_OVERFLOW);
 }
 
+template <bool PTO>
+__global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, uint32_t cb,
+                                              uint32_t cnb) {
+    const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t near_blocks = (nb + 3u) / 4u;
+    if (blockIdx.x >= near_blocks) {
+        const uint32_t ck = uni((blockIdx.x - near_blocks) * 4u + (threadIdx.x >> 6));     // wave-uniform: addresses in SGPRs
+        if (!PTO && ck < cnb) commit_rrt_sample(rc, cb, vwords, ck, lane);
+        return;
+    }
+    const uint32_t k = uni(blockIdx.x * 4u + (threadIdx.x >> 6));       // wave-uniform: addresses in SGPRs
+    if (k >= nb) return;
+    near_sample<PTO>(rc, b, i0, vwords, k, lane);
+}
+
 // Add the step's new nodes to the region pages (run by ONE workgroup, an extra block of the connect kernels:
 // positions and validity are final since k_near, ids follow from the valid mask).  Nothing reads the pages
 // between k_near of this step and k_near of the next.
@@ -860,8 +870,9 @@ __device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, u
         as_global(rc.t2_at)[b + 1] = as_global(rc.rad_T2)[n_next];
     }
     __syncthreads();
+    const uint32_t qo = q_off(rc, b);
     for (uint32_t k = threadIdx.x; k < nb; k += T)
-        if (rc.q_vid[k] >= 0) s_off[k] = (uint16_t)atomicAdd(&s_add[region_of(rc, as_global(rc.q_x)[k], as_global(rc.q_y)[k])], 1u);
+        if (rc.q_vid[qo + k] >= 0) s_off[k] = (uint16_t)atomicAdd(&s_add[region_of(rc, as_global(rc.q_x)[qo + k], as_global(rc.q_y)[qo + k])], 1u);
     __syncthreads();
     for (uint32_t r = threadIdx.x; r < kRegions; r += T) {
         const uint32_t add = s_add[r];
@@ -880,8 +891,8 @@ __device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, u
     const uint32_t N = as_global(rc.n_at)[b];
     dbl2 *pxy = reinterpret_cast<dbl2 *>(rc.pg_xy);
     for (uint32_t k = threadIdx.x; k < nb; k += T) {
-        if (rc.q_vid[k] < 0) continue;
-        const double x = as_global(rc.q_x)[k], y = as_global(rc.q_y)[k];
+        if (rc.q_vid[qo + k] < 0) continue;
+        const double x = as_global(rc.q_x)[qo + k], y = as_global(rc.q_y)[qo + k];
         const uint32_t r = region_of(rc, x, y);
         const uint32_t slot = rg_old[r] + s_off[k], j = slot / kPage;
         const uint32_t page = j ? __hip_atomic_load(&rc.rg_dir[(size_t)r * rc.rg_maxp + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : r;
@@ -891,6 +902,8 @@ __device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, u
         const uint32_t nid = N + rank_before(rc, b, vwords, k);
         as_global(rc.pg_id)[(size_t)page * kPage + (slot % kPage)] = (int)nid;
         as_global(rc.slot_of)[nid] = page * kPage + (slot % kPage);          // pg_d of the slot: the step's commit pass
+        // (with pipelined steps the next step's search reads the coordinates before the connect pass has stored them: same bits)
+        if (rc.q_stride) { as_global(rc.nx)[nid] = x; as_global(rc.ny)[nid] = y; }
     }
     __syncthreads();
     for (uint32_t r = threadIdx.x; r < kRegions; r += T) rg_new[r] = rg_old[r] + s_add[r];
@@ -1245,7 +1258,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
     bool deferred = false;
     if (nvalid == 0) {
         // rrt.rs:132-134: fall back to the nearest node, not collision-checked
-        best = as_global(rc.q_nn)[k];
+        best = as_global(rc.q_nn)[q_off(rc, b) + k];
         if (best < 0) best = nearest_search();      // k_nn2 did not need it (the sample was not steered): searched now, by the whole team
         best_cost = sqrt(dist2(as_global(rc.nx)[best], as_global(rc.ny)[best], px, py));
         dnew = gdA[best] + best_cost;
@@ -1479,6 +1492,53 @@ constexpr uint32_t kHeavyCand = 256;     // samples with more neighbours than th
 // One workgroup = kConnectWaves samples.  Phase 1: every wave serves its own sample if it is light.  Phase 2:
 // samples with more than kHeavyCand neighbours (the dense start of a tree, duplicates of the goal point) are
 // served one after the other by the whole workgroup as a 4-wave team.
+// (one workgroup's kConnectWaves samples; bx = the workgroup's index among the step's connect workgroups)
+template <bool LDSGRID>
+__device__ __forceinline__ void connect_block(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords, uint32_t bx, uint8_t *lds_tiles, double *s_d, int *s_i,
+                                              uint32_t *s_heavy) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t k = uni(bx * kConnectWaves + wv);
+    const uint32_t qo = q_off(rc, b);
+    const bool active = k < nb && as_global(rc.q_vid)[qo + (k < nb ? k : 0)] >= 0;
+    const uint32_t cnt = active ? cand_count(rc, b, k) : 0u;
+    const bool heavy = active && cnt > kHeavyCand;
+    if (lane == 0) s_heavy[wv] = heavy ? cnt : 0u;
+    const uint32_t TW = 2u * rc.tile_R + 1u;
+    const uint32_t tile_bytes = (TW * TW + 15u) & ~15u;
+    uint32_t err = 0;
+    if (active && !heavy) {
+        TileGrid grid;
+        if (LDSGRID) {
+            grid = load_tile(rc, lds_tiles + wv * tile_bytes, as_global(rc.q_x)[qo + k], as_global(rc.q_y)[qo + k], lane, 64u);
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0;
+        }
+        Team<1> tm;
+        tm.scr_d = nullptr; tm.scr_i = nullptr; tm.wave = 0; tm.lane = lane;
+        const uint32_t id = uni(uni(as_global(rc.n_at)[b]) + rank_before(rc, b, vwords, k));            // k is wave-uniform: scalars
+        const double px = uni_d(as_global(rc.q_x)[qo + k]), py = uni_d(as_global(rc.q_y)[qo + k]);
+        connect_rrt_sample(rc, tm, global_list(rc, b, k), grid, b, k, id, px, py, cnt, err);
+    }
+    __syncthreads();
+    Team<kConnectWaves> tmh;
+    tmh.scr_d = s_d; tmh.scr_i = s_i; tmh.wave = wv; tmh.lane = lane;
+    for (uint32_t w = 0; w < kConnectWaves; ++w) {
+        const uint32_t hc = s_heavy[w];            // workgroup-uniform
+        if (!hc) continue;
+        const uint32_t kh = bx * kConnectWaves + w;
+        TileGrid grid;
+        __syncthreads();
+        if (LDSGRID) grid = load_tile(rc, lds_tiles, rc.q_x[qo + kh], rc.q_y[qo + kh], threadIdx.x, kConnectWaves * 64u);
+        else { grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0; }
+        __syncthreads();
+        const uint32_t idh = uni(uni(as_global(rc.n_at)[b]) + rank_before(rc, b, vwords, kh));
+        const double pxh = uni_d(as_global(rc.q_x)[qo + kh]), pyh = uni_d(as_global(rc.q_y)[qo + kh]);
+        connect_rrt_sample(rc, tmh, global_list(rc, b, kh), grid, b, kh, idh, pxh, pyh, hc, err);
+    }
+    if (err) atomicOr(&rc.cnt->err, err);
+}
+
 template <bool LDSGRID>
 __global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_connect_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
                                                                      uint32_t vwords) {
@@ -1489,46 +1549,39 @@ __global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per
     __shared__ __attribute__((aligned(16))) uint8_t s_ins[kInsertLds];
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     if (blockIdx.x == gridDim.x - 1) { insert_step_pages(rc, b, nb, vwords, s_ins); return; }    // the extra block
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t k = uni(blockIdx.x * kConnectWaves + wv);
-    const bool active = k < nb && as_global(rc.q_vid)[k < nb ? k : 0] >= 0;
-    const uint32_t cnt = active ? cand_count(rc, b, k) : 0u;
-    const bool heavy = active && cnt > kHeavyCand;
-    if (lane == 0) s_heavy[wv] = heavy ? cnt : 0u;
-    const uint32_t TW = 2u * rc.tile_R + 1u;
-    const uint32_t tile_bytes = (TW * TW + 15u) & ~15u;
-    uint32_t err = 0;
-    if (active && !heavy) {
-        TileGrid grid;
-        if (LDSGRID) {
-            grid = load_tile(rc, lds_tiles + wv * tile_bytes, as_global(rc.q_x)[k], as_global(rc.q_y)[k], lane, 64u);
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0;
-        }
-        Team<1> tm;
-        tm.scr_d = nullptr; tm.scr_i = nullptr; tm.wave = 0; tm.lane = lane;
-        const uint32_t id = uni(uni(as_global(rc.n_at)[b]) + rank_before(rc, b, vwords, k));            // k is wave-uniform: scalars
-        const double px = uni_d(as_global(rc.q_x)[k]), py = uni_d(as_global(rc.q_y)[k]);
-        connect_rrt_sample(rc, tm, global_list(rc, b, k), grid, b, k, id, px, py, cnt, err);
-    }
-    __syncthreads();
-    Team<kConnectWaves> tmh;
-    tmh.scr_d = s_d; tmh.scr_i = s_i; tmh.wave = wv; tmh.lane = lane;
-    for (uint32_t w = 0; w < kConnectWaves; ++w) {
-        const uint32_t hc = s_heavy[w];            // workgroup-uniform
-        if (!hc) continue;
-        const uint32_t kh = blockIdx.x * kConnectWaves + w;
-        TileGrid grid;
-        __syncthreads();
-        if (LDSGRID) grid = load_tile(rc, lds_tiles, rc.q_x[kh], rc.q_y[kh], threadIdx.x, kConnectWaves * 64u);
-        else { grid.lds = nullptr; grid.glob = rc.cls; grid.W = rc.W; grid.TW = 0; grid.oi = 0; grid.oj = 0; }
-        __syncthreads();
-        const uint32_t idh = uni(uni(as_global(rc.n_at)[b]) + rank_before(rc, b, vwords, kh));
-        const double pxh = uni_d(as_global(rc.q_x)[kh]), pyh = uni_d(as_global(rc.q_y)[kh]);
-        connect_rrt_sample(rc, tmh, global_list(rc, b, kh), grid, b, kh, idh, pxh, pyh, hc, err);
-    }
-    if (err) atomicOr(&rc.cnt->err, err);
+    connect_block<LDSGRID>(rc, b, nb, vwords, blockIdx.x, lds_tiles, s_d, s_i, s_heavy);
+}
+
+// Pipelined steps (RRT*, one wave per sample): step b is connected while step b + 1 is searched, in ONE launch -- the two
+// touch disjoint data once the filing of a step's nodes has a kernel of its own (k_file_commit, between two of these):
+//   k_near(0), F(0), S(0) = connect(0) + search(1), F(1) = file(1) + rewire phase 2 of (0), S(1) = connect(1) + search(2), ...
+// The search of step b + 1 needs the pages, coordinates and counts of the nodes up to step b (F(b) wrote them: the
+// connect pass's own stores of nx / ny carry the same bits), never dist_root or parents; its per-sample results go to the
+// other half of q_* (q_stride) and the other parity of the neighbour lists.  A single query's chain of dependent kernels
+// is then max(search, connect) + file per step instead of search + connect.  The connect workgroups come first (they
+// take longer).
+template <bool LDSGRID>
+__global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_step_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
+                                                                  uint32_t i0_next, uint32_t nb_next, uint32_t vwords) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_tiles[];
+    __shared__ double s_d[kConnectWaves];
+    __shared__ int s_i[kConnectWaves];
+    __shared__ uint32_t s_heavy[kConnectWaves];
+    const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
+    const uint32_t cblocks = (nb + kConnectWaves - 1u) / kConnectWaves;
+    if (blockIdx.x < cblocks) { connect_block<LDSGRID>(rc, b, nb, vwords, blockIdx.x, lds_tiles, s_d, s_i, s_heavy); return; }
+    const uint32_t k = uni((blockIdx.x - cblocks) * 4u + (threadIdx.x >> 6));
+    if (k < nb_next) near_sample<false>(rc, b + 1u, i0_next, vwords, k, threadIdx.x & 63u);
+}
+
+// F(bf): block 0 files step bf's nodes (positions and validity are final since its search), the others run the rewire phase
+// 2 of step cb (cnb samples; cnb = 0: none)
+__global__ __launch_bounds__(256) void k_file_commit(const RunConst *__restrict__ rcp, uint32_t bf, uint32_t nbf, uint32_t cb, uint32_t cnb, uint32_t vwords) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_ins[kInsertLds];
+    const RunConst &rc = rcp[blockIdx.y];
+    if (blockIdx.x == 0) { insert_step_pages(rc, bf, nbf, vwords, s_ins); return; }
+    const uint32_t ck = uni((blockIdx.x - 1u) * 4u + (threadIdx.x >> 6));
+    if (ck < cnb) commit_rrt_sample(rc, cb, vwords, ck, threadIdx.x & 63u);
 }
 
 // RRT*: rewire phase 2 for sample k of step b (one wave).  A pair wins iff its candidate equals the accumulated

@@ -187,6 +187,12 @@ struct porrt_ctx {
     // (hipGraph) of its own on its own streams, so that one sub-batch's kernel tails and its kd side chain are filled by the
     // other's kernels.  0 (default): 2 from 32 contexts on, else 1.
     uint32_t opt_batch_streams = 0;
+    // "pipeline": RRT* steps of the one-wave-per-sample kernels as k_step_rrt / k_file_commit (step b + 1 is searched while step
+    // b is connected).  Off by default: measured on the bench's single query it does not pay yet -- connect + search in one
+    // launch take 34 us instead of 27 + 22, but the filing kernel between two of them is a 19 us chain of its own.
+    int opt_pipeline = 0;
+    bool pipe_on = false;                  // the choice in force for the running launch sequence (set with opt_group)
+    uint32_t pipe_near_done = 0xFFFFFFFFu; // pipelined: the step whose search and filing are already launched
     // porrt_get_trees (first context of the call): pinned staging slots and copy streams, one per worker thread
     std::vector<void *> dl_pin;
     std::vector<hipStream_t> dl_streams;
@@ -557,6 +563,35 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
         if (prof && ev_used < ev_pool.size()) (void)hipEventRecord(ev_pool[ev_used++], stream);
     };
     const bool rrt = mode == PORRT_MODE_RRT;
+    if (rrt && pipe_on && opt_group == 0) {
+        // pipelined steps (k_step_rrt): [k_near(b), F(b) unless launched ahead]  S(b) = connect(b) + search(b + 1)  F(b + 1)
+        const uint32_t cb4 = (nb + kConnectWaves - 1) / kConnectWaves;
+        ev();
+        if (pipe_near_done != b) {
+            hipLaunchKernelGGL(k_near<false>, dim3(wave_blocks, Q), dim3(256), 0, stream, rcp, b, i0, nb, vwords, 0xFFFFFFFFu, 0u);
+            const uint32_t cnb = commit_pend_b != 0xFFFFFFFFu ? commit_pend_nb : 0u;
+            hipLaunchKernelGGL(k_file_commit, dim3(1 + (cnb + 3) / 4, Q), dim3(256), 0, stream, rcp, b, nb, commit_pend_b, cnb, vwords);
+            commit_pend_b = 0xFFFFFFFFu;
+        }
+        ev();
+        (void)hipEventRecord(ev_steered, stream);          // positions and ids of step b are final
+        ev();
+        const dim3 sg(cb4 + (nxt_nb + 3) / 4, Q);
+        if (lds_bytes) hipLaunchKernelGGL(k_step_rrt<true>, sg, dim3(256), lds_bytes, stream, rcp, b, nb, nxt_i0, nxt_nb, vwords);
+        else hipLaunchKernelGGL(k_step_rrt<false>, sg, dim3(256), 0, stream, rcp, b, nb, nxt_i0, nxt_nb, vwords);
+        ev();
+        if (nxt_nb) {
+            hipLaunchKernelGGL(k_file_commit, dim3(1 + (nb + 3) / 4, Q), dim3(256), 0, stream, rcp, b + 1, nxt_nb, b, nb, vwords);
+            pipe_near_done = b + 1;
+        } else {
+            commit_pend_b = b; commit_pend_nb = nb;
+            pipe_near_done = 0xFFFFFFFFu;
+        }
+        kd_last_b = b; kd_last_nb = nb;
+        side_active = true;
+        if (b + 1 - kd_b0 >= kd_group) launch_kd_group();
+        return;
+    }
     ev();
     const uint32_t GLn = rrt ? opt_group : 0u;
     if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_near<true>, dim3(wave_blocks, Q), dim3(256), 0, stream, rcp, b, i0, nb, vwords, 0xFFFFFFFFu, 0u);
@@ -602,7 +637,6 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     } else if (lds_bytes) hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
     else hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
     ev();
-    (void)nxt_i0; (void)nxt_nb;
     commit_pend_b = b; commit_pend_nb = nb;
     kd_last_b = b; kd_last_nb = nb;
     side_active = true;
@@ -734,7 +768,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(d_vid.reserve(Nmax)); HIPCHK(d_finalflag.reserve(Nmax)); HIPCHK(d_finalmask.reserve(Nmax));
         HIPCHK(d_nat.reserve(steps_max + 2)); HIPCHK(d_validmask.reserve((steps_max + 2) * vwords));
         HIPCHK(d_sx.reserve(n_iter_max + 1)); HIPCHK(d_sy.reserve(n_iter_max + 1)); HIPCHK(d_sworld.reserve(n_iter_max + 1));
-        HIPCHK(d_qx.reserve(K)); HIPCHK(d_qy.reserve(K)); HIPCHK(d_qnn.reserve(K)); HIPCHK(d_qvid.reserve(K));
+        HIPCHK(d_qx.reserve(2 * Kpad)); HIPCHK(d_qy.reserve(2 * Kpad)); HIPCHK(d_qnn.reserve(2 * Kpad)); HIPCHK(d_qvid.reserve(2 * Kpad));      // two halves: pipelined steps (q_stride)
         // region pages: one static page per region + a pool that cannot run out (sum of ceil(n_r / 64) <= N / 64 + regions)
         const uint64_t rg_maxp = Nmax / kPage + 2, pg_cap = 2ull * kRegions + Nmax / kPage + 8;
         HIPCHK(d_rgcnt.reserve(2 * kRegions)); HIPCHK(d_rgocc.reserve(2 * kOccWords)); HIPCHK(d_rgdir.reserve((size_t)kRegions * rg_maxp));
@@ -813,6 +847,10 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.s_low0 = s_low[0]; c.s_low1 = s_low[1]; c.s_up0 = s_up[0]; c.s_up1 = s_up[1];
     c.max_step = max_step; c.mode = mode;
     c.part_stride = Kpad;
+    // pipelined steps only with the one-wave-per-sample kernels (the group kernels keep q_* in one half); a batch member's
+    // row is set by the leader, who knows which kernels will run
+    pipe_on = stage != 1 && mode == PORRT_MODE_RRT && opt_pipeline != 0 && (opt_group_req < 0 ? 0 : opt_group_req) == 0;
+    c.q_stride = pipe_on ? (uint32_t)Kpad : 0u;
     c.perm = d_perm.p; c.ssx = d_ssx.p; c.ssy = d_ssy.p; c.bq_x = d_bqx.p; c.bq_y = d_bqy.p; c.bq_k = d_bqk.p; c.t2_at = d_t2at.p;
 
     // ---- root (rrt.rs:105-106 / pto.rs:61-64)
@@ -986,6 +1024,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     opt_group = opt_group_req < 0 ? 0u : (uint32_t)opt_group_req;
     HIPCHK(hipEventRecord(ev_first, stream));
     side_active = false;
+    pipe_near_done = 0xFFFFFFFFu;
     commit_pend_b = 0xFFFFFFFFu;
     kd_b0 = 0; kd_last_b = 0; kd_last_nb = 0; kd_gidx = 0;
     kd_pend[0] = kd_pend[1] = false;
@@ -993,7 +1032,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     if (opt_graph && !prof && n_iter_min > 0) {
         // all steps up to n_iter_min as one hipGraph (two branches: main pipeline + kd insertion); the graph
         // only depends on the launch geometry, so it is instantiated once and replayed by later grows
-        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)launch_rcp, kd_group | ((uint64_t)launch_Q << 32) | ((uint64_t)opt_group << 48)};
+        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)launch_rcp, kd_group | ((uint64_t)launch_Q << 32) | ((uint64_t)opt_group << 48) | ((uint64_t)pipe_on << 56)};
         if (!graph_exec || memcmp(key, graph_key, sizeof key)) {
             double t0 = now_s();
             if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -2002,8 +2041,13 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             if (r) { if (cs[q] != L) L->set_err(cs[q]->err); return r; }
             if (cs[q]->run_lds_bytes != L->run_lds_bytes) { L->set_err("porrt_grow_batch: the contexts' rasters need different LDS tiles (max_step * ppm differs)"); return PORRT_ERR_INVALID; }
         }
+        L->opt_group = L->opt_group_req < 0 ? (n >= 8 ? 16u : 0u) : (uint32_t)L->opt_group_req;
+        L->pipe_on = mode == PORRT_MODE_RRT && L->opt_group == 0 && L->opt_pipeline != 0;
         L->rc_staging.resize(n);                 // one upload for all members (the vector outlives the copy: it is a member)
-        for (uint32_t q = 0; q < n; ++q) L->rc_staging[q] = cs[q]->rc;
+        for (uint32_t q = 0; q < n; ++q) {
+            cs[q]->rc.q_stride = L->pipe_on ? cs[q]->rc.part_stride : 0u;
+            L->rc_staging[q] = cs[q]->rc;
+        }
         HIPCHK_CTX(L, hipMemcpyAsync(L->d_rcarr, L->rc_staging.data(), (size_t)n * sizeof(RunConst), hipMemcpyHostToDevice, L->stream));
         if (mode == PORRT_MODE_RRT) {            // the members' preparation, all at once (k_batch_prep)
             const RunConst *rows = L->d_rcarr;
@@ -2016,8 +2060,8 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         // the leader: all steps, one hipGraph (or eager), grid rows = contexts
         L->launch_rcp = L->d_rcarr;
         L->launch_Q = n;
-        L->opt_group = L->opt_group_req < 0 ? (n >= 8 ? 16u : 0u) : (uint32_t)L->opt_group_req;
         L->side_active = false;
+        L->pipe_near_done = 0xFFFFFFFFu;
         L->commit_pend_b = 0xFFFFFFFFu;
         L->kd_b0 = 0; L->kd_last_b = 0; L->kd_last_nb = 0; L->kd_gidx = 0;
         L->kd_pend[0] = L->kd_pend[1] = false;
@@ -2041,7 +2085,9 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             uint32_t cb = 0;
             while (ci < n_iter) {
                 const uint32_t nb = (uint32_t)std::min<uint64_t>(K, n_iter - ci);
-                L->launch_step(cb, (uint32_t)ci, nb, vwords, L->run_lds_bytes, prof, ev_used, 0, 0);
+                const uint64_t i2 = ci + nb;                                                 // start of step cb + 1
+                const uint32_t nb2 = i2 < n_iter ? (uint32_t)std::min<uint64_t>(K, n_iter - i2) : 0;
+                L->launch_step(cb, (uint32_t)ci, nb, vwords, L->run_lds_bytes, prof, ev_used, (uint32_t)i2, nb2);
                 ci += nb;
                 ++cb;
             }
@@ -2050,7 +2096,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         };
         uint32_t steps = 0;
         if (L->opt_graph && !prof && !L->sub_eager) {
-            const uint64_t key[6] = {(uint64_t)mode, K, n_iter, L->run_lds_bytes, (uint64_t)(uintptr_t)L->launch_rcp, L->kd_group | ((uint64_t)n << 32) | ((uint64_t)L->opt_group << 48)};
+            const uint64_t key[6] = {(uint64_t)mode, K, n_iter, L->run_lds_bytes, (uint64_t)(uintptr_t)L->launch_rcp, L->kd_group | ((uint64_t)n << 32) | ((uint64_t)L->opt_group << 48) | ((uint64_t)L->pipe_on << 56)};
             if (!L->graph_exec || memcmp(key, L->graph_key, sizeof key)) {
                 if (L->graph_exec) { (void)hipGraphExecDestroy(L->graph_exec); L->graph_exec = nullptr; }
                 hipGraph_t g = nullptr;
@@ -2848,6 +2894,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "graph")) c->opt_graph = value != 0;
     else if (!strcmp(name, "group_lanes")) { if (value != -1 && value != 0 && value != 16 && value != 32 && value != 64) { c->set_err("group_lanes: -1 (auto), 0, 16, 32 or 64"); return PORRT_ERR_INVALID; } c->opt_group_req = (int)value; }
     else if (!strcmp(name, "dp_sweeps")) c->opt_dp_sweeps = value != 0;
+    else if (!strcmp(name, "pipeline")) c->opt_pipeline = value ? 1 : 0;
     else if (!strcmp(name, "batch_streams")) c->opt_batch_streams = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else if (!strcmp(name, "kd_group")) c->opt_kd_group = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else { c->set_err(std::string("unknown option ") + name); return PORRT_ERR_INVALID; }

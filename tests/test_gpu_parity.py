@@ -177,17 +177,50 @@ def test_headline_config_full_size(eng_mod):
     assert_same(e, o)
 
 
-@pytest.mark.parametrize("opts", [dict(graph=0), dict(kd_group=1), dict(kd_group=4), dict(graph=0, kd_group=3), dict(profile=1)],
+@pytest.mark.parametrize("opts", [dict(graph=0), dict(kd_group=1), dict(kd_group=4), dict(graph=0, kd_group=3), dict(profile=1), dict(pipeline=1),
+                                  dict(pipeline=1, graph=0), dict(pipeline=1, kd_group=1)],
                          ids=lambda o: ",".join("%s=%s" % kv for kv in o.items()))
 def test_launch_modes_do_not_change_results(eng_mod, opts):
-    """hipGraph replay vs eager launches, and how many steps' nodes enter the kd tie-order structure together (the
-    structure lags the steps; equal-cost parents that need it are settled later), must give the same tree."""
+    """hipGraph replay vs eager launches, how many steps' nodes enter the kd tie-order structure together (the
+    structure lags the steps; equal-cost parents that need it are settled later), and pipelined steps (k_step_rrt, option
+    pipeline) vs one kernel after the other, must give the same tree."""
     case = cases.cfg2(30000)
     e0, _ = run_gpu(eng_mod, case, 1024)
     e1, _ = run_gpu(eng_mod, case, 1024, **opts)
     assert_same(e1, e0)
     o, _ = run_orc(case, 1024)
     assert_same(e1, o)
+
+
+@pytest.mark.parametrize("K", [1, 64, 333, 1024])
+def test_pipelined_steps(eng_mod, K):
+    """option pipeline: connect(b) and search(b + 1) in one launch (k_step_rrt), filing and rewire phase 2 between two of them
+    (k_file_commit) -- small cases, odd batch sizes, the stepwise tail after n_iter_min, a batch of contexts, and a context
+    that goes back and forth between the two forms"""
+    for case in RRT_SMALL:
+        e, _ = run_gpu(eng_mod, case, K, pipeline=1)
+        o, _ = run_orc(case, K)
+        assert_same(e, o)
+    c = cases.cfg2(50)
+    c.update(n_iter_min=50, n_iter_max=30000)                  # stops on the goal: steps beyond n_iter_min launched one by one
+    e, _ = run_gpu(eng_mod, c, K, pipeline=1)
+    o, _ = run_orc(c, K)
+    assert_same(e, o)
+    if K >= 64:
+        cs = [cases.cfg2(6000, seed=s) for s in (0, 1, 2)]
+        engs = [cases.configure(eng_mod.Engine(), cc) for cc in cs]
+        engs[0].set_option("pipeline", 1)
+        eng_mod.Engine.grow_batch(engs, [cc.start for cc in cs], cs[0].max_step, cs[0].search_radius, cs[0].n_iter_min, K)
+        for e, cc in zip(engs, cs):
+            o, _ = run_orc(cc, K)
+            assert_same(e, o)
+        e = engs[1]                                             # was a member of a pipelined batch; now alone, off, on
+        for pipe in (0, 1):
+            e.set_option("pipeline", pipe)
+            e.set_sampler((-1.0, -1.0), (1.0, 1.0), cs[1].seed)
+            cases.grow(e, cs[1], K=K)
+            o, _ = run_orc(cs[1], K)
+            assert_same(e, o)
 
 
 @pytest.mark.parametrize("graph", [1, 0])
