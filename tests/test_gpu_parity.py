@@ -311,6 +311,26 @@ def test_get_trees_equals_get_tree(eng_mod):
         assert np.array_equal(xy, rxy) and np.array_equal(parent, rparent) and np.array_equal(dist, rdist) and xy.base is not None
 
 
+def test_grow_batch_splits_by_itself_from_32_contexts(eng_mod):
+    """33 RRT* contexts (sub-batches of 16 and 17 rows, group kernels) and 32 belief-space contexts (sub-batches of the PTO kernels):
+    the default batch_streams, nothing set"""
+    cs = [cases.cfg2(4000, seed=s, grid="map_benchmark_like_%s" % "abcdefghi"[s % 9]) for s in range(33)]
+    engs = [cases.configure(eng_mod.Engine(), c) for c in cs]
+    eng_mod.Engine.grow_batch(engs, [c.start for c in cs], cs[0].max_step, cs[0].search_radius, cs[0].n_iter_min, 512)
+    costs = eng_mod.Engine.best_cost_batch(engs)
+    for e, c, bc in zip(engs, cs, costs):
+        o, _ = run_orc(c, 512)
+        assert_same(e, o)
+        sol = o.best_solution()
+        assert (sol is None and np.isinf(bc)) or (sol is not None and bc == sol[1])
+    ps = [cases.cfg3(1500, 1500, seed=s) for s in range(32)]
+    pengs = [cases.configure(eng_mod.Engine(), c) for c in ps]
+    eng_mod.Engine.grow_batch(pengs, [c.start for c in ps], ps[0].max_step, ps[0].search_radius, 1500, 128, mode=cases.PTO)
+    for e, c in zip(pengs, ps):
+        o, _ = run_orc(c, 128)
+        assert_same(e, o, pto=True)
+
+
 def test_grow_batch_pto(eng_mod):
     cs = [cases.cfg3(6000, 6000, seed=s) for s in (0, 1)]
     engs = [cases.configure(eng_mod.Engine(), c) for c in cs]
