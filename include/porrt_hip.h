@@ -244,8 +244,8 @@ int porrt_get_metrics(const porrt_ctx *ctx, porrt_metrics *out);
  * step kernels: 16 / 32 / 64 lanes per sample, 0 = one wave per sample, -1 = chosen from the number
  * of contexts advanced together), "batch_streams" (on the FIRST context of a porrt_grow_batch: the
  * sub-batches it advances side by side, each on its own streams; 0 = 2 from 32 contexts on, else 1),
- * "pipeline" (RRT* steps of the one-wave-per-sample kernels: 1 = step b + 1 is searched while step b is connected,
- * in one launch; 0 (default) = one after the other), "dp_sweeps".  None of them changes a result. */
+ * "pipeline" (RRT* steps of the one-wave-per-sample kernels: 1 (default) = step b + 1 is searched while step b is
+ * connected, in one launch; 0 = one after the other), "dp_sweeps".  None of them changes a result. */
 int porrt_set_option(porrt_ctx *ctx, const char *name, int64_t value);
 
 /* Device arithmetic self-test: sqrt and divide of n doubles on the GPU versus the host's correctly

@@ -918,6 +918,106 @@ __device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, u
     if (threadIdx.x == 0) rc.cnt->n_pages += s_np;
 }
 
+// The same filing for k_file_commit (pipelined steps), where it is ON the chain of dependent kernels: one workgroup of 1024
+// threads, a thread per sample, and every load that does not depend on another thread's work issued before the first
+// barrier (the samples, the old counts of all regions -- kept in LDS --, the valid mask, the page counter): one round trip
+// to memory instead of five.  Same result as insert_step_pages up to the order of a step's nodes inside a region's
+// pages, which nothing depends on.
+constexpr uint32_t kFileLds = 2u * kRegions * 4u + 4096u * 2u + 64u * 8u + 66u * 4u + 32u;
+__device__ void file_step_fast(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords, uint8_t *scratch) {
+    uint32_t *s_add = reinterpret_cast<uint32_t *>(scratch);                               // [kRegions] new nodes per region
+    uint32_t *s_old = s_add + kRegions;                                                    // [kRegions] counts before the step
+    uint16_t *s_off = reinterpret_cast<uint16_t *>(s_old + kRegions);                      // [4096] a sample's place among its region's new nodes
+    unsigned long long *s_word = reinterpret_cast<unsigned long long *>(s_off + 4096);     // [64] the valid mask
+    uint32_t *s_pref = reinterpret_cast<uint32_t *>(s_word + 64);                          // [65] valid samples before word w
+    uint32_t *s_misc = s_pref + 66;                                                        // np, base, err, N
+    constexpr uint32_t T = 1024u, SPT = 4u;                                                // nb <= 4096 (batch_K)
+    const uint32_t tid = threadIdx.x, qo = q_off(rc, b);
+    auto rg_old = as_global(rc.rg_cnt) + (b & 1u) * kRegions, rg_new = as_global(rc.rg_cnt) + ((b + 1u) & 1u) * kRegions;
+    // ---- loads, all in flight together
+    int vid[SPT];
+    double x[SPT], y[SPT];
+#pragma unroll
+    for (uint32_t q = 0; q < SPT; ++q) {
+        const uint32_t k = tid + q * T;
+        vid[q] = k < nb ? as_global(rc.q_vid)[qo + k] : -1;
+        x[q] = k < nb ? as_global(rc.q_x)[qo + k] : 0.0;
+        y[q] = k < nb ? as_global(rc.q_y)[qo + k] : 0.0;
+    }
+    const uint32_t old0 = rg_old[tid], old1 = tid + T < kRegions ? rg_old[tid + T] : 0u;          // kRegions = 1600 <= 2 T
+    const unsigned long long word = tid < vwords ? as_global(rc.valid_mask)[(size_t)b * vwords + tid] : 0ull;
+    uint32_t n_pages = 0, N0 = 0;
+    if (tid == T - 1u) { n_pages = rc.cnt->n_pages; N0 = as_global(rc.n_at)[b]; }
+    s_add[tid] = 0; s_old[tid] = old0;
+    if (tid + T < kRegions) { s_add[tid + T] = 0; s_old[tid + T] = old1; }
+    if (tid < 64u) s_word[tid] = word;
+    if (tid == T - 1u) { s_misc[0] = 0; s_misc[1] = kRegions + n_pages; s_misc[2] = 0; s_misc[3] = N0; }
+    __syncthreads();
+    double t2_next = 0.0;
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (uint32_t w = 0; w < vwords; ++w) { s_pref[w] = acc; acc += (uint32_t)__popcll(s_word[w]); }
+        const uint32_t n_next = s_misc[3] + acc;
+        as_global(rc.n_at)[b + 1] = n_next;                              // tree size at the start of the next step
+        t2_next = as_global(rc.rad_T2)[n_next];                          // (in flight while the others go on; stored at the end)
+    }
+    uint32_t reg[SPT];
+#pragma unroll
+    for (uint32_t q = 0; q < SPT; ++q) {
+        reg[q] = 0;
+        if (vid[q] >= 0) { reg[q] = region_of(rc, x[q], y[q]); s_off[tid + q * T] = (uint16_t)atomicAdd(&s_add[reg[q]], 1u); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t h = 0; h < 2u; ++h) {
+        const uint32_t r = tid + h * T;
+        const uint32_t add = r < kRegions ? s_add[r] : 0u;
+        if (!add) continue;
+        const uint32_t old = s_old[r];
+        const uint32_t p_old = old ? (old + kPage - 1) / kPage : 1u, p_new = (old + add + kPage - 1) / kPage;
+        if (p_new > p_old) {
+            const uint32_t need = p_new - p_old;
+            const uint32_t at = s_misc[1] + atomicAdd(&s_misc[0], need);
+            if (at + need > rc.pg_cap || p_new > rc.rg_maxp) { atomicOr(&rc.cnt->err, (uint32_t)ERR_PAGE_OVERFLOW); s_misc[2] = 1u; continue; }
+            for (uint32_t i = 0; i < need; ++i) as_global(rc.rg_dir)[(size_t)r * rc.rg_maxp + p_old + i] = at + i;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (s_misc[2]) return;
+    const uint32_t N = s_misc[3];
+    dbl2 *pxy = reinterpret_cast<dbl2 *>(rc.pg_xy);
+#pragma unroll
+    for (uint32_t q = 0; q < SPT; ++q) {
+        if (vid[q] < 0) continue;
+        const uint32_t k = tid + q * T, r = reg[q];
+        const uint32_t slot = s_old[r] + s_off[k], j = slot / kPage;
+        const uint32_t page = j ? __hip_atomic_load(&rc.rg_dir[(size_t)r * rc.rg_maxp + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : r;
+        dbl2 v;
+        v.x = x[q]; v.y = y[q];
+        pxy[(size_t)page * kPage + (slot % kPage)] = v;
+        const uint32_t nid = N + s_pref[k >> 6] + (uint32_t)__popcll(s_word[k >> 6] & ((1ull << (k & 63u)) - 1ull));
+        as_global(rc.pg_id)[(size_t)page * kPage + (slot % kPage)] = (int)nid;
+        as_global(rc.slot_of)[nid] = page * kPage + (slot % kPage);
+        as_global(rc.nx)[nid] = x[q];        // the next step's search reads the coordinates before the connect pass has stored them: same bits
+        as_global(rc.ny)[nid] = y[q];
+    }
+#pragma unroll
+    for (uint32_t h = 0; h < 2u; ++h) {
+        const uint32_t r = tid + h * T;
+        if (r < kRegions) rg_new[r] = s_old[r] + s_add[r];
+    }
+    if (tid < kOccWords) {          // (a region never empties)
+        unsigned long long w = 0;
+        for (uint32_t i = 0; i < 64u; ++i) {
+            const uint32_t r = tid * 64u + i;
+            if (r < kRegions && s_old[r] + s_add[r] > 0u) w |= 1ull << i;
+        }
+        as_global(rc.rg_occ)[((b + 1u) & 1u) * kOccWords + tid] = w;
+    }
+    if (tid == 0) { as_global(rc.t2_at)[b + 1] = t2_next; rc.cnt->n_pages += s_misc[0]; }
+}
+
 // ------------------------------------------------------------------ connect
 __device__ __forceinline__ uint32_t rank_before(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k) {
     uint32_t r = 0;
@@ -1576,11 +1676,12 @@ __global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per
 
 // F(bf): block 0 files step bf's nodes (positions and validity are final since its search), the others run the rewire phase
 // 2 of step cb (cnb samples; cnb = 0: none)
-__global__ __launch_bounds__(256) void k_file_commit(const RunConst *__restrict__ rcp, uint32_t bf, uint32_t nbf, uint32_t cb, uint32_t cnb, uint32_t vwords) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_ins[kInsertLds];
+// (1024 threads: the filing is one workgroup's chain of dependent phases, a thread per sample keeps each phase to one pass)
+__global__ __launch_bounds__(1024) void k_file_commit(const RunConst *__restrict__ rcp, uint32_t bf, uint32_t nbf, uint32_t cb, uint32_t cnb, uint32_t vwords) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_ins[kFileLds];
     const RunConst &rc = rcp[blockIdx.y];
-    if (blockIdx.x == 0) { insert_step_pages(rc, bf, nbf, vwords, s_ins); return; }
-    const uint32_t ck = uni((blockIdx.x - 1u) * 4u + (threadIdx.x >> 6));
+    if (blockIdx.x == 0) { file_step_fast(rc, bf, nbf, vwords, s_ins); return; }
+    const uint32_t ck = uni((blockIdx.x - 1u) * 16u + (threadIdx.x >> 6));
     if (ck < cnb) commit_rrt_sample(rc, cb, vwords, ck, threadIdx.x & 63u);
 }
 

@@ -188,9 +188,9 @@ struct porrt_ctx {
     // other's kernels.  0 (default): 2 from 32 contexts on, else 1.
     uint32_t opt_batch_streams = 0;
     // "pipeline": RRT* steps of the one-wave-per-sample kernels as k_step_rrt / k_file_commit (step b + 1 is searched while step
-    // b is connected).  Off by default: measured on the bench's single query it does not pay yet -- connect + search in one
-    // launch take 34 us instead of 27 + 22, but the filing kernel between two of them is a 19 us chain of its own.
-    int opt_pipeline = 0;
+    // b is connected: the chain of dependent kernels of a single query is max(search, connect) + file per step instead of
+    // search + connect: 5.9 against 6.65 ms on the bench's query).  1 (default) / 0.
+    int opt_pipeline = 1;
     bool pipe_on = false;                  // the choice in force for the running launch sequence (set with opt_group)
     uint32_t pipe_near_done = 0xFFFFFFFFu; // pipelined: the step whose search and filing are already launched
     // porrt_get_trees (first context of the call): pinned staging slots and copy streams, one per worker thread
@@ -570,7 +570,7 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
         if (pipe_near_done != b) {
             hipLaunchKernelGGL(k_near<false>, dim3(wave_blocks, Q), dim3(256), 0, stream, rcp, b, i0, nb, vwords, 0xFFFFFFFFu, 0u);
             const uint32_t cnb = commit_pend_b != 0xFFFFFFFFu ? commit_pend_nb : 0u;
-            hipLaunchKernelGGL(k_file_commit, dim3(1 + (cnb + 3) / 4, Q), dim3(256), 0, stream, rcp, b, nb, commit_pend_b, cnb, vwords);
+            hipLaunchKernelGGL(k_file_commit, dim3(1 + (cnb + 15) / 16, Q), dim3(1024), 0, stream, rcp, b, nb, commit_pend_b, cnb, vwords);
             commit_pend_b = 0xFFFFFFFFu;
         }
         ev();
@@ -581,7 +581,7 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
         else hipLaunchKernelGGL(k_step_rrt<false>, sg, dim3(256), 0, stream, rcp, b, nb, nxt_i0, nxt_nb, vwords);
         ev();
         if (nxt_nb) {
-            hipLaunchKernelGGL(k_file_commit, dim3(1 + (nb + 3) / 4, Q), dim3(256), 0, stream, rcp, b + 1, nxt_nb, b, nb, vwords);
+            hipLaunchKernelGGL(k_file_commit, dim3(1 + (nb + 15) / 16, Q), dim3(1024), 0, stream, rcp, b + 1, nxt_nb, b, nb, vwords);
             pipe_near_done = b + 1;
         } else {
             commit_pend_b = b; commit_pend_nb = nb;

@@ -177,13 +177,13 @@ def test_headline_config_full_size(eng_mod):
     assert_same(e, o)
 
 
-@pytest.mark.parametrize("opts", [dict(graph=0), dict(kd_group=1), dict(kd_group=4), dict(graph=0, kd_group=3), dict(profile=1), dict(pipeline=1),
-                                  dict(pipeline=1, graph=0), dict(pipeline=1, kd_group=1)],
+@pytest.mark.parametrize("opts", [dict(graph=0), dict(kd_group=1), dict(kd_group=4), dict(graph=0, kd_group=3), dict(profile=1), dict(pipeline=0),
+                                  dict(pipeline=0, graph=0), dict(pipeline=0, kd_group=1)],
                          ids=lambda o: ",".join("%s=%s" % kv for kv in o.items()))
 def test_launch_modes_do_not_change_results(eng_mod, opts):
     """hipGraph replay vs eager launches, how many steps' nodes enter the kd tie-order structure together (the
-    structure lags the steps; equal-cost parents that need it are settled later), and pipelined steps (k_step_rrt, option
-    pipeline) vs one kernel after the other, must give the same tree."""
+    structure lags the steps; equal-cost parents that need it are settled later), and pipelined steps (k_step_rrt, the
+    default) vs one kernel after the other (pipeline=0), must give the same tree."""
     case = cases.cfg2(30000)
     e0, _ = run_gpu(eng_mod, case, 1024)
     e1, _ = run_gpu(eng_mod, case, 1024, **opts)
@@ -197,15 +197,13 @@ def test_pipelined_steps(eng_mod, K):
     """option pipeline: connect(b) and search(b + 1) in one launch (k_step_rrt), filing and rewire phase 2 between two of them
     (k_file_commit) -- small cases, odd batch sizes, the stepwise tail after n_iter_min, a batch of contexts, and a context
     that goes back and forth between the two forms"""
-    for case in RRT_SMALL:
-        e, _ = run_gpu(eng_mod, case, K, pipeline=1)
-        o, _ = run_orc(case, K)
-        assert_same(e, o)
     c = cases.cfg2(50)
     c.update(n_iter_min=50, n_iter_max=30000)                  # stops on the goal: steps beyond n_iter_min launched one by one
-    e, _ = run_gpu(eng_mod, c, K, pipeline=1)
-    o, _ = run_orc(c, K)
-    assert_same(e, o)
+    for pipe in (1, 0):
+        for case in RRT_SMALL + [c]:
+            e, _ = run_gpu(eng_mod, case, K, pipeline=pipe)
+            o, _ = run_orc(case, K)
+            assert_same(e, o)
     if K >= 64:
         cs = [cases.cfg2(6000, seed=s) for s in (0, 1, 2)]
         engs = [cases.configure(eng_mod.Engine(), cc) for cc in cs]
