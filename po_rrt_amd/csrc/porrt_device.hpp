@@ -121,6 +121,16 @@ struct Counters {
 #define PORRT_TACC_A(rc, slot) do {} while (0)
 #define PORRT_TACC_B(rc, slot) do {} while (0)
 #endif
+// =3: the timers of k_kd_locate
+#if defined(PORRT_TIMING) && PORRT_TIMING == 3
+#undef PORRT_TACC_B
+#define PORRT_TACC_B(rc, slot) do { (void)t__0; } while (0)
+#define PORRT_TACC_C(rc, slot) PORRT_TACC(rc, slot)
+#elif defined(PORRT_TIMING)
+#define PORRT_TACC_C(rc, slot) do { (void)t__0; } while (0)
+#else
+#define PORRT_TACC_C(rc, slot) do {} while (0)
+#endif
 
 struct BestCost {
     unsigned long long cost_bits;   // f64 bits of the best cost (+inf bits when there is no final node)
@@ -1809,6 +1819,7 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
     // The new nodes are the valid samples (positions known since k_near), id = n_at[b] + rank in their step.
     const size_t o2 = (size_t)b * rc.part_stride + (active ? k : 0u);
     if (active && as_global(rc.kq_vid)[o2] < 0) active = false;
+    PORRT_T0();
     const uint32_t bsnap = __hip_atomic_load(&rc.cnt->kd_snap, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t glen0 = as_global(rc.g_snap)[4 * bsnap + 0], n_nd = as_global(rc.g_snap)[4 * bsnap + 1];
     // (a goal path has a few dozen non-duplicate levels; the LDS of a side-stream workgroup is LDS the step kernels beside it
@@ -1843,6 +1854,7 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
         bd = (int)as_global(rc.kd_depth)[bu];
         if (!box_holds(load_box(rc.kd_box, (size_t)bu), vx, vy)) bu = -1;     // cannot happen (see k_kd_hint); the long way is always right
     }
+    PORRT_TACC_C(rc, 0);
     int cur;
     uint32_t dcur, side, gex = 0, flags = 0;
     KdBox bx;
@@ -1857,6 +1869,10 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
             kd_descend(rc, Nsnap, vx, vy, cur, dcur, side, bx);
         }
     }
+    PORRT_TACC_C(rc, 1);
+#if defined(PORRT_TIMING) && PORRT_TIMING == 3
+    if (LPN == 1) { const unsigned long long lw = __ballot(long_way); if ((threadIdx.x & 63u) == 0u) { atomicAdd(&rc.cnt->tim[6], (unsigned long long)__popcll(lw)); atomicAdd(&rc.cnt->tim[14], lw ? 1ull : 0ull); } }
+#endif
     if (long_way) {
         // Where does this node's descent leave the goal path G?  At the first level whose test it fails.  A level
         // held by an exact duplicate of the goal point tests `x < p.x` (even depth) or `y < p.y` (odd depth), and
@@ -1897,6 +1913,7 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
             kd_descend(rc, Nsnap, vx, vy, cur, dcur, side, bx);
         }
     }
+    PORRT_TACC_C(rc, 2);
     if (lane == 0) {
         const uint32_t lo = lpar * rc.loc_stride + t;
         rc.loc_cur[lo] = cur;
