@@ -954,12 +954,15 @@ __device__ void file_step_fast(const RunConst &rc, uint32_t b, uint32_t nb, uint
         x[q] = k < nb ? as_global(rc.q_x)[qo + k] : 0.0;
         y[q] = k < nb ? as_global(rc.q_y)[qo + k] : 0.0;
     }
-    const uint32_t old0 = rg_old[tid], old1 = tid + T < kRegions ? rg_old[tid + T] : 0u;          // kRegions = 1600 <= 2 T
+    constexpr uint32_t RPT = (kRegions + T - 1u) / T;                                              // regions per thread
+    uint32_t oldc[RPT];
+#pragma unroll
+    for (uint32_t h = 0; h < RPT; ++h) oldc[h] = tid + h * T < kRegions ? rg_old[tid + h * T] : 0u;
     const unsigned long long word = tid < vwords ? as_global(rc.valid_mask)[(size_t)b * vwords + tid] : 0ull;
     uint32_t n_pages = 0, N0 = 0;
     if (tid == T - 1u) { n_pages = rc.cnt->n_pages; N0 = as_global(rc.n_at)[b]; }
-    s_add[tid] = 0; s_old[tid] = old0;
-    if (tid + T < kRegions) { s_add[tid + T] = 0; s_old[tid + T] = old1; }
+#pragma unroll
+    for (uint32_t h = 0; h < RPT; ++h) if (tid + h * T < kRegions) { s_add[tid + h * T] = 0; s_old[tid + h * T] = oldc[h]; }
     if (tid < 64u) s_word[tid] = word;
     if (tid == T - 1u) { s_misc[0] = 0; s_misc[1] = kRegions + n_pages; s_misc[2] = 0; s_misc[3] = N0; }
     __syncthreads();
@@ -979,7 +982,7 @@ __device__ void file_step_fast(const RunConst &rc, uint32_t b, uint32_t nb, uint
     }
     __syncthreads();
 #pragma unroll
-    for (uint32_t h = 0; h < 2u; ++h) {
+    for (uint32_t h = 0; h < RPT; ++h) {
         const uint32_t r = tid + h * T;
         const uint32_t add = r < kRegions ? s_add[r] : 0u;
         if (!add) continue;
@@ -1013,7 +1016,7 @@ __device__ void file_step_fast(const RunConst &rc, uint32_t b, uint32_t nb, uint
         as_global(rc.ny)[nid] = y[q];
     }
 #pragma unroll
-    for (uint32_t h = 0; h < 2u; ++h) {
+    for (uint32_t h = 0; h < RPT; ++h) {
         const uint32_t r = tid + h * T;
         if (r < kRegions) rg_new[r] = s_old[r] + s_add[r];
     }
