@@ -263,7 +263,7 @@ __device__ __forceinline__ double region_gap2(const RunConst &rc, double qx, dou
 template <int GL>
 __device__ __forceinline__ void group_nn(const RunConst &rc, uint32_t b, const GTeam<GL> &tm, uint32_t N, double sqx, double sqy, int &nn, double &fx,
                                          double &fy) {
-    static_assert(GL >= 16, "a 4 x 4 block of regions, one lane each");
+    static_assert(GL >= 16, "a 4 x 4 block of regions, one lane each (8 x 8 on a fine grid: four each)");
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
     double bestD = INF, bestx = 0.0, besty = 0.0;
     int best = 0x7FFFFFFF;
@@ -291,24 +291,41 @@ __device__ __forceinline__ void group_nn(const RunConst &rc, uint32_t b, const G
     auto gcnt = as_global(rc.rg_cnt) + (b & 1u) * kRegions;
     int rx, ry;
     rep_cell(rc, sqx, sqy, kRG, rx, ry);
-    // ---- stage A: the block [bx0, bx0 + 4) x [by0, by0 + 4) with the sample's region in its middle half
+    // ---- stage A: the block [ax0, ax0 + SB) x [ay0, ay0 + SB) of regions with the sample's region in its middle; the block
+    // covers about the same area whatever the grid (a finer grid makes the radius searches cheaper and would otherwise
+    // send most nearest-neighbour searches on to stage B)
+    constexpr int SB = kRG >= 56 ? 8 : 4, NBLK = SB * SB, RPL = (NBLK + GL - 1) / GL;         // regions per lane
     const double fcx = (sqx - rc.bx0) * rc.binv_w * (double)kRG - (double)rx, fcy = (sqy - rc.by0) * rc.binv_h * (double)kRG - (double)ry;
-    int ax0 = rx - (fcx < 0.5 ? 2 : 1), ay0 = ry - (fcy < 0.5 ? 2 : 1);
-    ax0 = ax0 < 0 ? 0 : (ax0 > kRG - 4 ? kRG - 4 : ax0);
-    ay0 = ay0 < 0 ? 0 : (ay0 > kRG - 4 ? kRG - 4 : ay0);
+    int ax0 = rx - (fcx < 0.5 ? SB / 2 : SB / 2 - 1), ay0 = ry - (fcy < 0.5 ? SB / 2 : SB / 2 - 1);
+    ax0 = ax0 < 0 ? 0 : (ax0 > kRG - SB ? kRG - SB : ax0);
+    ay0 = ay0 < 0 ? 0 : (ay0 > kRG - SB ? kRG - SB : ay0);
     {
-        const int cx = ax0 + (int)(tm.gl & 3u), cy = ay0 + (int)((tm.gl >> 2) & 3u);
-        const uint32_t reg = (uint32_t)(cy * kRG + cx);
-        uint32_t cnt = tm.gl < 16u ? gcnt[reg] : 0u;
-        double gap = cnt ? region_gap2(rc, sqx, sqy, cx, cy) : INF;
+        uint32_t reg[RPL], cnt[RPL];
+        double gap[RPL];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            const int idx = (int)tm.gl + q * GL;
+            const bool in = idx < NBLK;
+            const int cx = ax0 + (in ? idx % SB : 0), cy = ay0 + (in ? idx / SB : 0);
+            reg[q] = (uint32_t)(cy * kRG + cx);
+            cnt[q] = in ? gcnt[reg[q]] : 0u;
+            gap[q] = cnt[q] ? region_gap2(rc, sqx, sqy, cx, cy) : INF;
+        }
         for (;;) {
-            double g = gap;
+            double g = gap[0];
+            uint32_t mreg = reg[0], mcnt = cnt[0];
+            int mq = 0;
+#pragma unroll
+            for (int q = 1; q < RPL; ++q) if (gap[q] < g) { g = gap[q]; mreg = reg[q]; mcnt = cnt[q]; mq = q; }
             int who = (int)tm.gl;
             tm.argmin(g, who);
             if (!(g <= thr) || g == INF) break;              // nothing left in the block that could hold a node as near
-            gscan_region<GL>(rc, tm, tm.shfl(reg, who), tm.shfl(cnt, who), visit);
+            gscan_region<GL>(rc, tm, tm.shfl(mreg, who), tm.shfl(mcnt, who), visit);
             group_best();
-            if ((int)tm.gl == who) gap = INF;
+            if ((int)tm.gl == who) {
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) if (q == mq) gap[q] = INF;
+            }
         }
     }
     // settled if no node outside the block can be as near: the gap to the block's complement (border regions reach to infinity)
@@ -317,9 +334,9 @@ __device__ __forceinline__ void group_nn(const RunConst &rc, uint32_t b, const G
         const double eps = 1e-9 * (1.0 + fabs(sqx) + fabs(sqy));
         double out = INF;
         if (ax0 > 0) { const double d = sqx - (rc.bx0 + (double)ax0 * wx) - eps; out = d < out ? d : out; }
-        if (ax0 + 4 < kRG) { const double d = (rc.bx0 + (double)(ax0 + 4) * wx) - sqx - eps; out = d < out ? d : out; }
+        if (ax0 + SB < kRG) { const double d = (rc.bx0 + (double)(ax0 + SB) * wx) - sqx - eps; out = d < out ? d : out; }
         if (ay0 > 0) { const double d = sqy - (rc.by0 + (double)ay0 * wy) - eps; out = d < out ? d : out; }
-        if (ay0 + 4 < kRG) { const double d = (rc.by0 + (double)(ay0 + 4) * wy) - sqy - eps; out = d < out ? d : out; }
+        if (ay0 + SB < kRG) { const double d = (rc.by0 + (double)(ay0 + SB) * wy) - sqy - eps; out = d < out ? d : out; }
         out = out > 0.0 ? out : 0.0;
         if (out * out > thr) { nn = best; fx = bestx; fy = besty; return; }
     }
@@ -335,7 +352,7 @@ __device__ __forceinline__ void group_nn(const RunConst &rc, uint32_t b, const G
             const uint32_t bit = (uint32_t)__builtin_ctzll(m);
             m &= m - 1;
             const int r = (int)(wi * 64u + bit), cx = r % kRG, cy = r / kRG;
-            if (cx >= ax0 && cx < ax0 + 4 && cy >= ay0 && cy < ay0 + 4) w[q] &= ~(1ull << bit);
+            if (cx >= ax0 && cx < ax0 + SB && cy >= ay0 && cy < ay0 + SB) w[q] &= ~(1ull << bit);
         }
     }
     for (;;) {
