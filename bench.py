@@ -47,6 +47,11 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option for every context (porrt_set_option), e.g. group_lanes=32")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps run with per-kernel HIP events for `roofline`")
     args = ap.parse_args()
+    # stdout carries the one JSON line and nothing else: RCCL prints a version banner there when the first communicator is made,
+    # and any other library may follow -- everything this process writes to descriptor 1 goes to stderr, the line to the real one
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -312,7 +317,7 @@ def main():
                     out["config"][key] = fn(local_rank, not args.no_cpu_baseline)
                 except Exception as ex:                      # noqa: BLE001
                     out["config"][key] = {"error": "%s: %s" % (type(ex).__name__, ex)}
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     comm.close()
     if world > 1:
         dist.destroy_process_group()
