@@ -1965,7 +1965,7 @@ int porrt_ctx::finish_batch_member(uint64_t n_iter_done, uint32_t steps, float d
 }
 
 // `want` streams of the current device of which any two run their kernels side by side, found by trying: a pair of single-wave
-// kernels that each wait 150 us takes 150 us on two hardware queues and 300 on one.  Fewer than `want` (the caller then keeps
+// kernels that each wait 150 us takes as long as one of them on two hardware queues and twice that on one.  Fewer than `want` (the caller then keeps
 // its own streams) if 4 * want candidates do not hold such a set.
 static std::vector<hipStream_t> pick_parallel_streams(uint32_t want) {
     std::vector<hipStream_t> chosen, rejected;
@@ -1977,14 +1977,26 @@ static std::vector<hipStream_t> pick_parallel_streams(uint32_t want) {
         (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
         return now_s() - t0;
     };
+    double t_one = 0.0;         // one such kernel alone (launch and wait included): what "side by side" is measured against
     for (uint32_t tries = 0; chosen.size() < want && tries < 4u * want; ++tries) {
         hipStream_t st = nullptr;
         if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
         hipLaunchKernelGGL(k_wait_us, dim3(1), dim3(64), 0, st, 1u);          // first use: the stream gets its queue
+        if (t_one == 0.0) {
+            double best = 1e9;
+            for (int rep = 0; rep < 3; ++rep) {
+                (void)hipStreamSynchronize(st);
+                const double t0 = now_s();
+                hipLaunchKernelGGL(k_wait_us, dim3(1), dim3(64), 0, st, 150u);
+                (void)hipStreamSynchronize(st);
+                best = std::min(best, now_s() - t0);
+            }
+            t_one = best;
+        }
         bool ok = true;
         for (hipStream_t c : chosen) {
             const double t = std::min(pair_s(c, st), pair_s(c, st));
-            if (t > 240e-6) { ok = false; break; }
+            if (t > 1.6 * t_one) { ok = false; break; }           // two on one queue: 2 x
         }
         (ok ? chosen : rejected).push_back(st);
     }
