@@ -1039,6 +1039,22 @@ __device__ __forceinline__ uint32_t rank_before(const RunConst &rc, uint32_t b, 
     r += __popcll(vm[k >> 6] & ((1ull << (k & 63u)) - 1ull));
     return r;
 }
+// The same by the `stride` lanes (a power of two <= 64, aligned in the wave) that serve sample k together, called by all of them:
+// a word of the mask per lane and a sum over the lanes instead of every lane reading every word (k is not wave-uniform when a
+// wave holds several samples, so those would be vector loads: up to 16 per lane at K = 1024).
+__device__ __forceinline__ uint32_t rank_before_lanes(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k, uint32_t lane, uint32_t stride) {
+    auto vm = as_global(rc.valid_mask) + (size_t)b * vwords;
+    const uint32_t wk = k >> 6;
+    uint32_t r = 0;
+    for (uint32_t w0 = 0; w0 <= wk; w0 += stride) {
+        const uint32_t w = w0 + lane;
+        unsigned long long v = w <= wk ? vm[w] : 0ull;
+        if (w == wk) v &= (1ull << (k & 63u)) - 1ull;
+        r += (uint32_t)__popcll(v);
+    }
+    for (uint32_t off = stride >> 1; off > 0; off >>= 1) r += (uint32_t)__shfl_xor((int)r, (int)off);
+    return r;
+}
 
 // Fill the calling wave's LDS tile with the (2R+1)^2 raster window centred on the pixel of (px,py).
 __device__ __forceinline__ TileGrid load_tile(const RunConst &rc, uint8_t *tile, double px, double py, uint32_t lane, uint32_t stride) {
@@ -1703,7 +1719,7 @@ __global__ __launch_bounds__(1024) void k_file_commit(const RunConst *__restrict
 __device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k, uint32_t lane, uint32_t stride) {
     if (!((as_global(rc.valid_mask)[(size_t)b * vwords + (k >> 6)] >> (k & 63u)) & 1ull)) return;
     const uint32_t N = as_global(rc.n_at)[b];
-    const int id = (int)(N + rank_before(rc, b, vwords, k));
+    const int id = (int)(N + (stride < 64u ? rank_before_lanes(rc, b, vwords, k, lane, stride) : rank_before(rc, b, vwords, k)));
     const uint32_t cnt = cand_count(rc, b, k);
     auto cid = as_global(rc.cand_id) + cand_off(rc, b, k);
     auto cval = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;

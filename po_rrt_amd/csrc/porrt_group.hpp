@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     grid.p = rc.cls; grid.W = rc.W;
     if (act) {
         // second round trip: the new node's id and the clearance around its pixel, beside the region counts of the search
-        id = N + rank_before(rc, b, vwords, k);
+        id = N + rank_before_lanes(rc, b, vwords, k, tm.gl, (uint32_t)GL);
         if (rc.has_grid) {
             uint32_t bi, bj;
             to_pixel(rc, px, py, bi, bj);
