@@ -599,7 +599,7 @@ __device__ __forceinline__ MemHits mem_hits(const RunConst &rc, uint32_t b, uint
 }
 
 template <int GL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_conn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_conn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
     static_assert(GL == 16 || GL == 32 || GL == 64, "group size");
     constexpr uint32_t SPB = 256u / GL;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];
