@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <unordered_map>
 #include <limits>
@@ -2414,8 +2415,12 @@ int porrt_grow_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, const double *start
     };
     {
         std::vector<std::thread> th;
-        for (uint32_t g = 1; g < G; ++g) th.emplace_back(part, g);
+        std::vector<uint32_t> inline_parts;                 // (a host that cannot start another thread: those sub-batches run here, afterwards)
+        for (uint32_t g = 1; g < G; ++g) {
+            try { th.emplace_back(part, g); } catch (const std::system_error &) { inline_parts.push_back(g); }
+        }
         part(0);
+        for (uint32_t g : inline_parts) part(g);
         for (auto &t : th) t.join();
     }
     int worst = PORRT_OK;
@@ -2497,8 +2502,12 @@ int porrt_get_trees(porrt_ctx *const *ctxs, uint32_t n_ctx, double *const *xy, i
     };
     {
         std::vector<std::thread> th;
-        for (uint32_t w = 1; w < W; ++w) th.emplace_back(work, w);
+        std::vector<uint32_t> inline_work;
+        for (uint32_t w = 1; w < W; ++w) {
+            try { th.emplace_back(work, w); } catch (const std::system_error &) { inline_work.push_back(w); }
+        }
         work(0);
+        for (uint32_t w : inline_work) work(w);
         for (auto &t : th) t.join();
     }
     for (uint32_t w = 0; w < W; ++w) if (rcs[w]) { top->set_err("porrt_get_trees: device copy failed"); return rcs[w]; }
