@@ -11,7 +11,10 @@ single-query figure is measured too and reported in `config.single_query`.  Inpu
 HBM before the timed region; the trees stay on the device (results are downloaded lazily).
 
   python bench.py --gpus N --steps K --warmup W
-For N > 1 it is launched by torch.distributed.run, one rank per GPU: every rank plans its own independent
+For N > 1 there is one rank per GPU.  Under a launcher (torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment) this process IS a rank; started bare (`python bench.py --gpus 8`) it starts the N rank processes itself, before
+anything has touched a GPU, relays rank 0's JSON line and exits with the worst rank's code (launch_ranks below; it refuses
+with exit code 3 when fewer than N devices are visible).  Every rank plans its own independent
 queries (different RNG seeds, at N > 1 spread over the nine maps map_benchmark_like_{a..i}; no data-path collective:
 weak scaling) and the job ends with ONE exchange behind the C ABI (porrt_exchange_best: ncclAllGather of the best path
 cost per map and rank, ncclBroadcast of the winning trees).
@@ -32,6 +35,79 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def launch_ranks(n, argv, check_only):
+    """`bench.py --gpus N` without a launcher's environment: start the N rank processes (children of this one; this process
+    never initialises a GPU -- torch.cuda.device_count() does not, on this image), rank 0's stdout is relayed, the others' goes to
+    stderr.  Returns the exit code: 0, the first failing rank's code, or 3 when fewer than N devices are visible."""
+    import socket
+    import subprocess
+    if not check_only:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but %d HIP device(s) visible: not started\n" % (n, have))
+            return 3
+    with socket.socket() as sk:                       # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # the host driver only supports dmabuf IPC (RCCL across processes)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    box = []
+    reader = threading.Thread(target=lambda: box.append(procs[0].stdout.read()), daemon=True)      # rank 0 writes its one line at the very end
+    reader.start()
+    code = 0
+    while any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            rc = p.poll()
+            if rc not in (None, 0) and code == 0:
+                code = rc if rc > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with code %d\n" % (r, rc))
+                for q in procs:                        # a rank that died leaves the others in a collective: end exactly these children
+                    if q.poll() is None:
+                        q.terminate()
+        time.sleep(0.1)
+    for r, p in enumerate(procs):
+        if p.returncode != 0 and code == 0:
+            code = p.returncode if p.returncode > 0 else 1
+            sys.stderr.write("bench.py: rank %d exited with code %d\n" % (r, p.returncode))
+    reader.join(10)
+    out0 = box[0] if box else b""
+    if code == 0:
+        sys.stdout.buffer.write(out0)
+        sys.stdout.flush()
+    return code
+
+
+def launch_check(rank, local_rank, world, real_stdout):
+    """--launch-check: what a rank does with the launcher's environment, without a GPU -- the gloo rendezvous, the partition of the
+    queries, and the exchange's two host-side decisions on gathered words.  Used by the CPU tests of the N > 1 start-up."""
+    import numpy as np
+    import torch.distributed as dist
+    from po_rrt_amd import sharding
+    from po_rrt_amd.engine import BEST_ENTRY
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = sharding.queries_of_rank(4 * world + 1, rank, world)
+    words = [None] * world
+    dist.all_gather_object(words, (0, 9))
+    rc, bad = sharding.agree_from_gathered(words, rank)
+    table = np.zeros(9, dtype=BEST_ENTRY)
+    table["cost"], table["rank"], table["n_nodes"] = 1.0 + ((rank + np.arange(9)) % world), rank, 10
+    tables = [None] * world
+    dist.all_gather_object(tables, table.tobytes())
+    win = sharding.decide_from_gathered(np.stack([np.frombuffer(t, dtype=BEST_ENTRY) for t in tables]))
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.stderr.write("launch-check rank %d of %d local_rank %d queries %s agree %d\n" % (rank, world, local_rank, mine, rc))
+    if rank == 0:
+        os.write(real_stdout, (json.dumps({"launch_check": True, "n_gpus": world, "agree": rc, "winners": win.tolist()}) + "\n").encode())
+    return 0 if rc == 0 and bad == -1 else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,7 +122,10 @@ def main():
     ap.add_argument("--no-belief", action="store_true", help="skip the belief-space expansion measurement (SURVEY 8f.1)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option for every context (porrt_set_option), e.g. group_lanes=32")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps run with per-kernel HIP events for `roofline`")
+    ap.add_argument("--launch-check", action="store_true", help="start the ranks, rendezvous over gloo and stop (no GPU needed)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.launch_check))
     # stdout carries the one JSON line and nothing else: RCCL prints a version banner there when the first communicator is made,
     # and any other library may follow -- everything this process writes to descriptor 1 goes to stderr, the line to the real one
     sys.stdout.flush()
@@ -56,8 +135,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.launch_check:
+        raise SystemExit(launch_check(rank, local_rank, world, real_stdout))
 
     import numpy as np
     import torch

@@ -53,7 +53,9 @@ enum {
     PORRT_ERR_DEVICE = -4,          /* HIP runtime error */
     PORRT_ERR_CAPACITY = -5,        /* a neighbour list outgrew its capacity even after regrowth */
     PORRT_ERR_NO_DEVICE = -6,
-    PORRT_ERR_IO = -7               /* a file could not be opened / written (the reference panics: "Impossible to open image") */
+    PORRT_ERR_IO = -7,              /* a file could not be opened / written (the reference panics: "Impossible to open image") */
+    PORRT_ERR_PEER = -8,            /* porrt_exchange_best: another rank of the collective failed; no rank went on */
+    PORRT_ERR_NOMEM = -9            /* a host allocation failed (std::bad_alloc never crosses the boundary) */
 };
 
 enum { PORRT_DOMAIN_SHELF = 0, PORRT_DOMAIN_DOOR = 1 };   /* MapShelfDomain / Map */
@@ -318,14 +320,20 @@ int         porrt_comm_unique_id(uint8_t id[PORRT_UNIQUE_ID_BYTES]);
 porrt_comm *porrt_comm_create(int device, int rank, int world, const uint8_t id[PORRT_UNIQUE_ID_BYTES]);   /* NULL on failure */
 void        porrt_comm_destroy(porrt_comm *comm);
 const char *porrt_comm_last_error(const porrt_comm *comm);
-/* ctxs[q] planned on map map_ids[q] (< n_maps); every rank passes the same n_maps.  winners[m] is the same
- * on every rank afterwards.  Collective: all ranks of the communicator must call it. */
+/* ctxs[q] (contexts of mode PORRT_MODE_RRT) planned on map map_ids[q] (< n_maps); every rank passes the same n_maps.
+ * winners[m] is the same on every rank afterwards.  Collective: all ranks of the communicator must call it -- and a rank
+ * whose own part fails (bad argument, a context without a tree, allocation) still takes part: before each data step the
+ * ranks all-gather a status word, and either all go on or all return -- the failing rank its own code, the others
+ * PORRT_ERR_PEER (porrt_comm_last_error names the rank); ranks called with different n_maps all get PORRT_ERR_INVALID. */
 int      porrt_exchange_best(porrt_comm *comm, porrt_ctx *const *ctxs, uint32_t n_ctx, const uint32_t *map_ids,
                              uint32_t n_maps, porrt_best_entry *winners);
 uint64_t porrt_exchange_num_nodes(const porrt_comm *comm, uint32_t map);
 int      porrt_exchange_get_tree(const porrt_comm *comm, uint32_t map, double *xy, int64_t *parent, double *dist_root);
 /* step 2 of the exchange on its own (pure host code): all[r * n_maps + m] -> win_rank[m] */
 int      porrt_exchange_decide(const porrt_best_entry *all, uint32_t world, uint32_t n_maps, int32_t *win_rank);
+/* the status decision on its own (pure host code): words[2r] = code of rank r (0 or negative), words[2r+1] = its n_maps;
+ * returns what rank my_rank must return (above), *bad_rank = the first failing / disagreeing rank or -1 */
+int      porrt_exchange_agree(const int32_t *words /* world x 2 */, uint32_t world, uint32_t my_rank, int32_t *bad_rank);
 
 /* The grown tree where it lives: device pointers into the context's arena (valid until the context's
  * next grow or its destruction).  n_nodes = 0 when there are no results. */

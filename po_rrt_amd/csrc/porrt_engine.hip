@@ -197,8 +197,9 @@ struct porrt_ctx {
     // porrt_get_trees (first context of the call): pinned staging slots and copy streams, one per worker thread
     std::vector<void *> dl_pin;
     std::vector<hipStream_t> dl_streams;
-    size_t dl_pin_bytes = 0;
+    std::vector<size_t> dl_pin_cap;                 // bytes of each pinned slot (slots made by different calls differ)
     bool sub_eager = false;                        // leader of a sub-batch on measured streams: launch step by step (see porrt_grow_batch)
+    uint32_t sub_streams_tried = 0;                 // a probe for this many streams already failed: not repeated call after call
     std::vector<hipStream_t> sub_streams;          // first context of such a call: the sub-batches' main streams (see porrt_grow_batch)
     bool opt_dp_sweeps = false;            // "dp_sweeps": expected costs by whole-graph sweeps instead of layer by layer
     uint32_t opt_cand_cap = 2048;
@@ -2223,15 +2224,15 @@ porrt_ctx *porrt_create(int device) {
 
 void porrt_destroy(porrt_ctx *c) {
     if (!c) return;
-    // a batch leader going away takes its RunConst array with it: its members must not look for it any more
-    for (hipStream_t st : c->sub_streams) (void)hipStreamDestroy(st);
-    for (hipStream_t st : c->dl_streams) (void)hipStreamDestroy(st);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (hipStream_t st : c->sub_streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (hipStream_t st : c->dl_streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (void *q : c->dl_pin) if (q) (void)hipHostFree(q);
+    // a batch leader going away takes its RunConst array with it: its members must not look for it any more
     for (porrt_ctx *m : c->batch_members) if (m && m != c && m->batch_leader == c) m->batch_leader = nullptr;
     if (c->batch_leader && c->batch_leader != c)
         for (porrt_ctx *&m : c->batch_leader->batch_members) if (m == c) m = nullptr;
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
     if (c->arena.base) (void)hipFree(c->arena.base);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -2398,9 +2399,10 @@ int porrt_grow_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, const double *start
     // measurement, once per leading context: pick_parallel_streams.
     porrt_ctx *top = ctxs[0];
     if (hipSetDevice(top->device) != hipSuccess) { top->set_err("hipSetDevice"); return PORRT_ERR_DEVICE; }
-    if (top->sub_streams.size() < 2u * G) {
+    if (top->sub_streams.size() < 2u * G && top->sub_streams_tried != 2u * G) {
         for (hipStream_t st : top->sub_streams) (void)hipStreamDestroy(st);
         top->sub_streams = pick_parallel_streams(2u * G);
+        if (top->sub_streams.size() < 2u * G) top->sub_streams_tried = 2u * G;      // (e.g. under a profiler that serialises kernels: every pair test fails)
     }
     const bool have_streams = top->sub_streams.size() >= 2u * G;
     auto part = [&](uint32_t g) {
@@ -2463,15 +2465,15 @@ int porrt_get_trees(porrt_ctx *const *ctxs, uint32_t n_ctx, double *const *xy, i
     if (hipSetDevice(top->device) != hipSuccess) { top->set_err("hipSetDevice"); return PORRT_ERR_DEVICE; }
     const uint32_t W = std::min<uint32_t>(8u, n_ctx);
     const size_t slot = (maxN * 28u + 4095u) & ~(size_t)4095u;          // nx, ny, dist_root (f64) and parent (i32) of one tree
-    if (top->dl_pin_bytes < slot) {
-        for (void *q : top->dl_pin) if (q) (void)hipHostFree(q);
-        top->dl_pin.clear(); top->dl_pin_bytes = 0;
-    }
-    while (top->dl_pin.size() < W) {
+    // every worker's slot must hold the largest tree of THIS call; slots are kept across calls, each with its own size
+    if (top->dl_pin.size() < W) { top->dl_pin.resize(W, nullptr); top->dl_pin_cap.resize(W, 0); }
+    for (uint32_t w = 0; w < W; ++w) {
+        if (top->dl_pin[w] && top->dl_pin_cap[w] >= slot) continue;
+        if (top->dl_pin[w]) { (void)hipHostFree(top->dl_pin[w]); top->dl_pin[w] = nullptr; top->dl_pin_cap[w] = 0; }
         void *q = nullptr;
         if (hipHostMalloc(&q, slot + slot / 8, hipHostMallocDefault) != hipSuccess) { top->set_err("hipHostMalloc (tree staging)"); return PORRT_ERR_DEVICE; }
-        top->dl_pin.push_back(q);
-        top->dl_pin_bytes = slot + slot / 8;
+        top->dl_pin[w] = q;
+        top->dl_pin_cap[w] = slot + slot / 8;
     }
     while (top->dl_streams.size() < W) {
         hipStream_t st = nullptr;

@@ -3,6 +3,8 @@
 // Planning queries are independent (map x seed, or the sub-queries of a TAMP search, src/map_shelves_tamp_rrt.rs:163-291):
 // query q runs on rank q mod world_size and nothing is communicated while the trees grow.  When a job ends every rank
 // holds, per map, its best tree (lowest path cost, RRT::get_best_solution src/rrt.rs:183-193).  The exchange:
+//   0. (before each of the steps below) ncclAllGather of a status word per rank: a rank that failed locally takes part, and
+//      either every rank goes on or every rank returns (porrt_exchange_agree, pure host code);
 //   1. ncclAllGather of one 16-byte entry (cost f64, rank i32, n_nodes i32) per map and rank;
 //   2. per map the first minimum of (cost, rank) wins (porrt_exchange_decide, pure host code);
 //   3. ncclBroadcast of the winner's node SoA (x, y, dist_root f64; parent i32 = 28 B per node) straight out of the
@@ -31,6 +33,7 @@ struct porrt_comm {
     hipStream_t stream = nullptr;
     std::string err;
     porrt_best_entry *d_send = nullptr, *d_recv = nullptr;
+    int32_t *d_status = nullptr;       // [2] this rank's status word, then [2 * world] the gathered ones (made with the communicator: agreeing must not need an allocation)
     size_t table_cap = 0;
     struct Tree {
         double *nx = nullptr, *ny = nullptr, *dist = nullptr;
@@ -80,7 +83,9 @@ porrt_comm *porrt_comm_create(int device, int rank, int world, const uint8_t id[
     c->device = device; c->rank = rank; c->world = world;
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || ncclCommInitRank(&c->comm, world, u, rank) != ncclSuccess) {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&c->d_status, (2 + 2 * (size_t)world) * sizeof(int32_t)) != hipSuccess ||
+        ncclCommInitRank(&c->comm, world, u, rank) != ncclSuccess) {
+        if (c->d_status) (void)hipFree(c->d_status);
         if (c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return nullptr;
@@ -95,6 +100,7 @@ void porrt_comm_destroy(porrt_comm *c) {
     for (auto &t : c->trees) comm_free_tree(t);
     if (c->d_send) (void)hipFree(c->d_send);
     if (c->d_recv) (void)hipFree(c->d_recv);
+    if (c->d_status) (void)hipFree(c->d_status);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -118,75 +124,140 @@ int porrt_exchange_decide(const porrt_best_entry *all, uint32_t world, uint32_t 
     return PORRT_OK;
 }
 
+// The worst status of a collective step, decided alike on every rank from the gathered status words (pure host code):
+// word r = {code of rank r (0 or a negative PORRT_ERR_*), the n_maps rank r was called with}.  Returns 0 when every rank
+// is fine and all agree on n_maps; otherwise the code this rank must return -- its own if it failed, PORRT_ERR_PEER if only
+// others did, PORRT_ERR_INVALID on every rank when the map counts differ -- and the first failing rank in *bad_rank.
+int porrt_exchange_agree(const int32_t *words /* world x 2 */, uint32_t world, uint32_t my_rank, int32_t *bad_rank) {
+    if (!words || world == 0 || my_rank >= world) return PORRT_ERR_INVALID;
+    int32_t bad = -1;
+    for (uint32_t r = 0; r < world && bad < 0; ++r)
+        if (words[2 * r] != 0) bad = (int32_t)r;
+    if (bad_rank) *bad_rank = bad;
+    if (bad >= 0) return words[2 * my_rank] != 0 ? words[2 * my_rank] : PORRT_ERR_PEER;
+    for (uint32_t r = 1; r < world; ++r)
+        if (words[2 * r + 1] != words[1]) { if (bad_rank) *bad_rank = (int32_t)r; return PORRT_ERR_INVALID; }
+    return PORRT_OK;
+}
+
+} // extern "C"
+
+// All ranks meet here before every data step: a rank that failed locally still takes part, so nobody is left waiting in a
+// collective the failed rank never enters.  16 bytes per rank through buffers made with the communicator.
+static int comm_agree(porrt_comm *c, int local, uint32_t n_maps, const char *what) {
+    int32_t mine[2] = {(int32_t)local, (int32_t)n_maps};
+    std::vector<int32_t> all(2 * (size_t)c->world);
+    XCHK(c, hipMemcpyAsync(c->d_status, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+    NCHK(c, ncclAllGather(c->d_status, c->d_status + 2, 2, ncclInt32, c->comm, c->stream));
+    XCHK(c, hipMemcpyAsync(all.data(), c->d_status + 2, all.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    XCHK(c, hipStreamSynchronize(c->stream));
+    int32_t bad = -1;
+    const int r = porrt_exchange_agree(all.data(), (uint32_t)c->world, (uint32_t)c->rank, &bad);
+    if (r == PORRT_ERR_PEER) c->set_err(std::string("exchange_best: rank ") + std::to_string(bad) + " failed " + what + " (code " + std::to_string(all[2 * bad]) + "); no rank went on");
+    else if (r != PORRT_OK && local == PORRT_OK) c->set_err("exchange_best: the ranks were called with different numbers of maps");
+    return r;
+}
+
+extern "C" {
+
+// Collective-safe by construction: everything that can fail on one rank alone (arguments, the cost evaluation, the view of
+// the winning context's arrays, allocation) happens BEFORE a collective step and its outcome is agreed on by all ranks
+// (comm_agree) -- either every rank enters the step or none does; nothing returns between ncclGroupStart and ncclGroupEnd.
 int porrt_exchange_best(porrt_comm *c, porrt_ctx *const *ctxs, uint32_t n_ctx, const uint32_t *map_ids, uint32_t n_maps, porrt_best_entry *winners) {
-    if (!c) return PORRT_ERR_INVALID;
-    if ((!ctxs && n_ctx) || (!map_ids && n_ctx) || !n_maps || !winners) { c->set_err("exchange_best: arguments"); return PORRT_ERR_INVALID; }
-    XCHK(c, hipSetDevice(c->device));
-    // this rank's best context per map (costs evaluated on the device: one launch for the members of a batch)
-    std::vector<double> costs(n_ctx, std::numeric_limits<double>::infinity());
-    if (n_ctx) {
-        const int r = porrt_best_cost_batch(ctxs, n_ctx, costs.data());
-        if (r < 0) { c->set_err(std::string("exchange_best: ") + porrt_last_error(ctxs[0])); return r; }
-    }
+    if (!c) return PORRT_ERR_INVALID;                        // no communicator: nothing to take part with
+    int local = PORRT_OK;
+    auto fail = [&](int code, const std::string &msg) { if (local == PORRT_OK) { local = code; c->set_err(msg); } };
+    if (hipSetDevice(c->device) != hipSuccess) fail(PORRT_ERR_DEVICE, "exchange_best: hipSetDevice");
+    if ((!ctxs && n_ctx) || (!map_ids && n_ctx) || !n_maps || !winners) fail(PORRT_ERR_INVALID, "exchange_best: arguments");
+    // ---- local: this rank's best context per map (costs evaluated on the device: one launch for the members of a batch)
     std::vector<porrt_best_entry> mine(n_maps);
-    std::vector<int> best_ctx(n_maps, -1);
-    for (uint32_t m = 0; m < n_maps; ++m) { mine[m].cost = std::numeric_limits<double>::infinity(); mine[m].rank = c->rank; mine[m].n_nodes = 0; }
-    for (uint32_t q = 0; q < n_ctx; ++q) {
-        if (map_ids[q] >= n_maps) { c->set_err("exchange_best: map id out of range"); return PORRT_ERR_INVALID; }
-        const uint32_t m = map_ids[q];
-        if (costs[q] < mine[m].cost) {                       // first minimum in context order (rrt.rs:190 keeps the first, too)
-            mine[m].cost = costs[q];
-            mine[m].n_nodes = (int32_t)porrt_num_nodes(ctxs[q]);
-            best_ctx[m] = (int)q;
+    std::vector<porrt_tree_device_view> view(n_maps);
+    for (uint32_t m = 0; m < n_maps; ++m) { mine[m].cost = std::numeric_limits<double>::infinity(); mine[m].rank = c->rank; mine[m].n_nodes = 0; view[m] = porrt_tree_device_view{}; }
+    if (local == PORRT_OK && n_ctx) {
+        std::vector<double> costs(n_ctx, std::numeric_limits<double>::infinity());
+        std::vector<int> best_ctx(n_maps, -1);
+        for (uint32_t q = 0; q < n_ctx && local == PORRT_OK; ++q) {
+            if (!ctxs[q]) fail(PORRT_ERR_INVALID, "exchange_best: null context");
+            else if (map_ids[q] >= n_maps) fail(PORRT_ERR_INVALID, "exchange_best: map id out of range");
+        }
+        if (local == PORRT_OK) {
+            const int r = porrt_best_cost_batch(ctxs, n_ctx, costs.data());
+            if (r < 0) fail(r, std::string("exchange_best: ") + porrt_last_error(ctxs[0]));
+        }
+        for (uint32_t q = 0; q < n_ctx && local == PORRT_OK; ++q) {
+            const uint32_t m = map_ids[q];
+            if (costs[q] < mine[m].cost) { mine[m].cost = costs[q]; best_ctx[m] = (int)q; }      // first minimum in context order (rrt.rs:190 keeps the first, too)
+        }
+        for (uint32_t m = 0; m < n_maps && local == PORRT_OK; ++m) {
+            if (best_ctx[m] < 0) continue;
+            view[m] = porrt_tree_device(ctxs[best_ctx[m]]);                                  // empty unless the context holds an RRT* tree
+            if (!view[m].nx || !view[m].ny || !view[m].dist_root || !view[m].parent || view[m].n_nodes == 0 || view[m].n_nodes > 0x7fffffffull)
+                fail(PORRT_ERR_INVALID, "exchange_best: a context with a solution holds no RRT* tree on the device (contexts of mode PORRT_MODE_RRT only)");
+            else mine[m].n_nodes = (int32_t)view[m].n_nodes;
         }
     }
-    // 1. all-gather of the tables
     const size_t need = (size_t)n_maps * (size_t)c->world;
-    if (c->table_cap < need) {
+    if (local == PORRT_OK && c->table_cap < need) {
         if (c->d_send) (void)hipFree(c->d_send);
         if (c->d_recv) (void)hipFree(c->d_recv);
         c->d_send = c->d_recv = nullptr; c->table_cap = 0;
-        XCHK(c, hipMalloc((void **)&c->d_send, n_maps * sizeof(porrt_best_entry)));
-        XCHK(c, hipMalloc((void **)&c->d_recv, need * sizeof(porrt_best_entry)));
-        c->table_cap = need;
+        if (hipMalloc((void **)&c->d_send, n_maps * sizeof(porrt_best_entry)) != hipSuccess || hipMalloc((void **)&c->d_recv, need * sizeof(porrt_best_entry)) != hipSuccess)
+            fail(PORRT_ERR_DEVICE, "exchange_best: hipMalloc of the gathered tables");
+        else c->table_cap = need;
     }
+    int st = comm_agree(c, local, n_maps, "before the all-gather");
+    if (st != PORRT_OK) return st;
+    // ---- 1. all-gather of the tables
     XCHK(c, hipMemcpyAsync(c->d_send, mine.data(), n_maps * sizeof(porrt_best_entry), hipMemcpyHostToDevice, c->stream));
     NCHK(c, ncclAllGather(c->d_send, c->d_recv, n_maps * sizeof(porrt_best_entry), ncclUint8, c->comm, c->stream));
     std::vector<porrt_best_entry> all(need);
     XCHK(c, hipMemcpyAsync(all.data(), c->d_recv, need * sizeof(porrt_best_entry), hipMemcpyDeviceToHost, c->stream));
     XCHK(c, hipStreamSynchronize(c->stream));
-    // 2. winners
+    // ---- 2. winners (the same decision on every rank), and room for their trees -- allocated before the broadcasts are agreed on
     std::vector<int32_t> win(n_maps);
     porrt_exchange_decide(all.data(), (uint32_t)c->world, n_maps, win.data());
-    // 3. the winning trees, device to device
     if (c->trees.size() < n_maps) c->trees.resize(n_maps);
-    NCHK(c, ncclGroupStart());
     for (uint32_t m = 0; m < n_maps; ++m) {
         porrt_comm::Tree &t = c->trees[m];
         t.n = 0;
+        if (win[m] < 0 || local != PORRT_OK) continue;
+        const size_t n = (size_t)all[(size_t)win[m] * n_maps + m].n_nodes;
+        if (t.cap < n) {
+            comm_free_tree(t);
+            if (hipMalloc((void **)&t.nx, n * 8) != hipSuccess || hipMalloc((void **)&t.ny, n * 8) != hipSuccess ||
+                hipMalloc((void **)&t.dist, n * 8) != hipSuccess || hipMalloc((void **)&t.parent, n * 4) != hipSuccess) {
+                comm_free_tree(t);
+                fail(PORRT_ERR_DEVICE, "exchange_best: hipMalloc of a winning tree's buffers");
+                continue;
+            }
+            t.cap = n;
+        }
+        if (win[m] == c->rank && view[m].n_nodes != n) fail(PORRT_ERR_INVALID, "exchange_best: the winning context's tree changed during the exchange");
+    }
+    st = comm_agree(c, local, n_maps, "before the broadcasts");
+    if (st != PORRT_OK) return st;
+    // ---- 3. the winning trees, device to device.  Every rank issues the same calls; an RCCL error is remembered and the group closed all the same.
+    ncclResult_t nerr = ncclGroupStart();
+    if (nerr != ncclSuccess) { c->set_err(std::string("ncclGroupStart: ") + ncclGetErrorString(nerr)); return PORRT_ERR_DEVICE; }
+    for (uint32_t m = 0; m < n_maps; ++m) {
+        porrt_comm::Tree &t = c->trees[m];
         if (win[m] < 0) { winners[m].cost = std::numeric_limits<double>::infinity(); winners[m].rank = -1; winners[m].n_nodes = 0; continue; }
         winners[m] = all[(size_t)win[m] * n_maps + m];
         const size_t n = (size_t)winners[m].n_nodes;
-        if (t.cap < n) {
-            comm_free_tree(t);
-            XCHK(c, hipMalloc((void **)&t.nx, n * 8)); XCHK(c, hipMalloc((void **)&t.ny, n * 8));
-            XCHK(c, hipMalloc((void **)&t.dist, n * 8)); XCHK(c, hipMalloc((void **)&t.parent, n * 4));
-            t.cap = n;
-        }
         t.n = (uint32_t)n;
         const void *sx = t.nx, *sy = t.ny, *sd = t.dist, *sp = t.parent;
-        if (win[m] == c->rank) {
-            const porrt_tree_device_view v = porrt_tree_device(ctxs[best_ctx[m]]);
-            if (!v.nx || v.n_nodes != n) { (void)ncclGroupEnd(); c->set_err("exchange_best: the winning context lost its tree"); return PORRT_ERR_INVALID; }
-            sx = v.nx; sy = v.ny; sd = v.dist_root; sp = v.parent;
-        }
-        NCHK(c, ncclBroadcast(sx, t.nx, n, ncclFloat64, win[m], c->comm, c->stream));
-        NCHK(c, ncclBroadcast(sy, t.ny, n, ncclFloat64, win[m], c->comm, c->stream));
-        NCHK(c, ncclBroadcast(sd, t.dist, n, ncclFloat64, win[m], c->comm, c->stream));
-        NCHK(c, ncclBroadcast(sp, t.parent, n, ncclInt32, win[m], c->comm, c->stream));
+        if (win[m] == c->rank) { sx = view[m].nx; sy = view[m].ny; sd = view[m].dist_root; sp = view[m].parent; }
+        ncclResult_t r;
+        if (nerr == ncclSuccess && (r = ncclBroadcast(sx, t.nx, n, ncclFloat64, win[m], c->comm, c->stream)) != ncclSuccess) nerr = r;
+        if (nerr == ncclSuccess && (r = ncclBroadcast(sy, t.ny, n, ncclFloat64, win[m], c->comm, c->stream)) != ncclSuccess) nerr = r;
+        if (nerr == ncclSuccess && (r = ncclBroadcast(sd, t.dist, n, ncclFloat64, win[m], c->comm, c->stream)) != ncclSuccess) nerr = r;
+        if (nerr == ncclSuccess && (r = ncclBroadcast(sp, t.parent, n, ncclInt32, win[m], c->comm, c->stream)) != ncclSuccess) nerr = r;
     }
-    NCHK(c, ncclGroupEnd());
-    XCHK(c, hipStreamSynchronize(c->stream));
+    const ncclResult_t gend = ncclGroupEnd();
+    if (nerr == ncclSuccess) nerr = gend;
+    const hipError_t herr = hipStreamSynchronize(c->stream);
+    if (nerr != ncclSuccess) { for (auto &t : c->trees) t.n = 0; c->set_err(std::string("exchange_best: ncclBroadcast: ") + ncclGetErrorString(nerr)); return PORRT_ERR_DEVICE; }
+    if (herr != hipSuccess) { for (auto &t : c->trees) t.n = 0; c->set_err(std::string("exchange_best: ") + hipGetErrorString(herr)); return PORRT_ERR_DEVICE; }
     return PORRT_OK;
 }
 

@@ -21,6 +21,11 @@
 
 #include "../../include/porrt_hip.h"
 
+// Nothing is thrown across the C boundary: an entry point whose body can allocate runs inside abi_guard.
+template <class F> static inline int abi_guard(F &&f) noexcept {
+    try { return f(); } catch (const std::bad_alloc &) { return PORRT_ERR_NOMEM; } catch (...) { return PORRT_ERR_INVALID; }
+}
+
 namespace porrt_fmt {
 
 inline bool read_file(const char *path, std::vector<uint8_t> &out) {
@@ -57,7 +62,9 @@ struct PnmCursor {
 };
 
 // 0 ok; PORRT_ERR_INVALID = not a gray image the reference accepts / malformed
-inline int decode_pgm(const uint8_t *bytes, size_t n, std::vector<uint8_t> &out, uint32_t &W, uint32_t &H) {
+// (header_only: W and H alone, nothing allocated.  The raster is only allocated once the bytes that must fill it are known to be there:
+// a binary raster's size, or for the ASCII kinds one byte per sample at least -- a 20-byte file cannot ask for 4 GiB.)
+inline int decode_pgm(const uint8_t *bytes, size_t n, std::vector<uint8_t> &out, uint32_t &W, uint32_t &H, bool header_only = false) {
     PnmCursor c{bytes, n};
     std::string magic;
     if (!c.token(magic) || magic.size() != 2 || magic[0] != 'P') return PORRT_ERR_INVALID;
@@ -69,12 +76,12 @@ inline int decode_pgm(const uint8_t *bytes, size_t n, std::vector<uint8_t> &out,
     if (maxval > 255) return PORRT_ERR_INVALID;                                                       // ImageLuma16: "Wrong image format!"
     W = (uint32_t)w; H = (uint32_t)h;
     const size_t np = (size_t)w * h;
-    out.resize(np);
+    if (header_only) return PORRT_OK;
     if (kind == '5') {                       // one whitespace byte, then the samples
         if (c.i >= n || !isspace(bytes[c.i])) return PORRT_ERR_INVALID;
         ++c.i;
         if (n - c.i < np) return PORRT_ERR_INVALID;
-        memcpy(out.data(), bytes + c.i, np);
+        out.assign(bytes + c.i, bytes + c.i + np);
         return PORRT_OK;
     }
     if (kind == '4') {                       // packed bits, rows padded to bytes, 1 = black
@@ -82,10 +89,13 @@ inline int decode_pgm(const uint8_t *bytes, size_t n, std::vector<uint8_t> &out,
         ++c.i;
         const size_t stride = (w + 7) / 8;
         if (n - c.i < stride * h) return PORRT_ERR_INVALID;
+        out.resize(np);
         for (size_t y = 0; y < h; ++y)
             for (size_t x = 0; x < w; ++x) out[y * w + x] = ((bytes[c.i + y * stride + x / 8] >> (7 - x % 8)) & 1) ? 0 : 255;
         return PORRT_OK;
     }
+    if (n - c.i < np) return PORRT_ERR_INVALID;      // ASCII kinds: a sample is one byte at least
+    out.resize(np);
     if (kind == '1') {                       // ASCII bits, whitespace optional between them
         size_t k = 0;
         while (k < np && c.i < n) {
@@ -233,9 +243,10 @@ struct JsonIn {
         if (err.empty()) err = "expected true / false";
         return false;
     }
-    bool skip_value() {                  // unknown key
+    bool skip_value(int depth = 0) {     // unknown key (nesting is bounded: the input is a file from anywhere)
         ws();
         if (p >= end) return false;
+        if (depth > 128) { err = "JSON nested too deeply"; return false; }
         if (*p == '"') { std::string s; return str(s); }
         if (*p == '{' || *p == '[') {
             const char open = *p, close = open == '{' ? '}' : ']';
@@ -243,7 +254,7 @@ struct JsonIn {
             if (eat(close)) return true;
             for (;;) {
                 if (open == '{') { std::string k; if (!str(k) || !expect(':')) return false; }
-                if (!skip_value()) return false;
+                if (!skip_value(depth + 1)) return false;
                 if (eat(',')) continue;
                 return expect(close);
             }
@@ -353,23 +364,27 @@ extern "C" {
 
 int porrt_read_pgm_mem(const uint8_t *bytes, size_t n, uint8_t *out, uint32_t *W, uint32_t *H) {
     if (!bytes || !W || !H) return PORRT_ERR_INVALID;
-    std::vector<uint8_t> px;
-    uint32_t w = 0, h = 0;
-    const int r = porrt_fmt::decode_pgm(bytes, n, px, w, h);
-    if (r) return r;
-    *W = w; *H = h;
-    if (out) memcpy(out, px.data(), px.size());
-    return PORRT_OK;
+    return abi_guard([&]() -> int {
+        std::vector<uint8_t> px;
+        uint32_t w = 0, h = 0;
+        const int r = porrt_fmt::decode_pgm(bytes, n, px, w, h, /*header_only=*/out == nullptr);      // the size query reads the header alone
+        if (r) return r;
+        *W = w; *H = h;
+        if (out) memcpy(out, px.data(), px.size());
+        return PORRT_OK;
+    });
 }
 
 int porrt_read_pgm(const char *path, uint8_t *out, uint32_t *W, uint32_t *H) {
     if (!path) return PORRT_ERR_INVALID;
-    std::vector<uint8_t> bytes;
-    if (!porrt_fmt::read_file(path, bytes)) return PORRT_ERR_IO;          // "Impossible to open image"
-    return porrt_read_pgm_mem(bytes.data(), bytes.size(), out, W, H);
+    return abi_guard([&]() -> int {
+        std::vector<uint8_t> bytes;
+        if (!porrt_fmt::read_file(path, bytes)) return PORRT_ERR_IO;          // "Impossible to open image"
+        return porrt_read_pgm_mem(bytes.data(), bytes.size(), out, W, H);
+    });
 }
 
-int porrt_graph_write_json(const char *path, uint64_t n_nodes, const double *xy, const uint64_t *node_validity, const uint64_t *child_off,
+static int graph_write_json_impl(const char *path, uint64_t n_nodes, const double *xy, const uint64_t *node_validity, const uint64_t *child_off,
                            const uint64_t *child_id, const uint64_t *child_validity, const uint64_t *parent_off, const uint64_t *parent_id,
                            const uint64_t *parent_validity, uint64_t n_validities, uint64_t n_worlds, const uint8_t *validities) {
     if (!path || (n_nodes && (!xy || !node_validity || !child_off || !parent_off))) return PORRT_ERR_INVALID;
@@ -384,7 +399,17 @@ int porrt_graph_write_json(const char *path, uint64_t n_nodes, const double *xy,
 // The PTO graph (or PRM roadmap) of the context's last grow as the reference's JSON.  Adjacency lists as the reference
 // holds them (pto.rs:111-120: a node's neighbours at its creation in kd pre-order, then the later nodes that chose it,
 // ascending; children and parents are the same list).
-int porrt_graph_save_json(const porrt_ctx *ctx, const char *path) {
+int porrt_graph_write_json(const char *path, uint64_t n_nodes, const double *xy, const uint64_t *node_validity, const uint64_t *child_off,
+                           const uint64_t *child_id, const uint64_t *child_validity, const uint64_t *parent_off, const uint64_t *parent_id,
+                           const uint64_t *parent_validity, uint64_t n_validities, uint64_t n_worlds, const uint8_t *validities) {
+    return abi_guard([&]() { return graph_write_json_impl(path, n_nodes, xy, node_validity, child_off, child_id, child_validity, parent_off, parent_id, parent_validity,
+                                                          n_validities, n_worlds, validities); });
+}
+
+static int graph_save_json_impl(const porrt_ctx *ctx, const char *path);
+int porrt_graph_save_json(const porrt_ctx *ctx, const char *path) { return abi_guard([&]() { return graph_save_json_impl(ctx, path); }); }
+
+static int graph_save_json_impl(const porrt_ctx *ctx, const char *path) {
     if (!ctx || !path) return PORRT_ERR_INVALID;
     const uint64_t n = porrt_num_nodes(ctx), ne = porrt_num_edges(ctx);
     if (!n) return PORRT_ERR_INVALID;
@@ -416,15 +441,22 @@ int porrt_graph_save_json(const porrt_ctx *ctx, const char *path) {
 porrt_graph_file *porrt_graph_load_json(const char *path, char *err, size_t err_cap) {
     auto fail = [&](const std::string &m) -> porrt_graph_file * { if (err && err_cap) { snprintf(err, err_cap, "%s", m.c_str()); } return nullptr; };
     if (!path) return fail("null path");
-    std::vector<uint8_t> bytes;
-    if (!porrt_fmt::read_file(path, bytes)) return fail("impossible to open file");
-    porrt_graph_file *g = new porrt_graph_file();
-    if (!porrt_fmt::parse_graph(std::string(bytes.begin(), bytes.end()), g->g)) { const std::string m = g->g.err; delete g; return fail(m); }
-    // what the reference's later code would index out of bounds on
-    const uint64_t n = g->g.node_validity.size();
-    for (uint64_t v : g->g.cid) if (v >= n) { delete g; return fail("child id out of range"); }
-    for (uint64_t v : g->g.pid) if (v >= n) { delete g; return fail("parent id out of range"); }
-    return g;
+    porrt_graph_file *g = nullptr;
+    try {
+        std::vector<uint8_t> bytes;
+        if (!porrt_fmt::read_file(path, bytes)) return fail("impossible to open file");
+        g = new porrt_graph_file();
+        if (!porrt_fmt::parse_graph(std::string(bytes.begin(), bytes.end()), g->g)) { const std::string m = g->g.err; delete g; return fail(m); }
+        // what the reference's later code would index out of bounds on
+        const uint64_t n = g->g.node_validity.size();
+        for (uint64_t v : g->g.cid) if (v >= n) { delete g; return fail("child id out of range"); }
+        for (uint64_t v : g->g.pid) if (v >= n) { delete g; return fail("parent id out of range"); }
+        return g;
+    } catch (...) {
+        delete g;
+        if (err && err_cap) snprintf(err, err_cap, "out of memory");
+        return nullptr;
+    }
 }
 void porrt_graph_file_free(porrt_graph_file *g) { delete g; }
 uint64_t porrt_graph_file_num_nodes(const porrt_graph_file *g) { return g ? g->g.node_validity.size() : 0; }

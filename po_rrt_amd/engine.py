@@ -33,7 +33,7 @@ SYMBOLS = [
     "porrt_bg_get_observable_zones", "porrt_bg_get_node_types", "porrt_bg_get_children", "porrt_bg_get_parents", "porrt_bg_get_seconds",
     "porrt_bg_compute_expected_costs", "porrt_bg_get_expected_costs", "porrt_bg_expected_cost_of", "porrt_bg_get_dp_info", "porrt_bg_extract_policy", "porrt_conditional_dijkstra",
     "porrt_comm_unique_id", "porrt_comm_create", "porrt_comm_destroy", "porrt_comm_last_error", "porrt_exchange_best", "porrt_exchange_num_nodes",
-    "porrt_exchange_get_tree", "porrt_exchange_decide", "porrt_tree_device",
+    "porrt_exchange_get_tree", "porrt_exchange_decide", "porrt_exchange_agree", "porrt_tree_device",
     "porrt_grow_mm_prm", "porrt_mm_num_modes", "porrt_mm_num_transitions", "porrt_mm_num_beliefs", "porrt_mm_get_mode", "porrt_mm_get_mode_graph",
     "porrt_mm_get_transition", "porrt_mm_get_transition_pairs", "porrt_mm_get_seconds",
     "porrt_read_pgm", "porrt_read_pgm_mem", "porrt_graph_write_json", "porrt_graph_save_json", "porrt_graph_load_json", "porrt_graph_file_free",
@@ -143,6 +143,7 @@ def load_library():
     sig("porrt_exchange_num_nodes", C.c_uint64, vp, C.c_uint32)
     sig("porrt_exchange_get_tree", C.c_int, vp, C.c_uint32, _f64p, _i64p, _f64p)
     sig("porrt_exchange_decide", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)
+    sig("porrt_exchange_agree", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32))
     sig("porrt_tree_device", TreeDeviceView, vp)
     sig("porrt_grow_mm_prm", C.c_int, vp, _f64p, _f64p, C.c_uint32, C.c_double, C.c_double, C.c_uint64)
     for nm in ("modes", "transitions", "beliefs"):
@@ -503,6 +504,15 @@ def exchange_decide(entries):
     if rc:
         raise PorrtError(rc, "porrt_exchange_decide")
     return win
+
+
+def exchange_agree(words, my_rank):
+    """porrt_exchange_agree: words[rank] = (status code, n_maps) -> (what rank my_rank must return, first failing rank or -1); host code only"""
+    L = load_library()
+    w = np.ascontiguousarray(words, dtype=np.int32).reshape(-1, 2)
+    bad = C.c_int32(-1)
+    rc = L.porrt_exchange_agree(w.ctypes.data_as(C.c_void_p), len(w), my_rank, C.byref(bad))
+    return rc, bad.value
 
 
 class Comm:

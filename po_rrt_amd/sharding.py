@@ -37,3 +37,10 @@ def decide_from_gathered(entries_by_rank):
     """Step 2 of the exchange alone (porrt_exchange_decide, host code): per map the first minimum of (cost, rank)."""
     from .engine import BEST_ENTRY, exchange_decide
     return exchange_decide(np.ascontiguousarray(entries_by_rank, dtype=BEST_ENTRY))
+
+
+def agree_from_gathered(words_by_rank, my_rank):
+    """Step 0 of the exchange alone (porrt_exchange_agree, host code): from every rank's (status, n_maps) word, what this rank
+    returns -- 0 only if every rank is fine and all were called with the same number of maps."""
+    from .engine import exchange_agree
+    return exchange_agree(words_by_rank, my_rank)

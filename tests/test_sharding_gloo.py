@@ -81,3 +81,99 @@ def test_decide_rules():
     e["n_nodes"] = [[10, 10, 0, 10], [10, 10, 0, 0], [10, 10, 0, 10]]
     e["rank"] = [[0] * 4, [1] * 4, [2] * 4]
     assert sharding.decide_from_gathered(e).tolist() == [1, 0, -1, 2]
+
+
+def test_partition_covers_every_query_once():
+    """the partition the exchange and bench.py's query -> map assignment rest on: q -> rank q mod world"""
+    from po_rrt_amd import sharding
+    for world in (1, 2, 3, 8):
+        parts = [sharding.queries_of_rank(576, r, world) for r in range(world)]
+        assert sorted(q for p in parts for q in p) == list(range(576))
+        assert all(q % world == r for r, p in enumerate(parts) for q in p)
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+    assert sharding.queries_of_rank(3, 5, 8) == [] and sharding.queries_of_rank(0, 0, 2) == []
+
+
+def test_agree_rules():
+    """porrt_exchange_agree (step 0 of porrt_exchange_best): every rank takes the same way out.  A failing rank returns its own
+    code, the others PORRT_ERR_PEER (-8); different map counts are PORRT_ERR_INVALID (-1) for all; only a clean table goes on."""
+    from po_rrt_amd import sharding
+    ok = [(0, 9)] * 4
+    assert [sharding.agree_from_gathered(ok, r) for r in range(4)] == [(0, -1)] * 4
+    one_bad = [(0, 9), (0, 9), (-4, 9), (0, 9)]
+    assert [sharding.agree_from_gathered(one_bad, r) for r in range(4)] == [(-8, 2), (-8, 2), (-4, 2), (-8, 2)]
+    two_bad = [(-1, 9), (0, 9), (-4, 9), (0, 9)]
+    assert [sharding.agree_from_gathered(two_bad, r)[0] for r in range(4)] == [-1, -8, -4, -8]
+    maps_differ = [(0, 9), (0, 9), (0, 8)]
+    assert [sharding.agree_from_gathered(maps_differ, r) for r in range(3)] == [(-1, 2)] * 3
+    # a failing rank outranks a map-count mismatch (its n_maps may be garbage)
+    assert sharding.agree_from_gathered([(0, 9), (-1, 0)], 0) == (-8, 1)
+    assert sharding.agree_from_gathered([(0, 1)], 0) == (0, -1)
+
+
+AGREE_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path[:0] = [%(root)r]
+    import torch.distributed as dist
+    from po_rrt_amd import sharding
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    for case, word in enumerate([(0, 9), (-5 if rank == 1 else 0, 9), (0, 9 - rank)]):      # clean; rank 1 fails; map counts differ
+        words = [None] * world
+        dist.all_gather_object(words, word)                 # the status all-gather of comm_agree
+        rc, bad = sharding.agree_from_gathered(words, rank)
+        went_on = [None] * world
+        dist.all_gather_object(went_on, rc == 0)
+        assert all(went_on) or not any(went_on), "some ranks would enter the next collective and some would not"
+        exp = [0, -5 if rank == 1 else -8, -1][case]
+        assert rc == exp, (case, rank, rc)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "agree ok")
+""")
+
+
+def test_two_ranks_agree_before_every_collective(tmp_path):
+    script = tmp_path / "agree_worker.py"
+    script.write_text(AGREE_WORKER % {"root": ROOT})
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29534", str(script)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count("agree ok") == 2
+
+
+def _bench(*args, env_drop=("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two rank processes itself (RANK / WORLD_SIZE / MASTER_* set,
+    rendezvous on 127.0.0.1) and relays rank 0's one line; --launch-check stops after the rendezvous, so no GPU is needed"""
+    import json
+    out = _bench("--gpus", "2", "--launch-check")
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["launch_check"] is True and rec["n_gpus"] == 2 and rec["agree"] == 0
+    for r in (0, 1):
+        assert "launch-check rank %d of 2 local_rank %d" % (r, r) in out.stderr
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """without N devices the launcher says so and exits non-zero -- it never silently benchmarks one GPU"""
+    import torch
+    n = torch.cuda.device_count() + 1
+    if n < 2:
+        n = 2
+    out = _bench("--gpus", str(n))
+    assert out.returncode == 3 and out.stdout.strip() == "" and "HIP device(s) visible" in out.stderr
+
+
+def test_bench_rank_checks_world_size():
+    """a rank started by a launcher with another world size than --gpus stops at once"""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="29535")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE=4" in out.stderr
