@@ -87,13 +87,47 @@ def empty_space(n_iter_min=1000, n_iter_max=10000, seed=0):
                 max_step=0.1, search_radius=1.0, n_iter_min=n_iter_min, n_iter_max=n_iter_max, seed=seed)
 
 
+def cfg_big(mode=RRT, n_iter=6000, seed=0):
+    """400 x 400 raster over [-1, 1)^2 (ppm 200; the reference opens 400 x 400 maps: data/map2_fov.pgm, map_io.rs:699, pto.rs:387-389):
+    RRT* with cfg2's parameters, or the 2-world belief-space RRG of cfg3 on it."""
+    if mode == RRT:
+        return Case(name="cfg_big_rrt", grid="big_shelf_map_400", zones=None, visibility=0.0, domain=SHELF, mode=RRT,
+                    start=(-0.8, -0.8), goals=[(0.68, 0.38)], masks=[1], l1=0.05, obs_zone=None,
+                    max_step=0.1, search_radius=2.0, n_iter_min=n_iter, n_iter_max=n_iter, seed=seed)
+    return Case(name="cfg_big_pto", grid="big_shelf_map_400", zones="big_shelf_map_400_zone_ids", visibility=0.5, domain=SHELF, mode=PTO,
+                start=(-0.8, -0.8), goals=[(0.68, -0.45), (0.68, 0.38)], masks=[1, 2], l1=0.05, obs_zone=None,
+                max_step=0.05, search_radius=5.0, n_iter_min=n_iter, n_iter_max=n_iter, seed=seed)
+
+
+def cfg_wide(mode=PTO, n_iter=4000, seed=0):
+    """300 x 200 raster over [-1.5, 1.5) x [-1, 1) (W != H; the transform of map_io.rs:176-181 is generic in both): door domain,
+    two doors (4 worlds); the sampler draws from the map's box."""
+    base = dict(grid="wide_door_map_300x200", low=(-1.5, -1.0), up=(1.5, 1.0), domain=DOOR, l1=0.05, obs_zone=None,
+                n_iter_min=n_iter, n_iter_max=n_iter, seed=seed)
+    if mode == RRT:      # (RRT* is only ever driven with the shelf adapter in the reference, tamp_rrt.rs:35-47: doors read as low obstacles)
+        return Case(name="cfg_wide_rrt", zones=None, visibility=0.0, mode=RRT, start=(-1.2, -0.7), goals=[(1.2, 0.7)], masks=[1],
+                    max_step=0.1, search_radius=2.0, **dict(base, domain=SHELF))
+    return Case(name="cfg_wide_pto", zones="wide_door_map_300x200_zone_ids", visibility=0.4, mode=PTO, start=(-1.2, -0.7),
+                goals=[(1.2, 0.7)], masks=[(1 << 4) - 1], max_step=0.05, search_radius=5.0, **base)
+
+
+def cfg_map4(n_iter_min=5000, seed=0):
+    """The reference's recorded end-to-end problem on its one recoverable raster (main.rs:893-908 test_plan_on_navigation_map4_pomdp;
+    results/maps_paper/map_4/costs_and_timings_*.txt): start (0.8, -0.8), goal (-0.8, 0.8) in all 16 worlds, max_step 0.1,
+    search_radius 5, visibility 0.25, n_iter_min 5000 / n_iter_max 100000, uniform prior."""
+    return Case(name="cfg_map4", grid="paper_map_4", zones="paper_map_4_zone_ids", visibility=0.25, domain=DOOR, mode=PTO,
+                start=(0.8, -0.8), goals=[(-0.8, 0.8)], masks=[(1 << 16) - 1], l1=0.05, obs_zone=None,
+                max_step=0.1, search_radius=5.0, n_iter_min=n_iter_min, n_iter_max=100000, seed=seed)
+
+
 def configure(eng, case):
     """Apply a case to an oracle or engine object (same method names on both)."""
+    low, up = case.get("low", (-1.0, -1.0)), case.get("up", (1.0, 1.0))
     if case.grid is not None:
-        eng.set_grid(load_map(case.grid), (-1.0, -1.0), (1.0, 1.0), case.domain)
+        eng.set_grid(load_map(case.grid), low, up, case.domain)
         if case.zones is not None:
             eng.set_zones(load_map(case.zones), case.visibility)
-    eng.set_sampler((-1.0, -1.0), (1.0, 1.0), case.seed)
+    eng.set_sampler(low, up, case.seed)
     if case.obs_zone is not None:
         eng.set_observation_goal(case.obs_zone)
     else:

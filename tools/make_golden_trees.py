@@ -69,9 +69,36 @@ def build(name, case, K, algo):
     return rec
 
 
+# bench.py's timed call (BASELINE.json configs[1] as the headline runs it): 128 queries of cfg2(111500), seeds = slot, K = 1024,
+# advanced together as two sub-batches of 64.  Frozen here: the first and last member of each sub-batch.
+BENCH = dict(Q=128, n_iter=111500, K=1024, members=(0, 63, 64, 127))
+
+
+def build_bench_member(j):
+    case = cases.cfg2(BENCH["n_iter"], seed=j)
+    o = cases.configure(orc.Oracle(), case)
+    cases.grow(o, case, K=BENCH["K"], algo=orc.ALGO_BATCHED_KD)
+    xy, parent, dist = o.tree()
+    sol = o.best_solution()
+    cost = sol[1] if sol is not None else float("inf")
+    return {"n_nodes_%d" % j: np.int64(len(xy)),
+            "digest_%d" % j: np.array(digest(xy.view(np.uint64), parent.astype(np.int32), dist.view(np.uint64), o.final_ids().astype(np.uint64))),
+            "cost_bits_%d" % j: np.array([cost]).view(np.uint64)}
+
+
+def build_bench():
+    rec = dict(Q=np.int64(BENCH["Q"]), n_iter=np.int64(BENCH["n_iter"]), K=np.int64(BENCH["K"]), members=np.array(BENCH["members"], dtype=np.int64))
+    for j in BENCH["members"]:
+        rec.update(build_bench_member(j))
+    return rec
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
+    if not only or "bench_members" in only:
+        np.savez_compressed(os.path.join(OUT, "bench_members.npz"), **build_bench())
+        print("bench_members")
     for name, case, K, algo in specs():
         if only and name not in only:
             continue

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate the synthetic 200x200 8-bit maps committed under tests/golden/maps/.
+"""Generate the synthetic 8-bit maps committed under tests/golden/maps/ (200x200, and since round 3 a 400x400 and a 300x200 one).
 
 Every .pgm/.png under the reference's data/ is a Git-LFS pointer, so
 the benchmark rasters are unavailable; these stand-ins keep the reference's
@@ -202,6 +202,64 @@ def door_map_like():
     return a
 
 
+class Canvas:
+    """A raster of any size over any box with the reference's transform (map_io.rs:176-181, map_shelves_io.rs:165-170:
+    ppm = W / (up0 - low0), row i = (H - 1) - (y - low1) ppm, column j = (x - low0) ppm) -- generic in W and H."""
+
+    def __init__(self, W, H, low, up, fill=255):
+        self.W, self.H, self.low, self.up = W, H, low, up
+        self.ppm = W / (up[0] - low[0])
+        self.a = np.full((H, W), fill, np.uint8)
+
+    def px(self, x, y):
+        i = int((self.H - 1) - (y - self.low[1]) * self.ppm)
+        j = int((x - self.low[0]) * self.ppm)
+        return min(max(i, 0), self.H - 1), min(max(j, 0), self.W - 1)
+
+    def rect(self, x0, y0, x1, y1, v):
+        i0, j0 = self.px(x0, y1)
+        i1, j1 = self.px(x1, y0)
+        self.a[i0:i1 + 1, j0:j1 + 1] = v
+
+
+def big_shelf_map_400():
+    """400 x 400 over [-1, 1)^2 (ppm 200: the reference opens 400 x 400 rasters, data/map2_fov.pgm) -- shelf domain, two shelves with
+    zones, walls, pillars; a free band wider than 255 pixels nowhere, but clearances up to ~90 pixels."""
+    c = Canvas(400, 400, (-1.0, -1.0), (1.0, 1.0))
+    z = Canvas(400, 400, (-1.0, -1.0), (1.0, 1.0))
+    c.rect(-0.3, -0.2, 0.9, -0.17, 0)
+    c.rect(-0.33, -0.6, -0.3, 0.5, 0)
+    c.rect(0.2, 0.3, 0.23, 0.8, 0)
+    c.rect(-0.8, 0.6, -0.5, 0.63, 200)
+    rng = np.random.default_rng(4242)
+    for _ in range(14):
+        cx, cy = rng.uniform(-0.85, 0.85), rng.uniform(-0.85, 0.85)
+        if abs(cx + 0.8) + abs(cy + 0.8) < 0.25:
+            continue
+        c.rect(cx - 0.02, cy - 0.02, cx + 0.02, cy + 0.02, 0 if rng.random() < 0.5 else 180)
+    c.rect(0.74, -0.55, 0.80, -0.35, 200)
+    c.rect(0.74, 0.28, 0.80, 0.48, 200)
+    z.rect(0.75, -0.48, 0.79, -0.42, 0)
+    z.rect(0.75, 0.35, 0.79, 0.41, 1)
+    for gx, gy in ((0.68, -0.45), (0.68, 0.38), (-0.8, -0.8)):
+        c.rect(gx - 0.04, gy - 0.04, gx + 0.04, gy + 0.04, 255)
+    return c.a, z.a
+
+
+def wide_door_map_300x200():
+    """300 x 200 over [-1.5, 1.5) x [-1, 1) (ppm 100, W != H) -- door domain: three rooms side by side, two doors (4 worlds)."""
+    c = Canvas(300, 200, (-1.5, -1.0), (1.5, 1.0))
+    c.rect(-0.52, -1.0, -0.48, 1.0, 0)
+    c.rect(0.48, -1.0, 0.52, 1.0, 0)
+    c.rect(-0.52, 0.3, -0.48, 0.5, 128)          # door 0
+    c.rect(0.48, -0.5, 0.52, -0.3, 128)          # door 1
+    c.rect(-0.52, -0.7, -0.48, -0.6, 255)        # an opening that is always there
+    c.rect(0.48, 0.6, 0.52, 0.7, 255)
+    c.rect(-0.1, -0.4, -0.06, 0.6, 0)
+    c.rect(0.9, 0.0, 1.3, 0.04, 0)
+    return c.a
+
+
 def extract_paper_map():
     from PIL import Image
     svg = "/root/reference/data/maps_paper/map_4/map.svg"
@@ -231,6 +289,12 @@ def main():
     d = door_map_like()
     write_pgm(os.path.join(OUT, "door_map_like.pgm"), d)
     write_pgm(os.path.join(OUT, "door_map_like_zone_ids.pgm"), door_zone_ids(d)[0])
+    a, z = big_shelf_map_400()
+    write_pgm(os.path.join(OUT, "big_shelf_map_400.pgm"), a)
+    write_pgm(os.path.join(OUT, "big_shelf_map_400_zone_ids.pgm"), z)
+    d = wide_door_map_300x200()
+    write_pgm(os.path.join(OUT, "wide_door_map_300x200.pgm"), d)
+    write_pgm(os.path.join(OUT, "wide_door_map_300x200_zone_ids.pgm"), door_zone_ids(d)[0])
     paper = os.path.join(OUT, "paper_map_4.pgm")
     if args.paper_map:
         write_pgm(paper, extract_paper_map())
