@@ -393,7 +393,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(case, args)
         if not args.no_belief and world == 1:
             # the rows after the growth are extras of the line: a failure there must not cost the headline measurement
-            for key, fn in (("belief_space", belief_space), ("prm_roadmap", prm_roadmap), ("mm_prm", mm_prm)):
+            for key, fn in (("tamp_queries", tamp_queries), ("belief_space", belief_space), ("prm_roadmap", prm_roadmap), ("mm_prm", mm_prm)):
                 try:
                     out["config"][key] = fn(local_rank, not args.no_cpu_baseline)
                 except Exception as ex:                      # noqa: BLE001
@@ -487,6 +487,51 @@ def belief_space(device, with_cpu):
                                "sample": "the same PTO graph with 8 of the 12 worlds possible (255 beliefs, %d edges): build_belief_graph %.2f s, "
                                          "conditional_dijkstra %.2f s (%.1f M edges/s; root cost %r); C restatement of pto.rs:185-275, "
                                          "belief_graph.rs:89-175 (oracle/belief.c, oracle/dp.c)" % (Eo, dt, dt2, Eo / dt2 / 1e6, float(d[0]))}
+    return out
+
+
+def tamp_queries(device, with_cpu, n_queries=1024, K=256):
+    """The reference's real many-query caller, outside the timed region: the TAMP search plans twice per search edge with
+    rrt.plan(.., max_step 0.1, search_radius 2.0, n_iter_min 2500, n_iter_max 10000) -- an ObservationGoal and a pickup SquareGoal,
+    starts of their own (map_shelves_tamp_rrt.rs:224,232; main.rs:532) -- thousands of independent queries.  Here: n_queries of them
+    in ONE porrt_grow_batch call, every member running the loop of rrt.rs:109 on its own and dropping out when it ends."""
+    import numpy as np
+    import cases
+    import po_rrt_amd
+    cs = cases.tamp_queries(n_queries)
+    t0 = time.perf_counter()
+    engs = [cases.configure(po_rrt_amd.Engine(device), c) for c in cs]
+    t_make = time.perf_counter() - t0
+    starts = [c.start for c in cs]
+    runs = []
+    for rep in range(4):
+        for j, e in enumerate(engs):
+            e.set_sampler((-1.0, -1.0), (1.0, 1.0), 1000 * rep + j)
+        t0 = time.perf_counter()
+        po_rrt_amd.Engine.grow_batch(engs, starts, 0.1, 2.0, 2500, K, n_iter_max=10000)
+        dt = time.perf_counter() - t0
+        runs.append((dt, sum(e.num_nodes() - 1 for e in engs), sum(e.num_iterations() for e in engs), sum(1 for e in engs if e.num_final() > 0)))
+    dt, nodes, its, solved = sorted(runs[1:])[1]
+    costs = po_rrt_amd.Engine.best_cost_batch(engs)
+    out = {"what": "%d TAMP-shaped RRT* queries in one porrt_grow_batch (alternating ObservationGoal / SquareGoal, per-query starts, n_iter_min 2500, "
+                   "n_iter_max 10000, K = %d): each runs the loop of rrt.rs:109 and leaves the launches when it ends" % (n_queries, K),
+           "ms_wall": 1e3 * dt, "queries_per_s": n_queries / dt, "node_expansions_per_s": nodes / dt, "iterations_per_s": its / dt,
+           "mean_iterations_per_query": its / n_queries, "queries_solved": solved, "queries_with_a_path_cost": int(np.isfinite(costs).sum()),
+           "ms_creating_the_contexts_once": 1e3 * t_make, "batch_K": K}
+    if with_cpu:
+        from oracle import orc
+        m = 32
+        t0 = time.perf_counter()
+        nodes_o = its_o = 0
+        for c in cs[:m]:
+            o = cases.configure(orc.Oracle(), c)
+            cases.grow(o, c, K=1, algo=orc.ALGO_SEQ)
+            nodes_o += o.num_nodes() - 1
+            its_o += o.num_iterations()
+        dto = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": m / dto, "unit": "queries/s", "cores": 1, "kind": "port",
+                               "sample": "the first %d of the queries, the reference's own loop (K = 1, rrt.rs:102-174 with its kd-tree; C restatement): "
+                                         "%.3f s, %d iterations, %.0f node-expansions/s" % (m, dto, its_o, nodes_o / dto)}
     return out
 
 

@@ -163,11 +163,14 @@ public:
         return {std::move(out), std::move(tree)};
     }
     // Many independent queries at once (the TAMP layer's pattern, map_shelves_tamp_rrt.rs:163-291): every planner keeps
-    // its own map, sampler state and result; all of them advance in one launch sequence (porrt_grow_batch) with a fixed
-    // iteration budget.  Same results as calling plan() on each, several times the throughput.
+    // its own map, sampler state and result; all of them advance in one launch sequence (porrt_grow_batch), each running the
+    // loop of rrt.rs:109 with the caller's n_iter_min / n_iter_max (the TAMP search passes 2500 / 10000, main.rs:532).  Same
+    // results as calling plan() on each, several times the throughput.
     template <class Goal>
     static std::vector<std::pair<std::optional<Solution>, RRTTree>> plan_batch(const std::vector<RRT *> &planners, const std::vector<State> &starts,
-                                                                                const Goal &goal, double max_step, double search_radius, size_t n_iter) {
+                                                                                const Goal &goal, double max_step, double search_radius, size_t n_iter_min,
+                                                                                size_t n_iter_max = 0) {
+        if (n_iter_max < n_iter_min) n_iter_max = n_iter_min;
         std::vector<porrt_ctx *> cs;
         std::vector<double> st;
         for (size_t q = 0; q < planners.size(); ++q) {
@@ -175,7 +178,7 @@ public:
             cs.push_back(planners[q]->ctx_.get());
             st.push_back(starts[q][0]); st.push_back(starts[q][1]);
         }
-        planners.at(0)->ctx_.check(porrt_grow_batch(cs.data(), (uint32_t)cs.size(), st.data(), max_step, search_radius, n_iter, planners[0]->batch_K,
+        planners.at(0)->ctx_.check(porrt_grow_batch(cs.data(), (uint32_t)cs.size(), st.data(), max_step, search_radius, n_iter_min, n_iter_max, planners[0]->batch_K,
                                                     PORRT_MODE_RRT));
         std::vector<std::pair<std::optional<Solution>, RRTTree>> out;
         for (RRT *p : planners) {

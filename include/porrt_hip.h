@@ -100,20 +100,24 @@ int porrt_set_observation_goal(porrt_ctx *ctx, uint32_t zone_id);
 int porrt_grow(porrt_ctx *ctx, const double start[2], double max_step, double search_radius,
                uint64_t n_iter_min, uint64_t n_iter_max, uint32_t batch_K, int mode);
 
+/* The same growth for several contexts of ONE device at once -- the form in which the reference's many-query caller uses the path:
+ * the TAMP search runs rrt.plan(.., n_iter_min 2500, n_iter_max 10000) twice per search edge (map_shelves_tamp_rrt.rs:224,232,355,
+ * 367,492,500; main.rs:532), thousands of independent queries.  Their dependent-load chains overlap inside each kernel launch (one
+ * grid row per context) instead of queueing behind each other.  Every context runs the loop of rrt.rs:109 / pto.rs:67,
+ *     while i < n_iter_min || (no solution yet && i < n_iter_max),
+ * on its own: a member whose loop has ended drops out of the later launches (a row mask kept on the device), the others go on.
+ * starts = n_ctx x 2.  Every context keeps its own map, goal, sampler state and results, exactly as after n_ctx porrt_grow calls
+ * with the same arguments; the getters are per context.  Contexts must not be used concurrently elsewhere during the call.
+ * Returns the worst member code (PORRT_INCOMPLETE if a PTO member's final set is incomplete).
+ * porrt_grow_batch_each: the same with n_iter_min[q], n_iter_max[q] per context. */
+int porrt_grow_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, const double *starts, double max_step,
+                     double search_radius, uint64_t n_iter_min, uint64_t n_iter_max, uint32_t batch_K, int mode);
+int porrt_grow_batch_each(porrt_ctx *const *ctxs, uint32_t n_ctx, const double *starts, double max_step,
+                          double search_radius, const uint64_t *n_iter_min, const uint64_t *n_iter_max, uint32_t batch_K, int mode);
+
 /* ---- results, copied into caller-owned buffers (query the sizes first).
  * Replaces: RRTTree{nodes: Vec<RRTNode{state,parent_id,dist_from_root}>} (rrt.rs:14-22)
  * and the final ids returned by grow_tree (rrt.rs:103,165-167). */
-/* The same growth for several contexts of ONE device at once, with a fixed iteration budget
- * (n_iter_min == n_iter_max == n_iter: the loop condition of rrt.rs:109 / pto.rs:67 is never consulted,
- * as in the reference's benchmark drivers, main.rs:532).  Independent queries -- the TAMP caller issues
- * thousands (map_shelves_tamp_rrt.rs:163-291) -- overlap their dependent-load chains inside each kernel
- * launch (one grid row per context) instead of queueing behind each other.  starts = n_ctx x 2.  Every
- * context keeps its own map, goal, sampler state and results, exactly as after n_ctx porrt_grow calls;
- * the getters are per context.  Contexts must not be used concurrently elsewhere during the call.
- * Returns the worst member code (PORRT_INCOMPLETE if a PTO member's final set is incomplete). */
-int porrt_grow_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, const double *starts, double max_step,
-                     double search_radius, uint64_t n_iter, uint32_t batch_K, int mode);
-
 uint64_t porrt_num_nodes(const porrt_ctx *ctx);
 uint64_t porrt_num_iterations(const porrt_ctx *ctx);
 int      porrt_get_tree(const porrt_ctx *ctx, double *xy /* N*2 */, int64_t *parent /* -1 = root */,

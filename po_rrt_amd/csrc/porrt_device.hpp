@@ -94,6 +94,8 @@ struct Counters {
     uint32_t dbg[4];            // developer statistics (kd claim: max / sum of losers, launches; non-duplicate levels of G)
     uint32_t clone_n;           // valid samples of the running step steered exactly onto the goal point (k_nn2 -> k_conn2)
     uint32_t clone_k[64];
+    uint32_t sched_stop;        // porrt_grow_batch with a loop condition: the first step this row did not run (0xFFFFFFFF: still running)
+    uint32_t sched_iter;        //   and the iterations it ran (rrt.rs:109 / pto.rs:67: i when the loop ended)
     unsigned long long tim[16]; // developer builds (-DPORRT_TIMING): phase durations summed over waves, 10 ns units, and wave counts
 };
 
@@ -253,6 +255,12 @@ struct RunConst {
     RunConst *self;             // the context's own copy on the device (kernels launched for it alone read that one)
     uint32_t *zero0;            // [zero0, zero0 + zero_words): counters, region counts, valid masks, kd hints, deferred-tie states
     unsigned long long zero_words;
+    // The row's own step schedule (porrt_grow_batch whose members have their own n_iter_min / n_iter_max, or a loop condition that
+    // can end a member early): step b takes iterations [sched_i0[b], sched_i0[b] + sched_nb[b]).  The plan is static -- steps of K
+    // up to n_iter_min, then steps of K up to n_iter_max -- and k_row_sched zeroes sched_nb[b] from the step on
+    // at which the loop condition ends the row.  Null: every row runs the launch's (i0, nb).
+    uint32_t *sched_i0, *sched_nb;
+    uint32_t sched_min, sched_max, sched_K, sched_steps;
 };
 
 // Pointers read out of RunConst have no known address space, so hipcc emits flat_* accesses and drains both
@@ -271,6 +279,14 @@ template <class T>
 __device__ __forceinline__ T g_atomic_min(GPTR(T) p, T v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ------------------------------------------------------------------ small helpers
+// what a kernel launched for step b with (i0, nb) does for THIS row
+__device__ __forceinline__ uint32_t row_nb(const RunConst &rc, uint32_t b, uint32_t nb_arg) {
+    return rc.sched_nb ? ((GPTR(const uint32_t))(uintptr_t)rc.sched_nb)[b] : nb_arg;
+}
+__device__ __forceinline__ uint32_t row_i0(const RunConst &rc, uint32_t b, uint32_t i0_arg) {
+    return rc.sched_i0 ? ((GPTR(const uint32_t))(uintptr_t)rc.sched_i0)[b] : i0_arg;
+}
+
 
 // neighbour list of sample k in step b (parity buffers)
 __device__ __forceinline__ uint32_t q_off(const RunConst &rc, uint32_t b) { return (b & 1u) * rc.q_stride; }
@@ -482,6 +498,7 @@ __global__ void k_gen_samples(const RunConst *__restrict__ rcp, const PcgJump *_
     if (!jt) { jt = rc.jump; st_lo = rc.rng_st_lo; st_hi = rc.rng_st_hi; inc_lo = rc.rng_inc_lo; inc_hi = rc.rng_inc_hi; }
     unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
+    if (rc.sched_nb && it0 + t >= rc.sched_max) return;       // a batch row with its own budget: its arrays end there
     unsigned long long idx = it0 + t;     // 0-based iteration of this grow call
     unsigned long long it = idx + 1;
     if (it % 100 == 0) {
@@ -849,12 +866,12 @@ __global__ __launch_bounds__(256) void k_near(const RunConst *__restrict__ rcp, 
     const uint32_t near_blocks = (nb + 3u) / 4u;
     if (blockIdx.x >= near_blocks) {
         const uint32_t ck = uni((blockIdx.x - near_blocks) * 4u + (threadIdx.x >> 6));     // wave-uniform: addresses in SGPRs
-        if (!PTO && ck < cnb) commit_rrt_sample(rc, cb, vwords, ck, lane);
+        if (!PTO && ck < cnb && ck < row_nb(rc, cb, cnb)) commit_rrt_sample(rc, cb, vwords, ck, lane);
         return;
     }
     const uint32_t k = uni(blockIdx.x * 4u + (threadIdx.x >> 6));       // wave-uniform: addresses in SGPRs
-    if (k >= nb) return;
-    near_sample<PTO>(rc, b, i0, vwords, k, lane);
+    if (k >= row_nb(rc, b, nb)) return;
+    near_sample<PTO>(rc, b, row_i0(rc, b, i0), vwords, k, lane);
 }
 
 // Add the step's new nodes to the region pages (run by ONE workgroup, an extra block of the connect kernels:
@@ -1677,7 +1694,9 @@ __global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per
     __shared__ uint32_t s_heavy[kConnectWaves];
     __shared__ __attribute__((aligned(16))) uint8_t s_ins[kInsertLds];
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
-    if (blockIdx.x == gridDim.x - 1) { insert_step_pages(rc, b, nb, vwords, s_ins); return; }    // the extra block
+    nb = row_nb(rc, b, nb);
+    if (blockIdx.x == gridDim.x - 1) { if (nb) insert_step_pages(rc, b, nb, vwords, s_ins); return; }    // the extra block
+    if (blockIdx.x * kConnectWaves >= nb) return;
     connect_block<LDSGRID>(rc, b, nb, vwords, blockIdx.x, lds_tiles, s_d, s_i, s_heavy);
 }
 
@@ -1761,7 +1780,7 @@ __device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vword
 // stand-alone form (last step of a launch sequence)
 __global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
     const uint32_t k = uni((blockIdx.x * 256u + threadIdx.x) >> 6);
-    if (k < nb) commit_rrt_sample(rcp[blockIdx.y], b, vwords, k, threadIdx.x & 63u);
+    if (k < nb && k < row_nb(rcp[blockIdx.y], b, nb)) commit_rrt_sample(rcp[blockIdx.y], b, vwords, k, threadIdx.x & 63u);
 }
 
 // Insert this step's nodes into the reference's kd-tree in id order (KdTree::add, nearest_neighbor.rs:29-46;
@@ -1832,6 +1851,7 @@ __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ 
     const uint32_t st = wid / K, ks = wid - st * K;
     bool active = st < nsteps && ks < (st + 1 == nsteps ? nb_last : K);
     const uint32_t b = b0 + (active ? st : 0u);
+    if (active && rc.sched_nb) active = ks < row_nb(rc, b, K);          // (the row's own step sizes: perm[] holds that many entries)
     // the step's samples in the spatial order of k_sort_samples: neighbouring threads descend through the same nodes, so a
     // wave's loads of a level fall into a few cache lines instead of 64
     const uint32_t k = active ? (uint32_t)as_global(rc.perm)[(size_t)b * rc.part_stride + ks] : 0u;
@@ -2250,7 +2270,8 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_tiles[];
     __shared__ __attribute__((aligned(16))) uint8_t s_ins[kInsertLds];
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
-    if (blockIdx.x == gridDim.x - 1) { insert_step_pages(rc, b, nb, vwords, s_ins); return; }    // the extra block
+    nb = row_nb(rc, b, nb);
+    if (blockIdx.x == gridDim.x - 1) { if (nb) insert_step_pages(rc, b, nb, vwords, s_ins); return; }    // the extra block
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = uni(blockIdx.x * kConnectWaves + (threadIdx.x >> 6));
     if (k >= nb || as_global(rc.q_vid)[k] < 0) return;
@@ -2349,6 +2370,8 @@ __global__ __launch_bounds__(256) void k_commit_pto(const RunConst *__restrict__
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t N = as_global(rc.n_at)[b];
+    nb = row_nb(rc, b, nb);
+    if (!nb) return;                               // (a row that has stopped: k_row_sched carried n_at on)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         uint32_t add = 0;
         for (uint32_t w = 0; w < vwords; ++w) add += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
@@ -2417,6 +2440,57 @@ __global__ __launch_bounds__(1024) void k_best_cost(const RunConst *__restrict__
         r.cost_bits = s_cost[0]; r.final_id = s_id[0]; r.path_len = s_len[0]; r.overflow = any_over ? 1u : 0u; r.pad = 0;
         *rc.bc_out = r;
     }
+}
+
+// ---- the rows' own step schedules (porrt_grow_batch with per-member n_iter_min / n_iter_max and the reference's loop condition)
+// The plan of a row, a function of (n_iter_min, n_iter_max, K) alone: steps of K iterations up to n_iter_min (the last one
+// shorter), where the condition `i < n_iter_min || (no solution && i < n_iter_max)` (rrt.rs:109, pto.rs:67) is first looked at,
+// then steps of K up to n_iter_max with the condition looked at after each -- the batched contract of DESIGN.md section 3.
+__global__ __launch_bounds__(256) void k_sched_init(const RunConst *__restrict__ rcp) {
+    const RunConst &rc = rcp[blockIdx.y];
+    if (!rc.sched_nb) return;
+    const uint32_t K = rc.sched_K, mn = rc.sched_min, mx = rc.sched_max, s1 = (mn + K - 1u) / K;
+    for (uint32_t b = blockIdx.x * 256u + threadIdx.x; b < rc.sched_steps; b += gridDim.x * 256u) {
+        uint32_t i0, nb;
+        if (b < s1) { i0 = b * K; nb = mn - i0 < K ? mn - i0 : K; }
+        else {
+            const unsigned long long at = (unsigned long long)mn + (unsigned long long)(b - s1) * K;
+            i0 = at < mx ? (uint32_t)at : mx;
+            nb = i0 < mx ? (mx - i0 < K ? mx - i0 : K) : 0u;
+        }
+        rc.sched_i0[b] = i0; rc.sched_nb[b] = nb;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { rc.cnt->sched_stop = 0xFFFFFFFFu; rc.cnt->sched_iter = 0; }
+}
+
+// Before step b: does row q still run?  One thread per row.  A row that has ended keeps sched_nb[b] = 0 for every later step (all
+// the step's kernels then leave it alone) and its tree size is carried along n_at, so that the launch's last step names every
+// row's final size.  active[b] counts the rows that run step b (the host stops launching when it reads 0).
+__global__ __launch_bounds__(64) void k_row_sched(const RunConst *__restrict__ rcp, uint32_t Q, uint32_t b, uint32_t *__restrict__ active) {
+    const uint32_t q = blockIdx.x * 64u + threadIdx.x;
+    bool runs = false;
+    if (q < Q) {
+        const RunConst &rc = rcp[q];
+        if (rc.sched_nb) {
+            Counters *c = rc.cnt;
+            bool stop = c->sched_stop != 0xFFFFFFFFu;
+            if (!stop) {
+                const uint32_t i = rc.sched_i0[b], nbp = rc.sched_nb[b];
+                const bool solved = rc.mode == 1 ? (c->n_final > 0 && (c->finality & rc.all_worlds) == rc.all_worlds) : c->n_final > 0;
+                stop = nbp == 0u || (i >= rc.sched_min && solved);              // i >= n_iter_max  ||  (i >= n_iter_min && solved)
+                if (stop) { c->sched_stop = b; c->sched_iter = i; }
+            }
+            if (stop) {
+                rc.sched_nb[b] = 0;
+                rc.n_at[b + 1] = rc.n_at[b];
+            }
+            runs = !stop;
+        } else {
+            runs = true;
+        }
+    }
+    const unsigned long long m = __ballot(runs);
+    if (threadIdx.x == 0 && m) atomicAdd(&active[b], (uint32_t)__popcll(m));
 }
 
 // porrt_grow_batch: every member's counters and final tree size into one array, so that the host needs one copy

@@ -30,6 +30,11 @@
 #include <memory>
 #include <vector>
 
+// Nothing is thrown across the C boundary: an entry point whose body can allocate runs inside abi_guard.
+template <class F> static inline int abi_guard(F &&f) noexcept {
+    try { return f(); } catch (const std::bad_alloc &) { return PORRT_ERR_NOMEM; } catch (...) { return PORRT_ERR_INVALID; }
+}
+
 using namespace porrt;
 typedef unsigned __int128 u128;
 
@@ -226,6 +231,7 @@ struct porrt_ctx {
     DevBuf<uint32_t> d_nat, d_sworld, d_candcnt, d_efrom, d_eto, d_etv;
     DevBuf<uint16_t> d_perm, d_bqk;
     DevBuf<uint32_t> d_slotof;
+    DevBuf<uint32_t> d_sched_i0, d_sched_nb;       // a batch row's own step plan (RunConst::sched_*)
     DevBuf<Counters> d_cnt;
     DevBuf<RunConst> d_rc;
     DevBuf<PcgJump> d_jump;
@@ -262,10 +268,15 @@ struct porrt_ctx {
              uint32_t K, int mode);
     int grow_once(const double start[2], double max_step, double search_radius, uint64_t n_iter_min, uint64_t n_iter_max,
                   uint32_t K, int mode, bool host_samples, int stage = 0);
-    int finish_batch_member(uint64_t n_iter_done, uint32_t steps, float device_ms);
+    int finish_batch_member(uint64_t n_iter_done, uint32_t steps, uint32_t own_steps, float device_ms);
     Counters batch_hc;
+    Pcg64 batch_drng0;                     // PTO member of a batch: the discrete sampler before the plan's worlds were drawn
+    size_t batch_wpos0 = 0;
+    uint64_t batch_world_draws = 0;
     uint32_t batch_nodes = 0;
     BatchOut *d_batch_out = nullptr;       // leader of a batch: gathered counters of the members
+    uint32_t *d_active = nullptr, *h_active = nullptr;     // leader of a batch with step plans: rows still running per step (device / pinned host)
+    size_t active_cap = 0;
     std::vector<RunConst> rc_staging;      // leader of a batch: the members' RunConst, uploaded in one copy
     std::vector<uint32_t> worlds_staging;  // sampled worlds of the last upload (PTO)
     size_t batch_out_cap = 0;
@@ -308,6 +319,11 @@ struct porrt_ctx {
     hipEvent_t ev_join = nullptr;
     void join_side();
     void launch_kd_group();
+    int ensure_side_stream() {
+        if (stream2) return PORRT_OK;
+        if (hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking) != hipSuccess) { stream2 = nullptr; set_err("hipStreamCreate (side stream)"); return PORRT_ERR_DEVICE; }
+        return PORRT_OK;
+    }
     uint32_t kd_b0 = 0, kd_last_b = 0, kd_last_nb = 0, kd_group = 1, kd_gidx = 0;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_step_done = nullptr, ev_kd[2] = {nullptr, nullptr}, ev_steered = nullptr;
@@ -330,7 +346,7 @@ int porrt_ctx::layout_buffers() {
                               &d_kdrec, &d_gx, &d_gy, &d_rgdir, &d_rep, &d_kdbox, &d_locbox, &d_kdlosers, &d_gsnap, &d_pendoff, &d_pendn, &d_pendcur,
                               &d_pendnew, &d_pendpool, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB, &d_finalmask, &d_vid, &d_finalflag, &d_cls,
                               &d_nat, &d_sworld, &d_candcnt, &d_efrom, &d_eto, &d_etv, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags,
-                              &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid, &d_bcscratch, &d_bcout, &d_bccursor, &d_perm, &d_pgd, &d_slotof, &d_ssx, &d_ssy, &d_bqx, &d_bqy, &d_t2at, &d_bqk, &d_rgocc};
+                              &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid, &d_bcscratch, &d_bcout, &d_bccursor, &d_perm, &d_pgd, &d_slotof, &d_ssx, &d_ssy, &d_bqx, &d_bqy, &d_t2at, &d_bqk, &d_rgocc, &d_sched_i0, &d_sched_nb};
         for (DevBufBase *b2 : list) all_bufs.push_back(b2);
     }
     bool grow_needed = false;
@@ -370,6 +386,7 @@ int porrt_ctx::layout_buffers() {
     d_locflags.p = (uint32_t *)d_locflags.vp; d_kdsurv.p = (uint32_t *)d_kdsurv.vp;
     d_gndx.p = (double *)d_gndx.vp; d_gndy.p = (double *)d_gndy.vp;
     d_kqx.p = (double *)d_kqx.vp; d_kqy.p = (double *)d_kqy.vp; d_kqvid.p = (int *)d_kqvid.vp;
+    d_sched_i0.p = (uint32_t *)d_sched_i0.vp; d_sched_nb.p = (uint32_t *)d_sched_nb.vp;
     d_cnt.p = (Counters *)d_cnt.vp; d_rc.p = (RunConst *)d_rc.vp; d_jump.p = (PcgJump *)d_jump.vp; d_perm.p = (uint16_t *)d_perm.vp; d_pgd.p = (double *)d_pgd.vp; d_slotof.p = (uint32_t *)d_slotof.vp; d_ssx.p = (double *)d_ssx.vp; d_ssy.p = (double *)d_ssy.vp; d_bqx.p = (double *)d_bqx.vp; d_bqy.p = (double *)d_bqy.vp; d_t2at.p = (double *)d_t2at.vp; d_bqk.p = (uint16_t *)d_bqk.vp; d_rgocc.p = (unsigned long long *)d_rgocc.vp;
     // cached uploads are gone
     rad_uploaded = 0;
@@ -784,6 +801,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(d_perm.reserve((steps_max + 2) * Kpad)); HIPCHK(d_ssx.reserve((steps_max + 2) * Kpad)); HIPCHK(d_ssy.reserve((steps_max + 2) * Kpad));
         HIPCHK(d_bqx.reserve(Kpad)); HIPCHK(d_bqy.reserve(Kpad)); HIPCHK(d_bqk.reserve(Kpad)); HIPCHK(d_t2at.reserve(steps_max + 4));
         HIPCHK(d_rep.reserve(kRepTotal));
+        HIPCHK(d_sched_i0.reserve(steps_max + 4)); HIPCHK(d_sched_nb.reserve(steps_max + 4));
         HIPCHK(d_kdrec.reserve(Nmax)); HIPCHK(d_gx.reserve(Nmax + 16)); HIPCHK(d_gy.reserve(Nmax + 16)); HIPCHK(d_kdup.reserve(Nmax)); HIPCHK(d_kddepth.reserve(Nmax)); HIPCHK(d_kdgexit.reserve(Nmax));
         HIPCHK(d_radT2.reserve(Nmax + 8));
         HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_jump.reserve(1));
@@ -1011,6 +1029,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     uint64_t i = 0;
     uint32_t b = 0;
     int rcode = PORRT_OK;
+    if (stage == 1) { batch_drng0 = drng; batch_wpos0 = inj_wpos; batch_world_draws = n_iter_min; }
     if (n_iter_min > 0) {
         double t0 = now_s();
         int r = ensure_radius_table(max_step, search_radius, n_iter_min + 4);
@@ -1021,6 +1040,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     }
     run_lds_bytes = lds_bytes;
     if (stage == 1) return PORRT_OK;
+    { int r = ensure_side_stream(); if (r) return r; }
     launch_rcp = d_rc.p;
     launch_Q = 1;
     opt_group = opt_group_req < 0 ? 0u : (uint32_t)opt_group_req;
@@ -1926,9 +1946,9 @@ int porrt_ctx::best_cost_device(double *cost, uint64_t *final_id) {
     return read_best_cost(cost, final_id);
 }
 
-// A member's bookkeeping after the leader of a porrt_grow_batch ran the steps (fixed iteration budget: the loop
-// condition is never consulted, n_iter_min == n_iter_max).
-int porrt_ctx::finish_batch_member(uint64_t n_iter_done, uint32_t steps, float device_ms) {
+// A member's bookkeeping after the leader of a porrt_grow_batch ran the steps: n_iter_done iterations in `steps` steps
+// (the budget, or where the loop condition of rrt.rs:109 / pto.rs:67 ended this member).
+int porrt_ctx::finish_batch_member(uint64_t n_iter_done, uint32_t steps, uint32_t own_steps, float device_ms) {
     // fetched by grow_batch for all members at once (batch_hc, batch_nodes)
     const Counters hc = batch_hc;
     const uint32_t n_final_nodes = batch_nodes;
@@ -1943,7 +1963,7 @@ int porrt_ctx::finish_batch_member(uint64_t n_iter_done, uint32_t steps, float d
                                        (unsigned long long)hc.tim[t + 8], 1e-5 * (double)hc.tim[t]);
     }
     n_iter = n_iter_done;
-    n_steps = steps;
+    n_steps = steps;                 // n_at[steps] is this member's final size (carried along by k_row_sched if it ended earlier)
     n_nodes = n_final_nodes;
     const unsigned long long all = rc.all_worlds;
     complete = mode == PORRT_MODE_PTO ? (hc.n_final > 0 && (hc.finality & all) == all) : hc.n_final > 0;
@@ -1952,10 +1972,16 @@ int porrt_ctx::finish_batch_member(uint64_t n_iter_done, uint32_t steps, float d
     const uint64_t calls = n_iter_done - n_iter_done / 100;
     if (has_inj) inj_pos += calls;
     else crng.advance((u128)2 * calls);
+    if (mode == PORRT_MODE_PTO && n_iter_done < batch_world_draws) {
+        // the worlds of the whole plan were drawn up front (one per iteration, pto.rs:142); the loop ended earlier: the discrete
+        // sampler stands where the reference's would -- after n_iter_done draws
+        if (has_inj_worlds) inj_wpos = batch_wpos0 + n_iter_done;
+        else { drng = batch_drng0; for (uint64_t t = 0; t < n_iter_done; ++t) (void)drng.gen_range_usize((uint64_t)n_worlds); }
+    }
     memset(&metrics, 0, sizeof metrics);
     metrics.n_iter = n_iter;
     metrics.n_nodes = n_nodes;
-    metrics.n_steps = n_steps;
+    metrics.n_steps = own_steps;
     metrics.n_tie_fallbacks = hc.tie_fallbacks + ((hc.err & ERR_GPATH_OVERFLOW) ? 1 : 0);
     metrics.device_s = device_ms * 1e-3;
     metrics.total_s = metrics.device_s;
@@ -2008,16 +2034,44 @@ static std::vector<hipStream_t> pick_parallel_streams(uint32_t want) {
     return chosen;
 }
 
-// porrt_grow_batch: the same growth, with a fixed iteration budget, for several contexts of one device at once.
+// porrt_grow_batch: the same growth for several contexts of one device at once, each with its own n_iter_min / n_iter_max
+// (nmin[q], nmax[q]) and the loop condition of rrt.rs:109 / pto.rs:67.
 // Context 0 leads: every step kernel is launched once with one grid row per context, so the contexts' dependent
-// load chains overlap inside each kernel instead of queueing behind each other.
-static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, double max_step, double search_radius, uint64_t n_iter,
-                      uint32_t K, int mode) {
+// load chains overlap inside each kernel instead of queueing behind each other.  When every member has the same fixed budget
+// (nmin == nmax, the same for all) the launch's (i0, nb) serve every row; otherwise each row follows its own step plan on the
+// device (RunConst::sched_*, k_sched_init) and k_row_sched takes it out of the later launches once its loop condition ends it --
+// results are those of separate porrt_grow calls either way.
+static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, double max_step, double search_radius, const uint64_t *nmin_in,
+                      const uint64_t *nmax_in, uint32_t K, int mode) {
     porrt_ctx *L = cs[0];
     if (K == 0 || K > 4096) { L->set_err("batch_K must be in 1..4096"); return PORRT_ERR_INVALID; }
     if (mode != PORRT_MODE_RRT && mode != PORRT_MODE_PTO) { L->set_err("bad mode"); return PORRT_ERR_INVALID; }
-    if (n_iter == 0 || n_iter + 2 >= 0x7FFFFFF0ull) { L->set_err("n_iter"); return PORRT_ERR_INVALID; }
     if (!(max_step > 0.0) || !(search_radius >= 0.0)) { L->set_err("max_step / search_radius"); return PORRT_ERR_INVALID; }
+    std::vector<uint64_t> nmin(nmin_in, nmin_in + n), nmax(nmax_in, nmax_in + n);
+    uint64_t n_iter = 0;                         // the longest budget: what the preparation kernels' grids cover
+    bool sched = false;
+    for (uint32_t q = 0; q < n; ++q) {
+        if (nmax[q] < nmin[q]) nmax[q] = nmin[q];                                  // as porrt_grow
+        if (nmax[q] == 0 || nmax[q] + 2 >= 0x7FFFFFF0ull) { L->set_err("n_iter_min / n_iter_max"); return PORRT_ERR_INVALID; }
+        if (nmin[q] != nmax[q] || nmax[q] != nmax[0]) sched = true;
+        n_iter = std::max(n_iter, nmax[q]);
+    }
+    // the rows' plans as the device will hold them (k_sched_init): steps up to n_iter_min, then up to n_iter_max
+    auto plan = [&](uint32_t q, uint32_t b, uint64_t &i0, uint32_t &nb) {
+        const uint64_t s1 = (nmin[q] + K - 1) / K;
+        if (b < s1) { i0 = (uint64_t)b * K; nb = (uint32_t)std::min<uint64_t>(K, nmin[q] - i0); }
+        else { i0 = std::min<uint64_t>(nmin[q] + (uint64_t)(b - s1) * K, nmax[q]); nb = (uint32_t)std::min<uint64_t>(K, nmax[q] - i0); }
+    };
+    uint32_t B_pot = 0, first_dec = 0xFFFFFFFFu;
+    for (uint32_t q = 0; q < n; ++q) {
+        const uint64_t s1 = (nmin[q] + K - 1) / K, s2 = (nmax[q] - nmin[q] + K - 1) / K;
+        B_pot = std::max<uint32_t>(B_pot, (uint32_t)(s1 + s2));
+        first_dec = std::min<uint32_t>(first_dec, (uint32_t)s1);
+    }
+    std::vector<uint32_t> nbmax(sched ? B_pot : 0u, 0u);
+    if (sched)
+        for (uint32_t q = 0; q < n; ++q)
+            for (uint32_t b2 = 0; b2 < B_pot; ++b2) { uint64_t i0; uint32_t nb; plan(q, b2, i0, nb); nbmax[b2] = std::max(nbmax[b2], nb); }
     for (uint32_t q = 0; q < n; ++q) {
         if (!cs[q] || cs[q]->device != L->device) { L->set_err("porrt_grow_batch: contexts of one device"); return PORRT_ERR_INVALID; }
         for (uint32_t r = 0; r < q; ++r) if (cs[r] == cs[q]) { L->set_err("porrt_grow_batch: a context appears twice"); return PORRT_ERR_INVALID; }
@@ -2031,6 +2085,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         cs[q]->batch_leader = nullptr;
     }
     HIPCHK_CTX(L, hipSetDevice(L->device));
+    { int r = L->ensure_side_stream(); if (r) return r; }
     for (porrt_ctx *m : L->batch_members) if (m && m->batch_leader == L) m->batch_leader = nullptr;      // the previous batch is over
     L->batch_members.clear();
     const uint64_t batch_gen = ++L->batch_gen_counter;
@@ -2050,26 +2105,36 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         for (uint32_t q = 0; q < n; ++q) {
             hipStream_t own = cs[q]->stream;
             cs[q]->stream = L->stream;          // the members' preparation is queued on the leader's stream: no host sync
-            int r = cs[q]->grow_once(starts + 2 * q, max_step, search_radius, n_iter, n_iter, K, mode, false, 1);
+            int r = cs[q]->grow_once(starts + 2 * q, max_step, search_radius, nmax[q], nmax[q], K, mode, false, 1);
             cs[q]->stream = own;
             if (r) { if (cs[q] != L) L->set_err(cs[q]->err); return r; }
             if (cs[q]->run_lds_bytes != L->run_lds_bytes) { L->set_err("porrt_grow_batch: the contexts' rasters need different LDS tiles (max_step * ppm differs)"); return PORRT_ERR_INVALID; }
         }
         L->opt_group = L->opt_group_req < 0 ? (n >= 8 ? 16u : 0u) : (uint32_t)L->opt_group_req;
-        L->pipe_on = mode == PORRT_MODE_RRT && L->opt_group == 0 && L->opt_pipeline != 0;
+        // (pipelined steps search step b + 1 while step b is connected: not with rows that may end after step b)
+        L->pipe_on = mode == PORRT_MODE_RRT && L->opt_group == 0 && L->opt_pipeline != 0 && !sched;
         L->rc_staging.resize(n);                 // one upload for all members (the vector outlives the copy: it is a member)
         for (uint32_t q = 0; q < n; ++q) {
-            cs[q]->rc.q_stride = L->pipe_on ? cs[q]->rc.part_stride : 0u;
-            L->rc_staging[q] = cs[q]->rc;
+            RunConst &rq = cs[q]->rc;
+            rq.q_stride = L->pipe_on ? rq.part_stride : 0u;
+            rq.sched_i0 = sched ? cs[q]->d_sched_i0.p : nullptr;
+            rq.sched_nb = sched ? cs[q]->d_sched_nb.p : nullptr;
+            rq.sched_min = (uint32_t)nmin[q]; rq.sched_max = (uint32_t)nmax[q]; rq.sched_K = K;
+            rq.sched_steps = (uint32_t)std::min<uint64_t>((uint64_t)B_pot + 2, cs[q]->d_sched_nb.n);
+            if (sched && (uint64_t)(nmin[q] + K - 1) / K + (nmax[q] - nmin[q] + K - 1) / K + 2 > cs[q]->d_sched_nb.n) { L->set_err("porrt_grow_batch: step plan"); return PORRT_ERR_DEVICE; }
+            L->rc_staging[q] = rq;
         }
         HIPCHK_CTX(L, hipMemcpyAsync(L->d_rcarr, L->rc_staging.data(), (size_t)n * sizeof(RunConst), hipMemcpyHostToDevice, L->stream));
         if (mode == PORRT_MODE_RRT) {            // the members' preparation, all at once (k_batch_prep)
             const RunConst *rows = L->d_rcarr;
             hipLaunchKernelGGL(k_batch_prep, dim3(32, n), dim3(256), 0, L->stream, rows);
+            if (sched) hipLaunchKernelGGL(k_sched_init, dim3(1, n), dim3(256), 0, L->stream, rows);
             hipLaunchKernelGGL(k_init_root, dim3(1, n), dim3(1), 0, L->stream, rows, 0.0, 0.0, 0ull, 0, 1);
             hipLaunchKernelGGL(k_gen_samples, dim3((unsigned)((n_iter + 255) / 256), n), dim3(256), 0, L->stream, rows, (const PcgJump *)nullptr, 0ull,
                                (unsigned long long)n_iter, 0ull, 0ull, 0ull, 0ull, 0ull);
-            hipLaunchKernelGGL(k_sort_samples, dim3((unsigned)((n_iter + K - 1) / K), n), dim3(256), 0, L->stream, rows, 0u, 0ull, (unsigned long long)n_iter, K);
+            hipLaunchKernelGGL(k_sort_samples, dim3(sched ? B_pot : (unsigned)((n_iter + K - 1) / K), n), dim3(256), 0, L->stream, rows, 0u, 0ull, (unsigned long long)n_iter, K);
+        } else if (sched) {
+            hipLaunchKernelGGL(k_sched_init, dim3(1, n), dim3(256), 0, L->stream, (const RunConst *)L->d_rcarr);
         }
         // the leader: all steps, one hipGraph (or eager), grid rows = contexts
         L->launch_rcp = L->d_rcarr;
@@ -2094,6 +2159,39 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
                 L->ev_pool.push_back(ev);
             }
         }
+        // rows with plans of their own: step by step, k_row_sched before every step at which a row's loop may end; the host reads
+        // the number of rows still running two steps behind its launches and stops when it is zero (the steps launched past that
+        // point find every row ended and do nothing)
+        int sched_rc = PORRT_OK;
+        auto sched_steps = [&]() -> uint32_t {
+            constexpr uint32_t LAG = 2, RING = 4;
+            if (L->active_cap < B_pot + 2u) {
+                if (L->d_active) (void)hipFree(L->d_active);
+                if (L->h_active) (void)hipHostFree(L->h_active);
+                L->d_active = nullptr; L->h_active = nullptr; L->active_cap = 0;
+                if (hipMalloc((void **)&L->d_active, (B_pot + 2u) * sizeof(uint32_t)) != hipSuccess ||
+                    hipHostMalloc((void **)&L->h_active, (B_pot + 2u) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { sched_rc = PORRT_ERR_DEVICE; return 0; }
+                L->active_cap = B_pot + 2u;
+            }
+            ScopedEvents<RING> ring;
+            if (ring.create() != hipSuccess) { sched_rc = PORRT_ERR_DEVICE; return 0; }
+            (void)hipMemsetAsync(L->d_active, 0, (B_pot + 2u) * sizeof(uint32_t), L->stream);
+            uint32_t cb = 0;
+            for (; cb < B_pot; ++cb) {
+                if (cb >= first_dec) {
+                    hipLaunchKernelGGL(k_row_sched, dim3((n + 63u) / 64u), dim3(64), 0, L->stream, (const RunConst *)L->d_rcarr, n, cb, L->d_active);
+                    (void)hipMemcpyAsync(L->h_active + cb, L->d_active + cb, sizeof(uint32_t), hipMemcpyDeviceToHost, L->stream);
+                    (void)hipEventRecord(ring.e[cb % RING], L->stream);
+                }
+                L->launch_step(cb, 0u, nbmax[cb], vwords, L->run_lds_bytes, prof, ev_used, 0u, 0u);
+                if (cb >= first_dec + LAG) {
+                    if (hipEventSynchronize(ring.e[(cb - LAG) % RING]) != hipSuccess) { sched_rc = PORRT_ERR_DEVICE; break; }
+                    if (L->h_active[cb - LAG] == 0u) { ++cb; break; }
+                }
+            }
+            L->join_side();
+            return cb;
+        };
         auto all_steps = [&]() {
             uint64_t ci = 0;
             uint32_t cb = 0;
@@ -2109,7 +2207,10 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             return cb;
         };
         uint32_t steps = 0;
-        if (L->opt_graph && !prof && !L->sub_eager) {
+        if (sched) {
+            steps = sched_steps();
+            if (sched_rc) { L->set_err("porrt_grow_batch: step schedule (device)"); return sched_rc; }
+        } else if (L->opt_graph && !prof && !L->sub_eager) {
             const uint64_t key[6] = {(uint64_t)mode, K, n_iter, L->run_lds_bytes, (uint64_t)(uintptr_t)L->launch_rcp, L->kd_group | ((uint64_t)n << 32) | ((uint64_t)L->opt_group << 48) | ((uint64_t)L->pipe_on << 56)};
             if (!L->graph_exec || memcmp(key, L->graph_key, sizeof key)) {
                 if (L->graph_exec) { (void)hipGraphExecDestroy(L->graph_exec); L->graph_exec = nullptr; }
@@ -2134,7 +2235,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             HIPCHK_CTX(L, hipMalloc((void **)&L->d_batch_out, (size_t)n * sizeof(BatchOut)));
             L->batch_out_cap = n;
         }
-        hipLaunchKernelGGL(k_batch_gather, dim3(n), dim3(64), 0, L->stream, (const RunConst *)L->d_rcarr, (uint32_t)((n_iter + K - 1) / K), L->d_batch_out);
+        hipLaunchKernelGGL(k_batch_gather, dim3(n), dim3(64), 0, L->stream, (const RunConst *)L->d_rcarr, sched ? steps : (uint32_t)((n_iter + K - 1) / K), L->d_batch_out);
         std::vector<BatchOut> h_out(n);
         HIPCHK_CTX(L, hipMemcpyAsync(h_out.data(), L->d_batch_out, (size_t)n * sizeof(BatchOut), hipMemcpyDeviceToHost, L->stream));
         HIPCHK_CTX(L, hipStreamSynchronize(L->stream));
@@ -2150,12 +2251,16 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         bool retry = false;
         int worst = PORRT_OK;
         for (uint32_t q = 0; q < n; ++q) {
-            int r = cs[q]->finish_batch_member(n_iter, steps, ms);
+            // where the member's loop ended: its own stop (k_row_sched), or the whole plan
+            uint64_t it_q = nmax[q];
+            uint32_t steps_q = steps;
+            if (sched && h_out[q].cnt.sched_stop != 0xFFFFFFFFu) { it_q = h_out[q].cnt.sched_iter; steps_q = h_out[q].cnt.sched_stop; }
+            int r = cs[q]->finish_batch_member(it_q, steps, steps_q, ms);
             if (r == -100) retry = true;
             else if (r < 0) { if (cs[q] != L) L->set_err(cs[q]->err); return r; }
             else if (r > worst) worst = r;
         }
-        if (!retry && prof) {
+        if (!retry && prof && !sched) {
             // events were recorded around k_near [0,1] and the connect kernel [2,3] of every step (all members at once);
             // the leader's metrics carry the batch totals
             double scan = 0, conn = 0, pairs = 0, bytes = 0;
@@ -2189,7 +2294,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             return worst;
         }
         for (uint32_t q = 0; q < n; ++q) {          // neighbour lists overflowed somewhere: regrow them everywhere and replay
-            cs[q]->opt_cand_cap = (uint32_t)std::min<uint64_t>((uint64_t)cs[q]->opt_cand_cap * 4, n_iter + 2);
+            cs[q]->opt_cand_cap = (uint32_t)std::min<uint64_t>((uint64_t)cs[q]->opt_cand_cap * 4, nmax[q] + 2);
             cs[q]->crng = c0[q]; cs[q]->drng = d0[q]; cs[q]->inj_pos = ip0[q]; cs[q]->inj_wpos = iw0[q];
             cs[q]->have_results = false;
         }
@@ -2207,8 +2312,8 @@ porrt_ctx *porrt_create(int device) {
     porrt_ctx *c = new porrt_ctx();
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
-    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_step_done, hipEventDisableTiming) != hipSuccess ||
+    // (the side stream is made when the context first leads a launch sequence: the thousand members of a large batch never do)
+    if (hipEventCreateWithFlags(&c->ev_step_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_kd[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_kd[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_steered, hipEventDisableTiming) != hipSuccess ||
@@ -2243,6 +2348,8 @@ void porrt_destroy(porrt_ctx *c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->d_rcarr) (void)hipFree(c->d_rcarr);
     if (c->d_batch_out) (void)hipFree(c->d_batch_out);
+    if (c->d_active) (void)hipFree(c->d_active);
+    if (c->h_active) (void)hipHostFree(c->h_active);
 
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -2376,16 +2483,22 @@ int porrt_set_observation_goal(porrt_ctx *c, uint32_t zone_id) {
 int porrt_grow(porrt_ctx *c, const double start[2], double max_step, double search_radius, uint64_t n_iter_min, uint64_t n_iter_max,
                uint32_t batch_K, int mode) {
     if (!c || !start) return PORRT_ERR_INVALID;
-    return c->grow(start, max_step, search_radius, n_iter_min, n_iter_max, batch_K, mode);
+    return abi_guard([&]() { return c->grow(start, max_step, search_radius, n_iter_min, n_iter_max, batch_K, mode); });
 }
 
-int porrt_grow_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, const double *starts, double max_step, double search_radius, uint64_t n_iter,
-                     uint32_t batch_K, int mode) {
-    if (!ctxs || !n_ctx || !starts || !ctxs[0]) return PORRT_ERR_INVALID;
+// joins the threads of a scope on every way out of it (an exception between emplace and join would otherwise terminate)
+struct ThreadJoiner {
+    std::vector<std::thread> th;
+    ~ThreadJoiner() { for (auto &t : th) if (t.joinable()) t.join(); }
+};
+
+static int grow_batch_each(porrt_ctx *const *ctxs, uint32_t n_ctx, const double *starts, double max_step, double search_radius, const uint64_t *n_iter_min,
+                           const uint64_t *n_iter_max, uint32_t batch_K, int mode) {
+    if (!ctxs || !n_ctx || !starts || !ctxs[0] || !n_iter_min || !n_iter_max) return PORRT_ERR_INVALID;
     for (uint32_t q = 0; q < n_ctx; ++q) if (!ctxs[q]) return PORRT_ERR_INVALID;
     uint32_t G = ctxs[0]->opt_batch_streams ? ctxs[0]->opt_batch_streams : (n_ctx >= 32 ? 2u : 1u);
     G = std::min(G, n_ctx);
-    if (G <= 1) return grow_batch(ctxs, n_ctx, starts, max_step, search_radius, n_iter, batch_K, mode);
+    if (G <= 1) return grow_batch(ctxs, n_ctx, starts, max_step, search_radius, n_iter_min, n_iter_max, batch_K, mode);
     for (uint32_t q = 0; q < n_ctx; ++q)          // checked here for the whole call: the sub-batches only see their own members
         for (uint32_t r = 0; r < q; ++r) if (ctxs[r] == ctxs[q]) { ctxs[0]->set_err("porrt_grow_batch: a context appears twice"); return PORRT_ERR_INVALID; }
     // contiguous runs of the argument, led by their first member; every run is a complete porrt_grow_batch of its own (its own
@@ -2412,18 +2525,17 @@ int porrt_grow_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, const double *start
         // choosing, and two replays side by side then share a queue more often than not (135-141 against 160 M expansions/s);
         // the launches (~900 per sub-batch) stay ahead of the GPU from a host thread each.
         if (have_streams) { Lg->stream = top->sub_streams[g]; Lg->stream2 = top->sub_streams[G + g]; Lg->sub_eager = true; }
-        rcs[g] = grow_batch(ctxs + lo[g], lo[g + 1] - lo[g], starts + 2 * (size_t)lo[g], max_step, search_radius, n_iter, batch_K, mode);
+        rcs[g] = grow_batch(ctxs + lo[g], lo[g + 1] - lo[g], starts + 2 * (size_t)lo[g], max_step, search_radius, n_iter_min + lo[g], n_iter_max + lo[g], batch_K, mode);
         Lg->stream = own; Lg->stream2 = own2; Lg->sub_eager = false;
     };
     {
-        std::vector<std::thread> th;
+        ThreadJoiner tj;
         std::vector<uint32_t> inline_parts;                 // (a host that cannot start another thread: those sub-batches run here, afterwards)
         for (uint32_t g = 1; g < G; ++g) {
-            try { th.emplace_back(part, g); } catch (const std::system_error &) { inline_parts.push_back(g); }
+            try { tj.th.emplace_back(part, g); } catch (const std::system_error &) { inline_parts.push_back(g); }
         }
         part(0);
         for (uint32_t g : inline_parts) part(g);
-        for (auto &t : th) t.join();
     }
     int worst = PORRT_OK;
     for (uint32_t g = 0; g < G; ++g) {
@@ -2431,6 +2543,20 @@ int porrt_grow_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, const double *start
         worst = std::max(worst, rcs[g]);
     }
     return worst;
+}
+
+int porrt_grow_batch_each(porrt_ctx *const *ctxs, uint32_t n_ctx, const double *starts, double max_step, double search_radius, const uint64_t *n_iter_min,
+                          const uint64_t *n_iter_max, uint32_t batch_K, int mode) {
+    return abi_guard([&]() { return grow_batch_each(ctxs, n_ctx, starts, max_step, search_radius, n_iter_min, n_iter_max, batch_K, mode); });
+}
+
+int porrt_grow_batch(porrt_ctx *const *ctxs, uint32_t n_ctx, const double *starts, double max_step, double search_radius, uint64_t n_iter_min,
+                     uint64_t n_iter_max, uint32_t batch_K, int mode) {
+    if (!n_ctx) return PORRT_ERR_INVALID;
+    return abi_guard([&]() {
+        const std::vector<uint64_t> mn(n_ctx, n_iter_min), mx(n_ctx, n_iter_max);
+        return grow_batch_each(ctxs, n_ctx, starts, max_step, search_radius, mn.data(), mx.data(), batch_K, mode);
+    });
 }
 
 uint64_t porrt_num_nodes(const porrt_ctx *c) { return c && c->have_results ? c->n_nodes : 0; }
@@ -2503,14 +2629,13 @@ int porrt_get_trees(porrt_ctx *const *ctxs, uint32_t n_ctx, double *const *xy, i
         }
     };
     {
-        std::vector<std::thread> th;
+        ThreadJoiner tj;
         std::vector<uint32_t> inline_work;
         for (uint32_t w = 1; w < W; ++w) {
-            try { th.emplace_back(work, w); } catch (const std::system_error &) { inline_work.push_back(w); }
+            try { tj.th.emplace_back(work, w); } catch (const std::system_error &) { inline_work.push_back(w); }
         }
         work(0);
         for (uint32_t w : inline_work) work(w);
-        for (auto &t : th) t.join();
     }
     for (uint32_t w = 0; w < W; ++w) if (rcs[w]) { top->set_err("porrt_get_trees: device copy failed"); return rcs[w]; }
     return PORRT_OK;

@@ -21,11 +21,6 @@
 
 #include "../../include/porrt_hip.h"
 
-// Nothing is thrown across the C boundary: an entry point whose body can allocate runs inside abi_guard.
-template <class F> static inline int abi_guard(F &&f) noexcept {
-    try { return f(); } catch (const std::bad_alloc &) { return PORRT_ERR_NOMEM; } catch (...) { return PORRT_ERR_INVALID; }
-}
-
 namespace porrt_fmt {
 
 inline bool read_file(const char *path, std::vector<uint8_t> &out) {

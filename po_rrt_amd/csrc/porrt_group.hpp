@@ -148,8 +148,12 @@ __global__ __launch_bounds__(256) void k_sort_samples(const RunConst *__restrict
     __shared__ uint32_t s_bin[kRegions];
     __shared__ uint32_t s_tot[256];
     const uint32_t s = blockIdx.x, b = b0 + s;
-    const unsigned long long i0 = it0 + (unsigned long long)s * K;
-    const uint32_t nb = (uint32_t)(n - (unsigned long long)s * K < K ? n - (unsigned long long)s * K : K);
+    unsigned long long i0 = it0 + (unsigned long long)s * K;
+    uint32_t nb = (unsigned long long)s * K < n ? (uint32_t)(n - (unsigned long long)s * K < K ? n - (unsigned long long)s * K : K) : 0u;
+    if (rc.sched_nb) {                          // the row's own plan (k_sched_init): step b may start anywhere and be shorter
+        if (b >= rc.sched_steps) return;
+        i0 = rc.sched_i0[b]; nb = rc.sched_nb[b];
+    }
     auto key_of = [&](uint32_t k) {
         int cx, cy;
         rep_cell(rc, rc.sx[i0 + k], rc.sy[i0 + k], kRG, cx, cy);
@@ -405,12 +409,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     if (bx >= near_blocks) {
         const uint32_t ck = (bx - near_blocks) * SPB + threadIdx.x / GL;
         PORRT_T0();
-        if (ck < cnb) commit_rrt_sample(rc, cb, vwords, ck, tm.gl, GL);
+        if (ck < cnb && ck < row_nb(rc, cb, cnb)) commit_rrt_sample(rc, cb, vwords, ck, tm.gl, GL);
         PORRT_TACC_A(rc, 4);
         return;
     }
     const uint32_t slot = bx * SPB + threadIdx.x / GL;
-    if (slot >= nb) return;
+    if (slot >= row_nb(rc, b, nb)) return;
     PORRT_T0();
     const size_t so = (size_t)b * rc.part_stride + slot;
     const uint32_t k = as_global(rc.perm)[so];
@@ -606,6 +610,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     uint32_t bx = blockIdx.x, by = blockIdx.y;
     const uint32_t role = xcd_swizzle_roles(bx, by, 2u);
     const RunConst &rc = rcp[by];               // one context per grid row (porrt_grow_batch)
+    nb = row_nb(rc, b, nb);
+    if (nb == 0) return;                        // (a row that has stopped, or does not run this step)
     if (role == 0) { insert_step_pages(rc, b, nb, vwords, lds_dyn); return; }    // the page-filing workgroup
     const uint32_t lane = threadIdx.x & 63u, si = threadIdx.x / GL;
     const uint32_t slot = bx * SPB + si;
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 template <int GL>
 __global__ __launch_bounds__(256) void k_commit2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
     const uint32_t k = (blockIdx.x * 256u + threadIdx.x) / GL;
-    if (k < nb) commit_rrt_sample(rcp[blockIdx.y], b, vwords, k, threadIdx.x % GL, GL);
+    if (k < nb && k < row_nb(rcp[blockIdx.y], b, nb)) commit_rrt_sample(rcp[blockIdx.y], b, vwords, k, threadIdx.x % GL, GL);
 }
 
 } // namespace porrt

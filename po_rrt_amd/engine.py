@@ -25,7 +25,7 @@ _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 SYMBOLS = [
     "porrt_create", "porrt_destroy", "porrt_last_error", "porrt_set_grid", "porrt_set_zones", "porrt_set_sampler",
     "porrt_set_discrete_seed", "porrt_set_samples", "porrt_set_worlds", "porrt_set_square_goal",
-    "porrt_set_observation_goal", "porrt_grow", "porrt_grow_batch", "porrt_grow_prm", "porrt_prm_plan_path", "porrt_num_nodes", "porrt_num_iterations", "porrt_get_tree", "porrt_get_trees",
+    "porrt_set_observation_goal", "porrt_grow", "porrt_grow_batch", "porrt_grow_batch_each", "porrt_grow_prm", "porrt_prm_plan_path", "porrt_num_nodes", "porrt_num_iterations", "porrt_get_tree", "porrt_get_trees",
     "porrt_num_final", "porrt_get_final_ids", "porrt_get_final_masks", "porrt_get_reach", "porrt_get_node_validity",
     "porrt_num_edges", "porrt_get_edges", "porrt_is_final_set_complete", "porrt_n_worlds", "porrt_get_validities",
     "porrt_get_zone_positions", "porrt_best_solution", "porrt_best_cost", "porrt_best_cost_batch", "porrt_get_metrics", "porrt_set_option", "porrt_selftest",
@@ -94,7 +94,8 @@ def load_library():
     sig("porrt_set_square_goal", C.c_int, vp, _f64p, _u64p, C.c_uint32, C.c_double)
     sig("porrt_set_observation_goal", C.c_int, vp, C.c_uint32)
     sig("porrt_grow", C.c_int, vp, _f64p, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int)
-    sig("porrt_grow_batch", C.c_int, C.POINTER(C.c_void_p), C.c_uint32, _f64p, C.c_double, C.c_double, C.c_uint64, C.c_uint32, C.c_int)
+    sig("porrt_grow_batch", C.c_int, C.POINTER(C.c_void_p), C.c_uint32, _f64p, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int)
+    sig("porrt_grow_batch_each", C.c_int, C.POINTER(C.c_void_p), C.c_uint32, _f64p, C.c_double, C.c_double, _u64p, _u64p, C.c_uint32, C.c_int)
     sig("porrt_num_nodes", C.c_uint64, vp)
     sig("porrt_num_iterations", C.c_uint64, vp)
     sig("porrt_get_tree", C.c_int, vp, _f64p, _i64p, _f64p)
@@ -247,19 +248,30 @@ class Engine:
                                             batch_K, mode))
 
     @staticmethod
-    def grow_batch(engines, starts, max_step, search_radius, n_iter, batch_K=1024, mode=MODE_RRT):
-        """porrt_grow_batch: the same fixed-budget growth for several contexts of one GPU in one launch sequence."""
+    def grow_batch(engines, starts, max_step, search_radius, n_iter_min, batch_K=1024, mode=MODE_RRT, n_iter_max=None):
+        """porrt_grow_batch / porrt_grow_batch_each: the same growth for several contexts of one GPU in one launch sequence, each
+        running the reference's loop `while i < n_iter_min || (no solution && i < n_iter_max)`.  n_iter_min / n_iter_max: one
+        number for all, or one per engine; n_iter_max = None: a fixed budget (= n_iter_min)."""
         engines = list(engines)
         arr = (C.c_void_p * len(engines))(*[e._c for e in engines])
         st = np.ascontiguousarray(np.asarray(starts, dtype=np.float64).reshape(len(engines), 2))
-        return engines[0]._chk(engines[0]._l.porrt_grow_batch(arr, len(engines), st.reshape(-1), max_step, search_radius,
-                                                               n_iter, batch_K, mode))
+        if n_iter_max is None:
+            n_iter_max = n_iter_min
+        if np.ndim(n_iter_min) == 0 and np.ndim(n_iter_max) == 0:
+            return engines[0]._chk(engines[0]._l.porrt_grow_batch(arr, len(engines), st.reshape(-1), max_step, search_radius,
+                                                                   int(n_iter_min), int(n_iter_max), batch_K, mode))
+        mn = np.ascontiguousarray(np.broadcast_to(np.asarray(n_iter_min, dtype=np.uint64), (len(engines),)))
+        mx = np.ascontiguousarray(np.broadcast_to(np.asarray(n_iter_max, dtype=np.uint64), (len(engines),)))
+        return engines[0]._chk(engines[0]._l.porrt_grow_batch_each(arr, len(engines), st.reshape(-1), max_step, search_radius, mn, mx, batch_K, mode))
 
     def num_nodes(self):
         return self._l.porrt_num_nodes(self._c)
 
     def num_iterations(self):
         return self._l.porrt_num_iterations(self._c)
+
+    def num_final(self):
+        return self._l.porrt_num_final(self._c)
 
     def tree(self):
         n = self.num_nodes()

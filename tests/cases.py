@@ -146,3 +146,22 @@ def cfg3_near(n_iter=1500, seed=0):
     c = cfg3(n_iter, n_iter, seed)
     c.update(name="cfg3_near", goals=[(0.68, -0.45), (0.5, -0.8)], start=(0.2, -0.6))
     return c
+
+
+def tamp_queries(n, seed0=0):
+    """Queries shaped like the TAMP search's (map_shelves_tamp_rrt.rs:224,232,355,367,492,500; main.rs:532): every search edge plans
+    twice -- to an ObservationGoal (see the shelf of a zone) and to a SquareGoal (pickup, L1 radius 0.05) -- with starts of their own,
+    max_step 0.1, search_radius 2, n_iter_min 2500, n_iter_max 10000, on the benchmark map with its six zones."""
+    z6 = [(-0.9, -0.5), (-0.9, 0.5), (-0.5, 0.9), (0.5, 0.9), (0.9, 0.5), (0.9, -0.5)]
+    starts = [(0.0, -1.0), (0.0, -0.8), (-0.3, -0.2), (0.3, 0.1), (-0.6, 0.3), (0.6, -0.4)]
+    out = []
+    for q in range(n):
+        c = cfg2(2500, seed=seed0 + q)
+        c.update(n_iter_max=10000, start=starts[(q // 2) % len(starts)], zones="map_benchmark_like_6_goals_zone_ids", visibility=0.5)
+        if q % 2 == 0:
+            c.update(name="tamp_obs", obs_zone=(q // 2) % 6, goals=None)
+        else:
+            gx, gy = z6[(q // 2) % 6]
+            c.update(name="tamp_pick", goals=[(0.92 * gx, 0.92 * gy)])
+        out.append(c)
+    return out

@@ -173,3 +173,64 @@ def test_sub_batches_on_an_odd_number_of_contexts(eng_mod):
             res.append([e.tree() + (e.final_ids(),) for e in engs])
         for a, b in zip(*res):
             assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+_tamp_cases = cases.tamp_queries
+
+
+@pytest.mark.parametrize("n,K", [(12, 256), (40, 1024), (9, 64)])
+def test_batch_with_loop_condition_equals_single_grows(eng_mod, n, K):
+    """porrt_grow_batch with n_iter_min < n_iter_max: every member runs the loop of rrt.rs:109 on its own and leaves the later launches
+    when it ends -- trees, iteration counts and sampler states equal those of separate porrt_grow calls (and the oracle's); members
+    end at different steps"""
+    cs = _tamp_cases(n)
+    engs = [cases.configure(eng_mod.Engine(), c) for c in cs]
+    eng_mod.Engine.grow_batch(engs, [c.start for c in cs], cs[0].max_step, cs[0].search_radius, 2500, K, n_iter_max=10000)
+    its = []
+    for c, e in zip(cs, engs):
+        s, _ = run_gpu(eng_mod, c, K)
+        assert_same(e, s)
+        its.append(e.num_iterations())
+    if K >= 256:             # (with small steps every query of this set is solved by n_iter_min)
+        assert len(set(its)) > 1, "the members are meant to end at different steps: %s" % its
+    assert min(its) >= 2500 and max(its) <= 10000
+    for c, e in list(zip(cs, engs))[:4]:
+        o, _ = run_orc(c, K)
+        assert_same(e, o)
+    # the samplers moved on by what each member consumed: a second batch equals second single grows
+    single = [run_gpu(eng_mod, c, K)[0] for c in cs[:3]]
+    for c, s in zip(cs[:3], single):
+        cases.grow(s, c, K=K)
+    eng_mod.Engine.grow_batch(engs[:3], [c.start for c in cs[:3]], cs[0].max_step, cs[0].search_radius, 2500, K, n_iter_max=10000)
+    for e, s in zip(engs[:3], single):
+        assert_same(e, s)
+
+
+def test_batch_each_with_budgets_of_their_own(eng_mod):
+    """porrt_grow_batch_each: per-member n_iter_min / n_iter_max, fixed and open budgets mixed (the partial step at n_iter_min falls
+    at different steps), K = 512; and a PTO batch whose members stop when their final sets are complete (pto.rs:67)"""
+    cs = _tamp_cases(10, seed0=50)
+    mn = [600, 2500, 1000, 3000, 512, 2500, 700, 1536, 2500, 4000]
+    mx = [600, 10000, 6000, 3000, 9000, 2500, 5000, 8000, 2501, 4100]
+    engs = [cases.configure(eng_mod.Engine(), c) for c in cs]
+    eng_mod.Engine.grow_batch(engs, [c.start for c in cs], cs[0].max_step, cs[0].search_radius, mn, 512, n_iter_max=mx)
+    for c, e, a, b in zip(cs, engs, mn, mx):
+        c2 = cases.Case(c, n_iter_min=a, n_iter_max=b)
+        s, _ = run_gpu(eng_mod, c2, 512)
+        assert_same(e, s)
+        o, _ = run_orc(c2, 512)
+        assert_same(e, o)
+    ps = [cases.cfg3(1000 + 300 * s, 30000, seed=s) for s in range(5)] + [cases.cfg3(2000, 2000, seed=9)]
+    pengs = [cases.configure(eng_mod.Engine(), c) for c in ps]
+    rc = eng_mod.Engine.grow_batch(pengs, [c.start for c in ps], ps[0].max_step, ps[0].search_radius, [c.n_iter_min for c in ps], 128, mode=cases.PTO,
+                                   n_iter_max=[c.n_iter_max for c in ps])
+    worst = 0
+    for c, e in zip(ps, pengs):
+        o, rco = run_orc(c, 128)
+        worst = max(worst, rco)
+        assert_same(e, o, pto=True)
+        s, _ = run_gpu(eng_mod, c, 128)           # ... and the discrete sampler stands where a single grow leaves it
+        cases.grow(s, c, K=128)
+        cases.grow(e, c, K=128)
+        assert_same(e, s, pto=True)
+    assert rc == worst
