@@ -8,7 +8,8 @@ reference's raster is a Git-LFS pointer), all Q advanced together by porrt_grow_
 grid row per query: their dependent-load chains overlap inside every kernel).  A single query is latency bound
 (8 ms); the TAMP caller issues thousands of independent ones, so throughput is what a GPU is for here.  The
 single-query figure is measured too and reported in `config.single_query`.  Inputs (grid, tables) are resident in
-HBM before the timed region; the trees stay on the device (results are downloaded lazily).
+HBM before the timed region.  `value` counts the device-to-host copy of every tree: a step's trees are fetched while
+the next step grows on a second set of contexts; `value_trees_on_device` is the same loop with the trees left on the GPU.
 
   python bench.py --gpus N --steps K --warmup W
 For N > 1 there is one rank per GPU.  Under a launcher (torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
@@ -162,17 +163,20 @@ def main():
     # N = 1: every query plans on the map_benchmark stand-in (configs[1], the configuration the metric is quoted on).
     # N > 1 (configs[4]): the queries of a rank are spread over the nine maps map_benchmark_like_{a..i}; same tree size,
     # same parameters, so the work per GPU stays what it is at N = 1 (weak scaling); the exchange picks a winner per map.
+    # Two sets of Q contexts: while one set grows, the trees of the other (the step before) are fetched to the host -- SURVEY 8(d)
+    # counts the D2H copy of every tree, and a planner that wants every tree would overlap it the same way.
     if world > 1:
         n_maps = 9
         map_ids = [j % n_maps for j in range(Q)]
-        engs = [cases.configure(po_rrt_amd.Engine(local_rank), cases.cfg2(args.n_iter, grid="map_benchmark_like_%s" % "abcdefghi"[m])) for m in map_ids]
+        sets = [[cases.configure(po_rrt_amd.Engine(local_rank), cases.cfg2(args.n_iter, grid="map_benchmark_like_%s" % "abcdefghi"[m])) for m in map_ids] for _ in range(2)]
     else:
         n_maps, map_ids = 1, [0] * Q
-        engs = [cases.configure(po_rrt_amd.Engine(local_rank), case) for _ in range(Q)]
+        sets = [[cases.configure(po_rrt_amd.Engine(local_rank), case) for _ in range(Q)] for _ in range(2)]
+    engs = sets[0]
     eng = engs[0]
     from po_rrt_amd import sharding
     comm = sharding.make_comm(local_rank, dist if world > 1 else None)      # RCCL communicator of the job's one exchange (outside the timed region)
-    for e in engs:
+    for e in sets[0] + sets[1]:
         e.set_option("profile", 0)
         for ov in args.opt:
             e.set_option(ov.split("=")[0], int(ov.split("=")[1]))
@@ -186,23 +190,69 @@ def main():
     G = min(G if G else (2 if Q >= 32 else 1), Q)
     Q_launch = Q // G
 
-    def run_step(s):
+    def run_step(s, which=0):
         """one step = Q queries; query ids (= RNG seeds) are unique over steps, ranks and slots"""
-        for j, e in enumerate(engs):
+        for j, e in enumerate(sets[which]):
             e.set_sampler((-1.0, -1.0), (1.0, 1.0), (s * world + rank) * Q + j)
-        po_rrt_amd.Engine.grow_batch(engs, starts, case.max_step, case.search_radius, case.n_iter_min, args.batch)
-        return sum(e.num_nodes() - 1 for e in engs)
+        po_rrt_amd.Engine.grow_batch(sets[which], starts, case.max_step, case.search_radius, case.n_iter_min, args.batch)
+        return sum(e.num_nodes() - 1 for e in sets[which])
+
+    # the caller's arrays for the trees are made once and reused, as a planner fetching trees query after query would (mapping
+    # 410 MB of fresh pages costs three times the copies)
+    cap = args.n_iter + 2
+    bufs = [(np.zeros((cap, 2)), np.zeros(cap, dtype=np.int64), np.zeros(cap)) for _ in range(Q)]
+    import threading
+
+    class Fetch(threading.Thread):
+        """porrt_get_trees of one set (eight worker threads inside, pinned staging, copy streams of their own) beside the next step"""
+        def __init__(self, which):
+            super().__init__()
+            self.which, self.err, self.seconds = which, None, 0.0
+
+        def run(self):
+            try:
+                t1 = time.perf_counter()
+                po_rrt_amd.Engine.trees(sets[self.which], bufs)
+                self.seconds = time.perf_counter() - t1
+            except Exception as ex:          # noqa: BLE001
+                self.err = ex
+
+    def timed_steps(first_seed, with_download):
+        nodes, pending, dl_s = 0, None, 0.0
+        for s in range(args.steps):
+            which = s % 2
+            nodes += run_step(first_seed + s, which)
+            if with_download:
+                if pending is not None:
+                    pending.join()
+                    dl_s += pending.seconds
+                    if pending.err:
+                        raise pending.err
+                pending = Fetch(which)
+                pending.start()
+        if pending is not None:
+            pending.join()
+            dl_s += pending.seconds
+            if pending.err:
+                raise pending.err
+        return nodes, dl_s
 
     for w in range(args.warmup):
-        run_step(10_000 + w)
+        run_step(10_000 + w, w % 2)
+    if args.warmup < 2:                       # both sets must have run once (buffers, streams, graphs), and the staging of the fetch exist
+        run_step(20_000, 1 if args.warmup == 1 else 0)
+        if args.warmup == 0:
+            run_step(20_001, 1)
+    po_rrt_amd.Engine.trees(sets[0], bufs)
+    po_rrt_amd.Engine.trees(sets[1], bufs)
 
     agg = dict(nodes=0, device_s=0.0, setup_s=0.0)
     barrier()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        agg["nodes"] += run_step(s)
-        agg["device_s"] += eng.metrics()["device_s"]
+    agg["nodes"], t_download_total = timed_steps(0, True)
     t_loop = time.perf_counter() - t0
+    engs = sets[(args.steps - 1) % 2]        # the set of the last step: its trees are what the exchange looks at
+    eng = engs[0]
     # the one exchange of the job (porrt_exchange_best, behind the C ABI): per map, who holds the best tree?  Path costs are
     # evaluated on the device, 16 bytes per map and rank are all-gathered, the winning trees are broadcast device to device
     # (RCCL) and stay on the device; one of them -- the best of all maps -- is fetched to the host here.
@@ -215,31 +265,25 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
+    # the same steps with the trees left on the device (a caller that only downloads the winner): the second figure of the line
+    barrier()
+    t1 = time.perf_counter()
+    nodes_dev, _ = timed_steps(50_000, False)
+    barrier()
+    elapsed_dev = time.perf_counter() - t1
+
     # max over ranks of the timed region, sum over ranks of the work
     if world > 1:
-        t_el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t_el = torch.tensor([elapsed, elapsed_dev], dtype=torch.float64, device="cuda")
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
-        elapsed = float(t_el.item())
-        t_nodes = torch.tensor([float(agg["nodes"])], dtype=torch.float64, device="cuda")
+        elapsed, elapsed_dev = float(t_el[0].item()), float(t_el[1].item())
+        t_nodes = torch.tensor([float(agg["nodes"]), float(nodes_dev)], dtype=torch.float64, device="cuda")
         dist.all_reduce(t_nodes, op=dist.ReduceOp.SUM)
-        total_nodes = float(t_nodes.item())
+        total_nodes, total_nodes_dev = float(t_nodes[0].item()), float(t_nodes[1].item())
     else:
-        total_nodes = float(agg["nodes"])
-
-    # SURVEY 8(d) counts the D2H copy of every tree; the headline keeps the trees on the device (a caller downloads the
-    # winner).  Measured here: all Q trees of the last step fetched (coordinates, parents, dist_root), per step.
-    # (the caller's arrays are made once and reused, as a planner fetching trees query after query would: mapping 410 MB of
-    # fresh pages costs three times the copies)
-    cap = args.n_iter + 2
-    bufs = [(np.zeros((cap, 2)), np.zeros(cap, dtype=np.int64), np.zeros(cap)) for _ in engs]
-    po_rrt_amd.Engine.trees(engs, bufs)        # first call: pinned staging and copy streams are made, the pages touched
-    t1 = time.perf_counter()
-    po_rrt_amd.Engine.trees(engs, bufs)        # porrt_get_trees: eight worker threads, pinned staging, copies and layout overlapped
-    t_download_step = time.perf_counter() - t1
-    if world > 1:
-        t_dl = torch.tensor([t_download_step], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t_dl, op=dist.ReduceOp.MAX)
-        t_download_step = float(t_dl.item())
+        total_nodes, total_nodes_dev = float(agg["nodes"]), float(nodes_dev)
+    engs = sets[0]
+    eng = engs[0]
 
     # latency mode for reference: the same query alone (porrt_grow, one context), outside the timed region
     single = None
@@ -283,7 +327,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "value_with_tree_download": total_nodes / (elapsed + args.steps * t_download_step),
+            "value_trees_on_device": total_nodes_dev / elapsed_dev,
+            "value_note": "value counts the device-to-host copy of EVERY tree (SURVEY 8d): the %d trees of a step are fetched (porrt_get_trees, %.1f ms per "
+                          "step on average) while the next step grows on a second set of contexts, and the last fetch is inside the timed region; "
+                          "value_trees_on_device is the same loop with the trees left on the GPU (only the exchange's winner is fetched)"
+                          % (Q, 1e3 * t_download_total / max(args.steps, 1)),
             "single_query": single,
             "config": {
                 "workload": "map_benchmark-like 200x200 synthetic map (reference raster is a Git-LFS pointer), 2D RRT* "
@@ -617,7 +665,7 @@ def cpu_baseline(case, args):
     import cases
     from oracle import orc
     orc.build()
-    reps, times, nodes = 3, [], 0
+    reps, times, nodes = 5, [], 0
     for r in range(reps):
         o = cases.configure(orc.Oracle(), cases.Case(case, seed=r))
         t0 = time.perf_counter()
