@@ -137,8 +137,9 @@ int      porrt_get_final_masks(const porrt_ctx *ctx, uint64_t *masks);
  * them (kd pre-order, nearest_neighbor.rs:101-117) -- so that adjacency lists rebuilt from it
  * equal the reference's element for element.  The reference also stores each reverse edge with
  * the same validity id (pto.rs:117-120).  The order is restored on the device when the edges are
- * first asked for (three sorts by the nodes' kd pre-order ranks, which the host supplies from a
- * kd-tree over the node coordinates); the growth itself does not need it. */
+ * first asked for (the edges are dealt into one bucket per node and each bucket is ordered by one
+ * wave, by the nodes' kd pre-order ranks, which the host supplies from a kd-tree over the node
+ * coordinates); the growth itself does not need it. */
 int      porrt_get_reach(const porrt_ctx *ctx, uint64_t *masks /* N */);
 int      porrt_get_node_validity(const porrt_ctx *ctx, uint32_t *validity_ids /* N */);
 uint64_t porrt_num_edges(const porrt_ctx *ctx);

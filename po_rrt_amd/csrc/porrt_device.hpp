@@ -261,6 +261,7 @@ struct RunConst {
     // at which the loop condition ends the row.  Null: every row runs the launch's (i0, nb).
     uint32_t *sched_i0, *sched_nb;
     uint32_t sched_min, sched_max, sched_K, sched_steps;
+    uint32_t sched_max_nodes, pad_;     // nodes this grow may create (n_iter_max + 2): what its preparation clears
 };
 
 // Pointers read out of RunConst have no known address space, so hipcc emits flat_* accesses and drains both
@@ -551,6 +552,7 @@ constexpr int kRepLevels = 3;
 __device__ __forceinline__ int rep_dim(int l) { return l == 0 ? 256 : (l == 1 ? 32 : 4); }
 __device__ __forceinline__ int rep_off(int l) { return l == 0 ? 0 : (l == 1 ? 65536 : 65536 + 1024); }
 constexpr int kRepTotal = 65536 + 1024 + 16;
+constexpr uint32_t kRepCoarseUntil = 32768;     // nodes with lower ids are entered into the coarse levels too
 
 __device__ __forceinline__ void rep_cell(const RunConst &rc, double x, double y, int G, int &cx, int &cy) {
     double fx = (x - rc.bx0) * rc.binv_w * (double)G, fy = (y - rc.by0) * rc.binv_h * (double)G;
@@ -1547,14 +1549,18 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
         auto g_nx = as_global(rc.nx), g_ny = as_global(rc.ny), g_dA = as_global(rc.distA);
         g_nx[id] = px;
         g_ny[id] = py;
+        // the pyramid only ever bounds a search (any node named by a cell will do): its coarse levels are complete long before the
+        // tree is, so only a young tree's nodes are entered there -- two scattered stores fewer per node
+        g_rep[rep_at[0]] = (int)id;
+        if (id < kRepCoarseUntil) {
 #pragma unroll
-        for (int l = 0; l < kRepLevels; ++l) g_rep[rep_at[l]] = (int)id;
+            for (int l = 1; l < kRepLevels; ++l) g_rep[rep_at[l]] = (int)id;
+        }
         g_par[id] = deferred ? kParentPending : best;
         g_dA[id] = dnew;
         g_dB[id] = dnew;
-        g_ff[id] = fin ? 1 : 0;
-        g_fm[id] = fin ? fmask : 0ull;
-        if (fin) atomicAdd(&rc.cnt->n_final, 1u);
+        // final_flag is cleared when a grow starts (RRT*); the mask is only ever read where the flag is set
+        if (fin) { g_ff[id] = 1; g_fm[id] = fmask; atomicAdd(&rc.cnt->n_final, 1u); }
     }
     if (n_clone) {
         if (goal_kind == 2) {                                            // the team's first lane made that test
@@ -1569,9 +1575,11 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
             as_global(rc.parent)[ic] = deferred ? kParentPending : best;
             as_global(rc.distA)[ic] = dnew;
             as_global(rc.distB)[ic] = dnew;
-            as_global(rc.final_flag)[ic] = fin ? 1 : 0;
-            as_global(rc.final_mask)[ic] = fin ? (goal_kind == 2 ? 1ull : fmask) : 0ull;
-            if (fin) atomicAdd(&rc.cnt->n_final, 1u);
+            if (fin) {
+                as_global(rc.final_flag)[ic] = 1;
+                as_global(rc.final_mask)[ic] = goal_kind == 2 ? 1ull : fmask;
+                atomicAdd(&rc.cnt->n_final, 1u);
+            }
         }
     }
     PORRT_TACC_B(rc, 6);

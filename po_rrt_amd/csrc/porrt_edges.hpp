@@ -7,12 +7,12 @@
 //     [neighbours at its creation, in kd pre-order]  ++  [later nodes that found X, in id order],
 // and everything downstream (porrt_get_edges, the belief graph's lists, extract_path) inherits that order.
 // The pre-order rank of every node comes from the host (a kd-tree of the coordinates built in id order: sequential
-// pointer chasing, 2 ms for 18k nodes); the edges never leave the device: three radix sorts (rocPRIM through hipCUB)
-// by (new node, rank of neighbour), (neighbour, new node) and (node, other end), counts and scans for the offsets.
+// pointer chasing, 2 ms for 18k nodes); the edges never leave the device: they are dealt into one bucket per node (degree counts,
+// a scan, a scatter) and every bucket -- a node's neighbours, a few hundred at most -- is ordered by one wave (k_eo_segsort: each
+// element counts the keys below its own): by the pre-order rank of the neighbour, by the neighbour's id, and the later nodes
+// that found the node by their id.
 #pragma once
 #include "porrt_belief.hpp"
-
-#include <hipcub/hipcub.hpp>
 
 namespace porrt {
 
@@ -58,22 +58,61 @@ static int eo_alloc(EdgeOrderState &st, T *&p, size_t n, std::string &err) {
     return PORRT_OK;
 }
 
-// keys of the three orders; `which`: 0 = (to, rank[from]) per edge, 1 = (from, to) per edge, 2 = (node, other end) per direction
-__global__ __launch_bounds__(256) void k_eo_keys(const uint32_t *__restrict__ from, const uint32_t *__restrict__ to, const uint32_t *__restrict__ rank,
-                                                 size_t E, unsigned long long *__restrict__ k0, unsigned long long *__restrict__ k1,
-                                                 unsigned long long *__restrict__ k2, uint32_t *__restrict__ idx, uint32_t *__restrict__ idx2,
-                                                 uint32_t *__restrict__ deg_to, uint32_t *__restrict__ deg_from) {
+// Edges into buckets: bucket of node t (its creation neighbours: edges f -> t) and bucket of node f (the later nodes that found f),
+// in arrival order -- with the keys the segment sorts below order them by.  Bucket offsets are the scanned degrees.
+__global__ __launch_bounds__(256) void k_eo_degrees(const uint32_t *__restrict__ from, const uint32_t *__restrict__ to, size_t E, uint32_t *__restrict__ deg_to,
+                                                    uint32_t *__restrict__ deg_from) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    atomicAdd(&deg_to[as_global(to)[e]], 1u);
+    atomicAdd(&deg_from[as_global(from)[e]], 1u);
+}
+__global__ __launch_bounds__(256) void k_eo_scatter(const uint32_t *__restrict__ from, const uint32_t *__restrict__ to, const uint32_t *__restrict__ rank, size_t E,
+                                                    const unsigned long long *__restrict__ off_to, const unsigned long long *__restrict__ off_from,
+                                                    uint32_t *__restrict__ cur_to, uint32_t *__restrict__ cur_from, uint32_t *__restrict__ bt_e,
+                                                    uint32_t *__restrict__ bt_rank, uint32_t *__restrict__ bt_from, uint32_t *__restrict__ bf_e,
+                                                    uint32_t *__restrict__ bf_to) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     const uint32_t f = as_global(from)[e], t = as_global(to)[e];
-    k0[e] = ((unsigned long long)t << 32) | as_global(rank)[f];
-    k1[e] = ((unsigned long long)f << 32) | t;
-    k2[2 * e] = ((unsigned long long)t << 32) | f;               // t's neighbour f
-    k2[2 * e + 1] = ((unsigned long long)f << 32) | t;           // f's neighbour t
-    idx[e] = (uint32_t)e;
-    idx2[2 * e] = (uint32_t)e; idx2[2 * e + 1] = (uint32_t)e;
-    atomicAdd(&deg_to[t], 1u);
-    atomicAdd(&deg_from[f], 1u);
+    const unsigned long long p = off_to[t] + atomicAdd(&cur_to[t], 1u), q = off_from[f] + atomicAdd(&cur_from[f], 1u);
+    bt_e[p] = (uint32_t)e; bt_rank[p] = as_global(rank)[f]; bt_from[p] = f;
+    bf_e[q] = (uint32_t)e; bf_to[q] = t;
+}
+
+// One wave per node: its bucket [off[x], off[x + 1]) ordered by key (keys are distinct inside a bucket: an edge f -> t exists once,
+// and ranks are a permutation) -- every element counts the keys below its own, which is its place.  A node has at most a few
+// hundred neighbours (the radius search's hits); buckets of up to kSegLds entries are staged in LDS, longer ones (the dense
+// start of a belief-space graph) are counted against the keys in memory.
+constexpr uint32_t kSegLds = 512;
+__global__ __launch_bounds__(256) void k_eo_segsort(const unsigned long long *__restrict__ off, const uint32_t *__restrict__ key, const uint32_t *__restrict__ val,
+                                                    uint32_t N, uint32_t *__restrict__ out) {
+    __shared__ uint32_t s_key[4][kSegLds];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t x = blockIdx.x * 4u + wv;
+    if (x >= N) return;
+    const unsigned long long a = off[x];
+    const uint32_t L = (uint32_t)(off[x + 1] - a);
+    if (L == 0) return;
+    auto gk = as_global(key) + a;
+    auto gv = as_global(val) + a;
+    if (L <= kSegLds) {
+        for (uint32_t i = lane; i < L; i += 64u) s_key[wv][i] = gk[i];
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < L; i += 64u) {
+            const uint32_t ki = s_key[wv][i];
+            uint32_t below = 0;
+            for (uint32_t j = 0; j < L; ++j) below += s_key[wv][j] < ki ? 1u : 0u;       // (all lanes read one word: a broadcast)
+            out[a + below] = gv[i];
+        }
+    } else {
+        for (uint32_t i = lane; i < L; i += 64u) {
+            const uint32_t ki = gk[i];
+            uint32_t below = 0;
+            for (uint32_t j = 0; j < L; ++j) below += gk[j] < ki ? 1u : 0u;
+            out[a + below] = gv[i];
+        }
+    }
 }
 
 // ordered forward edge list from sort 0
@@ -86,10 +125,10 @@ __global__ __launch_bounds__(256) void k_eo_gather(const uint32_t *__restrict__ 
     ofrom[k] = as_global(from)[e]; oto[k] = as_global(to)[e]; oval[k] = as_global(val)[e];
 }
 
-// adjacency of node x: [creation neighbours: sort 0's run of x] ++ [later nodes: sort 1's run of x]; radj: sort 2's run
+// adjacency of node x: [creation neighbours in kd pre-order: ord0's run of x] ++ [later nodes ascending: ord1's run of x];
+// radj (by ascending neighbour id): [creation neighbours by id: ordf's run of x -- all older than x] ++ [later nodes: ord1's run]
 __global__ __launch_bounds__(256) void k_eo_adjacency(const uint32_t *__restrict__ from, const uint32_t *__restrict__ to, const uint32_t *__restrict__ val,
-                                                      const uint32_t *__restrict__ ord0, const uint32_t *__restrict__ ord1,
-                                                      const unsigned long long *__restrict__ key2, const uint32_t *__restrict__ ord2,
+                                                      const uint32_t *__restrict__ ord0, const uint32_t *__restrict__ ord1, const uint32_t *__restrict__ ordf,
                                                       const unsigned long long *__restrict__ off_to, const unsigned long long *__restrict__ off_from,
                                                       uint32_t N, unsigned long long *__restrict__ adj_off, uint32_t *__restrict__ adj_id,
                                                       uint8_t *__restrict__ adj_val, uint32_t *__restrict__ radj_id, uint8_t *__restrict__ radj_val) {
@@ -100,11 +139,15 @@ __global__ __launch_bounds__(256) void k_eo_adjacency(const uint32_t *__restrict
     const unsigned long long base = a + c;                       // both offset arrays are prefix sums over the same node order
     adj_off[x] = base;
     unsigned long long w = base;
-    for (unsigned long long k = a; k < b; ++k, ++w) { const uint32_t e = ord0[k]; adj_id[w] = from[e]; adj_val[w] = (uint8_t)val[e]; }
-    for (unsigned long long k = c; k < d; ++k, ++w) { const uint32_t e = ord1[k]; adj_id[w] = to[e]; adj_val[w] = (uint8_t)val[e]; }
-    for (unsigned long long k = base; k < base + (b - a) + (d - c); ++k) {       // sort 2 is grouped by node in the same order
-        radj_id[k] = (uint32_t)(key2[k] & 0xFFFFFFFFull);
-        radj_val[k] = (uint8_t)val[ord2[k]];
+    for (unsigned long long k = a; k < b; ++k, ++w) {
+        const uint32_t e = ord0[k], e2 = ordf[k];
+        adj_id[w] = from[e]; adj_val[w] = (uint8_t)val[e];
+        radj_id[w] = from[e2]; radj_val[w] = (uint8_t)val[e2];
+    }
+    for (unsigned long long k = c; k < d; ++k, ++w) {
+        const uint32_t e = ord1[k];
+        adj_id[w] = to[e]; adj_val[w] = (uint8_t)val[e];
+        radj_id[w] = to[e]; radj_val[w] = (uint8_t)val[e];
     }
 }
 
@@ -115,44 +158,39 @@ static int edge_order_build(EdgeOrderState &st, uint64_t tag, size_t N, size_t E
     st.next_slot = 0;
     st.tag = ~0ull;
     st.N = N; st.E = E;
-    uint32_t *rank, *idx, *idx_out, *idx2, *idx2_out, *deg_to, *deg_from, *ord1;
-    unsigned long long *k0, *k0o, *k1, *k1o, *k2, *k2o, *off_to, *off_from, *tot;
+    uint32_t *rank, *deg_to, *deg_from, *cur_to, *cur_from, *bt_e, *bt_rank, *bt_from, *bf_e, *bf_to, *ord0, *ord1, *ordf;
+    unsigned long long *off_to, *off_from, *tot;
     int r;
     const size_t nblk = (N + 1 + kScanTile - 1) / kScanTile;
     if ((r = eo_alloc(st, st.d_from, E, err)) || (r = eo_alloc(st, st.d_to, E, err)) || (r = eo_alloc(st, st.d_val, E, err)) ||
         (r = eo_alloc(st, st.d_adj_off, N + 1, err)) || (r = eo_alloc(st, st.d_adj_id, 2 * E, err)) || (r = eo_alloc(st, st.d_radj_id, 2 * E, err)) ||
         (r = eo_alloc(st, st.d_adj_val, 2 * E, err)) || (r = eo_alloc(st, st.d_radj_val, 2 * E, err)) ||
-        (r = eo_alloc(st, rank, N, err)) || (r = eo_alloc(st, idx, E, err)) || (r = eo_alloc(st, idx_out, E, err)) || (r = eo_alloc(st, ord1, E, err)) ||
-        (r = eo_alloc(st, idx2, 2 * E, err)) || (r = eo_alloc(st, idx2_out, 2 * E, err)) || (r = eo_alloc(st, deg_to, N + 1, err)) ||
-        (r = eo_alloc(st, deg_from, N + 1, err)) || (r = eo_alloc(st, k0, E, err)) || (r = eo_alloc(st, k0o, E, err)) || (r = eo_alloc(st, k1, E, err)) ||
-        (r = eo_alloc(st, k1o, E, err)) || (r = eo_alloc(st, k2, 2 * E, err)) || (r = eo_alloc(st, k2o, 2 * E, err)) ||
+        (r = eo_alloc(st, rank, N, err)) || (r = eo_alloc(st, deg_to, N + 1, err)) || (r = eo_alloc(st, deg_from, N + 1, err)) ||
+        (r = eo_alloc(st, cur_to, N + 1, err)) || (r = eo_alloc(st, cur_from, N + 1, err)) ||
+        (r = eo_alloc(st, bt_e, E, err)) || (r = eo_alloc(st, bt_rank, E, err)) || (r = eo_alloc(st, bt_from, E, err)) || (r = eo_alloc(st, bf_e, E, err)) ||
+        (r = eo_alloc(st, bf_to, E, err)) || (r = eo_alloc(st, ord0, E, err)) || (r = eo_alloc(st, ord1, E, err)) || (r = eo_alloc(st, ordf, E, err)) ||
         (r = eo_alloc(st, off_to, N + 2, err)) || (r = eo_alloc(st, off_from, N + 2, err)) || (r = eo_alloc(st, tot, nblk + 2, err)))
         return r;
     EO_HIP(hipMemcpyAsync(rank, h_rank.data(), N * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     EO_HIP(hipMemsetAsync(deg_to, 0, (N + 1) * sizeof(uint32_t), s));
     EO_HIP(hipMemsetAsync(deg_from, 0, (N + 1) * sizeof(uint32_t), s));
+    EO_HIP(hipMemsetAsync(cur_to, 0, (N + 1) * sizeof(uint32_t), s));
+    EO_HIP(hipMemsetAsync(cur_from, 0, (N + 1) * sizeof(uint32_t), s));
     const dim3 block(256), egrid((unsigned)((std::max<size_t>(E, 1) + 255) / 256));
-    if (E) hipLaunchKernelGGL(k_eo_keys, egrid, block, 0, s, d_from, d_to, (const uint32_t *)rank, E, k0, k1, k2, idx, idx2, deg_to, deg_from);
+    if (E) hipLaunchKernelGGL(k_eo_degrees, egrid, block, 0, s, d_from, d_to, E, deg_to, deg_from);
     bg_scan(deg_to, N + 1, tot, off_to, s);                       // off[x] = edges whose new node (neighbour) is below x; off[N] = E
     bg_scan(deg_from, N + 1, tot, off_from, s);
     if (E) {
-        size_t tmp_bytes = 0, tb = 0;
-        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k2, k2o, idx2, idx2_out, (int)(2 * E), 0, 64, s);
-        tmp_bytes = tb;
-        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k0, k0o, idx, idx_out, (int)E, 0, 64, s);
-        tmp_bytes = std::max(tmp_bytes, tb);
-        unsigned char *tmp = nullptr;
-        if ((r = eo_alloc(st, tmp, tmp_bytes, err))) return r;
-        tb = tmp_bytes;
-        EO_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, k0, k0o, idx, idx_out, (int)E, 0, 64, s));
-        tb = tmp_bytes;
-        EO_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, k1, k1o, idx, ord1, (int)E, 0, 64, s));
-        tb = tmp_bytes;
-        EO_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, k2, k2o, idx2, idx2_out, (int)(2 * E), 0, 64, s));
-        hipLaunchKernelGGL(k_eo_gather, egrid, block, 0, s, d_from, d_to, d_val, (const uint32_t *)idx_out, E, st.d_from, st.d_to, st.d_val);
+        hipLaunchKernelGGL(k_eo_scatter, egrid, block, 0, s, d_from, d_to, (const uint32_t *)rank, E, (const unsigned long long *)off_to,
+                           (const unsigned long long *)off_from, cur_to, cur_from, bt_e, bt_rank, bt_from, bf_e, bf_to);
+        const dim3 ngrid((unsigned)((N + 3) / 4));
+        hipLaunchKernelGGL(k_eo_segsort, ngrid, block, 0, s, (const unsigned long long *)off_to, (const uint32_t *)bt_rank, (const uint32_t *)bt_e, (uint32_t)N, ord0);
+        hipLaunchKernelGGL(k_eo_segsort, ngrid, block, 0, s, (const unsigned long long *)off_to, (const uint32_t *)bt_from, (const uint32_t *)bt_e, (uint32_t)N, ordf);
+        hipLaunchKernelGGL(k_eo_segsort, ngrid, block, 0, s, (const unsigned long long *)off_from, (const uint32_t *)bf_to, (const uint32_t *)bf_e, (uint32_t)N, ord1);
+        hipLaunchKernelGGL(k_eo_gather, egrid, block, 0, s, d_from, d_to, d_val, (const uint32_t *)ord0, E, st.d_from, st.d_to, st.d_val);
     }
-    hipLaunchKernelGGL(k_eo_adjacency, dim3((unsigned)((N + 1 + 255) / 256)), block, 0, s, d_from, d_to, d_val, (const uint32_t *)idx_out,
-                       (const uint32_t *)ord1, (const unsigned long long *)k2o, (const uint32_t *)idx2_out, (const unsigned long long *)off_to,
+    hipLaunchKernelGGL(k_eo_adjacency, dim3((unsigned)((N + 1 + 255) / 256)), block, 0, s, d_from, d_to, d_val, (const uint32_t *)ord0,
+                       (const uint32_t *)ord1, (const uint32_t *)ordf, (const unsigned long long *)off_to,
                        (const unsigned long long *)off_from, (uint32_t)N, st.d_adj_off, st.d_adj_id, st.d_adj_val, st.d_radj_id, st.d_radj_val);
     EO_HIP(hipStreamSynchronize(s));
     EO_HIP(hipGetLastError());

@@ -498,6 +498,11 @@ __global__ __launch_bounds__(256) void k_batch_prep(const RunConst *__restrict__
         for (unsigned long long i = 4ull * n4 + tid; i < rc.zero_words; i += nth) rc.zero0[i] = 0u;
     }
     for (unsigned long long i = tid; i < (unsigned long long)kRepTotal; i += nth) rc.rep[i] = -1;
+    {   // final flags of the nodes this grow may create (connect_rrt_sample only writes the set ones)
+        unsigned long long *f8 = reinterpret_cast<unsigned long long *>(rc.final_flag);
+        const unsigned long long n8 = ((unsigned long long)rc.sched_max_nodes + 7ull) / 8ull;
+        for (unsigned long long i = tid; i < n8; i += nth) f8[i] = 0ull;
+    }
     if (blockIdx.x == 1u || gridDim.x == 1u) {          // the context's own copy of its run constants (porrt_best_cost and the like)
         static_assert(sizeof(RunConst) % 8 == 0, "RunConst is copied in 8-byte words");
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&rc);
@@ -784,7 +789,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         double t0 = now_s();
         HIPCHK(d_nx.reserve(Nmax)); HIPCHK(d_ny.reserve(Nmax)); HIPCHK(d_distA.reserve(Nmax)); HIPCHK(d_distB.reserve(Nmax));
         HIPCHK(d_parent.reserve(Nmax)); HIPCHK(d_reachA.reserve(Nmax)); HIPCHK(d_reachB.reserve(Nmax));
-        HIPCHK(d_vid.reserve(Nmax)); HIPCHK(d_finalflag.reserve(Nmax)); HIPCHK(d_finalmask.reserve(Nmax));
+        HIPCHK(d_vid.reserve(Nmax)); HIPCHK(d_finalflag.reserve(Nmax + 8)); HIPCHK(d_finalmask.reserve(Nmax));
         HIPCHK(d_nat.reserve(steps_max + 2)); HIPCHK(d_validmask.reserve((steps_max + 2) * vwords));
         HIPCHK(d_sx.reserve(n_iter_max + 1)); HIPCHK(d_sy.reserve(n_iter_max + 1)); HIPCHK(d_sworld.reserve(n_iter_max + 1));
         HIPCHK(d_qx.reserve(2 * Kpad)); HIPCHK(d_qy.reserve(2 * Kpad)); HIPCHK(d_qnn.reserve(2 * Kpad)); HIPCHK(d_qvid.reserve(2 * Kpad));      // two halves: pipelined steps (q_stride)
@@ -867,6 +872,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.s_low0 = s_low[0]; c.s_low1 = s_low[1]; c.s_up0 = s_up[0]; c.s_up1 = s_up[1];
     c.max_step = max_step; c.mode = mode;
     c.part_stride = Kpad;
+    c.sched_max_nodes = (uint32_t)Nmax;
     // pipelined steps only with the one-wave-per-sample kernels (the group kernels keep q_* in one half); a batch member's
     // row is set by the leader, who knows which kernels will run
     pipe_on = stage != 1 && mode == PORRT_MODE_RRT && opt_pipeline != 0 && (opt_group_req < 0 ? 0 : opt_group_req) == 0;
@@ -951,6 +957,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
             HIPCHK(hipMemsetAsync(z0, 0, (size_t)(z1 - z0), stream));
         }
         HIPCHK(hipMemsetAsync(d_rep.p, 0xFF, kRepTotal * sizeof(int), stream));
+        HIPCHK(hipMemsetAsync(d_finalflag.p, 0, (size_t)((Nmax + 7) & ~7ull), stream));      // connect_rrt_sample only writes the set flags
         t_setup += now_s() - t0;
     }
     if (!batch_prep) hipLaunchKernelGGL(k_init_root, dim3(1), dim3(1), 0, stream, d_rc.p, start[0], start[1], (unsigned long long)root_reach, root_vid, 0);
