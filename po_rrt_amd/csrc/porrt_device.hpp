@@ -94,6 +94,9 @@ struct Counters {
     uint32_t dbg[4];            // developer statistics (kd claim: max / sum of losers, launches; non-duplicate levels of G)
     uint32_t clone_n;           // valid samples of the running step steered exactly onto the goal point (k_nn2 -> k_conn2)
     uint32_t clone_k[64];
+    uint32_t coop_bar;          // persistent step loop (k_coop_rrt): arrivals at its grid barrier (monotone)
+    uint32_t coop_filed;        //   steps whose nodes have their positions, ids and page slots (what the kd kernels beside it wait for)
+    uint32_t coop_abort;        //   a barrier or a waiting kernel gave up (nothing should ever set it: a guard against a hung GPU)
     uint32_t sched_stop;        // porrt_grow_batch with a loop condition: the first step this row did not run (0xFFFFFFFF: still running)
     uint32_t sched_iter;        //   and the iterations it ran (rrt.rs:109 / pto.rs:67: i when the loop ended)
     unsigned long long tim[16]; // developer builds (-DPORRT_TIMING): phase durations summed over waves, 10 ns units, and wave counts
@@ -953,6 +956,7 @@ __device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, u
 // to memory instead of five.  Same result as insert_step_pages up to the order of a step's nodes inside a region's
 // pages, which nothing depends on.
 constexpr uint32_t kFileLds = 2u * kRegions * 4u + 4096u * 2u + 64u * 8u + 66u * 4u + 32u;
+template <uint32_t T = 1024u>
 __device__ void file_step_fast(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords, uint8_t *scratch) {
     uint32_t *s_add = reinterpret_cast<uint32_t *>(scratch);                               // [kRegions] new nodes per region
     uint32_t *s_old = s_add + kRegions;                                                    // [kRegions] counts before the step
@@ -960,7 +964,7 @@ __device__ void file_step_fast(const RunConst &rc, uint32_t b, uint32_t nb, uint
     unsigned long long *s_word = reinterpret_cast<unsigned long long *>(s_off + 4096);     // [64] the valid mask
     uint32_t *s_pref = reinterpret_cast<uint32_t *>(s_word + 64);                          // [65] valid samples before word w
     uint32_t *s_misc = s_pref + 66;                                                        // np, base, err, N
-    constexpr uint32_t T = 1024u, SPT = 4u;                                                // nb <= 4096 (batch_K)
+    constexpr uint32_t SPT = 4u;                                                           // nb <= 4 T (1024 threads: batch_K <= 4096)
     const uint32_t tid = threadIdx.x, qo = q_off(rc, b);
     auto rg_old = as_global(rc.rg_cnt) + (b & 1u) * kRegions, rg_new = as_global(rc.rg_cnt) + ((b + 1u) & 1u) * kRegions;
     // ---- loads, all in flight together
@@ -1471,6 +1475,10 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
                 }
                 tm.bcast2(rec, base);
                 if (rec < rc.pend_cap && base + m <= rc.pool_cap) {
+                    // the placeholder is in place before the record can be seen: k_tie_fix may settle a record the moment it is
+                    // published (CAS of the placeholder), from another stream
+                    if (tl == 0) as_global(rc.parent)[id] = kParentPending;
+                    for (uint32_t c = tl; c < n_clone; c += TS) as_global(rc.parent)[clone_ids[c]] = kParentPending;
                     if (my_fresh) {
                         each_tie([&](int j) { if ((uint32_t)j >= kd_done) rc.pend_pool[base + atomicAdd(&rc.pend_cur[rec], 1u)] = j; });
                         __threadfence();
@@ -1556,7 +1564,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
 #pragma unroll
             for (int l = 1; l < kRepLevels; ++l) g_rep[rep_at[l]] = (int)id;
         }
-        g_par[id] = deferred ? kParentPending : best;
+        if (!deferred) g_par[id] = best;           // (a deferred parent: the placeholder was stored before its record was published)
         g_dA[id] = dnew;
         g_dB[id] = dnew;
         // final_flag is cleared when a grow starts (RRT*); the mask is only ever read where the flag is set
@@ -1572,7 +1580,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
             const uint32_t ic = clone_ids[c];
             as_global(rc.nx)[ic] = px;
             as_global(rc.ny)[ic] = py;
-            as_global(rc.parent)[ic] = deferred ? kParentPending : best;
+            if (!deferred) as_global(rc.parent)[ic] = best;
             as_global(rc.distA)[ic] = dnew;
             as_global(rc.distB)[ic] = dnew;
             if (fin) {
@@ -1736,9 +1744,93 @@ __global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per
 __global__ __launch_bounds__(1024) void k_file_commit(const RunConst *__restrict__ rcp, uint32_t bf, uint32_t nbf, uint32_t cb, uint32_t cnb, uint32_t vwords) {
     __shared__ __attribute__((aligned(16))) uint8_t s_ins[kFileLds];
     const RunConst &rc = rcp[blockIdx.y];
-    if (blockIdx.x == 0) { file_step_fast(rc, bf, nbf, vwords, s_ins); return; }
+    if (blockIdx.x == 0) { file_step_fast<1024u>(rc, bf, nbf, vwords, s_ins); return; }
     const uint32_t ck = uni((blockIdx.x - 1u) * 16u + (threadIdx.x >> 6));
     if (ck < cnb) commit_rrt_sample(rc, cb, vwords, ck, threadIdx.x & 63u);
+}
+
+// ---- the persistent step loop of a single query (option pipeline = 2)
+// All steps of a grow in ONE launch: the same phases as k_step_rrt / k_file_commit, separated by a barrier over the grid instead
+// of a kernel boundary (two launch gaps per step are most of what a single query's 110-step chain has left to lose).  The grid is
+// small enough to be resident at once -- the launch is a cooperative one, which refuses instead of deadlocking when it is not --
+// and every workgroup takes the phase's work items in turn.  Per step b:
+//     S(b):  connect(b) in the first items, search(b + 1) in the rest          | barrier
+//     F(b):  workgroup 0 files step b + 1's nodes, the others run step b's rewire phase 2     | barrier, coop_filed = b + 2
+// The kd structure (tie order) is built beside it on the side stream, by kernels launched ahead that wait for coop_filed.
+// The barrier: arrivals are counted in one monotone counter; whoever waits longer than two seconds gives up for everybody.
+__device__ __forceinline__ bool coop_grid_sync(const RunConst &rc, uint32_t nblocks, uint32_t &phase) {
+    __shared__ uint32_t s_go;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ++phase;
+        const uint32_t target = phase * nblocks;
+        __threadfence();
+        __hip_atomic_fetch_add(&rc.cnt->coop_bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = wall_clock64();
+        uint32_t go = 1u;
+        while (__hip_atomic_load(&rc.cnt->coop_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {      // (relaxed: an acquire per poll would flush the CU's L1 under the workgroups still at work)
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 200000000ull || __hip_atomic_load(&rc.cnt->coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                atomicOr(&rc.cnt->coop_abort, 1u); go = 0u; break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_go = go;
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_dcache_inv();            // scalar loads of what other workgroups wrote before the barrier
+    return s_go != 0u;
+}
+
+template <bool LDSGRID>
+__global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_coop_rrt(const RunConst *__restrict__ rcp, uint32_t n_steps, uint32_t K,
+                                                                  uint32_t n_iter, uint32_t vwords) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_tiles[];
+    __shared__ double s_d[kConnectWaves];
+    __shared__ int s_i[kConnectWaves];
+    __shared__ uint32_t s_heavy[kConnectWaves];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ins[kFileLds];
+    const RunConst &rc = rcp[0];
+    const uint32_t bid = blockIdx.x, nblk = gridDim.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t phase = 0;
+    auto nb_of = [&](uint32_t b) { const uint32_t i0 = b * K; return b < n_steps ? (n_iter - i0 < K ? n_iter - i0 : K) : 0u; };
+    // search(0), file(0)
+    {
+        const uint32_t nb0 = nb_of(0);
+        for (uint32_t it = bid; it * 4u < nb0; it += nblk) {
+            const uint32_t k = uni(it * 4u + wv);
+            if (k < nb0) near_sample<false>(rc, 0u, 0u, vwords, k, lane);
+        }
+        if (!coop_grid_sync(rc, nblk, phase)) return;
+        if (bid == 0) file_step_fast<kConnectWaves * 64u>(rc, 0u, nb0, vwords, s_ins);
+        if (!coop_grid_sync(rc, nblk, phase)) return;
+        if (bid == 0 && threadIdx.x == 0) __hip_atomic_store(&rc.cnt->coop_filed, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (uint32_t b = 0; b < n_steps; ++b) {
+        const uint32_t nb = nb_of(b), nbn = nb_of(b + 1u), i0n = (b + 1u) * K;
+        const uint32_t cb4 = (nb + kConnectWaves - 1u) / kConnectWaves, items = cb4 + (nbn + 3u) / 4u;
+        for (uint32_t it = bid; it < items; it += nblk) {
+            if (it < cb4) {
+                connect_block<LDSGRID>(rc, b, nb, vwords, it, lds_tiles, s_d, s_i, s_heavy);
+                __syncthreads();                   // (the tiles and the team scratch are reused by the workgroup's next item)
+            } else {
+                const uint32_t k = uni((it - cb4) * 4u + wv);
+                if (k < nbn) near_sample<false>(rc, b + 1u, i0n, vwords, k, lane);
+            }
+        }
+        if (!coop_grid_sync(rc, nblk, phase)) return;
+        // F: the filing of step b + 1 by the first workgroup, step b's rewire phase 2 by the others (by all when nothing is filed)
+        const uint32_t first_commit = nbn ? 1u : 0u;
+        if (nbn && bid == 0) file_step_fast<kConnectWaves * 64u>(rc, b + 1u, nbn, vwords, s_ins);
+        if (bid >= first_commit) {
+            for (uint32_t it = bid - first_commit; it * 4u < nb; it += nblk - first_commit) {
+                const uint32_t ck = uni(it * 4u + wv);
+                if (ck < nb) commit_rrt_sample(rc, b, vwords, ck, lane);
+            }
+        }
+        if (!coop_grid_sync(rc, nblk, phase)) return;
+        if (bid == 0 && threadIdx.x == 0) __hip_atomic_store(&rc.cnt->coop_filed, b + 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // RRT*: rewire phase 2 for sample k of step b (one wave).  A pair wins iff its candidate equals the accumulated
@@ -1807,6 +1899,26 @@ __global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__
 //                takes the slot (atomicMin), the others step below it.  Contenders of one slot always arrive in
 //                the same round because they share the whole path above it, so this equals sequential insertion.
 enum : uint32_t { LOC_SIDE = 1u, LOC_ONPATH = 2u };
+// Beside a persistent step loop (k_coop_rrt) there are no stream events between the steps: the first kernel of a kd group is
+// launched ahead and waits here until the steps it inserts have been filed (one thread per workgroup polls, asleep in between).
+// Gives up after two seconds of wall clock and says so (coop_abort): a kernel that can wait must not be able to hang the GPU.
+constexpr uint32_t kWaitFiled = 0x80000000u;
+__device__ __forceinline__ bool coop_wait_filed(const RunConst &rc, uint32_t need) {
+    __shared__ uint32_t s_ok;
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        uint32_t ok = 1u;
+        while (__hip_atomic_load(&rc.cnt->coop_filed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(64);
+            if (wall_clock64() - t0 > 200000000ull || __hip_atomic_load(&rc.cnt->coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                atomicOr(&rc.cnt->coop_abort, 1u); ok = 0u; break;
+            }
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0u;
+}
 constexpr int kHG = 128;             // hint grid squares per axis
 
 __device__ __forceinline__ KdBox load_box(const KdBox *p, size_t i) {
@@ -1854,6 +1966,7 @@ template <int LPN>
 __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t K, uint32_t nb_last,
                                                     uint32_t vwords, uint32_t lpar) {
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
+    if (lpar & kWaitFiled) { if (!coop_wait_filed(rc, b0 + nsteps)) return; lpar &= ~kWaitFiled; }
     const uint32_t lane = LPN == 64 ? (threadIdx.x & 63u) : 0u;
     const uint32_t wid = LPN == 64 ? blockIdx.x * 4u + (threadIdx.x >> 6) : blockIdx.x * 256u + threadIdx.x;
     const uint32_t st = wid / K, ks = wid - st * K;

@@ -195,7 +195,8 @@ struct porrt_ctx {
     uint32_t opt_batch_streams = 0;
     // "pipeline": RRT* steps of the one-wave-per-sample kernels as k_step_rrt / k_file_commit (step b + 1 is searched while step
     // b is connected: the chain of dependent kernels of a single query is max(search, connect) + file per step instead of
-    // search + connect: 5.9 against 6.65 ms on the bench's query).  1 (default) / 0.
+    // search + connect: 5.9 against 6.65 ms on the bench's query).  1 (default) / 0.  2: the same phases as ONE persistent launch
+    // (k_coop_rrt: barriers over the grid instead of kernel boundaries, a cooperative launch; for batch_K <= 1024, else as 1).
     int opt_pipeline = 1;
     bool pipe_on = false;                  // the choice in force for the running launch sequence (set with opt_group)
     uint32_t pipe_near_done = 0xFFFFFFFFu; // pipelined: the step whose search and filing are already launched
@@ -319,6 +320,8 @@ struct porrt_ctx {
     hipEvent_t ev_join = nullptr;
     void join_side();
     void launch_kd_group();
+    int launch_coop(uint32_t n_steps, uint32_t K, uint64_t n_iter, uint32_t vwords, size_t lds_bytes);
+    int coop_blocks = 0;                      // grid of the persistent step loop on this device (0: not looked up yet)
     int ensure_side_stream() {
         if (stream2) return PORRT_OK;
         if (hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking) != hipSuccess) { stream2 = nullptr; set_err("hipStreamCreate (side stream)"); return PORRT_ERR_DEVICE; }
@@ -719,6 +722,52 @@ void porrt_ctx::flush_commit() {
     commit_pend_b = 0xFFFFFFFFu;
 }
 
+// The persistent step loop (option pipeline = 2): every step of a single query's grow in one cooperative launch on the main
+// stream, and -- queued behind it on the side stream, each group's first kernel waiting for the steps it inserts (coop_filed) --
+// the kd groups.  Returns PORRT_OK, or a code without having launched anything (the caller then takes the launches step by step).
+int porrt_ctx::launch_coop(uint32_t n_steps, uint32_t K, uint64_t n_iter, uint32_t vwords, size_t lds_bytes) {
+    const void *fn = lds_bytes ? reinterpret_cast<const void *>(&k_coop_rrt<true>) : reinterpret_cast<const void *>(&k_coop_rrt<false>);
+    if (!coop_blocks) {
+        int occ = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kConnectWaves * 64, lds_bytes) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || occ < 1 || cus < 1) { (void)hipGetLastError(); return PORRT_ERR_DEVICE; }
+        coop_blocks = cus * std::min(occ, 2);         // two workgroups per CU hold a step's 512 work items of K = 1024 in one round
+    }
+    // the side stream may not start before this grow's counters are cleared (it polls one of them)
+    (void)hipEventRecord(ev_steered, stream);
+    (void)hipStreamWaitEvent(stream2, ev_steered, 0);
+    const RunConst *rcp = launch_rcp;
+    uint32_t n_iter32 = (uint32_t)n_iter;
+    void *args[] = {(void *)&rcp, (void *)&n_steps, (void *)&K, (void *)&n_iter32, (void *)&vwords};
+    // 2: a cooperative launch (the runtime refuses a grid that is not resident at once); 3: the same grid as an ordinary launch
+    // (developer switch: the grid is sized from the occupancy query either way, and the barrier gives up rather than hang)
+    const hipError_t le = opt_pipeline == 3 ? hipLaunchKernel(fn, dim3((unsigned)coop_blocks), dim3(kConnectWaves * 64), args, lds_bytes, stream)
+                                            : hipLaunchCooperativeKernel(fn, dim3((unsigned)coop_blocks), dim3(kConnectWaves * 64), args, (unsigned)lds_bytes, stream);
+    if (le != hipSuccess) {
+        (void)hipGetLastError();
+        return PORRT_ERR_DEVICE;
+    }
+    for (uint32_t b0 = 0; b0 < n_steps; b0 += kd_group) {
+        const uint32_t ns = std::min<uint32_t>(kd_group, n_steps - b0), last = b0 + ns - 1u;
+        const uint32_t nb_last = (uint32_t)std::min<uint64_t>(K, n_iter - (uint64_t)last * K);
+        if ((uint64_t)ns * K >= 4096u) hipLaunchKernelGGL(k_kd_locate<1>, dim3((ns * K + 255) / 256, 1), dim3(256), 0, stream2, rcp, b0, ns, K, nb_last, vwords, kWaitFiled);
+        else hipLaunchKernelGGL(k_kd_locate<64>, dim3((ns * K * 64 + 255) / 256, 1), dim3(256), 0, stream2, rcp, b0, ns, K, nb_last, vwords, kWaitFiled);
+        hipLaunchKernelGGL(k_kd_link, dim3((ns * K + 255) / 256, 1), dim3(256), 0, stream2, rcp, b0, ns, vwords, 0u);
+        if ((uint64_t)ns * K <= 2048u) hipLaunchKernelGGL(k_kd_claim<2048>, dim3(1, 1), dim3(1024), 0, stream2, rcp, b0, ns, vwords);
+        else hipLaunchKernelGGL(k_kd_claim<kClaimMax>, dim3(1, 1), dim3(1024), 0, stream2, rcp, b0, ns, vwords);
+        hipLaunchKernelGGL(k_kd_hint, dim3((ns * K + 255) / 256, 1), dim3(256), 0, stream2, rcp, b0, ns, vwords);
+        hipLaunchKernelGGL(k_tie_fix<1024>, dim3(1, 1), dim3(1024), 0, stream2, rcp);
+    }
+    (void)hipEventRecord(ev_join, stream2);
+    (void)hipStreamWaitEvent(stream, ev_join, 0);
+    hipLaunchKernelGGL(k_tie_fix<1024>, dim3(1, 1), dim3(1024), 0, stream, rcp);
+    kd_pend[0] = kd_pend[1] = false;
+    side_active = false;
+    commit_pend_b = 0xFFFFFFFFu;
+    pipe_near_done = 0xFFFFFFFFu;
+    return PORRT_OK;
+}
+
 void porrt_ctx::join_side() {
     flush_commit();
     if (!side_active) return;
@@ -1058,7 +1107,17 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     kd_b0 = 0; kd_last_b = 0; kd_last_nb = 0; kd_gidx = 0;
     kd_pend[0] = kd_pend[1] = false;
     kd_group = kd_group_for(K, opt_kd_group, 1);
-    if (opt_graph && !prof && n_iter_min > 0) {
+    bool coop_done = false;
+    if (pipe_on && opt_pipeline >= 2 && K <= 1024 && !prof && n_iter_min > 0) {
+        uint32_t nst = (uint32_t)((n_iter_min + K - 1) / K);
+        if (launch_coop(nst, K, n_iter_min, vwords, lds_bytes) == PORRT_OK) {
+            coop_done = true;
+            i = n_iter_min; b = nst;
+            kd_b0 = b; kd_last_b = b ? b - 1 : 0;
+        }
+    }
+    if (coop_done) {
+    } else if (opt_graph && !prof && n_iter_min > 0) {
         // all steps up to n_iter_min as one hipGraph (two branches: main pipeline + kd insertion); the graph
         // only depends on the launch geometry, so it is instantiated once and replayed by later grows
         const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)launch_rcp, kd_group | ((uint64_t)launch_Q << 32) | ((uint64_t)opt_group << 48) | ((uint64_t)pipe_on << 56)};
@@ -1140,6 +1199,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ev_first, ev_last));
 
+    if (hc.coop_abort) { set_err("the persistent step loop gave up waiting (a barrier or a kd kernel beside it): results discarded"); return PORRT_ERR_DEVICE; }
     if (hc.err & ERR_CAND_OVERFLOW) return -100;
     if (hc.err & ERR_RNG_RETRY) {
         if (has_inj) { set_err("injected sample stream exhausted"); return PORRT_ERR_INVALID; }
@@ -3049,7 +3109,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "graph")) c->opt_graph = value != 0;
     else if (!strcmp(name, "group_lanes")) { if (value != -1 && value != 0 && value != 16 && value != 32 && value != 64) { c->set_err("group_lanes: -1 (auto), 0, 16, 32 or 64"); return PORRT_ERR_INVALID; } c->opt_group_req = (int)value; }
     else if (!strcmp(name, "dp_sweeps")) c->opt_dp_sweeps = value != 0;
-    else if (!strcmp(name, "pipeline")) c->opt_pipeline = value ? 1 : 0;
+    else if (!strcmp(name, "pipeline")) c->opt_pipeline = (value == 2 || value == 3) ? (int)value : (value ? 1 : 0);
     else if (!strcmp(name, "batch_streams")) c->opt_batch_streams = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else if (!strcmp(name, "kd_group")) c->opt_kd_group = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else { c->set_err(std::string("unknown option ") + name); return PORRT_ERR_INVALID; }

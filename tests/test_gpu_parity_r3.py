@@ -234,3 +234,19 @@ def test_batch_each_with_budgets_of_their_own(eng_mod):
         cases.grow(e, c, K=128)
         assert_same(e, s, pto=True)
     assert rc == worst
+
+
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3])
+def test_single_query_launch_forms_agree(eng_mod, pipeline):
+    """the single query's steps as separate kernels (0), pipelined pairs (1, the default), or ONE persistent launch with barriers over
+    the grid (2: cooperative launch, 3: the same grid launched ordinarily) -- identical trees, against the oracle"""
+    for case, K in ((cases.cfg2(30000, seed=4), 1024), (cases.cfg2_obs(2500, seed=2), 512), (cases.cfg1(3000), 64)):
+        e, _ = run_gpu(eng_mod, case, K, pipeline=pipeline)
+        o, _ = run_orc(case, K)
+        assert_same(e, o)
+        e2 = cases.configure(eng_mod.Engine(), case)     # the sampler moves on: a second grow on the same context
+        e2.set_option("pipeline", pipeline)
+        cases.grow(e2, case, K=K)
+        cases.grow(e2, case, K=K)
+        cases.grow(o, case, K=K, algo=orc.ALGO_BATCHED_KD)
+        assert_same(e2, o)
