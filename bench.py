@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option for every context (porrt_set_option), e.g. group_lanes=32")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps run with per-kernel HIP events for `roofline`")
     ap.add_argument("--launch-check", action="store_true", help="start the ranks, rendezvous over gloo and stop (no GPU needed)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure the HBM traffic of the step kernels")
+    ap.add_argument("--pmc-child", action="store_true", help="(internal) one grow step of --queries queries and nothing else: what the counter passes profile")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.launch_check))
@@ -160,6 +162,15 @@ def main():
 
     case = cases.cfg2(args.n_iter)
     Q = max(1, args.queries)
+    if args.pmc_child:
+        # profiled by rocprofv3 --pmc (measure_traffic below): the timed call once, nothing around it
+        ce = [cases.configure(po_rrt_amd.Engine(local_rank), cases.Case(case, seed=j)) for j in range(Q)]
+        for e in ce:
+            for ov in args.opt:
+                e.set_option(ov.split("=")[0], int(ov.split("=")[1]))
+        po_rrt_amd.Engine.grow_batch(ce, [case.start] * Q, case.max_step, case.search_radius, case.n_iter_min, args.batch)
+        os.write(real_stdout, b"{}\n")
+        return
     # N = 1: every query plans on the map_benchmark stand-in (configs[1], the configuration the metric is quoted on).
     # N > 1 (configs[4]): the queries of a rank are spread over the nine maps map_benchmark_like_{a..i}; same tree size,
     # same parameters, so the work per GPU stays what it is at N = 1 (weak scaling); the exchange picks a winner per map.
@@ -373,13 +384,16 @@ def main():
             conn_bytes = 8.0 * n_sum + Q_launch * grid_bytes + 28.0 * prof["nodes"] / L
             nn_us, conn_us = 1e6 * prof["scan_s"] / L, 1e6 * prof["connect_s"] / L
             pm, pm_src = {}, None
-            for cand in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):      # HBM traffic per launch from the committed rocprofv3 --pmc passes
-                try:
-                    pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
-                    pm_src = "profiles/" + cand
-                    break
-                except Exception:
-                    pass
+            if not args.no_pmc:
+                pm, pm_src = measure_traffic(args, Q)
+            if not pm:
+                for cand in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):      # committed rocprofv3 --pmc passes
+                    try:
+                        pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                        pm_src = "profiles/" + cand + " (committed; not measured in this run)"
+                        break
+                    except Exception:
+                        pass
 
             def traffic_of(prefix):
                 ks = [pm[k] for k in pm if k.startswith(prefix + "<16") or k == prefix] or [pm[k] for k in pm if k.startswith(prefix)]
@@ -411,7 +425,10 @@ def main():
                 "traffic": traffic_of(dom),
                 "traffic_source": pm_src,
                 "traffic_note": "HBM bytes per launch = 2 x FETCH_SIZE (gfx950 counts a 128-B request as 64 B for wide streaming reads; for gathers "
-                                "the raw figure may be the truer one) + WRITE_SIZE, separate --pmc passes of the same command; not measured in this run",
+                                "the raw figure may be the truer one) + WRITE_SIZE, each from its own rocprofv3 --pmc pass (they do not fit one) over one grow "
+                                "step of the same queries, run as child processes of this bench after the timed region (kernels are serialised while "
+                                "counters are collected)",
+                "traffic_raw": {k: pm[k] for k in pm if k.startswith("k_conn2") or k.startswith("k_nn2")} if pm else None,
                 "avg_launch_us": dom_us,
                 "launches": L,
                 "queries_per_launch": Q_launch,
@@ -450,6 +467,53 @@ def main():
     comm.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def measure_traffic(args, Q, timeout_s=240):
+    """HBM traffic of the step kernels, measured in this run: two child processes of this script under rocprofv3 --pmc -- FETCH_SIZE,
+    then WRITE_SIZE (MI355X_MICROARCH.md: they do not fit one pass; KiB units) -- each profiling one grow step of the same Q queries
+    (--pmc-child).  Returns ({kernel: {launches, fetch_bytes_per_launch_raw, write_bytes_per_launch}}, source) or ({}, None)."""
+    import collections
+    import csv
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return {}, None
+    acc = collections.defaultdict(dict)
+    for counter, key in (("FETCH_SIZE", "fetch_bytes_per_launch_raw"), ("WRITE_SIZE", "write_bytes_per_launch")):
+        d = tempfile.mkdtemp(prefix="porrt_pmc_", dir="/tmp")
+        cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+               "--queries", str(Q), "--n-iter", str(args.n_iter), "--batch", str(args.batch)] + [x for ov in args.opt for x in ("--opt", ov)]
+        try:
+            p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)          # exactly the child's own process group
+                p.wait()
+                rc = -9
+            if rc != 0:
+                return {}, None
+            files = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
+            if not files:
+                return {}, None
+            agg = collections.defaultdict(lambda: [0, 0.0])
+            for row in csv.DictReader(open(files[0])):
+                k = row["Kernel_Name"].split("(")[0].split("::")[-1]
+                agg[k][0] += 1
+                agg[k][1] += float(row["Counter_Value"])
+            for k, (n, v) in agg.items():
+                acc[k]["launches"] = n
+                acc[k][key] = v / n * 1024.0
+        except Exception:                                 # noqa: BLE001
+            return {}, None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {k: v for k, v in acc.items() if "fetch_bytes_per_launch_raw" in v and "write_bytes_per_launch" in v}
+    return out, "measured in this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, %d queries, one grow step)" % Q
 
 
 def belief_traffic():
@@ -515,6 +579,12 @@ def belief_space(device, with_cpu):
                                  "traffic = HBM bytes of one build (2 x FETCH_SIZE + WRITE_SIZE summed over the k_bg_* and k_scan_* launches, "
                                  "separate --pmc passes on the same graph, profiles/r1_belief_pmc_traffic.json)"}},
         "expected_costs": {"ms_wall": 1e3 * min(dps), "ms_device": 1e3 * info["device_s"], "sweeps": info["sweeps"], "root_cost": root_cost,
+                           "roofline": {"bound": "hbm", "kernel": "k_dp_level_sweep", "achieved": 10.0 * info["sweep_rows"] / info["device_s"] / 1e9, "peak": 8000.0,
+                                        "unit": "GB/s", "frac": 10.0 * info["sweep_rows"] / info["device_s"] / 1e9 / 8000.0,
+                                        "algorithmic_bytes": 10.0 * info["sweep_rows"], "sweep_rows": info["sweep_rows"], "traffic": None,
+                                        "note": "a sweep passes over its level's rows: per row the change flag read and the next one written (1 B each) and the "
+                                                "cost (8 B) -- 10 B per row and sweep, summed over the %d sweeps (the rows a sweep actually re-evaluates also read "
+                                                "their neighbours' costs: not counted), over the device time of the whole computation (HIP events)" % info["sweeps"]},
                            "edge_relaxations_per_s_lower_bound": E / min(dps),
                            "note": "conditional_dijkstra as sweeps to the same fixpoint; every edge is relaxed at least once"},
         "extract_policy": {"ms_wall": 1e3 * t_policy, "policy_nodes": int(len(oid)), "leafs": int(leaf.sum())},

@@ -212,6 +212,9 @@ int      porrt_bg_compute_expected_costs(porrt_ctx *ctx);
 int      porrt_bg_get_expected_costs(const porrt_ctx *ctx, double *out /* porrt_bg_num_nodes() */);
 int      porrt_bg_expected_cost_of(const porrt_ctx *ctx, uint64_t belief_node, double *out);   /* [0] = policy.expected_costs */
 int      porrt_bg_get_dp_info(const porrt_ctx *ctx, double *total_s, double *device_s, uint32_t *sweeps);
+/* belief nodes the sweeps of the last run passed over, summed over the sweeps (a sweep reads and writes a level's change flags and the
+ * costs of the rows that changed: the unit of that row's roofline in bench.py) */
+uint64_t porrt_bg_get_dp_sweep_rows(const porrt_ctx *ctx);
 /* PTO::extract_policy (src/pto.rs:277-283; extract_policy / get_best_expected_children src/belief_graph.rs:177-263) from
  * belief node 0.  Policy node k (in Policy::add_node order; node 0 is the root) has original_node_id original_ids[k],
  * parent parents[k] (-1 for the root) and is a leaf (expected cost 0) iff is_leaf[k]; its state and belief follow from

@@ -294,6 +294,7 @@ struct DpState {
     double *d_dist = nullptr;
     size_t n = 0;
     uint32_t sweeps = 0;
+    unsigned long long sweep_rows = 0;                // rows (belief nodes) the sweeps passed over, summed over the sweeps
     double t_total = 0, t_device = 0;
     std::vector<void *> owned;                        // scratch of the last run (flags, finals); dist lives in a grow-only slot
     size_t dist_cap = 0;
@@ -382,6 +383,7 @@ static int dp_run(DpState &st, DpConst c, bool implicit, const std::vector<unsig
                            (unsigned long long)finals.size(), st.d_dirty[0]);
     }
     uint32_t sweeps = 0, h_flags[1 + kDpGroup];
+    unsigned long long sweep_rows = 0;
     int cur = 0;
     for (bool more = !finals.empty(); more;) {
         DP_HIP(hipMemsetAsync(st.d_flags + 1, 0, kDpGroup * sizeof(uint32_t), s));
@@ -390,6 +392,7 @@ static int dp_run(DpState &st, DpConst c, bool implicit, const std::vector<unsig
             else hipLaunchKernelGGL(k_dp_sweep<false>, grid, block, 0, s, c, st.d_dirty[cur], st.d_dirty[cur ^ 1], k);
         }
         sweeps += kDpGroup;
+        sweep_rows += (unsigned long long)n * kDpGroup;
         DP_HIP(hipMemcpyAsync(h_flags, st.d_flags, sizeof h_flags, hipMemcpyDeviceToHost, s));
         DP_HIP(hipStreamSynchronize(s));
         if (h_flags[0]) break;
@@ -408,6 +411,7 @@ static int dp_run(DpState &st, DpConst c, bool implicit, const std::vector<unsig
     st.last = c;
     st.layered = false;
     st.sweeps = sweeps;
+    st.sweep_rows = sweep_rows;
     st.t_device = 1e-3 * (double)ms;
     st.t_total = bg_now() - t0;
     st.valid = true;
@@ -486,6 +490,7 @@ static int dp_run_layered(DpState &st, BeliefGraphState &bg, DpConst c, const st
                            (unsigned long long)finals.size());
     }
     uint32_t sweeps = 0, h_flags[1 + kDpGroup];
+    unsigned long long sweep_rows = 0;
     for (auto &lv : levels) {
         const uint32_t p0 = lv.first, W = lv.second - lv.first;
         const dim3 grid((unsigned)(((size_t)N * W + 255) / 256)), block(256);
@@ -499,6 +504,7 @@ static int dp_run_layered(DpState &st, BeliefGraphState &bg, DpConst c, const st
                 if (split) hipLaunchKernelGGL(k_dp_level_sweep<4>, sgrid, block, 0, s, L, p0, W, st.d_dirty[cur], st.d_dirty[cur ^ 1], k);
                 else hipLaunchKernelGGL(k_dp_level_sweep<1>, sgrid, block, 0, s, L, p0, W, st.d_dirty[cur], st.d_dirty[cur ^ 1], k);
             sweeps += kDpGroup;
+            sweep_rows += (unsigned long long)N * W * kDpGroup;
             DP_HIP(hipMemcpyAsync(h_flags, st.d_flags, sizeof h_flags, hipMemcpyDeviceToHost, s));
             DP_HIP(hipStreamSynchronize(s));
             more = h_flags[kDpGroup] != 0;
@@ -516,6 +522,7 @@ static int dp_run_layered(DpState &st, BeliefGraphState &bg, DpConst c, const st
     st.n = n;
     st.last = c;
     st.sweeps = sweeps;
+    st.sweep_rows = sweep_rows;
     st.layered = true;
     st.t_device = 1e-3 * (double)ms;
     st.t_total = bg_now() - t0;

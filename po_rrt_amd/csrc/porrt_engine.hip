@@ -184,6 +184,11 @@ struct porrt_ctx {
     bool opt_profile = false;
     bool opt_graph = true;
     uint32_t opt_kd_group = 0;     // steps per kd insertion (0 = choose by K)
+    // "kd_after": 1 = the kd structure (tie order) is not built beside the steps: every equal-cost parent is deferred and the
+    // structure is built after the last step, group by group with the GPU to itself, then the ties are settled (measured
+    // against the default).  0 (default).
+    bool opt_kd_after = false;
+    uint32_t kd_after_K = 0;               // batch_K of the running launch sequence (the deferred groups need it)
     // "group_lanes": lanes per sample of the RRT* step kernels.  16 / 32 / 64: k_nn2 + k_conn2 (several samples per wave: fewer
     // waves, hits kept in LDS -- throughput); 0: k_near + k_connect_rrt (one wave per sample: the shortest dependent chain per
     // step -- latency).  -1 (default): by the number of queries advanced together, 16 from 8 queries on, else 0.
@@ -616,7 +621,7 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
         }
         kd_last_b = b; kd_last_nb = nb;
         side_active = true;
-        if (b + 1 - kd_b0 >= kd_group) launch_kd_group();
+        if (!opt_kd_after && b + 1 - kd_b0 >= kd_group) launch_kd_group();
         return;
     }
     ev();
@@ -667,7 +672,7 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     commit_pend_b = b; commit_pend_nb = nb;
     kd_last_b = b; kd_last_nb = nb;
     side_active = true;
-    if (b + 1 - kd_b0 >= kd_group) launch_kd_group();
+    if (!opt_kd_after && b + 1 - kd_b0 >= kd_group) launch_kd_group();
 }
 
 // kd insertion of steps [kd_b0, kd_last_b] on the side stream (positions are final since the last k_near; the
@@ -771,6 +776,27 @@ int porrt_ctx::launch_coop(uint32_t n_steps, uint32_t K, uint64_t n_iter, uint32
 void porrt_ctx::join_side() {
     flush_commit();
     if (!side_active) return;
+    if (opt_kd_after) {
+        // the whole structure now, on the main stream: groups of as many steps as the claim kernel holds, in id order
+        const RunConst *rcp = launch_rcp;
+        const uint32_t Q = launch_Q, K = rc.cand_K, vwords = (K + 63) / 64;
+        const uint32_t g = std::max<uint32_t>(1u, std::min<uint32_t>(8u, kClaimMax / K));
+        while (kd_b0 <= kd_last_b) {
+            const uint32_t ns = std::min<uint32_t>(g, kd_last_b - kd_b0 + 1), last = kd_b0 + ns - 1;
+            const uint32_t nbl = last == kd_last_b ? kd_last_nb : K;
+            if ((uint64_t)ns * K * Q >= 4096u) hipLaunchKernelGGL(k_kd_locate<1>, dim3((ns * K + 255) / 256, Q), dim3(256), 0, stream, rcp, kd_b0, ns, K, nbl, vwords, 0u);
+            else hipLaunchKernelGGL(k_kd_locate<64>, dim3((ns * K * 64 + 255) / 256, Q), dim3(256), 0, stream, rcp, kd_b0, ns, K, nbl, vwords, 0u);
+            hipLaunchKernelGGL(k_kd_link, dim3((ns * K + 255) / 256, Q), dim3(256), 0, stream, rcp, kd_b0, ns, vwords, 0u);
+            if ((uint64_t)ns * K <= 2048u) hipLaunchKernelGGL(k_kd_claim<2048>, dim3(1, Q), dim3(1024), 0, stream, rcp, kd_b0, ns, vwords);
+            else hipLaunchKernelGGL(k_kd_claim<kClaimMax>, dim3(1, Q), dim3(1024), 0, stream, rcp, kd_b0, ns, vwords);
+            hipLaunchKernelGGL(k_kd_hint, dim3((ns * K + 255) / 256, Q), dim3(256), 0, stream, rcp, kd_b0, ns, vwords);
+            kd_b0 = last + 1;
+        }
+        if (Q > 1) hipLaunchKernelGGL(k_tie_fix<256>, dim3(1, Q), dim3(256), 0, stream, rcp);
+        else hipLaunchKernelGGL(k_tie_fix<1024>, dim3(1, Q), dim3(1024), 0, stream, rcp);
+        side_active = false;
+        return;
+    }
     launch_kd_group();
     (void)hipEventRecord(ev_join, stream2);
     (void)hipStreamWaitEvent(stream, ev_join, 0);
@@ -2985,6 +3011,7 @@ int porrt_bg_get_dp_info(const porrt_ctx *c, double *total_s, double *device_s, 
     if (sweeps) *sweeps = c->dp.sweeps;
     return PORRT_OK;
 }
+uint64_t porrt_bg_get_dp_sweep_rows(const porrt_ctx *c) { return c && c->dp.valid ? c->dp.sweep_rows : 0; }
 
 // PTO::extract_policy: returns the number of policy nodes (or a negative error); fills the arrays when they hold that many
 int64_t porrt_bg_extract_policy(porrt_ctx *c, uint64_t *original_ids, int64_t *parents, uint8_t *is_leaf, uint64_t cap, double *expected_costs) {
@@ -3111,6 +3138,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "dp_sweeps")) c->opt_dp_sweeps = value != 0;
     else if (!strcmp(name, "pipeline")) c->opt_pipeline = (value == 2 || value == 3) ? (int)value : (value ? 1 : 0);
     else if (!strcmp(name, "batch_streams")) c->opt_batch_streams = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
+    else if (!strcmp(name, "kd_after")) c->opt_kd_after = value != 0;
     else if (!strcmp(name, "kd_group")) c->opt_kd_group = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else { c->set_err(std::string("unknown option ") + name); return PORRT_ERR_INVALID; }
     return PORRT_OK;

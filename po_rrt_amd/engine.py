@@ -31,7 +31,7 @@ SYMBOLS = [
     "porrt_get_zone_positions", "porrt_best_solution", "porrt_best_cost", "porrt_best_cost_batch", "porrt_get_metrics", "porrt_set_option", "porrt_selftest",
     "porrt_build_belief_graph", "porrt_bg_num_beliefs", "porrt_bg_num_nodes", "porrt_bg_num_edges", "porrt_bg_get_beliefs",
     "porrt_bg_get_observable_zones", "porrt_bg_get_node_types", "porrt_bg_get_children", "porrt_bg_get_parents", "porrt_bg_get_seconds",
-    "porrt_bg_compute_expected_costs", "porrt_bg_get_expected_costs", "porrt_bg_expected_cost_of", "porrt_bg_get_dp_info", "porrt_bg_extract_policy", "porrt_conditional_dijkstra",
+    "porrt_bg_compute_expected_costs", "porrt_bg_get_expected_costs", "porrt_bg_expected_cost_of", "porrt_bg_get_dp_info", "porrt_bg_get_dp_sweep_rows", "porrt_bg_extract_policy", "porrt_conditional_dijkstra",
     "porrt_comm_unique_id", "porrt_comm_create", "porrt_comm_destroy", "porrt_comm_last_error", "porrt_exchange_best", "porrt_exchange_num_nodes",
     "porrt_exchange_get_tree", "porrt_exchange_decide", "porrt_exchange_agree", "porrt_tree_device",
     "porrt_grow_mm_prm", "porrt_mm_num_modes", "porrt_mm_num_transitions", "porrt_mm_num_beliefs", "porrt_mm_get_mode", "porrt_mm_get_mode_graph",
@@ -129,6 +129,7 @@ def load_library():
     sig("porrt_bg_get_expected_costs", C.c_int, vp, _f64p)
     sig("porrt_bg_expected_cost_of", C.c_int, vp, C.c_uint64, C.POINTER(C.c_double))
     sig("porrt_bg_get_dp_info", C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32))
+    sig("porrt_bg_get_dp_sweep_rows", C.c_uint64, vp)
     sig("porrt_bg_extract_policy", C.c_int64, vp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_double))
     sig("porrt_conditional_dijkstra", C.c_int, C.c_int, C.c_uint64, _f64p, _u32p, _f64p, C.c_uint32, C.c_uint32, _u8p, _u64p, _u32p, _u64p, _u32p,
         _u64p, C.c_uint64, _f64p)
@@ -438,7 +439,7 @@ class Engine:
     def dp_info(self):
         a, b, n = C.c_double(0), C.c_double(0), C.c_uint32(0)
         self._chk(self._l.porrt_bg_get_dp_info(self._c, C.byref(a), C.byref(b), C.byref(n)))
-        return dict(total_s=a.value, device_s=b.value, sweeps=n.value)
+        return dict(total_s=a.value, device_s=b.value, sweeps=n.value, sweep_rows=int(self._l.porrt_bg_get_dp_sweep_rows(self._c)))
 
     def selftest(self, n=1 << 20):
         a, b = C.c_uint64(0), C.c_uint64(0)
