@@ -194,6 +194,9 @@ struct porrt_ctx {
     // step -- latency).  -1 (default): by the number of queries advanced together, 16 from 8 queries on, else 0.
     int opt_group_req = -1;
     uint32_t opt_group = 0;        // the choice in force for the running launch sequence
+    // "early_wave_steps": the group kernels take one wave per sample (64 lanes, 320 hits in LDS) for this many first steps of a run,
+    // where the tree is a dense blob and a sample has hundreds of neighbours, and 16 lanes per sample afterwards
+    uint32_t opt_early_wave = 0;
     // "batch_streams": porrt_grow_batch advances its contexts as this many sub-batches side by side, each a launch sequence
     // (hipGraph) of its own on its own streams, so that one sub-batch's kernel tails and its kd side chain are filled by the
     // other's kernels.  0 (default): 2 from 32 contexts on, else 1.
@@ -626,6 +629,8 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     }
     ev();
     const uint32_t GLn = rrt ? opt_group : 0u;
+    // the connect pass of the first steps with one wave per sample (slots are slots whatever the group size)
+    const uint32_t GLc = (GLn == 16u && b < opt_early_wave) ? 64u : GLn;
     if (mode == PORRT_MODE_PTO) hipLaunchKernelGGL(k_near<true>, dim3(wave_blocks, Q), dim3(256), 0, stream, rcp, b, i0, nb, vwords, 0xFFFFFFFFu, 0u);
     else if (GLn) {
         // GL lanes per sample; the previous step's rewire phase 2 rides along in extra workgroups
@@ -660,11 +665,11 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     (void)hipEventRecord(ev_steered, stream);
     ev();
     if (GLn) {
-        const uint32_t spb = 256u / GLn;
+        const uint32_t spb = 256u / GLc;
         const dim3 g2((nb + spb - 1) / spb + 2, Q);       // + the clone workgroup + the page-filing workgroup
-        const size_t dyn = conn2_lds_bytes(GLn);
-        if (GLn == 16) hipLaunchKernelGGL(k_conn2<16>, g2, dim3(256), dyn, stream, rcp, b, nb, vwords);
-        else if (GLn == 32) hipLaunchKernelGGL(k_conn2<32>, g2, dim3(256), dyn, stream, rcp, b, nb, vwords);
+        const size_t dyn = conn2_lds_bytes(GLc);
+        if (GLc == 16) hipLaunchKernelGGL(k_conn2<16>, g2, dim3(256), dyn, stream, rcp, b, nb, vwords);
+        else if (GLc == 32) hipLaunchKernelGGL(k_conn2<32>, g2, dim3(256), dyn, stream, rcp, b, nb, vwords);
         else hipLaunchKernelGGL(k_conn2<64>, g2, dim3(256), dyn, stream, rcp, b, nb, vwords);
     } else if (lds_bytes) hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
     else hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
@@ -1146,7 +1151,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     } else if (opt_graph && !prof && n_iter_min > 0) {
         // all steps up to n_iter_min as one hipGraph (two branches: main pipeline + kd insertion); the graph
         // only depends on the launch geometry, so it is instantiated once and replayed by later grows
-        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)launch_rcp, kd_group | ((uint64_t)launch_Q << 32) | ((uint64_t)opt_group << 48) | ((uint64_t)pipe_on << 56)};
+        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)launch_rcp, kd_group | ((uint64_t)opt_early_wave << 8) | ((uint64_t)launch_Q << 32) | ((uint64_t)opt_group << 48) | ((uint64_t)pipe_on << 56)};
         if (!graph_exec || memcmp(key, graph_key, sizeof key)) {
             double t0 = now_s();
             if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -2304,7 +2309,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             steps = sched_steps();
             if (sched_rc) { L->set_err("porrt_grow_batch: step schedule (device)"); return sched_rc; }
         } else if (L->opt_graph && !prof && !L->sub_eager) {
-            const uint64_t key[6] = {(uint64_t)mode, K, n_iter, L->run_lds_bytes, (uint64_t)(uintptr_t)L->launch_rcp, L->kd_group | ((uint64_t)n << 32) | ((uint64_t)L->opt_group << 48) | ((uint64_t)L->pipe_on << 56)};
+            const uint64_t key[6] = {(uint64_t)mode, K, n_iter, L->run_lds_bytes, (uint64_t)(uintptr_t)L->launch_rcp, L->kd_group | ((uint64_t)L->opt_early_wave << 8) | ((uint64_t)n << 32) | ((uint64_t)L->opt_group << 48) | ((uint64_t)L->pipe_on << 56)};
             if (!L->graph_exec || memcmp(key, L->graph_key, sizeof key)) {
                 if (L->graph_exec) { (void)hipGraphExecDestroy(L->graph_exec); L->graph_exec = nullptr; }
                 hipGraph_t g = nullptr;
@@ -3139,6 +3144,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "pipeline")) c->opt_pipeline = (value == 2 || value == 3) ? (int)value : (value ? 1 : 0);
     else if (!strcmp(name, "batch_streams")) c->opt_batch_streams = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else if (!strcmp(name, "kd_after")) c->opt_kd_after = value != 0;
+    else if (!strcmp(name, "early_wave_steps")) c->opt_early_wave = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 64));
     else if (!strcmp(name, "kd_group")) c->opt_kd_group = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else { c->set_err(std::string("unknown option ") + name); return PORRT_ERR_INVALID; }
     return PORRT_OK;

@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 // dynamic LDS of k_conn2: per sample the LDS part of its hit list; the page-filing workgroup uses the same bytes as its
 // scratch
 __host__ __device__ inline size_t conn2_lds_bytes(uint32_t GL) {
-    const size_t spb = 256u / GL, a = spb * kHitBytes;
+    const size_t a = 4u * (64u / 16u) * kHitBytes;      // per workgroup whatever the group size: a wave's lists hold 4 x kLdsHits hits between them
     return a > kInsertLds ? a : kInsertLds;
 }
 
@@ -642,12 +642,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             to_pixel(rc, px, py, bi, bj);
             if (bi < rc.H && bj < rc.W) clr_b = as_global(rc.clr)[bi * rc.W + bj];
         }
-        uint8_t *hb = lds_dyn + si * kHitBytes;
+        // a sample's list: the wave's LDS share split between its 64 / GL samples (80 hits at 16 lanes per sample, 320 at 64)
+        constexpr uint32_t kHits = kLdsHits * (uint32_t)(GL / 16);
+        uint8_t *hb = lds_dyn + si * (kHits * 28u);
         LdsHits L;
         L.hx = reinterpret_cast<double *>(hb);
-        L.hy = L.hx + kLdsHits;
-        L.hd = L.hy + kLdsHits;
-        L.hid = reinterpret_cast<int *>(L.hd + kLdsHits);
+        L.hy = L.hx + kHits;
+        L.hd = L.hy + kHits;
+        L.hid = reinterpret_cast<int *>(L.hd + kHits);
         const MemHits M = mem_hits(rc, b, k);
         L.out_id = M.out_id; L.out_val = M.out_val; L.out_cnt = M.out_cnt; L.out_cap = M.out_cap;
         PORRT_TACC_B(rc, 0);
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             const unsigned long long hm = tm.ballot(in);
             const uint32_t pos = tot + (uint32_t)__popcll(hm & ((1ull << tm.gl) - 1ull));
             if (in) {
-                if (pos < kLdsHits) { L.hid[pos] = jd; L.hx[pos] = x; L.hy[pos] = y; L.hd[pos] = dA; }
+                if (pos < kHits) { L.hid[pos] = jd; L.hx[pos] = x; L.hy[pos] = y; L.hd[pos] = dA; }
                 else if (pos < cap) { M.sid[pos] = jd; dbl2 v; v.x = x; v.y = y; M.sxy[pos] = v; M.sd[pos] = dA; }
                 else err |= (uint32_t)ERR_CAND_OVERFLOW;
             }
@@ -664,7 +666,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         });
         __builtin_amdgcn_wave_barrier();
         PORRT_TACC_B(rc, 1);
-        if (tot <= kLdsHits) {
+        if (tot <= kHits) {
             connect_rrt_sample(rc, tm, L, grid, b, k, id, px, py, tot, err, nullptr, 0, clr_b,
                                [&]() { return group_nn_call<GL>(rc, b, tm.gl, tm.base, N, px, py); });
             PORRT_TACC_B(rc, 2);
@@ -673,7 +675,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             // join the rest in memory, and the whole wave serves the sample below
             heavy = true;
             if (tm.gl == 0) atomicAdd(&rc.cnt->n_heavy, 1u);
-            for (uint32_t a = tm.gl; a < kLdsHits; a += (uint32_t)GL) {
+            for (uint32_t a = tm.gl; a < kHits; a += (uint32_t)GL) {
                 M.sid[a] = L.hid[a];
                 dbl2 v;
                 v.x = L.hx[a]; v.y = L.hy[a];
