@@ -254,8 +254,12 @@ int porrt_get_metrics(const porrt_ctx *ctx, porrt_metrics *out);
  * step kernels: 16 / 32 / 64 lanes per sample, 0 = one wave per sample, -1 = chosen from the number
  * of contexts advanced together), "batch_streams" (on the FIRST context of a porrt_grow_batch: the
  * sub-batches it advances side by side, each on its own streams; 0 = 2 from 32 contexts on, else 1),
- * "pipeline" (RRT* steps of the one-wave-per-sample kernels: 1 (default) = step b + 1 is searched while step b is
- * connected, in one launch; 0 = one after the other), "dp_sweeps".  None of them changes a result. */
+ * "pipeline" (RRT* steps of the one-wave-per-sample kernels, i.e. of a single query: 0 = search, connect, commit one after the
+ * other; 1 = step b + 1 is searched while step b is connected, in one launch, the filing and the rewire commit in a second;
+ * 4 (default) = ONE launch per step: the filing of a step's nodes and its rewire commit run beside the next step's kernels
+ * (batch_K <= 1024, else as 1); 2 = all steps in one persistent cooperative launch with barriers over the grid (measured: far
+ * slower on eight XCDs, kept for the record), "kd_after" (1 = the tie-order structure is built after the last step instead of
+ * beside the steps: measured slower), "early_wave_steps", "dp_sweeps".  None of them changes a result. */
 int porrt_set_option(porrt_ctx *ctx, const char *name, int64_t value);
 
 /* Device arithmetic self-test: sqrt and divide of n doubles on the GPU versus the host's correctly

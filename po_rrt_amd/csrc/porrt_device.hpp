@@ -264,7 +264,8 @@ struct RunConst {
     // at which the loop condition ends the row.  Null: every row runs the launch's (i0, nb).
     uint32_t *sched_i0, *sched_nb;
     uint32_t sched_min, sched_max, sched_K, sched_steps;
-    uint32_t sched_max_nodes, pad_;     // nodes this grow may create (n_iter_max + 2): what its preparation clears
+    uint32_t sched_max_nodes;           // nodes this grow may create (n_iter_max + 2): what its preparation clears
+    uint32_t cand_par3;                 // 1: neighbour lists, counts and values in three buffers by step % 3 (cand_slot)
 };
 
 // Pointers read out of RunConst have no known address space, so hipcc emits flat_* accesses and drains both
@@ -294,9 +295,16 @@ __device__ __forceinline__ uint32_t row_i0(const RunConst &rc, uint32_t b, uint3
 
 // neighbour list of sample k in step b (parity buffers)
 __device__ __forceinline__ uint32_t q_off(const RunConst &rc, uint32_t b) { return (b & 1u) * rc.q_stride; }
-__device__ __forceinline__ size_t cand_off(const RunConst &rc, uint32_t b, uint32_t k) { return ((size_t)(b & 1u) * rc.cand_K + k) * rc.cand_cap; }
+// (two buffers by step parity; three, and the per-sample values too, when a step's lists are still read by the rewire commit while
+// the search two steps on writes: the one-kernel-per-step form of the single query, RunConst::cand_par3)
+__device__ __forceinline__ uint32_t cand_slot(const RunConst &rc, uint32_t b) { return rc.cand_par3 ? b % 3u : (b & 1u); }
+__device__ __forceinline__ size_t cand_off(const RunConst &rc, uint32_t b, uint32_t k) { return ((size_t)cand_slot(rc, b) * rc.cand_K + k) * rc.cand_cap; }
+__device__ __forceinline__ uint32_t cand_cnt_at(const RunConst &rc, uint32_t b, uint32_t k) { return cand_slot(rc, b) * rc.cand_K + k; }
+__device__ __forceinline__ size_t cand_val_off(const RunConst &rc, uint32_t b, uint32_t k) {
+    return rc.cand_par3 ? ((size_t)cand_slot(rc, b) * rc.cand_K + k) * rc.cand_cap : (size_t)k * rc.cand_cap;
+}
 __device__ __forceinline__ uint32_t cand_count(const RunConst &rc, uint32_t b, uint32_t k) {
-    const uint32_t c = as_global(rc.cand_cnt)[(b & 1u) * rc.cand_K + k];
+    const uint32_t c = as_global(rc.cand_cnt)[cand_cnt_at(rc, b, k)];
     return c < rc.cand_cap ? c : rc.cand_cap;
 }
 __device__ __forceinline__ unsigned long long f64_bits(double d) { return (unsigned long long)__double_as_longlong(d); }
@@ -617,7 +625,7 @@ __device__ __forceinline__ double nn_bound_wave(const RunConst &rc, uint32_t N, 
 // One WAVE serves one sample: lanes <-> the 64 slots of a page (coalesced 1 KiB + 256 B loads, four pages in
 // flight), hits are compacted with a ballot.
 __device__ __forceinline__ uint32_t rank_before(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k);
-__device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k, uint32_t lane, uint32_t stride = 64u);
+__device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k, uint32_t lane, uint32_t stride = 64u, bool lag = false);
 constexpr int kRG = 40;
 constexpr uint32_t kRegions = kRG * kRG;
 constexpr uint32_t kPage = 64;
@@ -859,7 +867,7 @@ __device__ __forceinline__ void near_sample(const RunConst &rc, uint32_t b, uint
         }
         tot += (uint32_t)__popcll(hm);
     });
-    if (lane == 0) as_global(rc.cand_cnt)[(b & 1u) * rc.cand_K + k] = tot;
+    if (lane == 0) as_global(rc.cand_cnt)[cand_cnt_at(rc, b, k)] = tot;
     if (over) atomicOr(&rc.cnt->err, (uint32_t)ERR_CAND_OVERFLOW);
 }
 
@@ -1308,7 +1316,7 @@ __device__ __forceinline__ GlobalList global_list(const RunConst &rc, uint32_t b
     GlobalList L;
     L.cid = as_global((const int *)rc.cand_id) + cand_off(rc, b, k);
     L.cxy = as_global(reinterpret_cast<const dbl2 *>(rc.cand_xy)) + cand_off(rc, b, k);
-    L.cval = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
+    L.cval = as_global(rc.cand_val) + cand_val_off(rc, b, k);
     L.gdA = as_global((const double *)rc.distA);
     return L;
 }
@@ -1360,14 +1368,16 @@ struct NoNearestSearch { __device__ int operator()() const { return 0; } };     
 template <class TeamT, class ListT, class Grid, class NNF = NoNearestSearch>
 __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const ListT &L, const Grid &grid, uint32_t b, uint32_t k, uint32_t id,
                                    double px, double py, uint32_t cnt, uint32_t &err, const uint32_t *clone_ids = nullptr, uint32_t n_clone = 0,
-                                   int clr_known = -1, NNF nearest_search = NNF()) {
+                                   int clr_known = -1, NNF nearest_search = NNF(), uint32_t swap = 0) {
+    // swap (the one-kernel-per-step form, k_step1_rrt): the two dist_root arrays trade places every step -- the step's snapshot is
+    // distB and its rewire accumulator distA on odd steps -- so that a step's rewire commit can run beside the next step's connect
     // clone_ids: further new nodes of this step at exactly (px, py), all with ids above `id` (the copies of the goal
     // point a step adds, rrt.rs:176-181).  The reference would run the same search n_clone + 1 times on the same
     // snapshot: same neighbours, same costs, same parent, same dist_root; of the rewires only the first copy's are
     // strict improvements (rrt.rs:157).  They get their nodes (and their own deferred-tie records) from this one pass.
     const uint32_t tl = tm.tl(), TS = TeamT::kSize;
     const int goal_kind = rc.goal_kind;
-    auto gdA = as_global(rc.distA);
+    auto gdA = as_global(swap ? rc.distB : rc.distA);
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
 
     // pass 1: raycast every neighbour, total cost through it (rrt.rs:124, 137-140).  A ray whose end pixels lie inside
@@ -1592,7 +1602,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
     }
     PORRT_TACC_B(rc, 6);
     // rewire phase 1 (rrt.rs:152-161): dist_root candidates, min wins
-    auto gdB = as_global(reinterpret_cast<unsigned long long *>(rc.distB));
+    auto gdB = as_global(reinterpret_cast<unsigned long long *>(swap ? rc.distA : rc.distB));
     if constexpr (ListT::kCompact) {
         // only the actual candidates are kept for the commit pass, compacted (rounds of one candidate per lane)
         {
@@ -1657,7 +1667,7 @@ constexpr uint32_t kHeavyCand = 256;     // samples with more neighbours than th
 // (one workgroup's kConnectWaves samples; bx = the workgroup's index among the step's connect workgroups)
 template <bool LDSGRID>
 __device__ __forceinline__ void connect_block(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords, uint32_t bx, uint8_t *lds_tiles, double *s_d, int *s_i,
-                                              uint32_t *s_heavy) {
+                                              uint32_t *s_heavy, uint32_t swap = 0) {
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t k = uni(bx * kConnectWaves + wv);
     const uint32_t qo = q_off(rc, b);
@@ -1680,7 +1690,9 @@ __device__ __forceinline__ void connect_block(const RunConst &rc, uint32_t b, ui
         tm.scr_d = nullptr; tm.scr_i = nullptr; tm.wave = 0; tm.lane = lane;
         const uint32_t id = uni(uni(as_global(rc.n_at)[b]) + rank_before(rc, b, vwords, k));            // k is wave-uniform: scalars
         const double px = uni_d(as_global(rc.q_x)[qo + k]), py = uni_d(as_global(rc.q_y)[qo + k]);
-        connect_rrt_sample(rc, tm, global_list(rc, b, k), grid, b, k, id, px, py, cnt, err);
+        GlobalList gl = global_list(rc, b, k);
+        if (swap) gl.gdA = as_global((const double *)rc.distB);
+        connect_rrt_sample(rc, tm, gl, grid, b, k, id, px, py, cnt, err, nullptr, 0, -1, NoNearestSearch(), swap);
     }
     __syncthreads();
     Team<kConnectWaves> tmh;
@@ -1696,7 +1708,9 @@ __device__ __forceinline__ void connect_block(const RunConst &rc, uint32_t b, ui
         __syncthreads();
         const uint32_t idh = uni(uni(as_global(rc.n_at)[b]) + rank_before(rc, b, vwords, kh));
         const double pxh = uni_d(as_global(rc.q_x)[qo + kh]), pyh = uni_d(as_global(rc.q_y)[qo + kh]);
-        connect_rrt_sample(rc, tmh, global_list(rc, b, kh), grid, b, kh, idh, pxh, pyh, hc, err);
+        GlobalList glh = global_list(rc, b, kh);
+        if (swap) glh.gdA = as_global((const double *)rc.distB);
+        connect_rrt_sample(rc, tmh, glh, grid, b, kh, idh, pxh, pyh, hc, err, nullptr, 0, -1, NoNearestSearch(), swap);
     }
     if (err) atomicOr(&rc.cnt->err, err);
 }
@@ -1736,6 +1750,168 @@ __global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per
     if (blockIdx.x < cblocks) { connect_block<LDSGRID>(rc, b, nb, vwords, blockIdx.x, lds_tiles, s_d, s_i, s_heavy); return; }
     const uint32_t k = uni((blockIdx.x - cblocks) * 4u + (threadIdx.x >> 6));
     if (k < nb_next) near_sample<false>(rc, b + 1u, i0_next, vwords, k, threadIdx.x & 63u);
+}
+
+// ---- one kernel per step (single query, option pipeline = 4)
+// The pipelined form above still has two kernels on a step's critical path, because two things wait for ALL of a phase: the filing
+// of a step's nodes for the step's searches, and the next connect pass for the rewire commit.  Neither has to:
+//   * the search of step b takes the nodes of steps < b - 1 from the pages and those of step b - 1 -- at most K, positions known
+//     since that step's search -- from the step's own arrays (near_sample_lag), so the filing of step b - 1 runs BESIDE it;
+//   * dist_root lives in two arrays that trade the roles of snapshot and rewire accumulator every step (connect_rrt_sample, swap),
+//     so the rewire commit of step b - 1 runs BESIDE the connect pass of step b (commit_rrt_sample, lag).
+// X(b) = connect(b) | search(b + 1) | file(b) | commit(b - 1): everything in it depends on X(b - 1) and nothing in it on anything else
+// in it.  One launch gap per step instead of two.
+// flat: the steered states of the step before, staged in LDS by the workgroup (one round trip for its four samples' two scans each)
+__device__ __forceinline__ void near_sample_lag(const RunConst &rc, uint32_t b, uint32_t i0, uint32_t vwords, uint32_t k, uint32_t lane, uint32_t nb_prev,
+                                                const dbl2 *flat) {
+    const uint32_t pb = b - 1u;
+    const uint32_t Np = uni(as_global(rc.n_at)[pb]);             // ids below it are in the pages (counts of parity pb & 1)
+    // the step before: its valid samples become the ids Np, Np + 1, ... in sample order; lane t holds word t of the mask
+    const unsigned long long word = lane < vwords ? as_global(rc.valid_mask)[(size_t)pb * vwords + lane] : 0ull;
+    uint32_t incl = (uint32_t)__popcll(word);
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if ((int)lane >= off) incl += v; }
+    const uint32_t excl = incl - (uint32_t)__popcll(word);
+    const uint32_t N = Np + uni(__shfl(incl, 63));
+    const double sqx = uni_d(as_global(rc.sx)[i0 + k]), sqy = uni_d(as_global(rc.sy)[i0 + k]);
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    const double T2 = rc.rad_T2[N];                             // rrt.rs:121: the size before insertion
+    double bestD = INF, bestx = 0.0, besty = 0.0, thr = INF;
+    int best = 0x7FFFFFFF;
+    auto take = [&](double x, double y, int id) {
+        const double d2 = dist2(x, y, sqx, sqy);
+        if (d2 > thr) return;
+        const double D = sqrt(d2);                               // the reference compares rounded distances
+        if (D < bestD || (D == bestD && id < best)) { bestD = D; best = id; bestx = x; besty = y; thr = d2 * (1.0 + 1e-15); }
+    };
+    auto wave_best = [&]() {
+        double rd = bestD;
+        int ri = best;
+        for (int off = 32; off > 0; off >>= 1) {
+            const double od = __shfl_xor(rd, off);
+            const int oi = __shfl_xor(ri, off);
+            if (od < rd || (od == rd && oi < ri)) { rd = od; ri = oi; }
+        }
+        const unsigned long long own = __ballot(best == ri && bestD == rd);
+        const int src = own ? (int)__builtin_ctzll(own) : 0;
+        thr = __shfl(thr, src); bestx = __shfl(bestx, src); besty = __shfl(besty, src);
+        bestD = rd; best = ri;
+    };
+    // the step before, from its arrays (all loads of a round are independent)
+    for (uint32_t t = 0; t * 64u < nb_prev; ++t) {
+        const unsigned long long w = __shfl(word, (int)t);
+        const uint32_t pre = __shfl(excl, (int)t);
+        if ((w >> lane) & 1ull) { const dbl2 v = flat[t * 64u + lane]; take(v.x, v.y, (int)(Np + pre + (uint32_t)__popcll(w & ((1ull << lane) - 1ull)))); }
+    }
+    wave_best();
+    {
+        auto visit = [&](double x, double y, int id, bool ok) { if (ok) take(x, y, id); };
+        const uint32_t own = uni(region_of(rc, sqx, sqy));
+        scan_disc(rc, pb, sqx, sqy, 0.0, Np, lane, visit);
+        wave_best();
+        double m2;
+        if (best != 0x7FFFFFFF) m2 = thr;
+        else { m2 = nn_bound_wave<false>(rc, Np, sqx, sqy, 0u, lane); thr = m2 * (1.0 + 1e-9); }
+        scan_disc(rc, pb, sqx, sqy, disc_radius(m2, sqx, sqy), Np, lane, visit, own);
+        wave_best();
+    }
+    const int nn = best == 0x7FFFFFFF ? 0 : best;
+    const double fx = best == 0x7FFFFFFF ? as_global(rc.nx)[0] : bestx, fy = best == 0x7FFFFFFF ? as_global(rc.ny)[0] : besty;
+    double tx = sqx, ty = sqy;
+    double step = fabs(tx - fx);                                  // common.rs:215-225
+    step += fabs(ty - fy);
+    if (step > rc.max_step) {
+        const double lambda = rc.max_step / step;
+        double ux = (tx - fx) * lambda, uy = (ty - fy) * lambda;
+        tx = fx + ux;
+        ty = fy + uy;
+    }
+    uint32_t err = 0;
+    bool valid = true;
+    if (rc.has_grid) {
+        const int cls = state_class(rc, tx, ty, &err);
+        valid = cls == CLS_FREE && !err;                           // RTTFuncs adapter (tamp_rrt.rs:40-42)
+    }
+    if (lane == 0) {
+        const uint32_t qo = q_off(rc, b);
+        as_global(rc.q_x)[qo + k] = tx;
+        as_global(rc.q_y)[qo + k] = ty;
+        const size_t o2 = (size_t)b * rc.part_stride + k;
+        as_global(rc.kq_x)[o2] = tx; as_global(rc.kq_y)[o2] = ty; as_global(rc.kq_vid)[o2] = valid ? 0 : -1;
+        as_global(rc.q_nn)[qo + k] = nn;
+        as_global(rc.q_vid)[qo + k] = valid ? 0 : -1;
+        if (valid) atomicOr(&rc.valid_mask[(size_t)b * vwords + (k >> 6)], 1ull << (k & 63u));
+        if (err) atomicOr(&rc.cnt->err, err);
+    }
+    if (!valid) return;
+    auto cid = as_global(rc.cand_id) + cand_off(rc, b, k);
+    auto cxy = as_global(reinterpret_cast<dbl2 *>(rc.cand_xy)) + cand_off(rc, b, k);
+    const uint32_t cap = rc.cand_cap;
+    uint32_t tot = 0;
+    bool over = false;
+    auto hit = [&](double x, double y, int id, bool in) {
+        const unsigned long long hm = __ballot(in);
+        const uint32_t pos = tot + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+        if (in) {
+            if (pos < cap) { cid[pos] = id; dbl2 v; v.x = x; v.y = y; cxy[pos] = v; }
+            else over = true;
+        }
+        tot += (uint32_t)__popcll(hm);
+    };
+    scan_disc(rc, pb, tx, ty, disc_radius(T2, tx, ty), Np, lane, [&](double x, double y, int id, bool ok) { hit(x, y, id, ok && dist2(x, y, tx, ty) <= T2); });
+    for (uint32_t t = 0; t * 64u < nb_prev; ++t) {
+        const unsigned long long w = __shfl(word, (int)t);
+        const uint32_t pre = __shfl(excl, (int)t);
+        const uint32_t kk = t * 64u + lane;
+        const dbl2 v = kk < nb_prev ? flat[kk] : dbl2{0.0, 0.0};
+        const bool in = ((w >> lane) & 1ull) && dist2(v.x, v.y, tx, ty) <= T2;
+        hit(v.x, v.y, (int)(Np + pre + (uint32_t)__popcll(w & ((1ull << lane) - 1ull))), in);
+    }
+    if (lane == 0) as_global(rc.cand_cnt)[cand_cnt_at(rc, b, k)] = tot;
+    if (over) atomicOr(&rc.cnt->err, (uint32_t)ERR_CAND_OVERFLOW);
+}
+
+// X(b): workgroups [file(b)] [connect(b)] [search(b + 1)] [commit(cb): cnb samples, cb = b - 1 or none]
+template <bool LDSGRID>
+__global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_step1_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
+                                                                   uint32_t i0_next, uint32_t nb_next, uint32_t vwords, uint32_t cb, uint32_t cnb) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_tiles[];
+    __shared__ double s_d[kConnectWaves];
+    __shared__ int s_i[kConnectWaves];
+    __shared__ uint32_t s_heavy[kConnectWaves];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ins[kFileLds];
+    const RunConst &rc = rcp[blockIdx.y];
+    // in launch order: the filing (one workgroup's chain of phases: it must start first), the connect pass (the longest waves),
+    // the searches, the rewire commit (short)
+    const uint32_t cblocks = (nb + kConnectWaves - 1u) / kConnectWaves, sblocks = (nb_next + 3u) / 4u;
+    uint32_t bx = blockIdx.x;
+    if (bx == 0) { file_step_fast<kConnectWaves * 64u>(rc, b, nb, vwords, s_ins); return; }
+    bx -= 1u;
+    if (bx < cblocks) { connect_block<LDSGRID>(rc, b, nb, vwords, bx, lds_tiles, s_d, s_i, s_heavy, b & 1u); return; }
+    bx -= cblocks;
+    if (bx < sblocks) {
+        // the step's own steered states, once per workgroup (the filing scratch is free in a search workgroup; nb <= 1024)
+        dbl2 *flat = reinterpret_cast<dbl2 *>(s_ins);
+        {
+            const uint32_t qp = q_off(rc, b);
+            auto pqx = as_global(rc.q_x) + qp, pqy = as_global(rc.q_y) + qp;
+            double fx[4], fy[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                const uint32_t kk = u * 256u + threadIdx.x;
+                fx[u] = kk < nb ? pqx[kk] : 0.0;
+                fy[u] = kk < nb ? pqy[kk] : 0.0;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) { dbl2 v; v.x = fx[u]; v.y = fy[u]; flat[u * 256u + threadIdx.x] = v; }
+        }
+        __syncthreads();
+        const uint32_t k = uni(bx * 4u + (threadIdx.x >> 6));
+        if (k < nb_next) near_sample_lag(rc, b + 1u, i0_next, vwords, k, threadIdx.x & 63u, nb, flat);
+        return;
+    }
+    bx -= sblocks;
+    const uint32_t ck = uni(bx * 4u + (threadIdx.x >> 6));
+    if (ck < cnb) commit_rrt_sample(rc, cb, vwords, ck, threadIdx.x & 63u, 64u, true);
 }
 
 // F(bf): block 0 files step bf's nodes (positions and validity are final since its search), the others run the rewire phase
@@ -1835,14 +2011,19 @@ __global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per
 
 // RRT*: rewire phase 2 for sample k of step b (one wave).  A pair wins iff its candidate equals the accumulated
 // minimum; among equal candidates the lowest new id wins (sequential order of the reference, strict `<`, rrt.rs:157).
-__device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k, uint32_t lane, uint32_t stride) {
+// lag (the one-kernel-per-step form): the step's accumulator and its snapshot are distB / distA on even steps and the other way
+// round on odd ones, the commit runs beside the next step's connect pass -- which reads the accumulator as ITS snapshot and
+// accumulates into the other array -- and carries the winners' values over with an atomic minimum (commutes with that pass).
+__device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k, uint32_t lane, uint32_t stride, bool lag) {
     if (!((as_global(rc.valid_mask)[(size_t)b * vwords + (k >> 6)] >> (k & 63u)) & 1ull)) return;
     const uint32_t N = as_global(rc.n_at)[b];
     const int id = (int)(N + (stride < 64u ? rank_before_lanes(rc, b, vwords, k, lane, stride) : rank_before(rc, b, vwords, k)));
     const uint32_t cnt = cand_count(rc, b, k);
     auto cid = as_global(rc.cand_id) + cand_off(rc, b, k);
-    auto cval = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
-    auto gdB = as_global(rc.distB);
+    auto cval = as_global(rc.cand_val) + cand_val_off(rc, b, k);
+    const bool odd = lag && (b & 1u);
+    auto gdB = as_global(odd ? rc.distA : rc.distB);                                       // what the step's connect pass accumulated into
+    auto gother = as_global(reinterpret_cast<unsigned long long *>(odd ? rc.distB : rc.distA));
     auto gpd = as_global(rc.pg_d);
     auto gso = as_global(rc.slot_of);
     // the new node's own dist_root goes to its page slot (filed by insert_step_pages beside the connect pass)
@@ -1871,16 +2052,17 @@ __device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vword
                 if (__hip_atomic_compare_exchange_strong(gpar, &expect, id, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                 old = expect;
             }
-            as_global(rc.distA)[j[u]] = via[u];
+            if (lag) g_atomic_min(gother + j[u], f64_bits(via[u]));
+            else as_global(rc.distA)[j[u]] = via[u];
             gpd[gso[j[u]]] = via[u];
         }
     }
 }
 
 // stand-alone form (last step of a launch sequence)
-__global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
+__global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords, uint32_t lag) {
     const uint32_t k = uni((blockIdx.x * 256u + threadIdx.x) >> 6);
-    if (k < nb && k < row_nb(rcp[blockIdx.y], b, nb)) commit_rrt_sample(rcp[blockIdx.y], b, vwords, k, threadIdx.x & 63u);
+    if (k < nb && k < row_nb(rcp[blockIdx.y], b, nb)) commit_rrt_sample(rcp[blockIdx.y], b, vwords, k, threadIdx.x & 63u, 64u, lag != 0u);
 }
 
 // Insert this step's nodes into the reference's kd-tree in id order (KdTree::add, nearest_neighbor.rs:29-46;
@@ -1962,10 +2144,25 @@ __device__ __forceinline__ void kd_descend(const RunConst &rc, uint32_t Nsnap, d
 // LPN = lanes per node: 64 (one wave per node: shortest latency, used when a launch has few nodes) or 1 (one thread
 // per node, the non-duplicate levels of G staged in LDS: 64x fewer waves, used when many contexts are grown together
 // and the GPU is short of wave slots, not of time).
+constexpr uint32_t kTieParts = 8;        // workgroups that look at the deferred ties when they ride in another kernel
+__device__ __forceinline__ void kd_hint_block(const RunConst &rc, uint32_t b0, uint32_t nsteps, uint32_t vwords, uint32_t bx);
+template <int T>
+__device__ __forceinline__ void tie_fix_block(const RunConst &rc, uint32_t part, uint32_t nparts);
+// hb0, hns (hns > 0: a single query's side chain): the workgroups after the locating ones raise the hints of the group BEFORE this
+// one (steps hb0 .. hb0 + hns - 1; a descent may start at any node whose cell holds the point, so hints that change under
+// the descents are as good as the old ones) and look at the deferred ties -- two kernels less on the chain locate -> link -> claim.
 template <int LPN>
 __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t K, uint32_t nb_last,
-                                                    uint32_t vwords, uint32_t lpar) {
+                                                    uint32_t vwords, uint32_t lpar, uint32_t hb0 = 0, uint32_t hns = 0) {
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
+    if (hns) {
+        const uint32_t lb = LPN == 64 ? (nsteps * K * 64u + 255u) / 256u : (nsteps * K + 255u) / 256u;
+        if (blockIdx.x >= lb) {
+            if (blockIdx.x + kTieParts >= gridDim.x) tie_fix_block<256>(rc, blockIdx.x + kTieParts - gridDim.x, kTieParts);
+            else kd_hint_block(rc, hb0, hns, vwords, blockIdx.x - lb);
+            return;
+        }
+    }
     if (lpar & kWaitFiled) { if (!coop_wait_filed(rc, b0 + nsteps)) return; lpar &= ~kWaitFiled; }
     const uint32_t lane = LPN == 64 ? (threadIdx.x & 63u) : 0u;
     const uint32_t wid = LPN == 64 ? blockIdx.x * 4u + (threadIdx.x >> 6) : blockIdx.x * 256u + threadIdx.x;
@@ -2164,11 +2361,14 @@ __global__ __launch_bounds__(256) void k_kd_link(const RunConst *__restrict__ rc
 
 // CAP: the most nodes a launch may hold (the slots in LDS, the losers in registers); the engine takes the smaller form when the
 // group's steps cannot hold more -- beside the step kernels every KB of LDS counts.
-template <uint32_t CAP>
+// LDSXY (a single query: the GPU's LDS is idle): the new nodes' coordinates are staged in LDS, so that a round's "step below the
+// winner" reads them there instead of through a dependent load from memory -- the rounds are this kernel's whole run time.
+template <uint32_t CAP, bool LDSXY = false>
 __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords) {
     static_assert(CAP % 1024u == 0 && CAP <= kClaimMax, "k_kd_claim: CAP");
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     __shared__ int s_ch[CAP][2];
+    __shared__ dbl2 s_xy[LDSXY ? CAP : 1];
     __shared__ uint32_t s_nact;
     __shared__ KdMove s_tail[64];
     const uint32_t N = as_global(rc.n_at)[b0], b = b0 + nsteps - 1u;
@@ -2177,7 +2377,10 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
     const uint32_t n_l = rc.cnt->n_losers;
     auto grec = as_global(rc.kd_rec);
     if (n_l) {
-        for (uint32_t t = threadIdx.x; t < n_new; t += 1024u) { s_ch[t][0] = kEmpty; s_ch[t][1] = kEmpty; }
+        for (uint32_t t = threadIdx.x; t < n_new; t += 1024u) {
+            s_ch[t][0] = kEmpty; s_ch[t][1] = kEmpty;
+            if (LDSXY) { dbl2 v; v.x = grec[N + t].x; v.y = grec[N + t].y; s_xy[t] = v; }
+        }
         constexpr int kPer = CAP / 1024;
         bool todo[kPer];
         KdMove mv[kPer];
@@ -2196,6 +2399,7 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
         auto settle = [&](KdMove &m, bool &td) {            // after the bids of a round
             const int w = s_ch[m.cur][m.side];
             if (w == (int)m.t) { kd_publish(rc, N, m, (int)(N + (uint32_t)m.cur)); td = false; }
+            else if (LDSXY) { const dbl2 v = s_xy[w]; kd_step_below(rc, m, (uint32_t)w, v.x, v.y); }
             else kd_step_below(rc, m, (uint32_t)w, grec[N + (uint32_t)w].x, grec[N + (uint32_t)w].y);
         };
         for (;;) {
@@ -2288,14 +2492,13 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
 // will ever fall into that square; the deepest such node is the best place to start a descent.  The squares between
 // cell(lo) and cell(hi), both excluded, lie inside [lo, hi) because the cell function is monotone; an infinite
 // bound includes the clamped border square.  hint = max over (depth, id), a commutative update.
-__global__ __launch_bounds__(256) void k_kd_hint(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords) {
-    const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
+__device__ __forceinline__ void kd_hint_block(const RunConst &rc, uint32_t b0, uint32_t nsteps, uint32_t vwords, uint32_t bx) {
     // One thread per new node: late in a run a node's cell covers no whole square, or a few, and the thread raises
     // them itself; the rare big cells (young tree) are parked in LDS and shared out to the workgroup's waves.
     __shared__ uint32_t s_nbig, s_big_id[256];
     __shared__ int s_big_r[256][4];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t t = bx * 256u + threadIdx.x;
     const uint32_t n_new = kd_group_size(rc, b0, nsteps, vwords);
     if (threadIdx.x == 0) s_nbig = 0;
     __syncthreads();
@@ -2342,8 +2545,7 @@ __global__ __launch_bounds__(256) void k_kd_hint(const RunConst *__restrict__ rc
 // once more at the end of a run.  The parent is only installed if no rewire replaced the placeholder in the
 // meantime (a rewire is final, rrt.rs:152-161).
 template <int T>
-__global__ __launch_bounds__(T) void k_tie_fix(const RunConst *__restrict__ rcp) {
-    const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
+__device__ __forceinline__ void tie_fix_block(const RunConst &rc, uint32_t part, uint32_t nparts) {
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     uint32_t n = __hip_atomic_load(&rc.cnt->pend_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     n = n < rc.pend_cap ? n : rc.pend_cap;
@@ -2351,7 +2553,7 @@ __global__ __launch_bounds__(T) void k_tie_fix(const RunConst *__restrict__ rcp)
     const uint32_t kd_done = __hip_atomic_load(&rc.cnt->kd_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     Team<1> tm;
     tm.scr_d = nullptr; tm.scr_i = nullptr; tm.wave = 0; tm.lane = lane;
-    for (uint32_t p = lo + wv; p < n; p += (uint32_t)(T / 64)) {
+    for (uint32_t p = lo + part * (uint32_t)(T / 64) + wv; p < n; p += nparts * (uint32_t)(T / 64)) {        // (records striped over the workgroups that look at them)
         if (__hip_atomic_load(&rc.pend_state[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1u) continue;
         const uint32_t base = as_global(rc.pend_off)[p], m = as_global(rc.pend_n)[p];
         int mx = -1;
@@ -2377,11 +2579,23 @@ __global__ __launch_bounds__(T) void k_tie_fix(const RunConst *__restrict__ rcp)
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {       // records settle roughly in order: skip the settled prefix next time
+    if (threadIdx.x == 0 && part == 0) {       // records settle roughly in order: skip the settled prefix next time
         uint32_t l = lo;
         while (l < n && __hip_atomic_load(&rc.pend_state[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u) ++l;
         rc.cnt->pend_lo = l;
     }
+}
+template <int T>
+__global__ __launch_bounds__(T) void k_tie_fix(const RunConst *__restrict__ rcp) {
+    tie_fix_block<T>(rcp[blockIdx.y], 0u, 1u);      // one context per grid row (porrt_grow_batch)
+}
+__global__ __launch_bounds__(256) void k_kd_hint(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords) {
+    kd_hint_block(rcp[blockIdx.y], b0, nsteps, vwords, blockIdx.x);      // one context per grid row (porrt_grow_batch)
+}
+// the same with the deferred ties looked at by one more workgroup (a single query's side chain: one kernel less on it)
+__global__ __launch_bounds__(256) void k_kd_hint_fix(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords) {
+    if (blockIdx.x + kTieParts >= gridDim.x) { tie_fix_block<256>(rcp[blockIdx.y], blockIdx.x + kTieParts - gridDim.x, kTieParts); return; }
+    kd_hint_block(rcp[blockIdx.y], b0, nsteps, vwords, blockIdx.x);
 }
 
 // PTO: edges to every neighbour with a valid transition, reachability phase 1 and 2 (pto.rs:95-124)
@@ -2411,14 +2625,14 @@ __global__ __launch_bounds__(kConnectWaves * 64) void k_connect_pto(const RunCon
     const uint32_t id = N + rank_before(rc, b, vwords, k);
     uint32_t cnt = cand_count(rc, b, k);
     int *cid = rc.cand_id + cand_off(rc, b, k);
-    double *cval = rc.cand_val + (size_t)k * rc.cand_cap;
+    double *cval = rc.cand_val + cand_val_off(rc, b, k);
     dbl2 *cxy = reinterpret_cast<dbl2 *>(rc.cand_xy) + cand_off(rc, b, k);
     if (cnt == 0) {                       // pto.rs:99: nobody in range -> the nearest node
         if (lane == 0) {                  // lane 0 is also the only reader of slot 0
             const int nn = as_global(rc.q_nn)[k];
             dbl2 v;
             v.x = as_global(rc.nx)[nn]; v.y = as_global(rc.ny)[nn];
-            cid[0] = nn; cxy[0] = v; as_global(rc.cand_cnt)[(b & 1u) * rc.cand_K + k] = 1;
+            cid[0] = nn; cxy[0] = v; as_global(rc.cand_cnt)[cand_cnt_at(rc, b, k)] = 1;
         }
         cnt = 1;
     }
@@ -2501,7 +2715,7 @@ __global__ __launch_bounds__(256) void k_commit_pto(const RunConst *__restrict__
     if (k >= nb || as_global(rc.q_vid)[k] < 0) return;
     const uint32_t cnt = cand_count(rc, b, k);
     const int *cid = rc.cand_id + cand_off(rc, b, k);
-    const double *cval = rc.cand_val + (size_t)k * rc.cand_cap;
+    const double *cval = rc.cand_val + cand_val_off(rc, b, k);
     for (uint32_t a = lane; a < cnt; a += 64) {
         if ((int)cval[a] < 0) continue;
         const int j = cid[a];

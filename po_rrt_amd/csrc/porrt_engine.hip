@@ -203,10 +203,14 @@ struct porrt_ctx {
     uint32_t opt_batch_streams = 0;
     // "pipeline": RRT* steps of the one-wave-per-sample kernels as k_step_rrt / k_file_commit (step b + 1 is searched while step
     // b is connected: the chain of dependent kernels of a single query is max(search, connect) + file per step instead of
-    // search + connect: 5.9 against 6.65 ms on the bench's query).  1 (default) / 0.  2: the same phases as ONE persistent launch
+    // search + connect: 5.9 against 6.65 ms on the bench's query).  1 / 0.  4 (default) below.  2: the same phases as ONE persistent launch
     // (k_coop_rrt: barriers over the grid instead of kernel boundaries, a cooperative launch; for batch_K <= 1024, else as 1).
-    int opt_pipeline = 1;
+    // 4: ONE kernel per step (k_step1_rrt: the filing of a step's nodes and its rewire commit run beside the next step; for
+    // batch_K <= 1024, else as 1).
+    int opt_pipeline = 4;
     bool pipe_on = false;                  // the choice in force for the running launch sequence (set with opt_group)
+    bool lag_on = false;                   // pipeline = 4: one kernel per step (k_step1_rrt); the data layout is the pipelined one (pipe_on)
+    uint32_t lag_near_done = 0xFFFFFFFFu;  //   the step whose search is already launched
     uint32_t pipe_near_done = 0xFFFFFFFFu; // pipelined: the step whose search and filing are already launched
     // porrt_get_trees (first context of the call): pinned staging slots and copy streams, one per worker thread
     std::vector<void *> dl_pin;
@@ -336,9 +340,10 @@ struct porrt_ctx {
         return PORRT_OK;
     }
     uint32_t kd_b0 = 0, kd_last_b = 0, kd_last_nb = 0, kd_group = 1, kd_gidx = 0;
+    uint32_t kd_hint_b0 = 0, kd_hint_ns = 0;   // single query: the group whose hints and deferred ties ride in the next group's locate kernel
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev_step_done = nullptr, ev_kd[2] = {nullptr, nullptr}, ev_steered = nullptr;
-    bool kd_pend[2] = {false, false}, side_active = false;
+    hipEvent_t ev_step_done = nullptr, ev_kd[3] = {nullptr, nullptr, nullptr}, ev_steered = nullptr;
+    bool kd_pend[3] = {false, false, false}, side_active = false;
     // cached hipGraph of the steps up to n_iter_min
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_key[6] = {0, 0, 0, 0, 0, 0};
@@ -598,6 +603,29 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
         if (prof && ev_used < ev_pool.size()) (void)hipEventRecord(ev_pool[ev_used++], stream);
     };
     const bool rrt = mode == PORRT_MODE_RRT;
+    if (rrt && lag_on && opt_group == 0) {
+        // one kernel per step: [k_near(b) unless its search rode in the step before]  X(b) = connect(b) | search(b + 1) | file(b) | commit(b - 1)
+        ev();
+        if (lag_near_done != b) {
+            // (everything before step b is filed -- the start of a run, or after a join: the plain search over the pages)
+            hipLaunchKernelGGL(k_near<false>, dim3(wave_blocks, Q), dim3(256), 0, stream, rcp, b, i0, nb, vwords, 0xFFFFFFFFu, 0u);
+        }
+        ev();
+        (void)hipEventRecord(ev_steered, stream);          // positions and ids of step b are final
+        ev();
+        const uint32_t cb4 = (nb + kConnectWaves - 1) / kConnectWaves;
+        const uint32_t cnb = commit_pend_b != 0xFFFFFFFFu ? commit_pend_nb : 0u;
+        const dim3 xg(cb4 + (nxt_nb + 3) / 4 + 1 + (cnb + 3) / 4, Q);
+        if (lds_bytes) hipLaunchKernelGGL(k_step1_rrt<true>, xg, dim3(256), lds_bytes, stream, rcp, b, nb, nxt_i0, nxt_nb, vwords, commit_pend_b, cnb);
+        else hipLaunchKernelGGL(k_step1_rrt<false>, xg, dim3(256), 0, stream, rcp, b, nb, nxt_i0, nxt_nb, vwords, commit_pend_b, cnb);
+        ev();
+        lag_near_done = nxt_nb ? b + 1 : 0xFFFFFFFFu;
+        commit_pend_b = b; commit_pend_nb = nb;
+        kd_last_b = b; kd_last_nb = nb;
+        side_active = true;
+        if (!opt_kd_after && b + 1 - kd_b0 >= kd_group) launch_kd_group();
+        return;
+    }
     if (rrt && pipe_on && opt_group == 0) {
         // pipelined steps (k_step_rrt): [k_near(b), F(b) unless launched ahead]  S(b) = connect(b) + search(b + 1)  F(b + 1)
         const uint32_t cb4 = (nb + kConnectWaves - 1) / kConnectWaves;
@@ -689,22 +717,38 @@ void porrt_ctx::launch_kd_group() {
     const uint32_t nsteps = kd_last_b - kd_b0 + 1, K = rc.cand_K, vwords = (K + 63) / 64;
     (void)hipStreamWaitEvent(stream2, ev_steered, 0);
     // few nodes: one wave per node (latency); many (several contexts at once): one thread per node (wave slots)
-    if ((uint64_t)nsteps * K * Q >= 4096u) hipLaunchKernelGGL(k_kd_locate<1>, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u);
-    else hipLaunchKernelGGL(k_kd_locate<64>, dim3((nsteps * K * 64 + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u);
+    // (a single query leaves most of the GPU idle: a wave per node whatever the group's size)
+    if (Q > 1 && (uint64_t)nsteps * K * Q >= 4096u) hipLaunchKernelGGL(k_kd_locate<1>, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u, 0u, 0u);
+    else if (Q > 1) hipLaunchKernelGGL(k_kd_locate<64>, dim3((nsteps * K * 64 + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u, 0u, 0u);
+    else {
+        // (a thread per node from 4096 nodes on: a wave per node is no faster there and takes the step kernels' wave slots)
+        const uint32_t extra = kd_hint_ns ? (kd_hint_ns * K + 255) / 256 + kTieParts : 0;
+        if ((uint64_t)nsteps * K >= 4096u) hipLaunchKernelGGL(k_kd_locate<1>, dim3((nsteps * K + 255) / 256 + extra, 1), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u, kd_hint_b0, kd_hint_ns);
+        else hipLaunchKernelGGL(k_kd_locate<64>, dim3((nsteps * K * 64 + 255) / 256 + extra, 1), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u, kd_hint_b0, kd_hint_ns);
+    }
     hipLaunchKernelGGL(k_kd_link, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords, 0u);
-    if ((uint64_t)nsteps * K <= 2048u) hipLaunchKernelGGL(k_kd_claim<2048>, dim3(1, Q), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
+    if (Q == 1) hipLaunchKernelGGL((k_kd_claim<kClaimMax, true>), dim3(1, 1), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
+    else if ((uint64_t)nsteps * K <= 2048u) hipLaunchKernelGGL(k_kd_claim<2048>, dim3(1, Q), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
     else hipLaunchKernelGGL(k_kd_claim<kClaimMax>, dim3(1, Q), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
-    hipLaunchKernelGGL(k_kd_hint, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords);
-    (void)hipEventRecord(ev_step_done, stream);
-    (void)hipStreamWaitEvent(stream2, ev_step_done, 0);
-    if (Q > 1) hipLaunchKernelGGL(k_tie_fix<256>, dim3(1, Q), dim3(256), 0, stream2, rcp);
-    else hipLaunchKernelGGL(k_tie_fix<1024>, dim3(1, Q), dim3(1024), 0, stream2, rcp);
+    if (Q == 1) {
+        // this group's hints and the deferred ties ride in the NEXT group's locate kernel (a record's placeholder parent is in
+        // place before the record can be seen: nothing to wait for on the main stream); join_side launches the last ones
+        kd_hint_b0 = kd_b0; kd_hint_ns = nsteps;
+    } else {
+        hipLaunchKernelGGL(k_kd_hint, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords);
+        (void)hipEventRecord(ev_step_done, stream);
+        (void)hipStreamWaitEvent(stream2, ev_step_done, 0);
+        hipLaunchKernelGGL(k_tie_fix<256>, dim3(1, Q), dim3(256), 0, stream2, rcp);
+    }
     // A lagging join: the main stream waits for the group BEFORE this one, which had a whole group of steps to finish.
     // It bounds how far the kd structure may fall behind and keeps a replayed hipGraph from running the side branch last.
-    const uint32_t par = kd_gidx & 1u;
+    // (a single query waits for the group before THAT: its first groups -- thousands of nodes into a tree of a few -- take several
+    // times as long as four steps, and the ties they leave deferred are few)
+    const uint32_t ring = Q == 1 ? 3u : 2u;
+    const uint32_t par = kd_gidx % ring, oldest = (kd_gidx + 1u) % ring;
     (void)hipEventRecord(ev_kd[par], stream2);
     kd_pend[par] = true;
-    if (kd_pend[par ^ 1u]) { (void)hipStreamWaitEvent(stream, ev_kd[par ^ 1u], 0); kd_pend[par ^ 1u] = false; }
+    if (kd_pend[oldest]) { (void)hipStreamWaitEvent(stream, ev_kd[oldest], 0); kd_pend[oldest] = false; }
     ++kd_gidx;
     kd_b0 = kd_last_b + 1;
 }
@@ -728,7 +772,7 @@ void porrt_ctx::flush_commit() {
     const uint32_t vwords = (rc.cand_K + 63) / 64;
     if (opt_group == 16) hipLaunchKernelGGL(k_commit2<16>, dim3((commit_pend_nb * 16 + 255) / 256, launch_Q), dim3(256), 0, stream, launch_rcp, commit_pend_b, commit_pend_nb, vwords);
     else if (opt_group == 32) hipLaunchKernelGGL(k_commit2<32>, dim3((commit_pend_nb * 32 + 255) / 256, launch_Q), dim3(256), 0, stream, launch_rcp, commit_pend_b, commit_pend_nb, vwords);
-    else hipLaunchKernelGGL(k_commit_rrt, dim3((commit_pend_nb * 64 + 255) / 256, launch_Q), dim3(256), 0, stream, launch_rcp, commit_pend_b, commit_pend_nb, vwords);
+    else hipLaunchKernelGGL(k_commit_rrt, dim3((commit_pend_nb * 64 + 255) / 256, launch_Q), dim3(256), 0, stream, launch_rcp, commit_pend_b, commit_pend_nb, vwords, lag_on ? 1u : 0u);
     commit_pend_b = 0xFFFFFFFFu;
 }
 
@@ -771,7 +815,7 @@ int porrt_ctx::launch_coop(uint32_t n_steps, uint32_t K, uint64_t n_iter, uint32
     (void)hipEventRecord(ev_join, stream2);
     (void)hipStreamWaitEvent(stream, ev_join, 0);
     hipLaunchKernelGGL(k_tie_fix<1024>, dim3(1, 1), dim3(1024), 0, stream, rcp);
-    kd_pend[0] = kd_pend[1] = false;
+    kd_pend[0] = kd_pend[1] = kd_pend[2] = false;
     side_active = false;
     commit_pend_b = 0xFFFFFFFFu;
     pipe_near_done = 0xFFFFFFFFu;
@@ -803,9 +847,13 @@ void porrt_ctx::join_side() {
         return;
     }
     launch_kd_group();
+    if (kd_hint_ns) {
+        hipLaunchKernelGGL(k_kd_hint_fix, dim3((kd_hint_ns * rc.cand_K + 255) / 256 + kTieParts, 1), dim3(256), 0, stream2, launch_rcp, kd_hint_b0, kd_hint_ns, (rc.cand_K + 63) / 64);
+        kd_hint_ns = 0;
+    }
     (void)hipEventRecord(ev_join, stream2);
     (void)hipStreamWaitEvent(stream, ev_join, 0);
-    kd_pend[0] = kd_pend[1] = false;
+    kd_pend[0] = kd_pend[1] = kd_pend[2] = false;
     if (launch_Q > 1) hipLaunchKernelGGL(k_tie_fix<256>, dim3(1, launch_Q), dim3(256), 0, stream, launch_rcp);
     else hipLaunchKernelGGL(k_tie_fix<1024>, dim3(1, launch_Q), dim3(1024), 0, stream, launch_rcp);
     side_active = false;
@@ -877,11 +925,11 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         const uint64_t rg_maxp = Nmax / kPage + 2, pg_cap = 2ull * kRegions + Nmax / kPage + 8;
         HIPCHK(d_rgcnt.reserve(2 * kRegions)); HIPCHK(d_rgocc.reserve(2 * kOccWords)); HIPCHK(d_rgdir.reserve((size_t)kRegions * rg_maxp));
         HIPCHK(d_pgxy.reserve(2 * (size_t)pg_cap * kPage)); HIPCHK(d_pgid.reserve((size_t)pg_cap * kPage)); HIPCHK(d_pgd.reserve((size_t)pg_cap * kPage)); HIPCHK(d_slotof.reserve(Nmax));
-        HIPCHK(d_candcnt.reserve(2 * (size_t)K)); HIPCHK(d_kdbox.reserve(Nmax)); HIPCHK(d_kdlosers.reserve(kClaimMax)); HIPCHK(d_bcscratch.reserve(8 * Nmax + 4096)); HIPCHK(d_bcout.reserve(1)); HIPCHK(d_bccursor.reserve(1)); HIPCHK(d_locbox.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_kdhint.reserve((size_t)kHG * kHG));
+        HIPCHK(d_candcnt.reserve(3 * (size_t)K)); HIPCHK(d_kdbox.reserve(Nmax)); HIPCHK(d_kdlosers.reserve(kClaimMax)); HIPCHK(d_bcscratch.reserve(8 * Nmax + 4096)); HIPCHK(d_bcout.reserve(1)); HIPCHK(d_bccursor.reserve(1)); HIPCHK(d_locbox.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_kdhint.reserve((size_t)kHG * kHG));
         HIPCHK(d_loccur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locdcur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locgex.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locflags.reserve(2 * (8 * (size_t)K + 4096)));
         HIPCHK(d_gsnap.reserve((steps_max + 4) * 4)); HIPCHK(d_pendoff.reserve(pend_cap)); HIPCHK(d_pendn.reserve(pend_cap)); HIPCHK(d_pendcur.reserve(pend_cap));
         HIPCHK(d_pendstate.reserve(pend_cap)); HIPCHK(d_pendnew.reserve(pend_cap)); HIPCHK(d_pendpool.reserve(pool_cap)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_gndx.reserve(Nmax)); HIPCHK(d_gndy.reserve(Nmax));
-        HIPCHK(d_kqx.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kqy.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kqvid.reserve((steps_max + 2) * Kpad)); HIPCHK(d_candid.reserve(2 * (size_t)K * cand_cap)); HIPCHK(d_candxy.reserve(4 * (size_t)K * cand_cap)); HIPCHK(d_candval.reserve((size_t)K * cand_cap));
+        HIPCHK(d_kqx.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kqy.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kqvid.reserve((steps_max + 2) * Kpad)); { const size_t np = (opt_pipeline == 4 && stage != 1 && K <= 1024) ? 3u : 2u; HIPCHK(d_candid.reserve(np * (size_t)K * cand_cap)); HIPCHK(d_candxy.reserve(2 * np * (size_t)K * cand_cap)); HIPCHK(d_candval.reserve((np == 3u ? 3u : 1u) * (size_t)K * cand_cap)); }
         HIPCHK(d_gid.reserve(Nmax));
         HIPCHK(d_perm.reserve((steps_max + 2) * Kpad)); HIPCHK(d_ssx.reserve((steps_max + 2) * Kpad)); HIPCHK(d_ssy.reserve((steps_max + 2) * Kpad));
         HIPCHK(d_bqx.reserve(Kpad)); HIPCHK(d_bqy.reserve(Kpad)); HIPCHK(d_bqk.reserve(Kpad)); HIPCHK(d_t2at.reserve(steps_max + 4));
@@ -956,7 +1004,10 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     // pipelined steps only with the one-wave-per-sample kernels (the group kernels keep q_* in one half); a batch member's
     // row is set by the leader, who knows which kernels will run
     pipe_on = stage != 1 && mode == PORRT_MODE_RRT && opt_pipeline != 0 && (opt_group_req < 0 ? 0 : opt_group_req) == 0;
+    lag_on = pipe_on && opt_pipeline == 4 && K <= 1024;
     c.q_stride = pipe_on ? (uint32_t)Kpad : 0u;
+    c.cand_par3 = lag_on ? 1u : 0u;
+    lag_near_done = 0xFFFFFFFFu;
     c.perm = d_perm.p; c.ssx = d_ssx.p; c.ssy = d_ssy.p; c.bq_x = d_bqx.p; c.bq_y = d_bqy.p; c.bq_k = d_bqk.p; c.t2_at = d_t2at.p;
 
     // ---- root (rrt.rs:105-106 / pto.rs:61-64)
@@ -1135,11 +1186,11 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     side_active = false;
     pipe_near_done = 0xFFFFFFFFu;
     commit_pend_b = 0xFFFFFFFFu;
-    kd_b0 = 0; kd_last_b = 0; kd_last_nb = 0; kd_gidx = 0;
-    kd_pend[0] = kd_pend[1] = false;
+    kd_b0 = 0; kd_last_b = 0; kd_last_nb = 0; kd_gidx = 0; kd_hint_ns = 0;
+    kd_pend[0] = kd_pend[1] = kd_pend[2] = false;
     kd_group = kd_group_for(K, opt_kd_group, 1);
     bool coop_done = false;
-    if (pipe_on && opt_pipeline >= 2 && K <= 1024 && !prof && n_iter_min > 0) {
+    if (pipe_on && (opt_pipeline == 2 || opt_pipeline == 3) && K <= 1024 && !prof && n_iter_min > 0) {
         uint32_t nst = (uint32_t)((n_iter_min + K - 1) / K);
         if (launch_coop(nst, K, n_iter_min, vwords, lds_bytes) == PORRT_OK) {
             coop_done = true;
@@ -1151,7 +1202,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     } else if (opt_graph && !prof && n_iter_min > 0) {
         // all steps up to n_iter_min as one hipGraph (two branches: main pipeline + kd insertion); the graph
         // only depends on the launch geometry, so it is instantiated once and replayed by later grows
-        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)launch_rcp, kd_group | ((uint64_t)opt_early_wave << 8) | ((uint64_t)launch_Q << 32) | ((uint64_t)opt_group << 48) | ((uint64_t)pipe_on << 56)};
+        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)launch_rcp, kd_group | ((uint64_t)opt_early_wave << 8) | ((uint64_t)launch_Q << 32) | ((uint64_t)opt_group << 48) | ((uint64_t)pipe_on << 56) | ((uint64_t)lag_on << 57)};
         if (!graph_exec || memcmp(key, graph_key, sizeof key)) {
             double t0 = now_s();
             if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -2211,6 +2262,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         L->opt_group = L->opt_group_req < 0 ? (n >= 8 ? 16u : 0u) : (uint32_t)L->opt_group_req;
         // (pipelined steps search step b + 1 while step b is connected: not with rows that may end after step b)
         L->pipe_on = mode == PORRT_MODE_RRT && L->opt_group == 0 && L->opt_pipeline != 0 && !sched;
+        L->lag_on = false;
         L->rc_staging.resize(n);                 // one upload for all members (the vector outlives the copy: it is a member)
         for (uint32_t q = 0; q < n; ++q) {
             RunConst &rq = cs[q]->rc;
@@ -2240,8 +2292,8 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         L->side_active = false;
         L->pipe_near_done = 0xFFFFFFFFu;
         L->commit_pend_b = 0xFFFFFFFFu;
-        L->kd_b0 = 0; L->kd_last_b = 0; L->kd_last_nb = 0; L->kd_gidx = 0;
-        L->kd_pend[0] = L->kd_pend[1] = false;
+        L->kd_b0 = 0; L->kd_last_b = 0; L->kd_last_nb = 0; L->kd_gidx = 0; L->kd_hint_ns = 0;
+        L->kd_pend[0] = L->kd_pend[1] = L->kd_pend[2] = false;
         L->kd_group = kd_group_for(K, L->opt_kd_group, n);
         ScopedEvents<2> bevs;
         HIPCHK_CTX(L, bevs.create());
@@ -2414,6 +2466,7 @@ porrt_ctx *porrt_create(int device) {
     if (hipEventCreateWithFlags(&c->ev_step_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_kd[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_kd[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_kd[2], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_steered, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
     c->crng.seed_from_u64(0);   // sample_space.rs:18
@@ -2440,7 +2493,7 @@ void porrt_destroy(porrt_ctx *c) {
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->ev_step_done) (void)hipEventDestroy(c->ev_step_done);
-    for (int p2 = 0; p2 < 2; ++p2) if (c->ev_kd[p2]) (void)hipEventDestroy(c->ev_kd[p2]);
+    for (int p2 = 0; p2 < 3; ++p2) if (c->ev_kd[p2]) (void)hipEventDestroy(c->ev_kd[p2]);
     if (c->ev_steered) (void)hipEventDestroy(c->ev_steered);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -3141,7 +3194,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "graph")) c->opt_graph = value != 0;
     else if (!strcmp(name, "group_lanes")) { if (value != -1 && value != 0 && value != 16 && value != 32 && value != 64) { c->set_err("group_lanes: -1 (auto), 0, 16, 32 or 64"); return PORRT_ERR_INVALID; } c->opt_group_req = (int)value; }
     else if (!strcmp(name, "dp_sweeps")) c->opt_dp_sweeps = value != 0;
-    else if (!strcmp(name, "pipeline")) c->opt_pipeline = (value == 2 || value == 3) ? (int)value : (value ? 1 : 0);
+    else if (!strcmp(name, "pipeline")) c->opt_pipeline = (value >= 2 && value <= 4) ? (int)value : (value ? 1 : 0);
     else if (!strcmp(name, "batch_streams")) c->opt_batch_streams = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else if (!strcmp(name, "kd_after")) c->opt_kd_after = value != 0;
     else if (!strcmp(name, "early_wave_steps")) c->opt_early_wave = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 64));

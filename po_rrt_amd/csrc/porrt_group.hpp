@@ -543,7 +543,7 @@ __device__ __forceinline__ void list_scan_wave(const RunConst &rc, uint32_t b, u
         }
         tot += (uint32_t)__popcll(hm);
     });
-    if (lane == 0) as_global(rc.cand_cnt)[(b & 1u) * rc.cand_K + kh] = tot;
+    if (lane == 0) as_global(rc.cand_cnt)[cand_cnt_at(rc, b, kh)] = tot;
     if (over) err |= (uint32_t)ERR_CAND_OVERFLOW;
 }
 
@@ -573,7 +573,7 @@ __device__ __attribute__((noinline)) void clone_workgroup(const RunConst &rc, ui
     }
     __syncthreads();
     const uint32_t kh = uni(s_ck[0]), idh = uni(s_cid[0]);
-    if (threadIdx.x >= 1 && threadIdx.x < n) as_global(rc.cand_cnt)[(b & 1u) * rc.cand_K + s_ck[threadIdx.x]] = 0u;     // no rewire candidates of their own
+    if (threadIdx.x >= 1 && threadIdx.x < n) as_global(rc.cand_cnt)[cand_cnt_at(rc, b, s_ck[threadIdx.x])] = 0u;     // no rewire candidates of their own
     const double pxh = uni_d(as_global(rc.q_x)[kh]), pyh = uni_d(as_global(rc.q_y)[kh]);
     if (wv == 0) {
         list_scan_wave(rc, b, N, T2, kh, pxh, pyh, lane, err);
@@ -594,10 +594,10 @@ __device__ __forceinline__ MemHits mem_hits(const RunConst &rc, uint32_t b, uint
     MemHits M;
     M.sid = as_global(rc.cand_id) + cand_off(rc, b, k);
     M.sxy = as_global(reinterpret_cast<dbl2 *>(rc.cand_xy)) + cand_off(rc, b, k);
-    M.sd = as_global(rc.cand_val) + (size_t)k * rc.cand_cap;
+    M.sd = as_global(rc.cand_val) + cand_val_off(rc, b, k);
     M.out_id = M.sid;
     M.out_val = M.sd;
-    M.out_cnt = as_global(rc.cand_cnt) + (b & 1u) * rc.cand_K + k;
+    M.out_cnt = as_global(rc.cand_cnt) + cand_cnt_at(rc, b, k);
     M.out_cap = rc.cand_cap;
     return M;
 }

@@ -236,10 +236,10 @@ def test_batch_each_with_budgets_of_their_own(eng_mod):
     assert rc == worst
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2, 3])
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4])
 def test_single_query_launch_forms_agree(eng_mod, pipeline):
-    """the single query's steps as separate kernels (0), pipelined pairs (1, the default), or ONE persistent launch with barriers over
-    the grid (2: cooperative launch, 3: the same grid launched ordinarily) -- identical trees, against the oracle"""
+    """the single query's steps as separate kernels (0), pipelined pairs (1), ONE persistent launch with barriers over the grid (2:
+    cooperative launch, 3: the same grid launched ordinarily), or one kernel per step (4) -- identical trees, against the oracle"""
     for case, K in ((cases.cfg2(30000, seed=4), 1024), (cases.cfg2_obs(2500, seed=2), 512), (cases.cfg1(3000), 64)):
         e, _ = run_gpu(eng_mod, case, K, pipeline=pipeline)
         o, _ = run_orc(case, K)

@@ -9,7 +9,7 @@ import cases, po_rrt_amd
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 111500
 case = cases.cfg2(n_iter)
 ref = None
-for pl in (1, 3, 2):
+for pl in [int(a) for a in sys.argv[2:]] or (1, 4, 0):
     e = cases.configure(po_rrt_amd.Engine(0), case)
     e.set_option("pipeline", pl)
     ts = []
