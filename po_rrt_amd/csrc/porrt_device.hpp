@@ -625,6 +625,7 @@ __device__ __forceinline__ double nn_bound_wave(const RunConst &rc, uint32_t N, 
 // One WAVE serves one sample: lanes <-> the 64 slots of a page (coalesced 1 KiB + 256 B loads, four pages in
 // flight), hits are compacted with a ballot.
 __device__ __forceinline__ uint32_t rank_before(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k);
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v);
 __device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k, uint32_t lane, uint32_t stride = 64u, bool lag = false);
 constexpr int kRG = 40;
 constexpr uint32_t kRegions = kRG * kRG;
@@ -901,13 +902,15 @@ __device__ void insert_step_pages(const RunConst &rc, uint32_t b, uint32_t nb, u
     // the new counts go to the other parity, for the next step
     auto rg_old = as_global(rc.rg_cnt) + (b & 1u) * kRegions, rg_new = as_global(rc.rg_cnt) + ((b + 1u) & 1u) * kRegions;
     for (uint32_t r = threadIdx.x; r < kRegions; r += T) s_add[r] = 0;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64u) {                 // (the first wave: a word of the valid mask per lane)
+        uint32_t add = threadIdx.x < vwords ? (uint32_t)__popcll(as_global(rc.valid_mask)[(size_t)b * vwords + threadIdx.x]) : 0u;
+        add = wave_sum(add);
+        if (threadIdx.x == 0) {
         s_np = 0; s_base = kRegions + rc.cnt->n_pages;
-        uint32_t add = 0;
-        for (uint32_t w = 0; w < vwords; ++w) add += __popcll(rc.valid_mask[(size_t)b * vwords + w]);
         const uint32_t n_next = as_global(rc.n_at)[b] + add;
         as_global(rc.n_at)[b + 1] = n_next;                              // tree size at the start of the next step
         as_global(rc.t2_at)[b + 1] = as_global(rc.rad_T2)[n_next];
+        }
     }
     __syncthreads();
     const uint32_t qo = q_off(rc, b);
@@ -2328,10 +2331,15 @@ __device__ __forceinline__ void kd_step_below(const RunConst &rc, KdMove &m, uin
     box_cut(m.box, wx, wy, dw, m.side);
 }
 
+// new nodes of the steps [b0, b0 + nsteps): called by whole waves (every lane gets the sum).  A word of the masks per lane and a
+// sum over the wave: one trip to memory (it used to be one thread's loop over up to 128 words through a pointer of unknown
+// address space -- a drained round trip per word, at the start of three kernels of every group).
 __device__ __forceinline__ uint32_t kd_group_size(const RunConst &rc, uint32_t b0, uint32_t nsteps, uint32_t vwords) {
+    auto vm = as_global(rc.valid_mask) + (size_t)b0 * vwords;
+    const uint32_t lane = threadIdx.x & 63u, nw = vwords * nsteps;
     uint32_t n_new = 0;
-    for (uint32_t w = 0; w < vwords * nsteps; ++w) n_new += __popcll(rc.valid_mask[(size_t)b0 * vwords + w]);
-    return n_new;
+    for (uint32_t w = lane; w < nw; w += 64u) n_new += (uint32_t)__popcll(vm[w]);
+    return wave_sum(n_new);
 }
 
 __global__ __launch_bounds__(256) void k_kd_link(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords, uint32_t lpar) {
@@ -2359,6 +2367,14 @@ __global__ __launch_bounds__(256) void k_kd_link(const RunConst *__restrict__ rc
     rc.kd_losers[atomicAdd(&rc.cnt->n_losers, 1u)] = m;
 }
 
+// A workgroup barrier that waits for the LDS traffic only: the rounds below talk through LDS alone, and a barrier that also
+// drains the global stores of kd_publish (what __syncthreads does) costs a round trip to memory per round.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");      // orders (and waits for) the LDS accesses only
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // CAP: the most nodes a launch may hold (the slots in LDS, the losers in registers); the engine takes the smaller form when the
 // group's steps cannot hold more -- beside the step kernels every KB of LDS counts.
 // LDSXY (a single query: the GPU's LDS is idle): the new nodes' coordinates are staged in LDS, so that a round's "step below the
@@ -2376,6 +2392,10 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
     if (n_new > CAP) { if (threadIdx.x == 0) atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW); return; }
     const uint32_t n_l = rc.cnt->n_losers;
     auto grec = as_global(rc.kd_rec);
+#ifdef PORRT_CLAIM_PROBE
+    const unsigned long long pt0 = wall_clock64();
+    uint32_t p_rounds = 0, p_tail = 0;
+#endif
     if (n_l) {
         for (uint32_t t = threadIdx.x; t < n_new; t += 1024u) {
             s_ch[t][0] = kEmpty; s_ch[t][1] = kEmpty;
@@ -2407,30 +2427,36 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
 #pragma unroll
             for (int r = 0; r < kPer; ++r) mine += todo[r] ? 1u : 0u;
             if (threadIdx.x == 0) s_nact = 0;
-            __syncthreads();
+            lds_barrier();
             if (mine) atomicAdd(&s_nact, mine);
-            __syncthreads();
+            lds_barrier();
             if (s_nact <= 64u) break;
+#ifdef PORRT_CLAIM_PROBE
+            ++p_rounds;
+#endif
 #pragma unroll
             for (int r = 0; r < kPer; ++r)
                 if (todo[r]) atomicMin(&s_ch[mv[r].cur][mv[r].side], (int)mv[r].t);
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int r = 0; r < kPer; ++r)
                 if (todo[r]) settle(mv[r], todo[r]);
         }
         if (s_nact) {
-            __syncthreads();
+            lds_barrier();
             if (threadIdx.x == 0) s_nact = 0;
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int r = 0; r < kPer; ++r)
                 if (todo[r]) s_tail[atomicAdd(&s_nact, 1u)] = mv[r];
-            __syncthreads();
+            lds_barrier();
             if (threadIdx.x < 64u) {
                 bool td = threadIdx.x < s_nact;
                 KdMove m = s_tail[td ? threadIdx.x : 0u];
                 while (__ballot(td)) {
+#ifdef PORRT_CLAIM_PROBE
+                    ++p_tail;
+#endif
                     {   // contenders of one slot that are all the same point form a chain in id order: settle it at once
                         const uint32_t slot = ((uint32_t)m.cur << 1) | m.side;
                         unsigned long long rem = __ballot(td);
@@ -2475,6 +2501,12 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
     // every record of the group is written: connect kernels running beside us may now trust ids < N + n_new
     __threadfence();
     __syncthreads();
+#ifdef PORRT_CLAIM_PROBE
+    if (threadIdx.x == 0) {      // developer statistics: losers (max, sum), launches, rounds, tail rounds, time
+        atomicMax(&rc.cnt->dbg[0], n_l); atomicAdd(&rc.cnt->dbg[1], n_l); atomicAdd(&rc.cnt->dbg[2], 1u); atomicAdd(&rc.cnt->dbg[3], p_rounds);
+        atomicAdd(&rc.cnt->tim[0], wall_clock64() - pt0); atomicAdd(&rc.cnt->tim[8], 1ull); atomicAdd(&rc.cnt->tim[1], (unsigned long long)p_tail * 100ull); atomicAdd(&rc.cnt->tim[9], 1ull);
+    }
+#endif
     if (threadIdx.x == 0) {
         rc.cnt->n_losers = 0;
         // G as the next k_kd_locate may see it

@@ -188,6 +188,7 @@ struct porrt_ctx {
     // structure is built after the last step, group by group with the GPU to itself, then the ties are settled (measured
     // against the default).  0 (default).
     bool opt_kd_after = false;
+    int opt_kd_ride = 0;                   // "kd_ride": 1 = also for several contexts the hints and deferred ties ride in the next group's locate kernel
     uint32_t kd_after_K = 0;               // batch_K of the running launch sequence (the deferred groups need it)
     // "group_lanes": lanes per sample of the RRT* step kernels.  16 / 32 / 64: k_nn2 + k_conn2 (several samples per wave: fewer
     // waves, hits kept in LDS -- throughput); 0: k_near + k_connect_rrt (one wave per sample: the shortest dependent chain per
@@ -717,22 +718,20 @@ void porrt_ctx::launch_kd_group() {
     const uint32_t nsteps = kd_last_b - kd_b0 + 1, K = rc.cand_K, vwords = (K + 63) / 64;
     (void)hipStreamWaitEvent(stream2, ev_steered, 0);
     // few nodes: one wave per node (latency); many (several contexts at once): one thread per node (wave slots)
-    // (a single query leaves most of the GPU idle: a wave per node whatever the group's size)
-    if (Q > 1 && (uint64_t)nsteps * K * Q >= 4096u) hipLaunchKernelGGL(k_kd_locate<1>, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u, 0u, 0u);
-    else if (Q > 1) hipLaunchKernelGGL(k_kd_locate<64>, dim3((nsteps * K * 64 + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u, 0u, 0u);
-    else {
-        // (a thread per node from 4096 nodes on: a wave per node is no faster there and takes the step kernels' wave slots)
-        const uint32_t extra = kd_hint_ns ? (kd_hint_ns * K + 255) / 256 + kTieParts : 0;
-        if ((uint64_t)nsteps * K >= 4096u) hipLaunchKernelGGL(k_kd_locate<1>, dim3((nsteps * K + 255) / 256 + extra, 1), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u, kd_hint_b0, kd_hint_ns);
-        else hipLaunchKernelGGL(k_kd_locate<64>, dim3((nsteps * K * 64 + 255) / 256 + extra, 1), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u, kd_hint_b0, kd_hint_ns);
-    }
+    // the hints of the group before and the deferred ties ride in this group's locate kernel (extra workgroups per row)
+    const bool ride = opt_kd_ride != 0 || Q == 1;
+    const uint32_t extra = (ride && kd_hint_ns) ? (kd_hint_ns * K + 255) / 256 + kTieParts : 0;
+    const uint32_t hb0 = extra ? kd_hint_b0 : 0u, hns = extra ? kd_hint_ns : 0u;
+    // (a thread per node from 4096 nodes on: a wave per node is no faster there and takes the step kernels' wave slots)
+    if ((uint64_t)nsteps * K * Q >= 4096u) hipLaunchKernelGGL(k_kd_locate<1>, dim3((nsteps * K + 255) / 256 + extra, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u, hb0, hns);
+    else hipLaunchKernelGGL(k_kd_locate<64>, dim3((nsteps * K * 64 + 255) / 256 + extra, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u, hb0, hns);
     hipLaunchKernelGGL(k_kd_link, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords, 0u);
     if (Q == 1) hipLaunchKernelGGL((k_kd_claim<kClaimMax, true>), dim3(1, 1), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
     else if ((uint64_t)nsteps * K <= 2048u) hipLaunchKernelGGL(k_kd_claim<2048>, dim3(1, Q), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
     else hipLaunchKernelGGL(k_kd_claim<kClaimMax>, dim3(1, Q), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
-    if (Q == 1) {
-        // this group's hints and the deferred ties ride in the NEXT group's locate kernel (a record's placeholder parent is in
-        // place before the record can be seen: nothing to wait for on the main stream); join_side launches the last ones
+    if (ride) {
+        // (a record's placeholder parent is in place before the record can be seen: nothing to wait for on the main stream);
+        // join_side launches the last group's
         kd_hint_b0 = kd_b0; kd_hint_ns = nsteps;
     } else {
         hipLaunchKernelGGL(k_kd_hint, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords);
@@ -848,7 +847,7 @@ void porrt_ctx::join_side() {
     }
     launch_kd_group();
     if (kd_hint_ns) {
-        hipLaunchKernelGGL(k_kd_hint_fix, dim3((kd_hint_ns * rc.cand_K + 255) / 256 + kTieParts, 1), dim3(256), 0, stream2, launch_rcp, kd_hint_b0, kd_hint_ns, (rc.cand_K + 63) / 64);
+        hipLaunchKernelGGL(k_kd_hint_fix, dim3((kd_hint_ns * rc.cand_K + 255) / 256 + kTieParts, launch_Q), dim3(256), 0, stream2, launch_rcp, kd_hint_b0, kd_hint_ns, (rc.cand_K + 63) / 64);
         kd_hint_ns = 0;
     }
     (void)hipEventRecord(ev_join, stream2);
@@ -3197,6 +3196,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "pipeline")) c->opt_pipeline = (value >= 2 && value <= 4) ? (int)value : (value ? 1 : 0);
     else if (!strcmp(name, "batch_streams")) c->opt_batch_streams = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else if (!strcmp(name, "kd_after")) c->opt_kd_after = value != 0;
+    else if (!strcmp(name, "kd_ride")) c->opt_kd_ride = value != 0;
     else if (!strcmp(name, "early_wave_steps")) c->opt_early_wave = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 64));
     else if (!strcmp(name, "kd_group")) c->opt_kd_group = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else { c->set_err(std::string("unknown option ") + name); return PORRT_ERR_INVALID; }
