@@ -631,6 +631,8 @@ def tamp_queries(device, with_cpu, n_queries=1024, K=256):
         runs.append((dt, sum(e.num_nodes() - 1 for e in engs), sum(e.num_iterations() for e in engs), sum(1 for e in engs if e.num_final() > 0)))
     dt, nodes, its, solved = sorted(runs[1:])[1]
     costs = po_rrt_amd.Engine.best_cost_batch(engs)
+    for e in engs:                      # (a thousand contexts: freed here, not by the collector in the middle of the next row)
+        e.close()
     out = {"what": "%d TAMP-shaped RRT* queries in one porrt_grow_batch (alternating ObservationGoal / SquareGoal, per-query starts, n_iter_min 2500, "
                    "n_iter_max 10000, K = %d): each runs the loop of rrt.rs:109 and leaves the launches when it ends" % (n_queries, K),
            "ms_wall": 1e3 * dt, "queries_per_s": n_queries / dt, "node_expansions_per_s": nodes / dt, "iterations_per_s": its / dt,
