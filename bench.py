@@ -365,6 +365,7 @@ def main():
                 "winner_nodes": win_nodes,
                 "loop_s_rank0": t_loop,
                 "launch_sequences": G,
+                "launch_mode": sets[0][0].get_option("launch_mode"),
                 "launch": ("%d launch sequences side by side (porrt_grow_batch, option batch_streams), each on a main and a side stream chosen by "
                            "measurement to sit on different hardware queues, launched step by step from a host thread each" % G) if G > 1 else
                           "hipGraph replay of all steps (main stream: search, connect; side stream: kd tie-order structure, never waited for)",
@@ -384,7 +385,7 @@ def main():
             conn_bytes = 8.0 * n_sum + Q_launch * grid_bytes + 28.0 * prof["nodes"] / L
             nn_us, conn_us = 1e6 * prof["scan_s"] / L, 1e6 * prof["connect_s"] / L
             pm, pm_src = {}, None
-            if not args.no_pmc:
+            if not args.no_pmc and world == 1:               # (N > 1: the other ranks must not wait for rank 0's counter passes)
                 pm, pm_src = measure_traffic(args, Q)
             if not pm:
                 for cand in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):      # committed rocprofv3 --pmc passes

@@ -261,6 +261,10 @@ int porrt_get_metrics(const porrt_ctx *ctx, porrt_metrics *out);
  * slower on eight XCDs, kept for the record), "kd_after" (1 = the tie-order structure is built after the last step instead of
  * beside the steps: measured slower), "early_wave_steps", "dp_sweeps".  None of them changes a result. */
 int porrt_set_option(porrt_ctx *ctx, const char *name, int64_t value);
+/* what was in force: "launch_mode" (the last porrt_grow_batch led by this context: 0 = one launch sequence, G = G sequences side by
+ * side on streams chosen by measurement, -G = G sequences on the contexts' own streams -- the probe found no parallel set, e.g. under a
+ * profiler that serialises kernels), "pipeline", "group_lanes" */
+int porrt_get_option(const porrt_ctx *ctx, const char *name, int64_t *value);
 
 /* Device arithmetic self-test: sqrt and divide of n doubles on the GPU versus the host's correctly
  * rounded results; both mismatch counts must be 0 for bit-exact parity (rrt.rs costs, common.rs:218). */

@@ -218,6 +218,8 @@ struct porrt_ctx {
     std::vector<hipStream_t> dl_streams;
     std::vector<size_t> dl_pin_cap;                 // bytes of each pinned slot (slots made by different calls differ)
     bool sub_eager = false;                        // leader of a sub-batch on measured streams: launch step by step (see porrt_grow_batch)
+    int last_launch_mode = 0;                      // how the last porrt_grow_batch led by this context ran: 0 one sequence (hipGraph / eager), G >= 2 sequences
+                                                   // on measured streams, -G sequences on the contexts' own streams (the stream probe found no set: e.g. under a profiler)
     uint32_t sub_streams_tried = 0;                 // a probe for this many streams already failed: not repeated call after call
     std::vector<hipStream_t> sub_streams;          // first context of such a call: the sub-batches' main streams (see porrt_grow_batch)
     bool opt_dp_sweeps = false;            // "dp_sweeps": expected costs by whole-graph sweeps instead of layer by layer
@@ -2648,7 +2650,7 @@ static int grow_batch_each(porrt_ctx *const *ctxs, uint32_t n_ctx, const double 
     for (uint32_t q = 0; q < n_ctx; ++q) if (!ctxs[q]) return PORRT_ERR_INVALID;
     uint32_t G = ctxs[0]->opt_batch_streams ? ctxs[0]->opt_batch_streams : (n_ctx >= 32 ? 2u : 1u);
     G = std::min(G, n_ctx);
-    if (G <= 1) return grow_batch(ctxs, n_ctx, starts, max_step, search_radius, n_iter_min, n_iter_max, batch_K, mode);
+    if (G <= 1) { ctxs[0]->last_launch_mode = 0; return grow_batch(ctxs, n_ctx, starts, max_step, search_radius, n_iter_min, n_iter_max, batch_K, mode); }
     for (uint32_t q = 0; q < n_ctx; ++q)          // checked here for the whole call: the sub-batches only see their own members
         for (uint32_t r = 0; r < q; ++r) if (ctxs[r] == ctxs[q]) { ctxs[0]->set_err("porrt_grow_batch: a context appears twice"); return PORRT_ERR_INVALID; }
     // contiguous runs of the argument, led by their first member; every run is a complete porrt_grow_batch of its own (its own
@@ -2668,6 +2670,7 @@ static int grow_batch_each(porrt_ctx *const *ctxs, uint32_t n_ctx, const double 
         if (top->sub_streams.size() < 2u * G) top->sub_streams_tried = 2u * G;      // (e.g. under a profiler that serialises kernels: every pair test fails)
     }
     const bool have_streams = top->sub_streams.size() >= 2u * G;
+    top->last_launch_mode = have_streams ? (int)G : -(int)G;
     auto part = [&](uint32_t g) {
         porrt_ctx *Lg = ctxs[lo[g]];
         hipStream_t own = Lg->stream, own2 = Lg->stream2;
@@ -3184,6 +3187,18 @@ porrt_tree_device_view porrt_tree_device(const porrt_ctx *c) {
     if (!c || !c->have_results || c->mode != PORRT_MODE_RRT) return v;
     v.nx = c->d_nx.p; v.ny = c->d_ny.p; v.dist_root = c->d_distA.p; v.parent = c->d_parent.p; v.n_nodes = c->n_nodes;
     return v;
+}
+
+// read-only views of what the options chose: "launch_mode" (last porrt_grow_batch led by this context: 0 = one launch sequence,
+// G = G sequences side by side on streams chosen by measurement, -G = G sequences on the contexts' own streams because the probe
+// found no set of parallel streams), "pipeline", "group_lanes" (in force for the last grow)
+int porrt_get_option(const porrt_ctx *c, const char *name, int64_t *value) {
+    if (!c || !name || !value) return PORRT_ERR_INVALID;
+    if (!strcmp(name, "launch_mode")) *value = c->last_launch_mode;
+    else if (!strcmp(name, "pipeline")) *value = c->lag_on ? 4 : (c->pipe_on ? 1 : 0);
+    else if (!strcmp(name, "group_lanes")) *value = c->opt_group;
+    else return PORRT_ERR_INVALID;
+    return PORRT_OK;
 }
 
 int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {

@@ -28,7 +28,7 @@ SYMBOLS = [
     "porrt_set_observation_goal", "porrt_grow", "porrt_grow_batch", "porrt_grow_batch_each", "porrt_grow_prm", "porrt_prm_plan_path", "porrt_num_nodes", "porrt_num_iterations", "porrt_get_tree", "porrt_get_trees",
     "porrt_num_final", "porrt_get_final_ids", "porrt_get_final_masks", "porrt_get_reach", "porrt_get_node_validity",
     "porrt_num_edges", "porrt_get_edges", "porrt_is_final_set_complete", "porrt_n_worlds", "porrt_get_validities",
-    "porrt_get_zone_positions", "porrt_best_solution", "porrt_best_cost", "porrt_best_cost_batch", "porrt_get_metrics", "porrt_set_option", "porrt_selftest",
+    "porrt_get_zone_positions", "porrt_best_solution", "porrt_best_cost", "porrt_best_cost_batch", "porrt_get_metrics", "porrt_set_option", "porrt_get_option", "porrt_selftest",
     "porrt_build_belief_graph", "porrt_bg_num_beliefs", "porrt_bg_num_nodes", "porrt_bg_num_edges", "porrt_bg_get_beliefs",
     "porrt_bg_get_observable_zones", "porrt_bg_get_node_types", "porrt_bg_get_children", "porrt_bg_get_parents", "porrt_bg_get_seconds",
     "porrt_bg_compute_expected_costs", "porrt_bg_get_expected_costs", "porrt_bg_expected_cost_of", "porrt_bg_get_dp_info", "porrt_bg_get_dp_sweep_rows", "porrt_bg_extract_policy", "porrt_conditional_dijkstra",
@@ -136,6 +136,7 @@ def load_library():
     sig("porrt_best_cost_batch", C.c_int, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_double))
     sig("porrt_get_metrics", C.c_int, vp, C.POINTER(Metrics))
     sig("porrt_set_option", C.c_int, vp, C.c_char_p, C.c_int64)
+    sig("porrt_get_option", C.c_int, vp, C.c_char_p, C.POINTER(C.c_int64))
     sig("porrt_selftest", C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
     sig("porrt_comm_unique_id", C.c_int, C.c_void_p)
     sig("porrt_comm_create", vp, C.c_int, C.c_int, C.c_int, C.c_void_p)
@@ -273,6 +274,11 @@ class Engine:
 
     def num_final(self):
         return self._l.porrt_num_final(self._c)
+
+    def get_option(self, name):
+        v = C.c_int64(0)
+        self._chk(self._l.porrt_get_option(self._c, name.encode(), C.byref(v)))
+        return v.value
 
     def tree(self):
         n = self.num_nodes()

@@ -250,3 +250,23 @@ def test_single_query_launch_forms_agree(eng_mod, pipeline):
         cases.grow(e2, case, K=K)
         cases.grow(o, case, K=K, algo=orc.ALGO_BATCHED_KD)
         assert_same(e2, o)
+
+
+@pytest.mark.parametrize("opts", [dict(kd_after=1), dict(kd_ride=1), dict(early_wave_steps=5), dict(kd_group=1), dict(kd_group=4)])
+def test_engine_options_do_not_change_results(eng_mod, opts):
+    """the developer options measured in DESIGN.md section 8 (kd structure after the steps, hints riding in the locate kernel, the first
+    steps' connect pass with one wave per sample, kd group sizes): same trees from a batch of nine and from a single query"""
+    cs = [cases.cfg2(12000, seed=30 + s) for s in range(9)]
+    engs = [cases.configure(eng_mod.Engine(), c) for c in cs]
+    for e in engs:
+        for k, v in opts.items():
+            e.set_option(k, v)
+    eng_mod.Engine.grow_batch(engs, [c.start for c in cs], cs[0].max_step, cs[0].search_radius, 12000, 1024)
+    for c, e in list(zip(cs, engs))[::4]:
+        o, _ = run_orc(c, 1024)
+        assert_same(e, o)
+    assert engs[0].get_option("launch_mode") == 0 and engs[0].get_option("group_lanes") == 16
+    e, _ = run_gpu(eng_mod, cs[1], 1024, **opts)
+    o, _ = run_orc(cs[1], 1024)
+    assert_same(e, o)
+    assert e.get_option("pipeline") == 4
