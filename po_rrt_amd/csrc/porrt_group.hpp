@@ -602,6 +602,53 @@ __device__ __forceinline__ MemHits mem_hits(const RunConst &rc, uint32_t b, uint
     return M;
 }
 
+// One sample with more hits than its LDS list holds, served by the whole wave (a function of its own: its registers are not the
+// step kernel's).  Its hits are in its slice of the lists in memory; when the wave's four LDS lists together hold them (4 x kLdsHits:
+// most such samples) they are read back into those lists in one coalesced pass and the three passes of the connect run on LDS.
+template <int GL>
+__device__ __attribute__((noinline)) void heavy_sample_wave(const RunConst &rc, uint32_t b, uint32_t N, uint32_t kh, uint32_t idh, uint32_t toth, int clrh,
+                                                            double pxh, double pyh, uint8_t *wb, uint32_t &err) {
+    const uint32_t lane = threadIdx.x & 63u;
+    constexpr uint32_t kWaveHits = (64u / (uint32_t)GL) * (kLdsHits * (uint32_t)(GL / 16));
+    Team<1> tw;
+    tw.scr_d = nullptr; tw.scr_i = nullptr; tw.wave = 0; tw.lane = lane;
+    GlobalGrid grid;
+    grid.p = rc.cls; grid.W = rc.W;
+    const uint32_t cap = rc.cand_cap;
+    const MemHits Mh = mem_hits(rc, b, kh);
+    if (toth <= kWaveHits) {
+        LdsHits Wl;
+        Wl.hx = reinterpret_cast<double *>(wb);
+        Wl.hy = Wl.hx + kWaveHits;
+        Wl.hd = Wl.hy + kWaveHits;
+        Wl.hid = reinterpret_cast<int *>(Wl.hd + kWaveHits);
+        Wl.out_id = Mh.out_id; Wl.out_val = Mh.out_val; Wl.out_cnt = Mh.out_cnt; Wl.out_cap = Mh.out_cap;
+        for (uint32_t a0 = 0; a0 < toth; a0 += 256u) {              // four entries per lane in flight
+            int jd[4];
+            dbl2 v[4];
+            double d[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                const uint32_t a = a0 + u * 64u + lane;
+                jd[u] = a < toth ? Mh.sid[a] : 0;
+                v[u] = a < toth ? Mh.sxy[a] : dbl2{0.0, 0.0};
+                d[u] = a < toth ? Mh.sd[a] : 0.0;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                const uint32_t a = a0 + u * 64u + lane;
+                if (a < toth) { Wl.hid[a] = jd[u]; Wl.hx[a] = v[u].x; Wl.hy[a] = v[u].y; Wl.hd[a] = d[u]; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        connect_rrt_sample(rc, tw, Wl, grid, b, kh, idh, pxh, pyh, toth, err, nullptr, 0, clrh, [&]() { return wave_nn(rc, b, N, pxh, pyh); });
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        connect_rrt_sample(rc, tw, Mh, grid, b, kh, idh, pxh, pyh, toth < cap ? toth : cap, err, nullptr, 0, clrh,
+                           [&]() { return wave_nn(rc, b, N, pxh, pyh); });
+    }
+}
+
 template <int GL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_conn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
     static_assert(GL == 16 || GL == 32 || GL == 64, "group size");
@@ -689,16 +736,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         // written by this wave: its own loads see the entries once its stores are counted down
         __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
         __builtin_amdgcn_wave_barrier();
-        Team<1> tw;
-        tw.scr_d = nullptr; tw.scr_i = nullptr; tw.wave = 0; tw.lane = lane;
+        uint8_t *wb = lds_dyn + (threadIdx.x >> 6) * (64u / (uint32_t)GL) * ((kLdsHits * (uint32_t)(GL / 16)) * 28u);      // the wave's lists as one (their samples are through)
         while (hv) {
             const int l = (int)__builtin_ctzll(hv);
             hv &= hv - 1;
             const uint32_t kh = uni((uint32_t)__shfl((int)k, l)), idh = uni((uint32_t)__shfl((int)id, l)), toth = uni((uint32_t)__shfl((int)tot, l));
             const int clrh = (int)uni((uint32_t)__shfl(clr_b, l));
             const double pxh = uni_d(__shfl(px, l)), pyh = uni_d(__shfl(py, l));
-            connect_rrt_sample(rc, tw, mem_hits(rc, b, kh), grid, b, kh, idh, pxh, pyh, toth < cap ? toth : cap, err, nullptr, 0, clrh,
-                               [&]() { return wave_nn(rc, b, N, pxh, pyh); });
+            heavy_sample_wave<GL>(rc, b, N, kh, idh, toth, clrh, pxh, pyh, wb, err);
         }
         PORRT_TACC_B(rc, 3);
     }
