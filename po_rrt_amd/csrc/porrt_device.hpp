@@ -361,11 +361,13 @@ __device__ __forceinline__ void oct_from(int o, int x, int y, int &ox, int &oy) 
 // the wave's private LDS tile (a (2R+1)^2 window around the new node: every neighbour lies within
 // radius <= max_step of it, so all of a sample's rays stay inside) and falls back to global outside it.
 struct GlobalGrid {
+    static constexpr int kRayChunk = 6;     // pixels of a ray fetched together (traversed_class_px): a trip to memory per chunk
     const uint8_t *p;
     uint32_t W;
     __device__ __forceinline__ int at(uint32_t i, uint32_t j) const { return as_global(p)[i * W + j]; }
 };
 struct TileGrid {
+    static constexpr int kRayChunk = 1;     // (the tile is in LDS: nothing to gain, and the one-wave-per-sample kernels have no registers to spare)
     const uint8_t *lds;     // TW x TW bytes
     const uint8_t *glob;
     uint32_t W;
@@ -405,22 +407,37 @@ __device__ int traversed_class_px(const RunConst &rc, const Grid &grid, uint32_t
     const int fb = (o == 1 || o == 6) ? 1 : ((o == 2 || o == 5) ? -1 : 0);
     const int fc = (o == 1 || o == 2) ? 1 : ((o == 5 || o == 6) ? -1 : 0);
     const int fd = (o == 0 || o == 3) ? 1 : ((o == 4 || o == 7) ? -1 : 0);
-    for (int x = sx, y = sy; x <= ex; ++x) {
-        const int pi = fa * x + fb * y, pj = fc * x + fd * y;
-        int c = grid.at((uint32_t)pi, (uint32_t)pj);
-        if (rc.domain == 0) {
-            if (c == CLS_HIGH0) return CLS_HIGH;       // lowest_pixel == 0: early return
-            worst = c > worst ? c : worst;
-        } else {
-            if (c != CLS_FREE) {
-                if (c == CLS_HIGH || c == CLS_HIGH0) return CLS_HIGH;   // Obstacle: immediate return
-                if (c == CLS_BAD) { *err |= ERR_RASTER; return CLS_HIGH; }
-                if (worst >= CLS_ZONE && worst != c) { *err |= ERR_RASTER; return CLS_HIGH; } // two zones: reference asserts
-                worst = c;
+    // The walk does not depend on what it reads (only its early return does), and it stays inside the bounding box of its end
+    // pixels: a chunk's pixels are addressed first and fetched together -- one trip to the raster per kRayChunk pixels instead of
+    // one per pixel -- and then tested in the reference's order.
+    constexpr int kRayChunk = Grid::kRayChunk;
+    for (int x = sx, y = sy; x <= ex;) {
+        int c[kRayChunk];
+        const int n = ex - x + 1 < kRayChunk ? ex - x + 1 : kRayChunk;
+#pragma unroll
+        for (int u = 0; u < kRayChunk; ++u) {
+            c[u] = CLS_FREE;
+            if (u < n) {
+                const int pi = fa * x + fb * y, pj = fc * x + fd * y;
+                c[u] = grid.at((uint32_t)pi, (uint32_t)pj);
+                if (e >= 0) { y += 1; e -= ddx; }
+                e += ddy;
+                ++x;
             }
         }
-        if (e >= 0) { y += 1; e -= ddx; }
-        e += ddy;
+#pragma unroll
+        for (int u = 0; u < kRayChunk; ++u) {
+            if (u >= n) break;
+            if (rc.domain == 0) {
+                if (c[u] == CLS_HIGH0) return CLS_HIGH;       // lowest_pixel == 0: early return
+                worst = c[u] > worst ? c[u] : worst;
+            } else if (c[u] != CLS_FREE) {
+                if (c[u] == CLS_HIGH || c[u] == CLS_HIGH0) return CLS_HIGH;   // Obstacle: immediate return
+                if (c[u] == CLS_BAD) { *err |= ERR_RASTER; return CLS_HIGH; }
+                if (worst >= CLS_ZONE && worst != c[u]) { *err |= ERR_RASTER; return CLS_HIGH; } // two zones: reference asserts
+                worst = c[u];
+            }
+        }
     }
     return worst;
 }
