@@ -2035,12 +2035,16 @@ __global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per
 // round on odd ones, the commit runs beside the next step's connect pass -- which reads the accumulator as ITS snapshot and
 // accumulates into the other array -- and carries the winners' values over with an atomic minimum (commutes with that pass).
 __device__ void commit_rrt_sample(const RunConst &rc, uint32_t b, uint32_t vwords, uint32_t k, uint32_t lane, uint32_t stride, bool lag) {
-    if (!((as_global(rc.valid_mask)[(size_t)b * vwords + (k >> 6)] >> (k & 63u)) & 1ull)) return;
+    // everything the sample's own first trip to memory can fetch is asked for before the first thing is looked at (the valid bit
+    // decides whether there is anything to do, and a test in front of the other loads is a trip of its own)
+    const unsigned long long vword = as_global(rc.valid_mask)[(size_t)b * vwords + (k >> 6)];
     const uint32_t N = as_global(rc.n_at)[b];
-    const int id = (int)(N + (stride < 64u ? rank_before_lanes(rc, b, vwords, k, lane, stride) : rank_before(rc, b, vwords, k)));
+    const uint32_t rank = stride < 64u ? rank_before_lanes(rc, b, vwords, k, lane, stride) : rank_before(rc, b, vwords, k);
     const uint32_t cnt = cand_count(rc, b, k);
     auto cid = as_global(rc.cand_id) + cand_off(rc, b, k);
     auto cval = as_global(rc.cand_val) + cand_val_off(rc, b, k);
+    if (!((vword >> (k & 63u)) & 1ull)) return;
+    const int id = (int)(N + rank);
     const bool odd = lag && (b & 1u);
     auto gdB = as_global(odd ? rc.distA : rc.distB);                                       // what the step's connect pass accumulated into
     auto gother = as_global(reinterpret_cast<unsigned long long *>(odd ? rc.distB : rc.distA));

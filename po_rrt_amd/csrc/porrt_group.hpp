@@ -246,8 +246,7 @@ __device__ __forceinline__ void gscan_region(const RunConst &rc, const GTeam<GL>
 
 // squared distance from q to the part of the plane region (cx, cy) takes its nodes from (rep_cell: border regions reach to
 // infinity), shrunk by a margin that covers the roundings of the cell function: a lower bound for every node of the region
-__device__ __forceinline__ double region_gap2(const RunConst &rc, double qx, double qy, int cx, int cy) {
-    const double wx = 1.0 / (rc.binv_w * (double)kRG), wy = 1.0 / (rc.binv_h * (double)kRG);
+__device__ __forceinline__ double region_gap2(const RunConst &rc, double qx, double qy, int cx, int cy, double wx, double wy) {
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
     const double xlo = cx == 0 ? -INF : rc.bx0 + (double)cx * wx, xhi = cx == kRG - 1 ? INF : rc.bx0 + (double)(cx + 1) * wx;
     const double ylo = cy == 0 ? -INF : rc.by0 + (double)cy * wy, yhi = cy == kRG - 1 ? INF : rc.by0 + (double)(cy + 1) * wy;
@@ -295,6 +294,7 @@ __device__ __forceinline__ void group_nn(const RunConst &rc, uint32_t b, const G
     auto gcnt = as_global(rc.rg_cnt) + (b & 1u) * kRegions;
     int rx, ry;
     rep_cell(rc, sqx, sqy, kRG, rx, ry);
+    const double rwx = 1.0 / (rc.binv_w * (double)kRG), rwy = 1.0 / (rc.binv_h * (double)kRG);      // a region's width and height (two divisions, once)
     // ---- stage A: the block [ax0, ax0 + SB) x [ay0, ay0 + SB) of regions with the sample's region in its middle; the block
     // covers about the same area whatever the grid (a finer grid makes the radius searches cheaper and would otherwise
     // send most nearest-neighbour searches on to stage B)
@@ -313,7 +313,7 @@ __device__ __forceinline__ void group_nn(const RunConst &rc, uint32_t b, const G
             const int cx = ax0 + (in ? idx % SB : 0), cy = ay0 + (in ? idx / SB : 0);
             reg[q] = (uint32_t)(cy * kRG + cx);
             cnt[q] = in ? gcnt[reg[q]] : 0u;
-            gap[q] = cnt[q] ? region_gap2(rc, sqx, sqy, cx, cy) : INF;
+            gap[q] = cnt[q] ? region_gap2(rc, sqx, sqy, cx, cy, rwx, rwy) : INF;
         }
         for (;;) {
             double g = gap[0];
@@ -334,7 +334,7 @@ __device__ __forceinline__ void group_nn(const RunConst &rc, uint32_t b, const G
     }
     // settled if no node outside the block can be as near: the gap to the block's complement (border regions reach to infinity)
     {
-        const double wx = 1.0 / (rc.binv_w * (double)kRG), wy = 1.0 / (rc.binv_h * (double)kRG);
+        const double wx = rwx, wy = rwy;
         const double eps = 1e-9 * (1.0 + fabs(sqx) + fabs(sqy));
         double out = INF;
         if (ax0 > 0) { const double d = sqx - (rc.bx0 + (double)ax0 * wx) - eps; out = d < out ? d : out; }
@@ -370,7 +370,7 @@ __device__ __forceinline__ void group_nn(const RunConst &rc, uint32_t b, const G
                 const uint32_t bit = (uint32_t)__builtin_ctzll(m);
                 m &= m - 1;
                 const int r = (int)(wi * 64u + bit);
-                const double g = region_gap2(rc, sqx, sqy, r % kRG, r / kRG);
+                const double g = region_gap2(rc, sqx, sqy, r % kRG, r / kRG, rwx, rwy);
                 if (!(g <= thr)) { w[q] &= ~(1ull << bit); continue; }       // can never matter again: thr only shrinks
                 if (g < gap) { gap = g; mine = r; }
             }
