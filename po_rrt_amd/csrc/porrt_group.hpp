@@ -433,6 +433,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     // needs the nearest node after all)
     const double lim = 0.7 * rc.max_step, t2b = as_global(rc.t2_at)[b];
     const double lim2 = lim * lim < t2b ? lim * lim : t2b;
+    // the class of the sample's own pixel, asked for now: most samples are not steered, and their validity would otherwise be a
+    // trip to the raster of its own at the end
+    uint32_t err = 0;
+    int cls_own = CLS_FREE;
+    if (rc.has_grid) cls_own = state_class(rc, sqx, sqy, &err);
     for (int l = 0; l < 2 && !easy; ++l) {           // the finest cells; then, for a thin tree, the 3x3 cells of the next level
         int cx, cy;
         const int G = rep_dim(l);
@@ -461,10 +466,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             ty = fy + uy;
         }
     }
-    uint32_t err = 0;
     bool valid = true;
     if (rc.has_grid) {
-        const int cls = state_class(rc, tx, ty, &err);
+        int cls = cls_own;
+        if (tx != sqx || ty != sqy) { err = 0; cls = state_class(rc, tx, ty, &err); }      // steered: the new state's pixel
         valid = cls == CLS_FREE && !err;                         // RTTFuncs adapter (tamp_rrt.rs:40-42)
     }
     PORRT_TACC_A(rc, 2);
