@@ -216,31 +216,46 @@ __device__ __forceinline__ double nn_bound_group(const RunConst &rc, const GTeam
     return m;
 }
 
-// one region's pages for a group: visit(x, y, id, ok) for its `cnt` nodes
+// one region's pages for a group: visit(x, y, id, ok) for its `cnt` nodes.  kRegPages pages in flight: a young tree is a dense
+// blob, its regions hold many pages each, and the samples far from it -- most of them, then -- walk those pages one trip at a time
+// otherwise.
+#ifndef PORRT_REG_PAGES
+#define PORRT_REG_PAGES 1
+#endif
 template <int GL, class Visit>
 __device__ __forceinline__ void gscan_region(const RunConst &rc, const GTeam<GL> &tm, uint32_t reg, uint32_t cnt, Visit visit) {
     auto gdir = as_global(rc.rg_dir);
     auto gxy = as_global(reinterpret_cast<const dbl2 *>(rc.pg_xy));
     auto gid = as_global(rc.pg_id);
-    constexpr int U = (int)kPage / GL;
-    uint32_t page = reg;
-    for (uint32_t s0 = 0; s0 < cnt; s0 += kPage) {
-        const uint32_t pc = cnt - s0 < kPage ? cnt - s0 : kPage;
-        uint32_t page_next = 0;
-        if (cnt - s0 > kPage) page_next = gdir[(size_t)reg * rc.rg_maxp + s0 / kPage + 1u];      // fetched beside the slots of this page
-        dbl2 v[U];
-        int id[U];
+    constexpr int U = (int)kPage / GL, RP = PORRT_REG_PAGES;
+    const uint32_t npages = (cnt + kPage - 1u) / kPage;
+    for (uint32_t j0 = 0; j0 < npages; j0 += (uint32_t)RP) {
+        uint32_t page[RP], pc[RP];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t sl = (uint32_t)(u * GL) + tm.gl;
-            const bool ld = sl < pc;
-            v[u] = ld ? gxy[(size_t)page * kPage + sl] : dbl2{0.0, 0.0};
-            id[u] = ld ? gid[(size_t)page * kPage + sl] : -1;
+        for (int q = 0; q < RP; ++q) {
+            const uint32_t j = j0 + (uint32_t)q;
+            page[q] = 0; pc[q] = 0;
+            if (j < npages) {
+                page[q] = j ? gdir[(size_t)reg * rc.rg_maxp + j] : reg;        // the first page of a region is static
+                pc[q] = cnt - j * kPage < kPage ? cnt - j * kPage : kPage;
+            }
         }
+        dbl2 v[RP][U];
+        int id[RP][U];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if ((uint32_t)(u * GL) < pc) visit(v[u].x, v[u].y, id[u], (uint32_t)(u * GL) + tm.gl < pc);
-        page = page_next;
+        for (int q = 0; q < RP; ++q)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t sl = (uint32_t)(u * GL) + tm.gl;
+                const bool ld = sl < pc[q];
+                v[q][u] = ld ? gxy[(size_t)page[q] * kPage + sl] : dbl2{0.0, 0.0};
+                id[q][u] = ld ? gid[(size_t)page[q] * kPage + sl] : -1;
+            }
+#pragma unroll
+        for (int q = 0; q < RP; ++q)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if ((uint32_t)(u * GL) < pc[q]) visit(v[q][u].x, v[q][u].y, id[q][u], (uint32_t)(u * GL) + tm.gl < pc[q]);
     }
 }
 
@@ -394,8 +409,11 @@ __device__ __forceinline__ void group_nn(const RunConst &rc, uint32_t b, const G
 
 // RRT* step, first kernel: GL lanes per sample.  grid.x = ceil(nb / SPB) search workgroups + ceil(cnb / SPB) workgroups
 // running the rewire phase 2 of step cb (commit_rrt_sample), SPB = 256 / GL samples per workgroup.
+#ifndef PORRT_NN2_WAVES
+#define PORRT_NN2_WAVES 5
+#endif
 template <int GL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_nn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, uint32_t cb,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PORRT_NN2_WAVES, 8))) void k_nn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t i0, uint32_t nb, uint32_t vwords, uint32_t cb,
                                              uint32_t cnb) {
     static_assert(GL == 16 || GL == 32 || GL == 64, "group size");
     constexpr uint32_t SPB = 256u / GL;
