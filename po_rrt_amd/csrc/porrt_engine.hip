@@ -188,6 +188,8 @@ struct porrt_ctx {
     // structure is built after the last step, group by group with the GPU to itself, then the ties are settled (measured
     // against the default).  0 (default).
     bool opt_kd_after = false;
+    int opt_kd_inline = 0;                 // "kd_inline": 1 = the kd groups run on the main stream between the steps (no side stream, no events): a sub-batch
+                                           // needs one hardware queue instead of two, so four sub-batches fit the four queues
     int opt_kd_ride = 0;                   // "kd_ride": 1 = also for several contexts the hints and deferred ties ride in the next group's locate kernel
     uint32_t kd_after_K = 0;               // batch_K of the running launch sequence (the deferred groups need it)
     // "group_lanes": lanes per sample of the RRT* step kernels.  16 / 32 / 64: k_nn2 + k_conn2 (several samples per wave: fewer
@@ -718,6 +720,18 @@ void porrt_ctx::launch_kd_group() {
     const RunConst *rcp = launch_rcp;
     const uint32_t Q = launch_Q;
     const uint32_t nsteps = kd_last_b - kd_b0 + 1, K = rc.cand_K, vwords = (K + 63) / 64;
+    if (opt_kd_inline && Q > 1) {
+        // on the main stream, between two steps: stream order is all the synchronisation there is
+        if ((uint64_t)nsteps * K * Q >= 4096u) hipLaunchKernelGGL(k_kd_locate<1>, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u, 0u, 0u);
+        else hipLaunchKernelGGL(k_kd_locate<64>, dim3((nsteps * K * 64 + 255) / 256, Q), dim3(256), 0, stream, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u, 0u, 0u);
+        hipLaunchKernelGGL(k_kd_link, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream, rcp, kd_b0, nsteps, vwords, 0u);
+        if ((uint64_t)nsteps * K <= 2048u) hipLaunchKernelGGL(k_kd_claim<2048>, dim3(1, Q), dim3(1024), 0, stream, rcp, kd_b0, nsteps, vwords);
+        else hipLaunchKernelGGL(k_kd_claim<kClaimMax>, dim3(1, Q), dim3(1024), 0, stream, rcp, kd_b0, nsteps, vwords);
+        hipLaunchKernelGGL(k_kd_hint_fix, dim3((nsteps * K + 255) / 256 + kTieParts, Q), dim3(256), 0, stream, rcp, kd_b0, nsteps, vwords);
+        ++kd_gidx;
+        kd_b0 = kd_last_b + 1;
+        return;
+    }
     (void)hipStreamWaitEvent(stream2, ev_steered, 0);
     // few nodes: one wave per node (latency); many (several contexts at once): one thread per node (wave slots)
     // the hints of the group before and the deferred ties ride in this group's locate kernel (extra workgroups per row)
@@ -848,6 +862,12 @@ void porrt_ctx::join_side() {
         return;
     }
     launch_kd_group();
+    if (opt_kd_inline && launch_Q > 1) {
+        hipLaunchKernelGGL(k_tie_fix<256>, dim3(1, launch_Q), dim3(256), 0, stream, launch_rcp);
+        kd_pend[0] = kd_pend[1] = kd_pend[2] = false;
+        side_active = false;
+        return;
+    }
     if (kd_hint_ns) {
         hipLaunchKernelGGL(k_kd_hint_fix, dim3((kd_hint_ns * rc.cand_K + 255) / 256 + kTieParts, launch_Q), dim3(256), 0, stream2, launch_rcp, kd_hint_b0, kd_hint_ns, (rc.cand_K + 63) / 64);
         kd_hint_ns = 0;
@@ -2664,12 +2684,13 @@ static int grow_batch_each(porrt_ctx *const *ctxs, uint32_t n_ctx, const double 
     // measurement, once per leading context: pick_parallel_streams.
     porrt_ctx *top = ctxs[0];
     if (hipSetDevice(top->device) != hipSuccess) { top->set_err("hipSetDevice"); return PORRT_ERR_DEVICE; }
-    if (top->sub_streams.size() < 2u * G && top->sub_streams_tried != 2u * G) {
+    const uint32_t per = top->opt_kd_inline ? 1u : 2u;       // streams per sub-batch (main + side, or main alone)
+    if (top->sub_streams.size() < per * G && top->sub_streams_tried != per * G) {
         for (hipStream_t st : top->sub_streams) (void)hipStreamDestroy(st);
-        top->sub_streams = pick_parallel_streams(2u * G);
-        if (top->sub_streams.size() < 2u * G) top->sub_streams_tried = 2u * G;      // (e.g. under a profiler that serialises kernels: every pair test fails)
+        top->sub_streams = pick_parallel_streams(per * G);
+        if (top->sub_streams.size() < per * G) top->sub_streams_tried = per * G;      // (e.g. under a profiler that serialises kernels: every pair test fails)
     }
-    const bool have_streams = top->sub_streams.size() >= 2u * G;
+    const bool have_streams = top->sub_streams.size() >= per * G;
     top->last_launch_mode = have_streams ? (int)G : -(int)G;
     auto part = [&](uint32_t g) {
         porrt_ctx *Lg = ctxs[lo[g]];
@@ -2677,7 +2698,8 @@ static int grow_batch_each(porrt_ctx *const *ctxs, uint32_t n_ctx, const double 
         // On these streams the steps are launched one by one: a replayed hipGraph puts its branches on streams of the runtime's
         // choosing, and two replays side by side then share a queue more often than not (135-141 against 160 M expansions/s);
         // the launches (~900 per sub-batch) stay ahead of the GPU from a host thread each.
-        if (have_streams) { Lg->stream = top->sub_streams[g]; Lg->stream2 = top->sub_streams[G + g]; Lg->sub_eager = true; }
+        if (have_streams) { Lg->stream = top->sub_streams[g]; if (per == 2u) Lg->stream2 = top->sub_streams[G + g]; Lg->sub_eager = true; }
+        Lg->opt_kd_inline = top->opt_kd_inline;
         rcs[g] = grow_batch(ctxs + lo[g], lo[g + 1] - lo[g], starts + 2 * (size_t)lo[g], max_step, search_radius, n_iter_min + lo[g], n_iter_max + lo[g], batch_K, mode);
         Lg->stream = own; Lg->stream2 = own2; Lg->sub_eager = false;
     };
@@ -3212,6 +3234,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "batch_streams")) c->opt_batch_streams = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else if (!strcmp(name, "kd_after")) c->opt_kd_after = value != 0;
     else if (!strcmp(name, "kd_ride")) c->opt_kd_ride = value != 0;
+    else if (!strcmp(name, "kd_inline")) c->opt_kd_inline = value != 0;
     else if (!strcmp(name, "early_wave_steps")) c->opt_early_wave = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 64));
     else if (!strcmp(name, "kd_group")) c->opt_kd_group = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else { c->set_err(std::string("unknown option ") + name); return PORRT_ERR_INVALID; }

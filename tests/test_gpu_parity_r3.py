@@ -252,7 +252,7 @@ def test_single_query_launch_forms_agree(eng_mod, pipeline):
         assert_same(e2, o)
 
 
-@pytest.mark.parametrize("opts", [dict(kd_after=1), dict(kd_ride=1), dict(early_wave_steps=5), dict(kd_group=1), dict(kd_group=4)])
+@pytest.mark.parametrize("opts", [dict(kd_after=1), dict(kd_ride=1), dict(kd_inline=1), dict(early_wave_steps=5), dict(kd_group=1), dict(kd_group=4)])
 def test_engine_options_do_not_change_results(eng_mod, opts):
     """the developer options measured in DESIGN.md section 8 (kd structure after the steps, hints riding in the locate kernel, the first
     steps' connect pass with one wave per sample, kd group sizes): same trees from a batch of nine and from a single query"""
