@@ -186,7 +186,14 @@ def main():
     engs = sets[0]
     eng = engs[0]
     from po_rrt_amd import sharding
-    comm = sharding.make_comm(local_rank, dist if world > 1 else None)      # RCCL communicator of the job's one exchange (outside the timed region)
+    # RCCL communicator of the job's one exchange (outside the timed region).  The exchange is not the metric: if the communicator
+    # cannot be made, or the exchange fails (collectively: every rank gets a code), the line still carries the growth's numbers and
+    # says so in config.exchange_error -- the local best costs then stand in for the winners.
+    exchange_error = None
+    try:
+        comm = sharding.make_comm(local_rank, dist if world > 1 else None)
+    except Exception as ex:                  # noqa: BLE001
+        comm, exchange_error = None, "communicator: %s" % ex
     for e in sets[0] + sets[1]:
         e.set_option("profile", 0)
         for ov in args.opt:
@@ -267,12 +274,27 @@ def main():
     # the one exchange of the job (porrt_exchange_best, behind the C ABI): per map, who holds the best tree?  Path costs are
     # evaluated on the device, 16 bytes per map and rank are all-gathered, the winning trees are broadcast device to device
     # (RCCL) and stay on the device; one of them -- the best of all maps -- is fetched to the host here.
-    win = sharding.exchange_best_per_map(comm, engs, map_ids, n_maps)
+    win = None
+    if comm is not None:
+        try:
+            win = sharding.exchange_best_per_map(comm, engs, map_ids, n_maps)
+        except Exception as ex:              # noqa: BLE001
+            exchange_error = "exchange: %s" % ex
+    if win is None:                          # this rank's own best trees per map (costs evaluated on the device all the same)
+        from po_rrt_amd.engine import BEST_ENTRY
+        costs = po_rrt_amd.Engine.best_cost_batch(engs)
+        win = np.zeros(n_maps, dtype=BEST_ENTRY)
+        win["cost"], win["rank"] = np.inf, -1
+        for j, cj in enumerate(costs):
+            if cj < win["cost"][map_ids[j]]:
+                win["cost"][map_ids[j]], win["rank"][map_ids[j]], win["n_nodes"][map_ids[j]] = cj, rank, engs[j].num_nodes()
     solved = [m for m in range(n_maps) if win[m]["rank"] >= 0]
     mbest = min(solved, key=lambda m: (win[m]["cost"], m)) if solved else 0
     winner, win_cost = int(win[mbest]["rank"]), float(win[mbest]["cost"])
-    _, wparent, _ = comm.tree(mbest)
-    win_nodes = len(wparent)
+    win_nodes = 0
+    if comm is not None and exchange_error is None:
+        _, wparent, _ = comm.tree(mbest)
+        win_nodes = len(wparent)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -360,6 +382,7 @@ def main():
                                "(porrt_exchange_best: ncclAllGather of 16 B per map and rank + ncclBroadcast of the winning trees, device to device)" % (Q, world),
                 "maps": "map_benchmark_like" if world == 1 else "map_benchmark_like_{a..i}, queries of a rank spread over the nine (configs[4])",
                 "exchange_winners": [{"map": m, "rank": int(win[m]["rank"]), "cost": float(win[m]["cost"]), "nodes": int(win[m]["n_nodes"])} for m in range(n_maps)],
+                "exchange_error": exchange_error,
                 "best_path_cost": win_cost,
                 "winner_rank": winner,
                 "winner_nodes": win_nodes,
@@ -465,7 +488,8 @@ def main():
                 except Exception as ex:                      # noqa: BLE001
                     out["config"][key] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    comm.close()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 
