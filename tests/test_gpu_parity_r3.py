@@ -270,3 +270,18 @@ def test_engine_options_do_not_change_results(eng_mod, opts):
     o, _ = run_orc(cs[1], 1024)
     assert_same(e, o)
     assert e.get_option("pipeline") == 4
+
+
+def test_single_query_full_size_default_form(eng_mod):
+    """configs[1] at the bench's size as ONE query in the default launch form (one kernel per step: the filing and the rewire commit
+    run beside the next step, dist_root alternates between two arrays) against the oracle, twice on one context"""
+    case = cases.cfg2(111500, seed=778)
+    e, _ = run_gpu(eng_mod, case, 1024)
+    assert e.get_option("pipeline") == 4
+    o, _ = run_orc(case, 1024)
+    assert e.num_nodes() > 90000
+    assert_same(e, o)
+    assert e.best_cost() == o.best_solution()[1]
+    cases.grow(e, case, K=1024)
+    cases.grow(o, case, K=1024, algo=orc.ALGO_BATCHED_KD)
+    assert_same(e, o)
