@@ -16,15 +16,39 @@ def queries_of_rank(n_queries, rank, world_size):
     return list(range(rank, n_queries, world_size))
 
 
-def make_comm(device, dist=None):
-    """porrt_comm for this process: rank 0 makes the RCCL unique id, the process group carries its 128 bytes."""
+def make_comm(device, dist=None, _factory=None):
+    """porrt_comm for this process: rank 0 makes the RCCL unique id, the process group carries its 128 bytes.
+    Collective over `dist`: either every rank returns a communicator or every rank raises (a rank that cannot make the id or
+    its communicator tells the others through the process group, so that none walks on into a collective alone).
+    _factory: (unique_id, Comm) stand-ins for the CPU tests of this protocol."""
     from .engine import Comm
+    make_id, make = _factory if _factory else (Comm.unique_id, Comm)
     if dist is None or not dist.is_initialized():
-        return Comm(device, 0, 1, Comm.unique_id())
+        return make(device, 0, 1, make_id())
     rank, world = dist.get_rank(), dist.get_world_size()
-    box = [Comm.unique_id() if rank == 0 else None]
+    uid, err = None, None
+    if rank == 0:
+        try:
+            uid = make_id()
+        except Exception as ex:              # noqa: BLE001
+            err = "rank 0: %s" % ex
+    box = [(uid, err)]
     dist.broadcast_object_list(box, src=0)
-    return Comm(device, rank, world, box[0])
+    uid, err = box[0]
+    comm = None
+    if uid is not None:
+        try:
+            comm = make(device, rank, world, uid)
+        except Exception as ex:              # noqa: BLE001
+            err = "rank %d: %s" % (rank, ex)
+    said = [None] * world
+    dist.all_gather_object(said, None if comm is not None else err)
+    bad = [e for e in said if e]
+    if bad:
+        if comm is not None:
+            comm.close()
+        raise RuntimeError("make_comm: " + bad[0])
+    return comm
 
 
 def exchange_best_per_map(comm, engines, map_ids, n_maps):

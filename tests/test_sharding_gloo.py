@@ -143,6 +143,60 @@ def test_two_ranks_agree_before_every_collective(tmp_path):
     assert out.stdout.count("agree ok") == 2
 
 
+COMM_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path[:0] = [%(root)r]
+    import torch.distributed as dist
+    from po_rrt_amd import sharding
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Stub:                                              # stands in for engine.Comm (RCCL needs one GPU per rank)
+        closed = 0
+        def __init__(self, device, rank, world, uid):
+            if FAIL == ("create", rank):
+                raise RuntimeError("no communicator here")
+            self.uid = uid
+        def close(self):
+            Stub.closed += 1
+
+    def make_id():
+        if FAIL == ("id", 0):
+            raise RuntimeError("no unique id")
+        return b"u" * 128
+
+    for FAIL in (None, ("id", 0), ("create", 1), ("create", 0)):
+        Stub.closed = 0
+        try:
+            c = sharding.make_comm(0, dist, _factory=(make_id, Stub))
+            got = "comm"
+            assert c.uid == b"u" * 128
+        except RuntimeError as ex:
+            got = str(ex)
+        outcomes = [None] * world
+        dist.all_gather_object(outcomes, got == "comm")
+        assert all(outcomes) or not any(outcomes), "some ranks hold a communicator and some do not"
+        assert (got == "comm") == (FAIL is None), (FAIL, got)
+        if FAIL is not None:                                 # every rank names the failing rank; a made communicator is closed again
+            assert "rank %%d" %% FAIL[1] in got, got
+            assert Stub.closed == (1 if FAIL[0] == "create" and FAIL[1] != rank else 0), (FAIL, rank, Stub.closed)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "make_comm ok")
+""")
+
+
+def test_two_ranks_make_comm_all_or_none(tmp_path):
+    """sharding.make_comm: a rank that cannot make the unique id or its communicator takes every rank out the same way"""
+    script = tmp_path / "comm_worker.py"
+    script.write_text(COMM_WORKER % {"root": ROOT})
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29536", str(script)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count("make_comm ok") == 2
+
+
 def _bench(*args, env_drop=("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")):
     env = {k: v for k, v in os.environ.items() if k not in env_drop}
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), env=env, capture_output=True, text=True, timeout=600)
