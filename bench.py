@@ -42,7 +42,7 @@ def launch_ranks(n, argv, check_only):
     stderr.  Returns the exit code: 0, the first failing rank's code, or 3 when fewer than N devices are visible."""
     import socket
     import subprocess
-    if not check_only:
+    if not check_only and not os.environ.get("PORRT_BENCH_REHEARSE"):
         import torch
         have = torch.cuda.device_count()
         if have < n:
@@ -150,10 +150,19 @@ def main():
     import cases
     import po_rrt_amd
 
+    # PORRT_BENCH_REHEARSE=1: the N > 1 flow on a box with fewer GPUs than ranks (ranks share devices, the process group is gloo;
+    # RCCL refuses two ranks on one device, so the exchange reports that and the line carries it).  Never a measurement: the
+    # line says "rehearsal": true.
+    rehearse = bool(os.environ.get("PORRT_BENCH_REHEARSE")) and world > 1
+    if rehearse:
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if world > 1:
@@ -360,6 +369,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            **({"rehearsal": True} if rehearse else {}),
             "value_trees_on_device": total_nodes_dev / elapsed_dev,
             "value_note": "value counts the device-to-host copy of EVERY tree (SURVEY 8d): the %d trees of a step are fetched (porrt_get_trees, %.1f ms per "
                           "step on average) while the next step grows on a second set of contexts, and the last fetch is inside the timed region; "

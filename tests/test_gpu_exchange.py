@@ -35,3 +35,32 @@ def test_exchange_best_per_map_one_rank():
     win2 = sharding.exchange_best_per_map(comm, engs[:3], map_ids[:3], 4)
     assert [w["rank"] for w in win2] == [0, 0, 0, -1]
     comm.close()
+
+
+def test_bench_two_ranks_rehearsal():
+    """`bench.py --gpus 2` end to end on this box: the launcher starts two ranks, both grow their queries, the timings are
+    reduced over ranks and rank 0 prints the one line.  PORRT_BENCH_REHEARSE lets the ranks share a device when the box has one
+    (process group gloo); RCCL then refuses the communicator on every rank alike (make_comm is all-or-none), the line says so
+    and carries each map's local winner.  With two devices the exchange itself runs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PORRT_BENCH_REHEARSE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--queries", "9", "--steps", "2", "--warmup", "1",
+                          "--n-iter", "20000", "--no-single-query", "--no-profile"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rehearsal"] is True and d["steps"] == 2 and d["value"] > 0
+    assert d["config"]["queries_per_step_per_gpu"] == 9
+    win = d["config"]["exchange_winners"]
+    assert len(win) == 9 and all(w["rank"] in (0, 1) and w["cost"] > 0 for w in win)
+    if torch.cuda.device_count() < 2:
+        assert "make_comm" in d["config"]["exchange_error"]
+    else:
+        assert not d["config"].get("exchange_error")
