@@ -339,6 +339,9 @@ __device__ __forceinline__ void group_nn(const RunConst &rc, uint32_t b, const G
             int who = (int)tm.gl;
             tm.argmin(g, who);
             if (!(g <= thr) || g == INF) break;              // nothing left in the block that could hold a node as near
+#if defined(PORRT_TIMING) && PORRT_TIMING == 1
+            if (tm.gl == 0) atomicAdd(&rc.cnt->tim[5], 100ull);
+#endif
             gscan_region<GL>(rc, tm, tm.shfl(mreg, who), tm.shfl(mcnt, who), visit);
             group_best();
             if ((int)tm.gl == who) {
@@ -357,50 +360,75 @@ __device__ __forceinline__ void group_nn(const RunConst &rc, uint32_t b, const G
         if (ay0 > 0) { const double d = sqy - (rc.by0 + (double)ay0 * wy) - eps; out = d < out ? d : out; }
         if (ay0 + SB < kRG) { const double d = (rc.by0 + (double)(ay0 + SB) * wy) - sqy - eps; out = d < out ? d : out; }
         out = out > 0.0 ? out : 0.0;
+#if defined(PORRT_TIMING) && PORRT_TIMING == 1
+        if (tm.gl == 0) { atomicAdd(&rc.cnt->tim[13], 1ull); if (!(out * out > thr)) atomicAdd(&rc.cnt->tim[14], 1ull); }
+#endif
         if (out * out > thr) { nn = best; fx = bestx; fy = besty; return; }
     }
-    // ---- stage B: every occupied region outside the block, from the bitmap (lane l: words l and l + GL)
+    // ---- stage B: the occupied regions outside the block, a row of regions at a time (lane l: rows l, l + GL, ...).  Along a row
+    // the gap grows with the distance in x from the sample's column, so a row's nearest pending region is one of two bits of its
+    // occupancy: the first at or right of the column, the last left of it.  A lane keeps the better of the two per row and looks
+    // again only when its row lost a region; a side whose nearest region is already too far is dropped whole (thr only shrinks).
     auto gocc = as_global(rc.rg_occ) + (b & 1u) * kOccWords;
-    unsigned long long w[(kOccWords + GL - 1) / GL];
+    constexpr int ROWS = (kRG + GL - 1) / GL;
+    static_assert(kRG <= 64, "a row of regions is one word of bits");
+    unsigned long long rowbits[ROWS];
+    double rgap[ROWS];
+    int rreg[ROWS];
+    const unsigned long long below = (1ull << rx) - 1ull;       // the columns left of the sample's
 #pragma unroll
-    for (uint32_t q = 0; q < (kOccWords + GL - 1) / GL; ++q) {
-        const uint32_t wi = tm.gl + q * (uint32_t)GL;
-        w[q] = wi < kOccWords ? gocc[wi] : 0ull;
-        // (the block's regions are done)
-        for (unsigned long long m = w[q]; m;) {
-            const uint32_t bit = (uint32_t)__builtin_ctzll(m);
-            m &= m - 1;
-            const int r = (int)(wi * 64u + bit), cx = r % kRG, cy = r / kRG;
-            if (cx >= ax0 && cx < ax0 + SB && cy >= ay0 && cy < ay0 + SB) w[q] &= ~(1ull << bit);
+    for (int q = 0; q < ROWS; ++q) {
+        const int y = (int)tm.gl + q * GL;
+        unsigned long long m = 0ull;
+        if (y < kRG) {
+            const uint32_t o = (uint32_t)y * (uint32_t)kRG, wi = o >> 6, sh = o & 63u;
+            m = gocc[wi] >> sh;
+            if (sh + (uint32_t)kRG > 64u) m |= gocc[wi + 1u] << (64u - sh);
+            m &= (1ull << kRG) - 1ull;
+            if (y >= ay0 && y < ay0 + SB) m &= ~((((1ull << SB) - 1ull)) << ax0);      // (the block's regions are done)
         }
+        rowbits[q] = m;
     }
-    for (;;) {
-        // this lane's nearest pending region
-        double gap = INF;
-        int mine = -1;
-#pragma unroll
-        for (uint32_t q = 0; q < (kOccWords + GL - 1) / GL; ++q) {
-            const uint32_t wi = tm.gl + q * (uint32_t)GL;
-            for (unsigned long long m = w[q]; m;) {
-                const uint32_t bit = (uint32_t)__builtin_ctzll(m);
-                m &= m - 1;
-                const int r = (int)(wi * 64u + bit);
-                const double g = region_gap2(rc, sqx, sqy, r % kRG, r / kRG, rwx, rwy);
-                if (!(g <= thr)) { w[q] &= ~(1ull << bit); continue; }       // can never matter again: thr only shrinks
-                if (g < gap) { gap = g; mine = r; }
-            }
+    auto row_best = [&](int q, unsigned long long &m) {
+        const int y = (int)tm.gl + q * GL;
+        double g = INF;
+        int r = -1;
+        const unsigned long long hi = m >> rx;
+        if (hi) {
+            const int cx = rx + (int)__builtin_ctzll(hi);
+            const double gg = region_gap2(rc, sqx, sqy, cx, y, rwx, rwy);
+            if (gg <= thr) { g = gg; r = y * kRG + cx; }
+            else m &= below;
         }
-        double g = gap;
+        const unsigned long long lo = m & below;
+        if (lo) {
+            const int cx = 63 - (int)__builtin_clzll(lo);
+            const double gg = region_gap2(rc, sqx, sqy, cx, y, rwx, rwy);
+            if (!(gg <= thr)) m &= ~below;
+            else if (gg < g) { g = gg; r = y * kRG + cx; }
+        }
+        rgap[q] = g; rreg[q] = r;
+    };
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) row_best(q, rowbits[q]);
+    for (;;) {
+        double g = rgap[0];
+        int mine = rreg[0], mq = 0;
+#pragma unroll
+        for (int q = 1; q < ROWS; ++q) if (rgap[q] < g) { g = rgap[q]; mine = rreg[q]; mq = q; }
         int who = (int)tm.gl;
         tm.argmin(g, who);
         if (!(g <= thr) || g == INF) break;
+#if defined(PORRT_TIMING) && PORRT_TIMING == 1
+        if (tm.gl == 0) atomicAdd(&rc.cnt->tim[6], 100ull);
+#endif
         const uint32_t reg = (uint32_t)tm.shfl(mine, who);
         gscan_region<GL>(rc, tm, reg, gcnt[reg], visit);
         group_best();
         if ((int)tm.gl == who) {
-            const uint32_t wi = reg / 64u, q = (wi - tm.gl) / (uint32_t)GL;
 #pragma unroll
-            for (uint32_t qq = 0; qq < (kOccWords + GL - 1) / GL; ++qq) if (qq == q) w[qq] &= ~(1ull << (reg % 64u));
+            for (int q = 0; q < ROWS; ++q)
+                if (q == mq) { rowbits[q] &= ~(1ull << (reg % (uint32_t)kRG)); row_best(q, rowbits[q]); }
         }
     }
     nn = best; fx = bestx; fy = besty;
