@@ -266,6 +266,7 @@ struct RunConst {
     uint32_t sched_min, sched_max, sched_K, sched_steps;
     uint32_t sched_max_nodes;           // nodes this grow may create (n_iter_max + 2): what its preparation clears
     uint32_t cand_par3;                 // 1: neighbour lists, counts and values in three buffers by step % 3 (cand_slot)
+    uint32_t hint_max;                  // kd_hint_block: cells covering more hint squares leave the hints alone (a batch of many rows)
 };
 
 // Pointers read out of RunConst have no known address space, so hipcc emits flat_* accesses and drains both
@@ -2126,6 +2127,7 @@ __device__ __forceinline__ bool coop_wait_filed(const RunConst &rc, uint32_t nee
     return s_ok != 0u;
 }
 constexpr int kHG = 128;             // hint grid squares per axis
+constexpr uint32_t kHintMaxSquares = 256;    // (hint_max of the rows of a batch)    // cells covering more squares leave the hints alone (kd_hint_block)
 
 __device__ __forceinline__ KdBox load_box(const KdBox *p, size_t i) {
     auto g = as_global(p);
@@ -2398,11 +2400,14 @@ __device__ __forceinline__ void lds_barrier() {
 
 // CAP: the most nodes a launch may hold (the slots in LDS, the losers in registers); the engine takes the smaller form when the
 // group's steps cannot hold more -- beside the step kernels every KB of LDS counts.
+// TPB: threads of the workgroup (CAP / TPB losers per thread; the losers are the first n_l entries, so with few of them only the
+// first one or two per thread exist).  A workgroup must find all its wave slots free at once: beside the step kernels of a batch a
+// 16-wave workgroup waits for them several times longer than its rounds take, a 4-wave one does not.
 // LDSXY (a single query: the GPU's LDS is idle): the new nodes' coordinates are staged in LDS, so that a round's "step below the
 // winner" reads them there instead of through a dependent load from memory -- the rounds are this kernel's whole run time.
-template <uint32_t CAP, bool LDSXY = false>
-__global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords) {
-    static_assert(CAP % 1024u == 0 && CAP <= kClaimMax, "k_kd_claim: CAP");
+template <uint32_t CAP, bool LDSXY = false, uint32_t TPB = 1024>
+__global__ __launch_bounds__(TPB) void k_kd_claim(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords) {
+    static_assert(CAP % TPB == 0 && TPB % 64u == 0 && TPB <= 1024u && CAP <= kClaimMax, "k_kd_claim: CAP, TPB");
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
     __shared__ int s_ch[CAP][2];
     __shared__ dbl2 s_xy[LDSXY ? CAP : 1];
@@ -2418,21 +2423,21 @@ __global__ __launch_bounds__(1024) void k_kd_claim(const RunConst *__restrict__ 
     uint32_t p_rounds = 0, p_tail = 0;
 #endif
     if (n_l) {
-        for (uint32_t t = threadIdx.x; t < n_new; t += 1024u) {
+        for (uint32_t t = threadIdx.x; t < n_new; t += TPB) {
             s_ch[t][0] = kEmpty; s_ch[t][1] = kEmpty;
             if (LDSXY) { dbl2 v; v.x = grec[N + t].x; v.y = grec[N + t].y; s_xy[t] = v; }
         }
-        constexpr int kPer = CAP / 1024;
+        constexpr int kPer = CAP / TPB;
         bool todo[kPer];
         KdMove mv[kPer];
 #pragma unroll
         for (int r = 0; r < kPer; ++r) {
-            const uint32_t q = threadIdx.x + r * 1024u;
+            const uint32_t q = threadIdx.x + r * TPB;
             todo[r] = q < n_l;
             mv[r] = rc.kd_losers[todo[r] ? q : 0u];
         }
         __syncthreads();
-        // Losers are few next to the 1024 threads (a few hundred of a group's 2048 nodes): a wave none of whose lanes holds one
+        // Losers are few next to the threads (a few hundred of a group's 2048 nodes): a wave none of whose lanes holds one
         // has nothing to do in any round and leaves now -- the barriers below count the waves that are still there -- so that
         // the step kernels running beside this workgroup get its wave slots and registers back.  (Wave 0 holds the first
         // losers and does the closing part.)
@@ -2568,7 +2573,12 @@ __device__ __forceinline__ void kd_hint_block(const RunConst &rc, uint32_t b0, u
         const int iy0 = bx.loy == -INF ? 0 : ly + 1, iy1 = bx.hiy == INF ? kHG - 1 : uy - 1;
         if (ix0 <= ix1 && iy0 <= iy1) {
             const uint32_t w = (uint32_t)(ix1 - ix0 + 1), n = w * (uint32_t)(iy1 - iy0 + 1);
-            if (n <= 8u) {
+            if (n > rc.hint_max) {
+                // (a young tree's shallow nodes in a batch of many rows: a hint only shortens a descent, and a square they cover is soon
+                // covered by deeper nodes; raising thousands of squares per node -- with a thousand young trees grown together, tens
+                // of millions of atomics per group -- costs more than the levels it saves.  A single query keeps them: its kd chain
+                // is on its critical path and the atomics are few)
+            } else if (n <= 8u) {
                 const unsigned long long val = ((unsigned long long)as_global(rc.kd_depth)[id] << 32) | id;
                 for (uint32_t i = 0; i < n; ++i) {
                     const uint32_t ry = i / w;

@@ -190,6 +190,7 @@ struct porrt_ctx {
     bool opt_kd_after = false;
     int opt_kd_inline = 0;                 // "kd_inline": 1 = the kd groups run on the main stream between the steps (no side stream, no events): a sub-batch
                                            // needs one hardware queue instead of two, so four sub-batches fit the four queues
+    uint32_t opt_claim_threads = 0;        // "kd_claim_threads": 0 = the engine's choice (256 beside a batch's step kernels), else 256 / 512 / 1024
     int opt_kd_ride = 0;                   // "kd_ride": 1 = also for several contexts the hints and deferred ties ride in the next group's locate kernel
     uint32_t kd_after_K = 0;               // batch_K of the running launch sequence (the deferred groups need it)
     // "group_lanes": lanes per sample of the RRT* step kernels.  16 / 32 / 64: k_nn2 + k_conn2 (several samples per wave: fewer
@@ -713,6 +714,29 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     if (!opt_kd_after && b + 1 - kd_b0 >= kd_group) launch_kd_group();
 }
 
+// k_kd_claim of one group: the form by the group's size, the row count and (developer option) kd_claim_threads
+static void launch_kd_claim(hipStream_t st, const RunConst *rcp, uint32_t Q, uint32_t b0, uint32_t ns, uint32_t K, uint32_t vwords, uint32_t threads) {
+    const uint64_t nodes = (uint64_t)ns * K;
+    if (Q == 1 && threads == 0) {
+        if (nodes <= 2048u) hipLaunchKernelGGL(k_kd_claim<2048>, dim3(1, 1), dim3(1024), 0, st, rcp, b0, ns, vwords);
+        else hipLaunchKernelGGL(k_kd_claim<kClaimMax>, dim3(1, 1), dim3(1024), 0, st, rcp, b0, ns, vwords);
+        return;
+    }
+    if (threads == 0) threads = 256u;
+    if (nodes <= 1024u) {
+        if (threads <= 256u) hipLaunchKernelGGL((k_kd_claim<1024, false, 256>), dim3(1, Q), dim3(256), 0, st, rcp, b0, ns, vwords);
+        else if (threads <= 512u) hipLaunchKernelGGL((k_kd_claim<1024, false, 512>), dim3(1, Q), dim3(512), 0, st, rcp, b0, ns, vwords);
+        else hipLaunchKernelGGL((k_kd_claim<1024, false, 1024>), dim3(1, Q), dim3(1024), 0, st, rcp, b0, ns, vwords);
+    } else if (nodes <= 2048u) {
+        if (threads <= 256u) hipLaunchKernelGGL((k_kd_claim<2048, false, 256>), dim3(1, Q), dim3(256), 0, st, rcp, b0, ns, vwords);
+        else if (threads <= 512u) hipLaunchKernelGGL((k_kd_claim<2048, false, 512>), dim3(1, Q), dim3(512), 0, st, rcp, b0, ns, vwords);
+        else hipLaunchKernelGGL((k_kd_claim<2048, false, 1024>), dim3(1, Q), dim3(1024), 0, st, rcp, b0, ns, vwords);
+    } else {
+        if (threads <= 512u) hipLaunchKernelGGL((k_kd_claim<kClaimMax, false, 512>), dim3(1, Q), dim3(512), 0, st, rcp, b0, ns, vwords);
+        else hipLaunchKernelGGL((k_kd_claim<kClaimMax, false, 1024>), dim3(1, Q), dim3(1024), 0, st, rcp, b0, ns, vwords);
+    }
+}
+
 // kd insertion of steps [kd_b0, kd_last_b] on the side stream (positions are final since the last k_near; the
 // deferred ties are looked at again once the last commit is through)
 void porrt_ctx::launch_kd_group() {
@@ -725,8 +749,7 @@ void porrt_ctx::launch_kd_group() {
         if ((uint64_t)nsteps * K * Q >= 4096u) hipLaunchKernelGGL(k_kd_locate<1>, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u, 0u, 0u);
         else hipLaunchKernelGGL(k_kd_locate<64>, dim3((nsteps * K * 64 + 255) / 256, Q), dim3(256), 0, stream, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u, 0u, 0u);
         hipLaunchKernelGGL(k_kd_link, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream, rcp, kd_b0, nsteps, vwords, 0u);
-        if ((uint64_t)nsteps * K <= 2048u) hipLaunchKernelGGL(k_kd_claim<2048>, dim3(1, Q), dim3(1024), 0, stream, rcp, kd_b0, nsteps, vwords);
-        else hipLaunchKernelGGL(k_kd_claim<kClaimMax>, dim3(1, Q), dim3(1024), 0, stream, rcp, kd_b0, nsteps, vwords);
+        launch_kd_claim(stream, rcp, Q, kd_b0, nsteps, K, vwords, opt_claim_threads);
         hipLaunchKernelGGL(k_kd_hint_fix, dim3((nsteps * K + 255) / 256 + kTieParts, Q), dim3(256), 0, stream, rcp, kd_b0, nsteps, vwords);
         ++kd_gidx;
         kd_b0 = kd_last_b + 1;
@@ -743,8 +766,7 @@ void porrt_ctx::launch_kd_group() {
     else hipLaunchKernelGGL(k_kd_locate<64>, dim3((nsteps * K * 64 + 255) / 256 + extra, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, K, kd_last_nb, vwords, 0u, hb0, hns);
     hipLaunchKernelGGL(k_kd_link, dim3((nsteps * K + 255) / 256, Q), dim3(256), 0, stream2, rcp, kd_b0, nsteps, vwords, 0u);
     if (Q == 1) hipLaunchKernelGGL((k_kd_claim<kClaimMax, true>), dim3(1, 1), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
-    else if ((uint64_t)nsteps * K <= 2048u) hipLaunchKernelGGL(k_kd_claim<2048>, dim3(1, Q), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
-    else hipLaunchKernelGGL(k_kd_claim<kClaimMax>, dim3(1, Q), dim3(1024), 0, stream2, rcp, kd_b0, nsteps, vwords);
+    else launch_kd_claim(stream2, rcp, Q, kd_b0, nsteps, K, vwords, opt_claim_threads);
     if (ride) {
         // (a record's placeholder parent is in place before the record can be seen: nothing to wait for on the main stream);
         // join_side launches the last group's
@@ -851,8 +873,7 @@ void porrt_ctx::join_side() {
             if ((uint64_t)ns * K * Q >= 4096u) hipLaunchKernelGGL(k_kd_locate<1>, dim3((ns * K + 255) / 256, Q), dim3(256), 0, stream, rcp, kd_b0, ns, K, nbl, vwords, 0u);
             else hipLaunchKernelGGL(k_kd_locate<64>, dim3((ns * K * 64 + 255) / 256, Q), dim3(256), 0, stream, rcp, kd_b0, ns, K, nbl, vwords, 0u);
             hipLaunchKernelGGL(k_kd_link, dim3((ns * K + 255) / 256, Q), dim3(256), 0, stream, rcp, kd_b0, ns, vwords, 0u);
-            if ((uint64_t)ns * K <= 2048u) hipLaunchKernelGGL(k_kd_claim<2048>, dim3(1, Q), dim3(1024), 0, stream, rcp, kd_b0, ns, vwords);
-            else hipLaunchKernelGGL(k_kd_claim<kClaimMax>, dim3(1, Q), dim3(1024), 0, stream, rcp, kd_b0, ns, vwords);
+            launch_kd_claim(stream, rcp, Q, kd_b0, ns, K, vwords, opt_claim_threads);
             hipLaunchKernelGGL(k_kd_hint, dim3((ns * K + 255) / 256, Q), dim3(256), 0, stream, rcp, kd_b0, ns, vwords);
             kd_b0 = last + 1;
         }
@@ -1028,6 +1049,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     lag_on = pipe_on && opt_pipeline == 4 && K <= 1024;
     c.q_stride = pipe_on ? (uint32_t)Kpad : 0u;
     c.cand_par3 = lag_on ? 1u : 0u;
+    c.hint_max = 0xFFFFFFFFu;              // (porrt_grow_batch lowers it for its rows)
     lag_near_done = 0xFFFFFFFFu;
     c.perm = d_perm.p; c.ssx = d_ssx.p; c.ssy = d_ssy.p; c.bq_x = d_bqx.p; c.bq_y = d_bqy.p; c.bq_k = d_bqk.p; c.t2_at = d_t2at.p;
 
@@ -2291,6 +2313,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             rq.sched_i0 = sched ? cs[q]->d_sched_i0.p : nullptr;
             rq.sched_nb = sched ? cs[q]->d_sched_nb.p : nullptr;
             rq.sched_min = (uint32_t)nmin[q]; rq.sched_max = (uint32_t)nmax[q]; rq.sched_K = K;
+            rq.hint_max = n >= 8 ? kHintMaxSquares : 0xFFFFFFFFu;
             rq.sched_steps = (uint32_t)std::min<uint64_t>((uint64_t)B_pot + 2, cs[q]->d_sched_nb.n);
             if (sched && (uint64_t)(nmin[q] + K - 1) / K + (nmax[q] - nmin[q] + K - 1) / K + 2 > cs[q]->d_sched_nb.n) { L->set_err("porrt_grow_batch: step plan"); return PORRT_ERR_DEVICE; }
             L->rc_staging[q] = rq;
@@ -2430,6 +2453,14 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             if (r == -100) retry = true;
             else if (r < 0) { if (cs[q] != L) L->set_err(cs[q]->err); return r; }
             else if (r > worst) worst = r;
+        }
+        if (!retry && prof && sched && getenv("PORRT_DEBUG_STEPS")) {
+            for (uint32_t s2 = 0; s2 < steps && (size_t)(4 * s2 + 3) < ev_used; ++s2) {
+                float a = 0, r2 = 0;
+                (void)hipEventElapsedTime(&a, L->ev_pool[4 * s2 + 0], L->ev_pool[4 * s2 + 1]);
+                (void)hipEventElapsedTime(&r2, L->ev_pool[4 * s2 + 2], L->ev_pool[4 * s2 + 3]);
+                fprintf(stderr, "[porrt] batch step %u near %.1f us connect %.1f us\n", s2, a * 1e3, r2 * 1e3);
+            }
         }
         if (!retry && prof && !sched) {
             // events were recorded around k_near [0,1] and the connect kernel [2,3] of every step (all members at once);
@@ -3234,10 +3265,13 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "batch_streams")) c->opt_batch_streams = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else if (!strcmp(name, "kd_after")) c->opt_kd_after = value != 0;
     else if (!strcmp(name, "kd_ride")) c->opt_kd_ride = value != 0;
+    else if (!strcmp(name, "kd_claim_threads")) { if (value != 0 && value != 256 && value != 512 && value != 1024) return PORRT_ERR_INVALID; c->opt_claim_threads = (uint32_t)value; }
     else if (!strcmp(name, "kd_inline")) c->opt_kd_inline = value != 0;
     else if (!strcmp(name, "early_wave_steps")) c->opt_early_wave = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 64));
     else if (!strcmp(name, "kd_group")) c->opt_kd_group = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else { c->set_err(std::string("unknown option ") + name); return PORRT_ERR_INVALID; }
+    // a captured launch sequence has the options of its capture in it: the next grow captures again
+    if (strcmp(name, "profile") && c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
     return PORRT_OK;
 }
 

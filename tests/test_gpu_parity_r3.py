@@ -178,7 +178,7 @@ def test_sub_batches_on_an_odd_number_of_contexts(eng_mod):
 _tamp_cases = cases.tamp_queries
 
 
-@pytest.mark.parametrize("n,K", [(12, 256), (40, 1024), (9, 64)])
+@pytest.mark.parametrize("n,K", [(12, 256), (40, 1024), (9, 64), (20, 128)])
 def test_batch_with_loop_condition_equals_single_grows(eng_mod, n, K):
     """porrt_grow_batch with n_iter_min < n_iter_max: every member runs the loop of rrt.rs:109 on its own and leaves the later launches
     when it ends -- trees, iteration counts and sampler states equal those of separate porrt_grow calls (and the oracle's); members

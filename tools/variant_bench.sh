@@ -4,7 +4,7 @@ tag=$1; shift
 i=0
 for flags in "$@"; do
   PORRT_CXXFLAGS="$flags" python -c "from po_rrt_amd import build as b; b.build(force=True)" > gpurun_out/${tag}_build_$i.log 2>&1 || { tail -5 gpurun_out/${tag}_build_$i.log; exit 1; }
-  timeout -k 10 300 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-belief > gpurun_out/${tag}_$i.json 2> gpurun_out/${tag}_$i.err || { tail -5 gpurun_out/${tag}_$i.err; exit 1; }
+  timeout -k 10 300 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-belief --no-pmc > gpurun_out/${tag}_$i.json 2> gpurun_out/${tag}_$i.err || { tail -5 gpurun_out/${tag}_$i.err; exit 1; }
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/${tag}_$i.json").read().strip().splitlines()[-1])
