@@ -69,9 +69,9 @@ def build(name, case, K, algo):
     return rec
 
 
-# bench.py's timed call (BASELINE.json configs[1] as the headline runs it): 128 queries of cfg2(111500), seeds = slot, K = 1024,
-# advanced together as two sub-batches of 64.  Frozen here: the first and last member of each sub-batch.
-BENCH = dict(Q=128, n_iter=111500, K=1024, members=(0, 63, 64, 127))
+# bench.py's timed call (BASELINE.json configs[1] as the headline runs it): 256 queries of cfg2(111500), seeds = slot, K = 1024,
+# advanced together as two sub-batches of 128.  Frozen here: the first and last member of each sub-batch.
+BENCH = dict(Q=256, n_iter=111500, K=1024, members=(0, 127, 128, 255))
 
 
 def build_bench_member(j):
