@@ -643,7 +643,7 @@ def belief_space(device, with_cpu):
     return out
 
 
-def tamp_queries(device, with_cpu, n_queries=1024, K=128):
+def tamp_queries(device, with_cpu, n_queries=1024, K=128, opts=()):
     """The reference's real many-query caller, outside the timed region: the TAMP search plans twice per search edge with
     rrt.plan(.., max_step 0.1, search_radius 2.0, n_iter_min 2500, n_iter_max 10000) -- an ObservationGoal and a pickup SquareGoal,
     starts of their own (map_shelves_tamp_rrt.rs:224,232; main.rs:532) -- thousands of independent queries.  Here: n_queries of them
@@ -655,6 +655,9 @@ def tamp_queries(device, with_cpu, n_queries=1024, K=128):
     t0 = time.perf_counter()
     engs = [cases.configure(po_rrt_amd.Engine(device), c) for c in cs]
     t_make = time.perf_counter() - t0
+    for e in engs:
+        for name, val in opts:
+            e.set_option(name, val)
     starts = [c.start for c in cs]
     runs = []
     for rep in range(4):

@@ -259,11 +259,16 @@ int porrt_get_metrics(const porrt_ctx *ctx, porrt_metrics *out);
  * 4 (default) = ONE launch per step: the filing of a step's nodes and its rewire commit run beside the next step's kernels
  * (batch_K <= 1024, else as 1); 2 = all steps in one persistent cooperative launch with barriers over the grid (measured: far
  * slower on eight XCDs, kept for the record), "kd_after" (1 = the tie-order structure is built after the last step instead of
- * beside the steps: measured slower), "early_wave_steps", "dp_sweeps".  None of them changes a result. */
+ * beside the steps: measured slower), "kd_lazy" (RRT* with the group kernels, i.e. batches: 1 (default) = beside the steps only the
+ * goal path of the reference's kd-tree is kept -- it orders every tie between copies of the goal point and their parent -- and the
+ * whole structure is built after the steps in the rare run where two other nodes tie; 0 = the whole structure beside the steps on
+ * a second stream, as a single query does), "kd_claim_threads", "kd_ride", "kd_inline", "early_wave_steps", "dp_sweeps".  None of
+ * them changes a result. */
 int porrt_set_option(porrt_ctx *ctx, const char *name, int64_t value);
 /* what was in force: "launch_mode" (the last porrt_grow_batch led by this context: 0 = one launch sequence, G = G sequences side by
  * side on streams chosen by measurement, -G = G sequences on the contexts' own streams -- the probe found no parallel set, e.g. under a
- * profiler that serialises kernels), "pipeline", "group_lanes" */
+ * profiler that serialises kernels), "pipeline", "group_lanes", "kd_lazy", "kd_built_after" (1: a tie of the last grow needed the
+ * whole kd structure, which was built after its steps) */
 int porrt_get_option(const porrt_ctx *ctx, const char *name, int64_t *value);
 
 /* Device arithmetic self-test: sqrt and divide of n doubles on the GPU versus the host's correctly

@@ -99,6 +99,8 @@ struct Counters {
     uint32_t coop_abort;        //   a barrier or a waiting kernel gave up (nothing should ever set it: a guard against a hung GPU)
     uint32_t sched_stop;        // porrt_grow_batch with a loop condition: the first step this row did not run (0xFFFFFFFF: still running)
     uint32_t sched_iter;        //   and the iterations it ran (rrt.rs:109 / pto.rs:67: i when the loop ended)
+    uint32_t n_lca;             // kd_lazy: ties between nodes at different places off the goal path (the kd structure is built after the steps then)
+    uint32_t lca_next;          // kd_lazy: 1 + the last step with such a tie -- the structure is built for the steps before it only
     unsigned long long tim[16]; // developer builds (-DPORRT_TIMING): phase durations summed over waves, 10 ns units, and wave counts
 };
 
@@ -267,6 +269,7 @@ struct RunConst {
     uint32_t sched_max_nodes;           // nodes this grow may create (n_iter_max + 2): what its preparation clears
     uint32_t cand_par3;                 // 1: neighbour lists, counts and values in three buffers by step % 3 (cand_slot)
     uint32_t hint_max;                  // kd_hint_block: cells covering more hint squares leave the hints alone (a batch of many rows)
+    uint32_t kd_lazy;                   // 1: only the goal path of the kd-tree is kept beside the steps (g_track_step); see there
 };
 
 // Pointers read out of RunConst have no known address space, so hipcc emits flat_* accesses and drains both
@@ -1469,6 +1472,26 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
             uint32_t kd_done = 0, unused = 0;
             if (tl == 0) kd_done = __hip_atomic_load(&rc.cnt->kd_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
             tm.bcast2(kd_done, unused);       // one answer for the whole team
+            bool lazy_ok = false;
+            if (rc.kd_lazy) {
+                // Only the goal path is kept beside the steps (g_track_step).  Tied nodes off it that all lie at ONE place are a chain of
+                // ancestors in the kd-tree (a point inserted again follows the path of its first copy and goes on below it): the lowest
+                // id is first, as on the goal path.  (The goal-biased samples of a tree that has not reached its goal yet are steered to
+                // the same point again and again: such clusters are the off-path ties of an ordinary run.)  Tied nodes at different
+                // places off the path may need the whole structure: every tied node then counts as not yet known and the record waits
+                // for the build after the steps.
+                int off_min = kEmpty;
+                each_tie([&](int j) { if (!(as_global(rc.kd_gexit)[j] & kOnG)) off_min = j < off_min ? j : off_min; });
+                off_min = tm.min_i(off_min);
+                uint32_t n_else = 0;
+                if (off_min != kEmpty) {
+                    const double ox = as_global(rc.nx)[off_min], oy = as_global(rc.ny)[off_min];
+                    each_tie([&](int j) { if (!(as_global(rc.kd_gexit)[j] & kOnG) && (as_global(rc.nx)[j] != ox || as_global(rc.ny)[j] != oy)) ++n_else; });
+                    n_else = tm.sum(n_else);
+                }
+                if (n_else) { kd_done = 0; if (tl == 0) { atomicAdd(&rc.cnt->n_lca, 1u); atomicMax(&rc.cnt->lca_next, b + 1u); } }
+                else lazy_ok = true;
+            }
             // first in pre-order among the tied nodes the kd structure already holds
             int on_min = kEmpty;        // tied nodes ON the goal path: an ancestor chain, the lowest id is first
             int off_best = kEmpty;      // pre-order-first tied node off the goal path
@@ -1476,10 +1499,11 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
             each_tie([&](int j) {
                 if ((uint32_t)j >= kd_done) { ++n_fresh; return; }
                 if (as_global(rc.kd_gexit)[j] & kOnG) on_min = j < on_min ? j : on_min;
+                else if (lazy_ok) off_best = j < off_best ? j : off_best;              // (one place: the lowest id)
                 else if (off_best == kEmpty || kd_preorder_less(rc, j, off_best)) off_best = j;
             });
             on_min = tm.min_i(on_min);
-            off_best = tm.first_preorder(rc, off_best);
+            off_best = lazy_ok ? tm.min_i(off_best) : tm.first_preorder(rc, off_best);
             int known;
             if (off_best == kEmpty) known = on_min;
             else if (on_min == kEmpty) known = off_best;
@@ -2090,6 +2114,142 @@ __global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__
     if (k < nb && k < row_nb(rcp[blockIdx.y], b, nb)) commit_rrt_sample(rcp[blockIdx.y], b, vwords, k, threadIdx.x & 63u, 64u, lag != 0u);
 }
 
+// ---- kd_lazy: the tie order without the kd-tree.
+// kd_preorder_less settles every pair of tied nodes from where their root paths leave the goal path G (kd_gexit) -- except two
+// nodes off G that leave it at the same node.  And where a new node leaves G depends on G alone: the levels that are not copies
+// of the goal point are real tests (g_nd*), the copies reduce to two comparisons (k_kd_locate's long way).  So beside the steps
+// only G is kept: one workgroup per row and step (it rides in k_conn2) gives every new node its exit level, and lets the nodes
+// that stay on G to its end extend it, in id order.  A tie between two nodes off G is left deferred and counted (n_lca); the host
+// then builds the whole structure after the steps, as with option kd_after, and k_tie_fix settles those records.  Equal costs
+// through different parents off G take coordinates made to collide; the copies of the goal point, the ties of every run that
+// reaches its goal, are all on G.
+__device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords, uint8_t *lds) {
+    constexpr uint32_t kNd = 128;                                            // non-duplicate levels staged in LDS (more: read from memory)
+    uint16_t *s_k = reinterpret_cast<uint16_t *>(lds);                       // [4096] sample of the t-th new node
+    unsigned long long *s_cand = reinterpret_cast<unsigned long long *>(lds + 8192);      // [64] new nodes on G to its end
+    uint32_t *s_wpre = reinterpret_cast<uint32_t *>(lds + 8192 + 512);       // [65] valid samples before each mask word
+    double *s_ndx = reinterpret_cast<double *>(lds + 8192 + 512 + 272);      // [kNd]
+    double *s_ndy = s_ndx + kNd;
+    uint32_t *s_ndi = reinterpret_cast<uint32_t *>(s_ndy + kNd);             // [kNd]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    auto vm = as_global(rc.valid_mask) + (size_t)b * vwords;
+    const uint32_t N = as_global(rc.n_at)[b];
+    const uint32_t glen0 = rc.cnt->g_len, n_nd = rc.cnt->g_nd_len, d0 = rc.cnt->g_first_dup[0], d1 = rc.cnt->g_first_dup[1];
+    if (tid < 64u) s_cand[tid] = 0ull;
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (uint32_t w = 0; w < vwords; ++w) { s_wpre[w] = acc; acc += (uint32_t)__popcll(vm[w]); }
+        s_wpre[vwords] = acc;
+    }
+    for (uint32_t t2 = tid; t2 < n_nd && t2 < kNd; t2 += blockDim.x) {
+        s_ndi[t2] = as_global(rc.g_nd)[t2]; s_ndx[t2] = as_global(rc.g_nd_x)[t2]; s_ndy[t2] = as_global(rc.g_nd_y)[t2];
+    }
+    __syncthreads();
+    const uint32_t n_new = s_wpre[vwords];
+    for (uint32_t k = tid; k < nb; k += blockDim.x) {
+        const unsigned long long w = vm[k >> 6];
+        if ((w >> (k & 63u)) & 1ull) s_k[s_wpre[k >> 6] + (uint32_t)__popcll(w & ((1ull << (k & 63u)) - 1ull))] = (uint16_t)k;
+    }
+    __syncthreads();
+    const double px = rc.gp_x, py = rc.gp_y;
+    auto gex = as_global(rc.kd_gexit);
+    const uint32_t qo = q_off(rc, b);
+    // every new node against G as it stands before the step
+    for (uint32_t t = tid; t < n_new; t += blockDim.x) {
+        const uint32_t k = s_k[t];
+        const double vx = as_global(rc.q_x)[qo + k], vy = as_global(rc.q_y)[qo + k];
+        uint32_t E = 0xFFFFFFFFu;
+        for (uint32_t s0 = 0; s0 < n_nd; ++s0) {
+            uint32_t ii;
+            double wx, wy;
+            if (s0 < kNd) { ii = s_ndi[s0]; wx = s_ndx[s0]; wy = s_ndy[s0]; }
+            else { ii = as_global(rc.g_nd)[s0]; wx = as_global(rc.g_nd_x)[s0]; wy = as_global(rc.g_nd_y)[s0]; }
+            if (kd_left(vx, vy, wx, wy, ii) != kd_left(px, py, wx, wy, ii) && ii < E) E = ii;
+        }
+        if (vx < px && d0 < E) E = d0;
+        if (vy < py && d1 < E) E = d1;
+        if (E != 0xFFFFFFFFu) gex[N + t] = E;
+        else atomicOr(&s_cand[t >> 6], 1ull << (t & 63u));
+    }
+    __syncthreads();
+    // the nodes that follow G to its end, in id order: the first extends it, the next ones are tested against the levels added
+    // before them (64 levels at a time) and extend it in their turn if they pass them all
+    if (tid < 64u) {
+        uint32_t len = glen0;
+        auto gx = as_global(reinterpret_cast<unsigned long long *>(rc.g_x)), gy = as_global(reinterpret_cast<unsigned long long *>(rc.g_y));
+        for (uint32_t w = 0; w < (n_new + 63u) / 64u; ++w) {
+            for (unsigned long long m = s_cand[w]; m;) {
+                const uint32_t t = w * 64u + (uint32_t)__builtin_ctzll(m);
+                m &= m - 1ull;
+                const uint32_t k = s_k[t];
+                const double vx = as_global(rc.q_x)[qo + k], vy = as_global(rc.q_y)[qo + k];
+                uint32_t E = 0xFFFFFFFFu;
+                if (!(vx == px && vy == py)) {                               // (a copy of the goal point passes every level)
+                    for (uint32_t l0 = glen0; l0 < len && E == 0xFFFFFFFFu; l0 += 64u) {
+                        const uint32_t lvl = l0 + lane;
+                        bool out = false;
+                        if (lvl < len) {
+                            const double wx = __longlong_as_double((long long)__hip_atomic_load(gx + lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            const double wy = __longlong_as_double((long long)__hip_atomic_load(gy + lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            out = kd_left(vx, vy, wx, wy, lvl) != kd_left(px, py, wx, wy, lvl);
+                        }
+                        const unsigned long long ob = __ballot(out);
+                        if (ob) E = l0 + (uint32_t)__builtin_ctzll(ob);
+                    }
+                }
+                if (lane == 0) {
+                    if (E != 0xFFFFFFFFu) {
+                        gex[N + t] = E;
+                    } else {
+                        if (len + 8u < rc.g_cap) {
+                            as_global(rc.g_id)[len] = (int)(N + t);
+                            __hip_atomic_store(gx + len, (unsigned long long)__double_as_longlong(vx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(gy + len, (unsigned long long)__double_as_longlong(vy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else {
+                            atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW);
+                        }
+                        gex[N + t] = len | kOnG;
+                        if (vx == px && vy == py) { if (len < rc.cnt->g_first_dup[len & 1u]) rc.cnt->g_first_dup[len & 1u] = len; }
+                        else {
+                            const uint32_t sl = rc.cnt->g_nd_len;
+                            as_global(rc.g_nd)[sl] = len; as_global(rc.g_nd_x)[sl] = vx; as_global(rc.g_nd_y)[sl] = vy;
+                            rc.cnt->g_nd_len = sl + 1u;
+                        }
+                    }
+                }
+                if (E == 0xFFFFFFFFu) ++len;
+                __builtin_amdgcn_s_waitcnt(0);                               // the level is in memory before the next node reads it
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (lane == 0) {
+            rc.cnt->g_len = len;
+            __threadfence();
+            __hip_atomic_store(&rc.cnt->kd_done, N + n_new, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+constexpr uint32_t kGTrackLds = 8192u + 512u + 272u + 128u * 20u;        // bytes of LDS g_track_step needs
+
+// the kd state of a grow's start (k_init_root), for the full build after lazily tracked steps; grid (64, rows) x 256
+__global__ __launch_bounds__(256) void k_kd_reset(const RunConst *__restrict__ rcp) {
+    const RunConst &rc = rcp[blockIdx.y];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)(128 * 128); i += gridDim.x * 256u) rc.kd_hint[i] = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double x = rc.nx[0], y = rc.ny[0];
+        rc.cnt->g_len = 1;
+        rc.cnt->g_first_dup[0] = 0xFFFFFFFFu;
+        rc.cnt->g_first_dup[1] = 0xFFFFFFFFu;
+        if (x == rc.gp_x && y == rc.gp_y) { rc.cnt->g_first_dup[0] = 0; rc.cnt->g_nd_len = 0; }
+        else { rc.g_nd[0] = 0; rc.g_nd_x[0] = x; rc.g_nd_y[0] = y; rc.cnt->g_nd_len = 1; }
+        rc.kd_rec[0].child[0] = kEmpty; rc.kd_rec[0].child[1] = kEmpty;
+        rc.cnt->kd_done = 1;
+        rc.cnt->kd_snap = 0;
+        rc.cnt->n_losers = 0;
+        rc.g_snap[0] = 1; rc.g_snap[1] = rc.cnt->g_nd_len; rc.g_snap[2] = rc.cnt->g_first_dup[0]; rc.g_snap[3] = rc.cnt->g_first_dup[1];
+    }
+}
+
 // Insert this step's nodes into the reference's kd-tree in id order (KdTree::add, nearest_neighbor.rs:29-46;
 // rrt.rs:163) -- only the STRUCTURE is kept (child / parent / depth / cell), searches never use it.  It exists to
 // reproduce the order in which the reference resolves equal-cost parents (kd pre-order).  Two kernels:
@@ -2181,6 +2341,7 @@ template <int LPN>
 __global__ __launch_bounds__(256) void k_kd_locate(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t K, uint32_t nb_last,
                                                     uint32_t vwords, uint32_t lpar, uint32_t hb0 = 0, uint32_t hns = 0) {
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
+    if (rc.kd_lazy && rc.cnt->lca_next <= b0) return;      // (the build after lazily tracked steps: only the rows and steps a tie asked for)
     if (hns) {
         const uint32_t lb = LPN == 64 ? (nsteps * K * 64u + 255u) / 256u : (nsteps * K + 255u) / 256u;
         if (blockIdx.x >= lb) {
@@ -2367,6 +2528,7 @@ __device__ __forceinline__ uint32_t kd_group_size(const RunConst &rc, uint32_t b
 
 __global__ __launch_bounds__(256) void k_kd_link(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords, uint32_t lpar) {
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
+    if (rc.kd_lazy && rc.cnt->lca_next <= b0) return;
     const uint32_t N = as_global(rc.n_at)[b0];
     const uint32_t n_new = kd_group_size(rc, b0, nsteps, vwords);
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -2409,6 +2571,7 @@ template <uint32_t CAP, bool LDSXY = false, uint32_t TPB = 1024>
 __global__ __launch_bounds__(TPB) void k_kd_claim(const RunConst *__restrict__ rcp, uint32_t b0, uint32_t nsteps, uint32_t vwords) {
     static_assert(CAP % TPB == 0 && TPB % 64u == 0 && TPB <= 1024u && CAP <= kClaimMax, "k_kd_claim: CAP, TPB");
     const RunConst &rc = rcp[blockIdx.y];      // one context per grid row (porrt_grow_batch)
+    if (rc.kd_lazy && rc.cnt->lca_next <= b0) return;
     __shared__ int s_ch[CAP][2];
     __shared__ dbl2 s_xy[LDSXY ? CAP : 1];
     __shared__ uint32_t s_nact;
@@ -2530,7 +2693,7 @@ __global__ __launch_bounds__(TPB) void k_kd_claim(const RunConst *__restrict__ r
 #ifdef PORRT_CLAIM_PROBE
     if (threadIdx.x == 0) {      // developer statistics: losers (max, sum), launches, rounds, tail rounds, time
         atomicMax(&rc.cnt->dbg[0], n_l); atomicAdd(&rc.cnt->dbg[1], n_l); atomicAdd(&rc.cnt->dbg[2], 1u); atomicAdd(&rc.cnt->dbg[3], p_rounds);
-        atomicAdd(&rc.cnt->tim[0], wall_clock64() - pt0); atomicAdd(&rc.cnt->tim[8], 1ull); atomicAdd(&rc.cnt->tim[1], (unsigned long long)p_tail * 100ull); atomicAdd(&rc.cnt->tim[9], 1ull);
+        { const unsigned long long dt = wall_clock64() - pt0; atomicAdd(&rc.cnt->tim[0], dt); atomicMax(&rc.cnt->tim[2], dt); rc.cnt->tim[10] = 1ull; } atomicAdd(&rc.cnt->tim[8], 1ull); atomicAdd(&rc.cnt->tim[1], (unsigned long long)p_tail * 100ull); atomicAdd(&rc.cnt->tim[9], 1ull);
     }
 #endif
     if (threadIdx.x == 0) {
@@ -2557,6 +2720,7 @@ __device__ __forceinline__ void kd_hint_block(const RunConst &rc, uint32_t b0, u
     __shared__ int s_big_r[256][4];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t t = bx * 256u + threadIdx.x;
+    if (rc.kd_lazy && rc.cnt->lca_next <= b0) return;
     const uint32_t n_new = kd_group_size(rc, b0, nsteps, vwords);
     if (threadIdx.x == 0) s_nbig = 0;
     __syncthreads();

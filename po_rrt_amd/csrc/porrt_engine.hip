@@ -190,6 +190,11 @@ struct porrt_ctx {
     bool opt_kd_after = false;
     int opt_kd_inline = 0;                 // "kd_inline": 1 = the kd groups run on the main stream between the steps (no side stream, no events): a sub-batch
                                            // needs one hardware queue instead of two, so four sub-batches fit the four queues
+    int opt_kd_lazy = 1;                   // "kd_lazy": 1 (default) = with the group kernels only the goal path of the kd order is kept beside the steps
+                                           // (g_track_step) and the whole structure is built after them if a tie needs it; 0 = built beside the steps
+    int kd_built_after = 0;
+    bool kd_lazy = false, kd_build_now = false;    // in force for the running grow; the build after the steps is being launched
+    int kd_full_build(const std::vector<std::pair<uint32_t, uint32_t>> &segs);
     uint32_t opt_claim_threads = 0;        // "kd_claim_threads": 0 = the engine's choice (256 beside a batch's step kernels), else 256 / 512 / 1024
     int opt_kd_ride = 0;                   // "kd_ride": 1 = also for several contexts the hints and deferred ties ride in the next group's locate kernel
     uint32_t kd_after_K = 0;               // batch_K of the running launch sequence (the deferred groups need it)
@@ -342,6 +347,12 @@ struct porrt_ctx {
     int coop_blocks = 0;                      // grid of the persistent step loop on this device (0: not looked up yet)
     int ensure_side_stream() {
         if (stream2) return PORRT_OK;
+        if (getenv("PORRT_KD_PRIORITY")) {       // (experiment: the side chain ahead of the step kernels in the dispatcher)
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, hi) == hipSuccess) return PORRT_OK;
+            stream2 = nullptr;
+        }
         if (hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking) != hipSuccess) { stream2 = nullptr; set_err("hipStreamCreate (side stream)"); return PORRT_ERR_DEVICE; }
         return PORRT_OK;
     }
@@ -700,18 +711,19 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     ev();
     if (GLn) {
         const uint32_t spb = 256u / GLc;
-        const dim3 g2((nb + spb - 1) / spb + 2, Q);       // + the clone workgroup + the page-filing workgroup
+        const uint32_t lazy = kd_lazy ? 1u : 0u;
+        const dim3 g2((nb + spb - 1) / spb + 2 + lazy, Q);       // + the clone workgroup + the page-filing workgroup (+ the goal path's)
         const size_t dyn = conn2_lds_bytes(GLc);
-        if (GLc == 16) hipLaunchKernelGGL(k_conn2<16>, g2, dim3(256), dyn, stream, rcp, b, nb, vwords);
-        else if (GLc == 32) hipLaunchKernelGGL(k_conn2<32>, g2, dim3(256), dyn, stream, rcp, b, nb, vwords);
-        else hipLaunchKernelGGL(k_conn2<64>, g2, dim3(256), dyn, stream, rcp, b, nb, vwords);
+        if (GLc == 16) hipLaunchKernelGGL(k_conn2<16>, g2, dim3(256), dyn, stream, rcp, b, nb, vwords, lazy);
+        else if (GLc == 32) hipLaunchKernelGGL(k_conn2<32>, g2, dim3(256), dyn, stream, rcp, b, nb, vwords, lazy);
+        else hipLaunchKernelGGL(k_conn2<64>, g2, dim3(256), dyn, stream, rcp, b, nb, vwords, lazy);
     } else if (lds_bytes) hipLaunchKernelGGL(k_connect_rrt<true>, cgrid, cblock, lds_bytes, stream, rcp, b, nb, vwords);
     else hipLaunchKernelGGL(k_connect_rrt<false>, cgrid, cblock, 0, stream, rcp, b, nb, vwords);
     ev();
     commit_pend_b = b; commit_pend_nb = nb;
     kd_last_b = b; kd_last_nb = nb;
     side_active = true;
-    if (!opt_kd_after && b + 1 - kd_b0 >= kd_group) launch_kd_group();
+    if (!opt_kd_after && !(kd_lazy && GLn) && b + 1 - kd_b0 >= kd_group) launch_kd_group();
 }
 
 // k_kd_claim of one group: the form by the group's size, the row count and (developer option) kd_claim_threads
@@ -862,7 +874,8 @@ int porrt_ctx::launch_coop(uint32_t n_steps, uint32_t K, uint64_t n_iter, uint32
 void porrt_ctx::join_side() {
     flush_commit();
     if (!side_active) return;
-    if (opt_kd_after) {
+    if (kd_lazy && opt_group != 0 && !kd_build_now) { side_active = false; return; }        // (the goal path rode in the step kernels; nothing runs beside them)
+    if (opt_kd_after || kd_build_now) {
         // the whole structure now, on the main stream: groups of as many steps as the claim kernel holds, in id order
         const RunConst *rcp = launch_rcp;
         const uint32_t Q = launch_Q, K = rc.cand_K, vwords = (K + 63) / 64;
@@ -899,6 +912,26 @@ void porrt_ctx::join_side() {
     if (launch_Q > 1) hipLaunchKernelGGL(k_tie_fix<256>, dim3(1, launch_Q), dim3(256), 0, stream, launch_rcp);
     else hipLaunchKernelGGL(k_tie_fix<1024>, dim3(1, launch_Q), dim3(1024), 0, stream, launch_rcp);
     side_active = false;
+}
+
+// kd_lazy, after the steps: a tie needed more than the goal path (Counters::n_lca).  The kd state goes back to the grow's start and
+// the whole structure is built in id order on the main stream (what option kd_after does after every run); k_tie_fix then settles
+// the records that waited for it.
+int porrt_ctx::kd_full_build(const std::vector<std::pair<uint32_t, uint32_t>> &segs) {
+    // segs: (last step, its sample count) of every run of steps in which only the last one may be short (the steps up to
+    // n_iter_min, then the steps of the loop's tail)
+    hipLaunchKernelGGL(k_kd_reset, dim3(64, launch_Q), dim3(256), 0, stream, launch_rcp);
+    kd_b0 = 0; kd_gidx = 0; kd_hint_ns = 0;
+    commit_pend_b = 0xFFFFFFFFu;
+    kd_build_now = true;
+    for (const auto &sg : segs) {
+        if (sg.first + 1u <= kd_b0) continue;
+        kd_last_b = sg.first; kd_last_nb = sg.second;
+        side_active = true;
+        join_side();
+    }
+    kd_build_now = false;
+    return hipGetLastError() == hipSuccess ? PORRT_OK : PORRT_ERR_DEVICE;
 }
 
 int porrt_ctx::grow(const double start[2], double max_step, double search_radius, uint64_t n_iter_min, uint64_t n_iter_max,
@@ -1225,6 +1258,12 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     launch_rcp = d_rc.p;
     launch_Q = 1;
     opt_group = opt_group_req < 0 ? 0u : (uint32_t)opt_group_req;
+    kd_lazy = opt_kd_lazy && opt_group != 0 && mode == PORRT_MODE_RRT && !opt_kd_after;
+    kd_built_after = 0;
+    if ((c.kd_lazy != 0u) != kd_lazy) {          // (the run constants were uploaded above)
+        c.kd_lazy = kd_lazy ? 1u : 0u;
+        HIPCHK(hipMemcpyAsync(d_rc.p, &c, sizeof c, hipMemcpyHostToDevice, stream));
+    }
     HIPCHK(hipEventRecord(ev_first, stream));
     side_active = false;
     pipe_near_done = 0xFFFFFFFFu;
@@ -1265,7 +1304,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
             }
             join_side();
             HIPCHK(hipStreamEndCapture(stream, &g));
-            HIPCHK(hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0));
+            HIPCHK(getenv("PORRT_KD_PRIORITY") ? hipGraphInstantiateWithFlags(&graph_exec, g, hipGraphInstantiateFlagUseNodePriority) : hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
             memcpy(graph_key, key, sizeof key);
             t_setup += now_s() - t0;
@@ -1310,6 +1349,22 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         join_side();
         i += nb;
         ++b;
+        r = read_counters();
+        if (r) return r;
+    }
+    if (kd_lazy && hc.n_lca && !(hc.err & (ERR_CAND_OVERFLOW | ERR_RNG_RETRY))) {
+        // a tie between two nodes off the goal path: the whole kd structure after all, then the records that waited for it
+        // (for the steps up to the last such tie: its record names older nodes only)
+        std::vector<std::pair<uint32_t, uint32_t>> segs;
+        const uint32_t s1 = (uint32_t)((n_iter_min + K - 1) / K), S = std::min<uint32_t>(hc.lca_next, b);
+        if (S <= s1) segs.emplace_back(S - 1u, S == s1 ? (uint32_t)(n_iter_min - (uint64_t)(s1 - 1u) * K) : K);
+        else {
+            segs.emplace_back(s1 - 1u, (uint32_t)(n_iter_min - (uint64_t)(s1 - 1u) * K));
+            segs.emplace_back(S - 1u, S == b ? (uint32_t)(i - n_iter_min - (uint64_t)(b - 1u - s1) * K) : K);
+        }
+        int r = kd_full_build(segs);
+        if (r) return r;
+        kd_built_after = 1;
         r = read_counters();
         if (r) return r;
     }
@@ -2147,6 +2202,7 @@ int porrt_ctx::finish_batch_member(uint64_t n_iter_done, uint32_t steps, uint32_
     if (hc.err & ERR_CAND_OVERFLOW) return -100;
     if (hc.err & ERR_RNG_RETRY) { set_err("a float draw would have been redrawn: grow this context on its own"); return PORRT_ERR_INVALID; }
     counters = hc;
+    if (getenv("PORRT_DEBUG_ALL") && hc.tim[10]) fprintf(stderr, "[porrt] member %u: longest k_kd_claim workgroup %.1f us, mean %.1f us\n", batch_slot, 1e-2 * (double)hc.tim[2], hc.tim[8] ? 1e-2 * (double)hc.tim[0] / (double)hc.tim[8] : 0.0);
     if (getenv("PORRT_DEBUG") && batch_slot == 0) {
         fprintf(stderr, "[porrt] batch member 0: samples served through the lists in memory %u; kd claim losers max %u mean %.1f over %u launches; g_nd %u; deferred ties %u (pooled ids %u)\n",
                 hc.n_heavy, hc.dbg[0], hc.dbg[2] ? (double)hc.dbg[1] / hc.dbg[2] : 0.0, hc.dbg[2], hc.dbg[3], hc.pend_cnt, hc.pool_n);
@@ -2200,7 +2256,11 @@ static std::vector<hipStream_t> pick_parallel_streams(uint32_t want) {
     double t_one = 0.0;         // one such kernel alone (launch and wait included): what "side by side" is measured against
     for (uint32_t tries = 0; chosen.size() < want && tries < 4u * want; ++tries) {
         hipStream_t st = nullptr;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+        if (getenv("PORRT_KD_PRIORITY") && chosen.size() >= want / 2u) {      // (experiment: the second half become side streams)
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) != hipSuccess) break;
+        } else if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
         hipLaunchKernelGGL(k_wait_us, dim3(1), dim3(64), 0, st, 1u);          // first use: the stream gets its queue
         if (t_one == 0.0) {
             double best = 1e9;
@@ -2303,6 +2363,8 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             if (cs[q]->run_lds_bytes != L->run_lds_bytes) { L->set_err("porrt_grow_batch: the contexts' rasters need different LDS tiles (max_step * ppm differs)"); return PORRT_ERR_INVALID; }
         }
         L->opt_group = L->opt_group_req < 0 ? (n >= 8 ? 16u : 0u) : (uint32_t)L->opt_group_req;
+        L->kd_lazy = L->opt_kd_lazy && L->opt_group != 0 && mode == PORRT_MODE_RRT && !L->opt_kd_after;
+        L->kd_built_after = 0;
         // (pipelined steps search step b + 1 while step b is connected: not with rows that may end after step b)
         L->pipe_on = mode == PORRT_MODE_RRT && L->opt_group == 0 && L->opt_pipeline != 0 && !sched;
         L->lag_on = false;
@@ -2314,6 +2376,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             rq.sched_nb = sched ? cs[q]->d_sched_nb.p : nullptr;
             rq.sched_min = (uint32_t)nmin[q]; rq.sched_max = (uint32_t)nmax[q]; rq.sched_K = K;
             rq.hint_max = n >= 8 ? kHintMaxSquares : 0xFFFFFFFFu;
+            rq.kd_lazy = (L->opt_kd_lazy && L->opt_group != 0 && mode == PORRT_MODE_RRT && !L->opt_kd_after) ? 1u : 0u;
             rq.sched_steps = (uint32_t)std::min<uint64_t>((uint64_t)B_pot + 2, cs[q]->d_sched_nb.n);
             if (sched && (uint64_t)(nmin[q] + K - 1) / K + (nmax[q] - nmin[q] + K - 1) / K + 2 > cs[q]->d_sched_nb.n) { L->set_err("porrt_grow_batch: step plan"); return PORRT_ERR_DEVICE; }
             L->rc_staging[q] = rq;
@@ -2412,7 +2475,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
                 HIPCHK_CTX(L, hipStreamBeginCapture(L->stream, hipStreamCaptureModeThreadLocal));
                 (void)all_steps();
                 HIPCHK_CTX(L, hipStreamEndCapture(L->stream, &g));
-                HIPCHK_CTX(L, hipGraphInstantiate(&L->graph_exec, g, nullptr, nullptr, 0));
+                HIPCHK_CTX(L, getenv("PORRT_KD_PRIORITY") ? hipGraphInstantiateWithFlags(&L->graph_exec, g, hipGraphInstantiateFlagUseNodePriority) : hipGraphInstantiate(&L->graph_exec, g, nullptr, nullptr, 0));
                 (void)hipGraphDestroy(g);
                 memcpy(L->graph_key, key, sizeof key);
             }
@@ -2433,6 +2496,27 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         std::vector<BatchOut> h_out(n);
         HIPCHK_CTX(L, hipMemcpyAsync(h_out.data(), L->d_batch_out, (size_t)n * sizeof(BatchOut), hipMemcpyDeviceToHost, L->stream));
         HIPCHK_CTX(L, hipStreamSynchronize(L->stream));
+        if (L->kd_lazy) {
+            bool need = false;
+            for (uint32_t q = 0; q < n; ++q) need = need || (h_out[q].cnt.n_lca && !(h_out[q].cnt.err & (ERR_CAND_OVERFLOW | ERR_RNG_RETRY)));
+            if (need) {
+                // a tie between two nodes off the goal path in some row: the whole kd structure after all (every row of the launch:
+                // the kernels take rows as they come), then the records that waited for it
+                // (for the steps up to the last such tie of any row: a record names older nodes only)
+                uint32_t S = 0;
+                for (uint32_t q = 0; q < n; ++q) S = std::max(S, h_out[q].cnt.lca_next);
+                S = std::min(S, steps);
+                std::vector<std::pair<uint32_t, uint32_t>> segs;
+                if (sched || S < steps) segs.emplace_back(S - 1u, K);                          // (rows cut their own steps: row_nb)
+                else segs.emplace_back(steps - 1u, (uint32_t)(n_iter - (uint64_t)(steps - 1u) * K));
+                int r = L->kd_full_build(segs);
+                if (r) { L->set_err("porrt_grow_batch: kd structure after the steps"); return r; }
+                L->kd_built_after = 1;
+                hipLaunchKernelGGL(k_batch_gather, dim3(n), dim3(64), 0, L->stream, (const RunConst *)L->d_rcarr, sched ? steps : (uint32_t)((n_iter + K - 1) / K), L->d_batch_out);
+                HIPCHK_CTX(L, hipMemcpyAsync(h_out.data(), L->d_batch_out, (size_t)n * sizeof(BatchOut), hipMemcpyDeviceToHost, L->stream));
+                HIPCHK_CTX(L, hipStreamSynchronize(L->stream));
+            }
+        }
         for (uint32_t q = 0; q < n; ++q) { cs[q]->batch_hc = h_out[q].cnt; cs[q]->batch_nodes = h_out[q].nodes; }
         {
             hipError_t e = hipGetLastError();
@@ -3250,6 +3334,9 @@ int porrt_get_option(const porrt_ctx *c, const char *name, int64_t *value) {
     if (!strcmp(name, "launch_mode")) *value = c->last_launch_mode;
     else if (!strcmp(name, "pipeline")) *value = c->lag_on ? 4 : (c->pipe_on ? 1 : 0);
     else if (!strcmp(name, "group_lanes")) *value = c->opt_group;
+    else if (!strcmp(name, "kd_lazy")) *value = c->kd_lazy ? 1 : 0;                 // in force for the last grow (of a batch: ask its first context)
+    else if (!strcmp(name, "kd_lca_steps")) *value = (int64_t)c->counters.lca_next;      // this context's own need: 1 + the last step with a tie that took the structure
+    else if (!strcmp(name, "kd_built_after")) *value = c->kd_built_after;           // 1: a tie of the last grow needed the whole kd structure, built after the steps
     else return PORRT_ERR_INVALID;
     return PORRT_OK;
 }
@@ -3265,6 +3352,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "batch_streams")) c->opt_batch_streams = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else if (!strcmp(name, "kd_after")) c->opt_kd_after = value != 0;
     else if (!strcmp(name, "kd_ride")) c->opt_kd_ride = value != 0;
+    else if (!strcmp(name, "kd_lazy")) c->opt_kd_lazy = value != 0;
     else if (!strcmp(name, "kd_claim_threads")) { if (value != 0 && value != 256 && value != 512 && value != 1024) return PORRT_ERR_INVALID; c->opt_claim_threads = (uint32_t)value; }
     else if (!strcmp(name, "kd_inline")) c->opt_kd_inline = value != 0;
     else if (!strcmp(name, "early_wave_steps")) c->opt_early_wave = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 64));

@@ -546,6 +546,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PORRT_NN2_W
 // scratch
 __host__ __device__ inline size_t conn2_lds_bytes(uint32_t GL) {
     const size_t a = 4u * (64u / 16u) * kHitBytes;      // per workgroup whatever the group size: a wave's lists hold 4 x kLdsHits hits between them
+    static_assert(kGTrackLds <= 4u * (64u / 16u) * kHitBytes, "g_track_step uses the same bytes");
     return a > kInsertLds ? a : kInsertLds;
 }
 
@@ -701,16 +702,18 @@ __device__ __attribute__((noinline)) void heavy_sample_wave(const RunConst &rc, 
 }
 
 template <int GL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_conn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_conn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords, uint32_t lazy) {
     static_assert(GL == 16 || GL == 32 || GL == 64, "group size");
     constexpr uint32_t SPB = 256u / GL;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];
     uint32_t bx = blockIdx.x, by = blockIdx.y;
-    const uint32_t role = xcd_swizzle_roles(bx, by, 2u);
+    const uint32_t ns = lazy ? 3u : 2u;         // the rows' special workgroups: page filing, goal-point copies, (lazy) the goal path of the kd order
+    const uint32_t role = xcd_swizzle_roles(bx, by, ns);
     const RunConst &rc = rcp[by];               // one context per grid row (porrt_grow_batch)
     nb = row_nb(rc, b, nb);
     if (nb == 0) return;                        // (a row that has stopped, or does not run this step)
     if (role == 0) { insert_step_pages(rc, b, nb, vwords, lds_dyn); return; }    // the page-filing workgroup
+    if (lazy && role == 2u) { g_track_step(rc, b, nb, vwords, lds_dyn); return; }
     const uint32_t lane = threadIdx.x & 63u, si = threadIdx.x / GL;
     const uint32_t slot = bx * SPB + si;
     // first round trip: everything that depends on nothing
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const double T2 = as_global(rc.t2_at)[b];              // rad_T2[N], rrt.rs:121: the size before insertion
     uint32_t k = 0xFFFFu;
     double px = 0.0, py = 0.0;
-    if (role == 2u && slot < nb) { k = as_global(rc.bq_k)[slot]; px = as_global(rc.bq_x)[slot]; py = as_global(rc.bq_y)[slot]; }
+    if (role == ns && slot < nb) { k = as_global(rc.bq_k)[slot]; px = as_global(rc.bq_x)[slot]; py = as_global(rc.bq_y)[slot]; }
     if (role == 1) { clone_workgroup(rc, b, vwords, N, T2); return; }
     GTeam<GL> tm;
     tm.gl = threadIdx.x % GL;

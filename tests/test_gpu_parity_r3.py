@@ -285,3 +285,65 @@ def test_single_query_full_size_default_form(eng_mod):
     cases.grow(e, case, K=1024)
     cases.grow(o, case, K=1024, algo=orc.ALGO_BATCHED_KD)
     assert_same(e, o)
+
+
+def _dup_samples(n, seed):
+    rng = np.random.default_rng(seed)
+    xy = np.stack([rng.uniform(-0.02, 0.02, n), rng.uniform(-0.92, -0.88, n)], axis=1)
+    xy[::3] = xy[(np.arange(0, n, 3) // 7) * 2 + 1]          # exact duplicates of other samples: equal-cost parents off the goal path
+    return xy
+
+
+def test_goal_path_tie_order_and_the_build_after_the_steps(eng_mod):
+    """kd_lazy (the group kernels' default): beside the steps only the goal path of the kd order is kept.  A run on the bench's
+    workload never needs more (the ties are copies of the goal point and their parent); injected exact duplicates tie off the goal
+    path, the whole structure is built after the steps, and the trees still equal the oracle's -- for one context with the group
+    kernels, with the loop's tail, and for a batch of eight with different sample sets; kd_lazy = 0 gives the same trees."""
+    n = 4000
+    case = cases.cfg2(n - n // 100 - 5)
+    # (a) one context, group kernels
+    xy = _dup_samples(n, 7)
+    for K in (1024, 256):
+        e = cases.configure(eng_mod.Engine(), case)
+        e.set_option("group_lanes", 16)
+        e.set_samples(xy)
+        cases.grow(e, case, K=K)
+        assert e.get_option("kd_lazy") == 1 and e.get_option("kd_built_after") == 1
+        o = cases.configure(orc.Oracle(), case)
+        o.set_samples(xy)
+        cases.grow(o, case, K=K, algo=orc.ALGO_BATCHED_KD)
+        assert_same(e, o)
+        e0 = cases.configure(eng_mod.Engine(), case)
+        e0.set_option("group_lanes", 16)
+        e0.set_option("kd_lazy", 0)
+        e0.set_samples(xy)
+        cases.grow(e0, case, K=K)
+        assert e0.get_option("kd_lazy") == 0 and e0.get_option("kd_built_after") == 0
+        assert_same(e0, o)
+    # (b) a batch of eight, duplicates in three of them
+    sets = [_dup_samples(n, 20 + j) if j % 3 == 0 else None for j in range(8)]
+    engs, orcs = [], []
+    for j in range(8):
+        c = cases.Case(case, seed=50 + j)
+        e = cases.configure(eng_mod.Engine(), c)
+        o = cases.configure(orc.Oracle(), c)
+        if sets[j] is not None:
+            e.set_samples(sets[j])
+            o.set_samples(sets[j])
+        cases.grow(o, c, K=512, algo=orc.ALGO_BATCHED_KD)
+        engs.append(e)
+        orcs.append(o)
+    eng_mod.Engine.grow_batch(engs, [case.start] * 8, case.max_step, case.search_radius, case.n_iter_min, 512)
+    assert engs[0].get_option("kd_lazy") == 1 and engs[0].get_option("kd_built_after") == 1
+    for e, o in zip(engs, orcs):
+        assert_same(e, o)
+    # (c) the bench's workload, shortened but past its goal: copies of the goal point tie with their parent in every step and
+    # the goal path alone orders them
+    c2 = cases.cfg2(30000)
+    es = [cases.configure(eng_mod.Engine(), cases.Case(c2, seed=j)) for j in range(8)]
+    eng_mod.Engine.grow_batch(es, [c2.start] * 8, c2.max_step, c2.search_radius, c2.n_iter_min, 1024)
+    assert es[0].get_option("kd_lazy") == 1 and es[0].get_option("kd_built_after") == 0
+    assert all(e.num_final() > 0 for e in es)
+    for j in (0, 5):
+        o, _ = run_orc(cases.Case(c2, seed=j), 1024)
+        assert_same(es[j], o)

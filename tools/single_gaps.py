@@ -18,5 +18,11 @@ print("kernels", len(main), "span us %.0f" % ((int(main[-1]["End_Timestamp"]) - 
 import collections
 g = sorted(gaps)
 print("gap us: median %.1f  p90 %.1f  max %.1f" % (g[len(g) // 2], g[int(0.9 * len(g))], g[-1]))
-print("first 40 gaps:", " ".join("%.0f" % x for x in gaps[:40]))
+print("gaps:", " ".join("%.0f" % x for x in gaps))
+print("durations:", " ".join("%.0f" % x for x in durs))
+side = [r for r in rows if int(r["Start_Timestamp"]) > t_last and nm(r).startswith(("k_kd", "k_tie"))]
+import collections
+agg = collections.defaultdict(list)
+for r in side: agg[nm(r)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, v in agg.items(): print("side", k, "calls", len(v), "first 8 us:", " ".join("%.0f" % x for x in v[:8]), "median %.0f" % sorted(v)[len(v) // 2])
 print("names:", " ".join(nm(r)[2:8] for r in main[:12]))
