@@ -1916,9 +1916,12 @@ __device__ __forceinline__ void near_sample_lag(const RunConst &rc, uint32_t b, 
 }
 
 // X(b): workgroups [file(b)] [connect(b)] [search(b + 1)] [commit(cb): cnb samples, cb = b - 1 or none]
+__device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords, uint8_t *lds);
+constexpr uint32_t kGTrackLds0 = 8192u + 512u + 272u + 192u * 20u, kGTrackLds = kGTrackLds0 + 256u * 16u + 128u * 16u + 129u * 4u + 4u;        // bytes of LDS g_track_step needs
+static_assert(kGTrackLds <= kFileLds, "g_track_step uses the filing scratch of k_step1_rrt");
 template <bool LDSGRID>
 __global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_step1_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
-                                                                   uint32_t i0_next, uint32_t nb_next, uint32_t vwords, uint32_t cb, uint32_t cnb) {
+                                                                   uint32_t i0_next, uint32_t nb_next, uint32_t vwords, uint32_t cb, uint32_t cnb, uint32_t lazy) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_tiles[];
     __shared__ double s_d[kConnectWaves];
     __shared__ int s_i[kConnectWaves];
@@ -1931,6 +1934,10 @@ __global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per
     uint32_t bx = blockIdx.x;
     if (bx == 0) { file_step_fast<kConnectWaves * 64u>(rc, b, nb, vwords, s_ins); return; }
     bx -= 1u;
+    if (lazy) {                                  // the goal path of the kd order (kd_lazy): one workgroup, like the filing
+        if (bx == 0) { g_track_step(rc, b, nb, vwords, s_ins); return; }
+        bx -= 1u;
+    }
     if (bx < cblocks) { connect_block<LDSGRID>(rc, b, nb, vwords, bx, lds_tiles, s_d, s_i, s_heavy, b & 1u); return; }
     bx -= cblocks;
     if (bx < sblocks) {
@@ -2124,22 +2131,36 @@ __global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__
 // through different parents off G take coordinates made to collide; the copies of the goal point, the ties of every run that
 // reaches its goal, are all on G.
 __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords, uint8_t *lds) {
-    constexpr uint32_t kNd = 128;                                            // non-duplicate levels staged in LDS (more: read from memory)
+#ifdef PORRT_GTRACK_TIMING
+    const unsigned long long gt0 = wall_clock64();
+#define GT_MARK(slot) do { if (threadIdx.x == 0) { atomicAdd(&rc.cnt->tim[slot], wall_clock64() - gt0); atomicAdd(&rc.cnt->tim[(slot) + 8], 1ull); } } while (0)
+#else
+#define GT_MARK(slot) do {} while (0)
+#endif
+    constexpr uint32_t kNd = 192;                                            // non-duplicate levels staged in LDS (more: read from memory)
     uint16_t *s_k = reinterpret_cast<uint16_t *>(lds);                       // [4096] sample of the t-th new node
     unsigned long long *s_cand = reinterpret_cast<unsigned long long *>(lds + 8192);      // [64] new nodes on G to its end
     uint32_t *s_wpre = reinterpret_cast<uint32_t *>(lds + 8192 + 512);       // [65] valid samples before each mask word
     double *s_ndx = reinterpret_cast<double *>(lds + 8192 + 512 + 272);      // [kNd]
     double *s_ndy = s_ndx + kNd;
     uint32_t *s_ndi = reinterpret_cast<uint32_t *>(s_ndy + kNd);             // [kNd]
+    constexpr uint32_t kApp = 256, kCand = 128;
+    double *s_ax = reinterpret_cast<double *>(lds + kGTrackLds0), *s_ay = s_ax + kApp;      // the levels this step adds to G
+    double *s_cx = s_ay + kApp, *s_cy = s_cx + kCand;                         // the nodes on G to its end, as the threads find them
+    uint32_t *s_ct = reinterpret_cast<uint32_t *>(s_cy + kCand);              // [kCand] + count
+    uint32_t &s_nc = s_ct[kCand];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     auto vm = as_global(rc.valid_mask) + (size_t)b * vwords;
     const uint32_t N = as_global(rc.n_at)[b];
     const uint32_t glen0 = rc.cnt->g_len, n_nd = rc.cnt->g_nd_len, d0 = rc.cnt->g_first_dup[0], d1 = rc.cnt->g_first_dup[1];
     if (tid < 64u) s_cand[tid] = 0ull;
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (uint32_t w = 0; w < vwords; ++w) { s_wpre[w] = acc; acc += (uint32_t)__popcll(vm[w]); }
-        s_wpre[vwords] = acc;
+    if (tid == 0) s_nc = 0u;
+    if (tid < 64u) {                             // valid samples before each word of the mask: a word per lane, a prefix sum over the wave
+        const uint32_t c = tid < vwords ? (uint32_t)__popcll(vm[tid]) : 0u;
+        uint32_t inc = c;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, off); if ((int)lane >= off) inc += o; }
+        if (tid < vwords) s_wpre[tid] = inc - c;
+        if (tid == 63u) s_wpre[vwords] = inc;
     }
     for (uint32_t t2 = tid; t2 < n_nd && t2 < kNd; t2 += blockDim.x) {
         s_ndi[t2] = as_global(rc.g_nd)[t2]; s_ndx[t2] = as_global(rc.g_nd_x)[t2]; s_ndy[t2] = as_global(rc.g_nd_y)[t2];
@@ -2154,43 +2175,67 @@ __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32
     const double px = rc.gp_x, py = rc.gp_y;
     auto gex = as_global(rc.kd_gexit);
     const uint32_t qo = q_off(rc, b);
+    GT_MARK(0);
     // every new node against G as it stands before the step
     for (uint32_t t = tid; t < n_new; t += blockDim.x) {
         const uint32_t k = s_k[t];
         const double vx = as_global(rc.q_x)[qo + k], vy = as_global(rc.q_y)[qo + k];
+        // (only this function adds levels in a lazily tracked run, one after the other: the list is in the order of the levels, and
+        // the first level a node fails is the one it leaves G at -- a random point fails one of the first few)
         uint32_t E = 0xFFFFFFFFu;
-        for (uint32_t s0 = 0; s0 < n_nd; ++s0) {
+        const bool copy = vx == px && vy == py;              // (a copy of the goal point passes every level)
+        for (uint32_t s0 = 0; s0 < n_nd && !copy; ++s0) {
             uint32_t ii;
             double wx, wy;
             if (s0 < kNd) { ii = s_ndi[s0]; wx = s_ndx[s0]; wy = s_ndy[s0]; }
             else { ii = as_global(rc.g_nd)[s0]; wx = as_global(rc.g_nd_x)[s0]; wy = as_global(rc.g_nd_y)[s0]; }
-            if (kd_left(vx, vy, wx, wy, ii) != kd_left(px, py, wx, wy, ii) && ii < E) E = ii;
+            if (kd_left(vx, vy, wx, wy, ii) != kd_left(px, py, wx, wy, ii)) { E = ii; break; }
         }
         if (vx < px && d0 < E) E = d0;
         if (vy < py && d1 < E) E = d1;
         if (E != 0xFFFFFFFFu) gex[N + t] = E;
-        else atomicOr(&s_cand[t >> 6], 1ull << (t & 63u));
+        else {
+            atomicOr(&s_cand[t >> 6], 1ull << (t & 63u));
+            const uint32_t sl = atomicAdd(&s_nc, 1u);
+            if (sl < kCand) { s_ct[sl] = t; s_cx[sl] = vx; s_cy[sl] = vy; }
+        }
     }
     __syncthreads();
+    GT_MARK(1);
     // the nodes that follow G to its end, in id order: the first extends it, the next ones are tested against the levels added
-    // before them (64 levels at a time) and extend it in their turn if they pass them all
+    // before them and extend it in their turn if they pass them all.  One wave; the threads that found such nodes left their
+    // coordinates in LDS (the first kCand of them), the levels this step adds are kept there too (the first kApp): in an ordinary
+    // step -- a handful of copies of the goal point -- nothing in the loop waits for memory.
     if (tid < 64u) {
-        uint32_t len = glen0;
+        uint32_t len = glen0, nd_len = n_nd, fd0 = d0, fd1 = d1;
         auto gx = as_global(reinterpret_cast<unsigned long long *>(rc.g_x)), gy = as_global(reinterpret_cast<unsigned long long *>(rc.g_y));
+        const uint32_t n_held = s_nc < kCand ? s_nc : kCand;
         for (uint32_t w = 0; w < (n_new + 63u) / 64u; ++w) {
             for (unsigned long long m = s_cand[w]; m;) {
                 const uint32_t t = w * 64u + (uint32_t)__builtin_ctzll(m);
                 m &= m - 1ull;
-                const uint32_t k = s_k[t];
-                const double vx = as_global(rc.q_x)[qo + k], vy = as_global(rc.q_y)[qo + k];
+                // its coordinates: where the thread that found it left them (or, past the table's end, in memory)
+                double vx = 0.0, vy = 0.0;
+                {
+                    unsigned long long hit = 0ull;
+                    uint32_t base = 0;
+                    for (; base < n_held && !hit; base += 64u) hit = __ballot(base + lane < n_held && s_ct[base + lane] == t);
+                    if (hit) { const uint32_t at = base - 64u + (uint32_t)__builtin_ctzll(hit); vx = s_cx[at]; vy = s_cy[at]; }
+                    else { const uint32_t k = s_k[t]; vx = as_global(rc.q_x)[qo + k]; vy = as_global(rc.q_y)[qo + k]; }
+                }
                 uint32_t E = 0xFFFFFFFFu;
                 if (!(vx == px && vy == py)) {                               // (a copy of the goal point passes every level)
                     for (uint32_t l0 = glen0; l0 < len && E == 0xFFFFFFFFu; l0 += 64u) {
                         const uint32_t lvl = l0 + lane;
                         bool out = false;
                         if (lvl < len) {
-                            const double wx = __longlong_as_double((long long)__hip_atomic_load(gx + lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                            const double wy = __longlong_as_double((long long)__hip_atomic_load(gy + lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            double wx, wy;
+                            if (lvl - glen0 < kApp) { wx = s_ax[lvl - glen0]; wy = s_ay[lvl - glen0]; }
+                            else {
+                                __builtin_amdgcn_s_waitcnt(0);               // (more levels in one step than LDS keeps: from memory, once the stores are through)
+                                wx = __longlong_as_double((long long)__hip_atomic_load(gx + lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                                wy = __longlong_as_double((long long)__hip_atomic_load(gy + lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            }
                             out = kd_left(vx, vy, wx, wy, lvl) != kd_left(px, py, wx, wy, lvl);
                         }
                         const unsigned long long ob = __ballot(out);
@@ -2208,28 +2253,32 @@ __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32
                         } else {
                             atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW);
                         }
+                        if (len - glen0 < kApp) { s_ax[len - glen0] = vx; s_ay[len - glen0] = vy; }
                         gex[N + t] = len | kOnG;
-                        if (vx == px && vy == py) { if (len < rc.cnt->g_first_dup[len & 1u]) rc.cnt->g_first_dup[len & 1u] = len; }
-                        else {
-                            const uint32_t sl = rc.cnt->g_nd_len;
-                            as_global(rc.g_nd)[sl] = len; as_global(rc.g_nd_x)[sl] = vx; as_global(rc.g_nd_y)[sl] = vy;
-                            rc.cnt->g_nd_len = sl + 1u;
+                        if (!(vx == px && vy == py)) {
+                            as_global(rc.g_nd)[nd_len] = len; as_global(rc.g_nd_x)[nd_len] = vx; as_global(rc.g_nd_y)[nd_len] = vy;
                         }
                     }
                 }
-                if (E == 0xFFFFFFFFu) ++len;
-                __builtin_amdgcn_s_waitcnt(0);                               // the level is in memory before the next node reads it
+                if (E == 0xFFFFFFFFu) {
+                    if (vx == px && vy == py) { if (len & 1u) fd1 = len < fd1 ? len : fd1; else fd0 = len < fd0 ? len : fd0; }
+                    else ++nd_len;
+                    ++len;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");      // (the level is in LDS before the next node reads it)
                 __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             }
         }
+        GT_MARK(2);
         if (lane == 0) {
-            rc.cnt->g_len = len;
+            rc.cnt->g_len = len; rc.cnt->g_nd_len = nd_len; rc.cnt->g_first_dup[0] = fd0; rc.cnt->g_first_dup[1] = fd1;
             __threadfence();
             __hip_atomic_store(&rc.cnt->kd_done, N + n_new, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
+        GT_MARK(3);
     }
 }
-constexpr uint32_t kGTrackLds = 8192u + 512u + 272u + 128u * 20u;        // bytes of LDS g_track_step needs
 
 // the kd state of a grow's start (k_init_root), for the full build after lazily tracked steps; grid (64, rows) x 256
 __global__ __launch_bounds__(256) void k_kd_reset(const RunConst *__restrict__ rcp) {

@@ -632,15 +632,16 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
         ev();
         const uint32_t cb4 = (nb + kConnectWaves - 1) / kConnectWaves;
         const uint32_t cnb = commit_pend_b != 0xFFFFFFFFu ? commit_pend_nb : 0u;
-        const dim3 xg(cb4 + (nxt_nb + 3) / 4 + 1 + (cnb + 3) / 4, Q);
-        if (lds_bytes) hipLaunchKernelGGL(k_step1_rrt<true>, xg, dim3(256), lds_bytes, stream, rcp, b, nb, nxt_i0, nxt_nb, vwords, commit_pend_b, cnb);
-        else hipLaunchKernelGGL(k_step1_rrt<false>, xg, dim3(256), 0, stream, rcp, b, nb, nxt_i0, nxt_nb, vwords, commit_pend_b, cnb);
+        const uint32_t lazy = kd_lazy ? 1u : 0u;
+        const dim3 xg(cb4 + (nxt_nb + 3) / 4 + 1 + lazy + (cnb + 3) / 4, Q);
+        if (lds_bytes) hipLaunchKernelGGL(k_step1_rrt<true>, xg, dim3(256), lds_bytes, stream, rcp, b, nb, nxt_i0, nxt_nb, vwords, commit_pend_b, cnb, lazy);
+        else hipLaunchKernelGGL(k_step1_rrt<false>, xg, dim3(256), 0, stream, rcp, b, nb, nxt_i0, nxt_nb, vwords, commit_pend_b, cnb, lazy);
         ev();
         lag_near_done = nxt_nb ? b + 1 : 0xFFFFFFFFu;
         commit_pend_b = b; commit_pend_nb = nb;
         kd_last_b = b; kd_last_nb = nb;
         side_active = true;
-        if (!opt_kd_after && b + 1 - kd_b0 >= kd_group) launch_kd_group();
+        if (!opt_kd_after && !kd_lazy && b + 1 - kd_b0 >= kd_group) launch_kd_group();
         return;
     }
     if (rrt && pipe_on && opt_group == 0) {
@@ -723,7 +724,7 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
     commit_pend_b = b; commit_pend_nb = nb;
     kd_last_b = b; kd_last_nb = nb;
     side_active = true;
-    if (!opt_kd_after && !(kd_lazy && GLn) && b + 1 - kd_b0 >= kd_group) launch_kd_group();
+    if (!opt_kd_after && !kd_lazy && b + 1 - kd_b0 >= kd_group) launch_kd_group();
 }
 
 // k_kd_claim of one group: the form by the group's size, the row count and (developer option) kd_claim_threads
@@ -874,7 +875,7 @@ int porrt_ctx::launch_coop(uint32_t n_steps, uint32_t K, uint64_t n_iter, uint32
 void porrt_ctx::join_side() {
     flush_commit();
     if (!side_active) return;
-    if (kd_lazy && opt_group != 0 && !kd_build_now) { side_active = false; return; }        // (the goal path rode in the step kernels; nothing runs beside them)
+    if (kd_lazy && !kd_build_now) { side_active = false; return; }        // (the goal path rode in the step kernels; nothing runs beside them)
     if (opt_kd_after || kd_build_now) {
         // the whole structure now, on the main stream: groups of as many steps as the claim kernel holds, in id order
         const RunConst *rcp = launch_rcp;
@@ -1258,7 +1259,9 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     launch_rcp = d_rc.p;
     launch_Q = 1;
     opt_group = opt_group_req < 0 ? 0u : (uint32_t)opt_group_req;
-    kd_lazy = opt_kd_lazy && opt_group != 0 && mode == PORRT_MODE_RRT && !opt_kd_after;
+    // (a single query's one-kernel-per-step form can carry the goal path's workgroup too -- opt_kd_lazy == 2 -- but there the workgroup is
+    // the longest of the step's kernel: measured 62 against 33 us per step)
+    kd_lazy = opt_kd_lazy && (opt_group != 0 || (lag_on && opt_kd_lazy == 2)) && mode == PORRT_MODE_RRT && !opt_kd_after;
     kd_built_after = 0;
     if ((c.kd_lazy != 0u) != kd_lazy) {          // (the run constants were uploaded above)
         c.kd_lazy = kd_lazy ? 1u : 0u;
@@ -3352,7 +3355,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "batch_streams")) c->opt_batch_streams = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else if (!strcmp(name, "kd_after")) c->opt_kd_after = value != 0;
     else if (!strcmp(name, "kd_ride")) c->opt_kd_ride = value != 0;
-    else if (!strcmp(name, "kd_lazy")) c->opt_kd_lazy = value != 0;
+    else if (!strcmp(name, "kd_lazy")) c->opt_kd_lazy = value == 2 ? 2 : (value != 0);
     else if (!strcmp(name, "kd_claim_threads")) { if (value != 0 && value != 256 && value != 512 && value != 1024) return PORRT_ERR_INVALID; c->opt_claim_threads = (uint32_t)value; }
     else if (!strcmp(name, "kd_inline")) c->opt_kd_inline = value != 0;
     else if (!strcmp(name, "early_wave_steps")) c->opt_early_wave = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 64));

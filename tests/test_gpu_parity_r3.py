@@ -252,10 +252,14 @@ def test_single_query_launch_forms_agree(eng_mod, pipeline):
         assert_same(e2, o)
 
 
-@pytest.mark.parametrize("opts", [dict(kd_after=1), dict(kd_ride=1), dict(kd_inline=1), dict(early_wave_steps=5), dict(kd_group=1), dict(kd_group=4)])
+@pytest.mark.parametrize("opts", [dict(kd_lazy=0), dict(kd_lazy=2), dict(kd_lazy=0, kd_after=1), dict(kd_lazy=0, kd_ride=1), dict(kd_lazy=0, kd_inline=1),
+                                  dict(early_wave_steps=5), dict(kd_lazy=0, kd_group=1), dict(kd_lazy=0, kd_group=4), dict(kd_lazy=0, kd_claim_threads=1024)],
+                         ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
 def test_engine_options_do_not_change_results(eng_mod, opts):
-    """the developer options measured in DESIGN.md section 8 (kd structure after the steps, hints riding in the locate kernel, the first
-    steps' connect pass with one wave per sample, kd group sizes): same trees from a batch of nine and from a single query"""
+    """the developer options measured in DESIGN.md section 8 (the whole kd structure beside the steps instead of the goal path alone
+    -- kd_lazy = 0, with its variants: after the steps, hints riding in the locate kernel, group sizes, claim workgroup sizes -- the goal
+    path's workgroup in a single query's step kernel -- kd_lazy = 2 --, the first steps' connect pass with one wave per sample): same
+    trees from a batch of nine and from a single query"""
     cs = [cases.cfg2(12000, seed=30 + s) for s in range(9)]
     engs = [cases.configure(eng_mod.Engine(), c) for c in cs]
     for e in engs:
@@ -266,7 +270,9 @@ def test_engine_options_do_not_change_results(eng_mod, opts):
         o, _ = run_orc(c, 1024)
         assert_same(e, o)
     assert engs[0].get_option("launch_mode") == 0 and engs[0].get_option("group_lanes") == 16
+    assert engs[0].get_option("kd_lazy") == (0 if opts.get("kd_lazy", 1) == 0 else 1)
     e, _ = run_gpu(eng_mod, cs[1], 1024, **opts)
+    assert e.get_option("kd_lazy") == (1 if opts.get("kd_lazy", 1) == 2 else 0)
     o, _ = run_orc(cs[1], 1024)
     assert_same(e, o)
     assert e.get_option("pipeline") == 4
