@@ -347,12 +347,6 @@ struct porrt_ctx {
     int coop_blocks = 0;                      // grid of the persistent step loop on this device (0: not looked up yet)
     int ensure_side_stream() {
         if (stream2) return PORRT_OK;
-        if (getenv("PORRT_KD_PRIORITY")) {       // (experiment: the side chain ahead of the step kernels in the dispatcher)
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            if (hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, hi) == hipSuccess) return PORRT_OK;
-            stream2 = nullptr;
-        }
         if (hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking) != hipSuccess) { stream2 = nullptr; set_err("hipStreamCreate (side stream)"); return PORRT_ERR_DEVICE; }
         return PORRT_OK;
     }
@@ -1307,7 +1301,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
             }
             join_side();
             HIPCHK(hipStreamEndCapture(stream, &g));
-            HIPCHK(getenv("PORRT_KD_PRIORITY") ? hipGraphInstantiateWithFlags(&graph_exec, g, hipGraphInstantiateFlagUseNodePriority) : hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0));
+            HIPCHK(hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
             memcpy(graph_key, key, sizeof key);
             t_setup += now_s() - t0;
@@ -2259,11 +2253,7 @@ static std::vector<hipStream_t> pick_parallel_streams(uint32_t want) {
     double t_one = 0.0;         // one such kernel alone (launch and wait included): what "side by side" is measured against
     for (uint32_t tries = 0; chosen.size() < want && tries < 4u * want; ++tries) {
         hipStream_t st = nullptr;
-        if (getenv("PORRT_KD_PRIORITY") && chosen.size() >= want / 2u) {      // (experiment: the second half become side streams)
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) != hipSuccess) break;
-        } else if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
         hipLaunchKernelGGL(k_wait_us, dim3(1), dim3(64), 0, st, 1u);          // first use: the stream gets its queue
         if (t_one == 0.0) {
             double best = 1e9;
@@ -2478,7 +2468,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
                 HIPCHK_CTX(L, hipStreamBeginCapture(L->stream, hipStreamCaptureModeThreadLocal));
                 (void)all_steps();
                 HIPCHK_CTX(L, hipStreamEndCapture(L->stream, &g));
-                HIPCHK_CTX(L, getenv("PORRT_KD_PRIORITY") ? hipGraphInstantiateWithFlags(&L->graph_exec, g, hipGraphInstantiateFlagUseNodePriority) : hipGraphInstantiate(&L->graph_exec, g, nullptr, nullptr, 0));
+                HIPCHK_CTX(L, hipGraphInstantiate(&L->graph_exec, g, nullptr, nullptr, 0));
                 (void)hipGraphDestroy(g);
                 memcpy(L->graph_key, key, sizeof key);
             }
