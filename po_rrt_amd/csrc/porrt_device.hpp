@@ -1917,7 +1917,7 @@ __device__ __forceinline__ void near_sample_lag(const RunConst &rc, uint32_t b, 
 
 // X(b): workgroups [file(b)] [connect(b)] [search(b + 1)] [commit(cb): cnb samples, cb = b - 1 or none]
 __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords, uint8_t *lds);
-constexpr uint32_t kGTrackLds0 = 8192u + 512u + 272u + 192u * 20u, kGTrackLds = kGTrackLds0 + 256u * 16u + 128u * 16u + 129u * 4u + 4u;        // bytes of LDS g_track_step needs
+constexpr uint32_t kGTrackLds0 = 8192u + 512u + 272u + 192u * 20u, kGTrackLds = kGTrackLds0 + 256u * 16u + 160u * 16u;        // bytes of LDS g_track_step needs
 static_assert(kGTrackLds <= kFileLds, "g_track_step uses the filing scratch of k_step1_rrt");
 template <bool LDSGRID>
 __global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_step1_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
@@ -2144,17 +2144,14 @@ __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32
     double *s_ndx = reinterpret_cast<double *>(lds + 8192 + 512 + 272);      // [kNd]
     double *s_ndy = s_ndx + kNd;
     uint32_t *s_ndi = reinterpret_cast<uint32_t *>(s_ndy + kNd);             // [kNd]
-    constexpr uint32_t kApp = 256, kCand = 128;
+    constexpr uint32_t kApp = 256, kCand = 160;
     double *s_ax = reinterpret_cast<double *>(lds + kGTrackLds0), *s_ay = s_ax + kApp;      // the levels this step adds to G
-    double *s_cx = s_ay + kApp, *s_cy = s_cx + kCand;                         // the nodes on G to its end, as the threads find them
-    uint32_t *s_ct = reinterpret_cast<uint32_t *>(s_cy + kCand);              // [kCand] + count
-    uint32_t &s_nc = s_ct[kCand];
+    double *s_cx = s_ay + kApp, *s_cy = s_cx + kCand;                         // the nodes on G to its end, in id order
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     auto vm = as_global(rc.valid_mask) + (size_t)b * vwords;
     const uint32_t N = as_global(rc.n_at)[b];
     const uint32_t glen0 = rc.cnt->g_len, n_nd = rc.cnt->g_nd_len, d0 = rc.cnt->g_first_dup[0], d1 = rc.cnt->g_first_dup[1];
     if (tid < 64u) s_cand[tid] = 0ull;
-    if (tid == 0) s_nc = 0u;
     if (tid < 64u) {                             // valid samples before each word of the mask: a word per lane, a prefix sum over the wave
         const uint32_t c = tid < vwords ? (uint32_t)__popcll(vm[tid]) : 0u;
         uint32_t inc = c;
@@ -2194,35 +2191,42 @@ __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32
         if (vx < px && d0 < E) E = d0;
         if (vy < py && d1 < E) E = d1;
         if (E != 0xFFFFFFFFu) gex[N + t] = E;
-        else {
-            atomicOr(&s_cand[t >> 6], 1ull << (t & 63u));
-            const uint32_t sl = atomicAdd(&s_nc, 1u);
-            if (sl < kCand) { s_ct[sl] = t; s_cx[sl] = vx; s_cy[sl] = vy; }
-        }
+        else atomicOr(&s_cand[t >> 6], 1ull << (t & 63u));
+    }
+    __syncthreads();
+    // the coordinates of the nodes that stay on G to its end, in id order (the first kCand of them), for the wave below
+    if (tid < 64u) {
+        const uint32_t c = (uint32_t)__popcll(s_cand[tid]);
+        uint32_t inc = c;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, off); if ((int)lane >= off) inc += o; }
+        s_wpre[tid] = inc - c;                                               // (the sample prefix is no longer needed)
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < n_new; t += blockDim.x) {
+        const unsigned long long w = s_cand[t >> 6];
+        if (!((w >> (t & 63u)) & 1ull)) continue;
+        const uint32_t rank = s_wpre[t >> 6] + (uint32_t)__popcll(w & ((1ull << (t & 63u)) - 1ull));
+        if (rank < kCand) { const uint32_t k = s_k[t]; s_cx[rank] = as_global(rc.q_x)[qo + k]; s_cy[rank] = as_global(rc.q_y)[qo + k]; }
     }
     __syncthreads();
     GT_MARK(1);
     // the nodes that follow G to its end, in id order: the first extends it, the next ones are tested against the levels added
-    // before them and extend it in their turn if they pass them all.  One wave; the threads that found such nodes left their
-    // coordinates in LDS (the first kCand of them), the levels this step adds are kept there too (the first kApp): in an ordinary
-    // step -- a handful of copies of the goal point -- nothing in the loop waits for memory.
+    // before them and extend it in their turn if they pass them all.  One wave; their coordinates are in LDS (the first kCand of
+    // them), the levels this step adds are kept there too (the first kApp): in an ordinary step -- a handful of copies of the goal
+    // point -- nothing in the loop waits for memory.
     if (tid < 64u) {
         uint32_t len = glen0, nd_len = n_nd, fd0 = d0, fd1 = d1;
         auto gx = as_global(reinterpret_cast<unsigned long long *>(rc.g_x)), gy = as_global(reinterpret_cast<unsigned long long *>(rc.g_y));
-        const uint32_t n_held = s_nc < kCand ? s_nc : kCand;
+        uint32_t c_at = 0;
         for (uint32_t w = 0; w < (n_new + 63u) / 64u; ++w) {
             for (unsigned long long m = s_cand[w]; m;) {
                 const uint32_t t = w * 64u + (uint32_t)__builtin_ctzll(m);
                 m &= m - 1ull;
-                // its coordinates: where the thread that found it left them (or, past the table's end, in memory)
-                double vx = 0.0, vy = 0.0;
-                {
-                    unsigned long long hit = 0ull;
-                    uint32_t base = 0;
-                    for (; base < n_held && !hit; base += 64u) hit = __ballot(base + lane < n_held && s_ct[base + lane] == t);
-                    if (hit) { const uint32_t at = base - 64u + (uint32_t)__builtin_ctzll(hit); vx = s_cx[at]; vy = s_cy[at]; }
-                    else { const uint32_t k = s_k[t]; vx = as_global(rc.q_x)[qo + k]; vy = as_global(rc.q_y)[qo + k]; }
-                }
+                // its coordinates: from the table (or, past the table's end, from memory)
+                double vx, vy;
+                if (c_at < kCand) { vx = s_cx[c_at]; vy = s_cy[c_at]; }
+                else { const uint32_t k = s_k[t]; vx = as_global(rc.q_x)[qo + k]; vy = as_global(rc.q_y)[qo + k]; }
+                ++c_at;
                 uint32_t E = 0xFFFFFFFFu;
                 if (!(vx == px && vy == py)) {                               // (a copy of the goal point passes every level)
                     for (uint32_t l0 = glen0; l0 < len && E == 0xFFFFFFFFu; l0 += 64u) {
