@@ -2173,25 +2173,55 @@ __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32
     auto gex = as_global(rc.kd_gexit);
     const uint32_t qo = q_off(rc, b);
     GT_MARK(0);
-    // every new node against G as it stands before the step
-    for (uint32_t t = tid; t < n_new; t += blockDim.x) {
-        const uint32_t k = s_k[t];
-        const double vx = as_global(rc.q_x)[qo + k], vy = as_global(rc.q_y)[qo + k];
-        // (only this function adds levels in a lazily tracked run, one after the other: the list is in the order of the levels, and
-        // the first level a node fails is the one it leaves G at -- a random point fails one of the first few)
-        uint32_t E = 0xFFFFFFFFu;
-        const bool copy = vx == px && vy == py;              // (a copy of the goal point passes every level)
-        for (uint32_t s0 = 0; s0 < n_nd && !copy; ++s0) {
-            uint32_t ii;
-            double wx, wy;
-            if (s0 < kNd) { ii = s_ndi[s0]; wx = s_ndx[s0]; wy = s_ndy[s0]; }
-            else { ii = as_global(rc.g_nd)[s0]; wx = as_global(rc.g_nd_x)[s0]; wy = as_global(rc.g_nd_y)[s0]; }
-            if (kd_left(vx, vy, wx, wy, ii) != kd_left(px, py, wx, wy, ii)) { E = ii; break; }
+    // every new node against G as it stands before the step: four nodes per thread, their coordinates fetched together; the levels
+    // come through LDS kNd at a time (only this function adds levels in a lazily tracked run, one after the other: the list is in
+    // the order of the levels, and the first level a node fails is the one it leaves G at -- a random point fails one of the first
+    // few, a node by the goal point hundreds of levels later)
+    for (uint32_t t0 = tid; t0 < ((n_new + blockDim.x - 1u) / blockDim.x) * blockDim.x; t0 += 4u * blockDim.x) {
+        double cvx[4], cvy[4];
+        uint32_t cE[4];
+        bool open[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t t = t0 + u * blockDim.x;
+            const uint32_t k = t < n_new ? s_k[t] : 0u;
+            cvx[u] = t < n_new ? as_global(rc.q_x)[qo + k] : 0.0;
+            cvy[u] = t < n_new ? as_global(rc.q_y)[qo + k] : 0.0;
+            cE[u] = 0xFFFFFFFFu;
+            open[u] = t < n_new && !(cvx[u] == px && cvy[u] == py);         // (a copy of the goal point passes every level)
         }
-        if (vx < px && d0 < E) E = d0;
-        if (vy < py && d1 < E) E = d1;
-        if (E != 0xFFFFFFFFu) gex[N + t] = E;
-        else atomicOr(&s_cand[t >> 6], 1ull << (t & 63u));
+        for (uint32_t c0 = 0; c0 < n_nd; c0 += kNd) {
+            if (c0 != 0u || t0 != tid) {                                     // (the first chunk is staged above)
+                __syncthreads();
+                for (uint32_t t2 = tid; t2 < kNd && c0 + t2 < n_nd; t2 += blockDim.x) {
+                    s_ndi[t2] = as_global(rc.g_nd)[c0 + t2]; s_ndx[t2] = as_global(rc.g_nd_x)[c0 + t2]; s_ndy[t2] = as_global(rc.g_nd_y)[c0 + t2];
+                }
+                __syncthreads();
+            }
+            const uint32_t nl = n_nd - c0 < kNd ? n_nd - c0 : kNd;
+            bool any = false;
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                if (!open[u]) continue;
+                for (uint32_t s0 = 0; s0 < nl; ++s0) {
+                    const uint32_t ii = s_ndi[s0];
+                    const double wx = s_ndx[s0], wy = s_ndy[s0];
+                    if (kd_left(cvx[u], cvy[u], wx, wy, ii) != kd_left(px, py, wx, wy, ii)) { cE[u] = ii; open[u] = false; break; }
+                }
+                any = any || open[u];
+            }
+            if (c0 + kNd < n_nd && !__syncthreads_or(any ? 1 : 0)) break;    // nobody is still on the path: the later levels are not needed
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t t = t0 + u * blockDim.x;
+            if (t >= n_new) continue;
+            uint32_t E = cE[u];
+            if (cvx[u] < px && d0 < E) E = d0;
+            if (cvy[u] < py && d1 < E) E = d1;
+            if (E != 0xFFFFFFFFu) gex[N + t] = E;
+            else atomicOr(&s_cand[t >> 6], 1ull << (t & 63u));
+        }
     }
     __syncthreads();
     // the coordinates of the nodes that stay on G to its end, in id order (the first kCand of them), for the wave below

@@ -1387,7 +1387,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     counters = hc;
     if (getenv("PORRT_DEBUG")) {
         fprintf(stderr, "[porrt] tie fallbacks %u g_len %u; samples served through the lists in memory %u\n", hc.tie_fallbacks, hc.g_len, hc.n_heavy);
-        fprintf(stderr, "[porrt] deferred ties: records %u pooled ids %u settled %u\n", hc.pend_cnt, hc.pool_n, hc.n_deferred);
+        fprintf(stderr, "[porrt] deferred ties: records %u pooled ids %u settled %u; goal path: %u levels, %u of them not copies of the goal point\n", hc.pend_cnt, hc.pool_n, hc.n_deferred, hc.g_len, hc.g_nd_len);
         for (int t = 0; t < 8; ++t)
             if (hc.tim[t + 8]) fprintf(stderr, "[porrt] phase %d: %.2f us per wave over %llu waves (total %.1f wave-ms)\n", t, 1e-2 * (double)hc.tim[t] / (double)hc.tim[t + 8],
                                        (unsigned long long)hc.tim[t + 8], 1e-5 * (double)hc.tim[t]);
