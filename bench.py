@@ -399,9 +399,12 @@ def main():
                 "loop_s_rank0": t_loop,
                 "launch_sequences": G,
                 "launch_mode": sets[0][0].get_option("launch_mode"),
-                "launch": ("%d launch sequences side by side (porrt_grow_batch, option batch_streams), each on a main and a side stream chosen by "
-                           "measurement to sit on different hardware queues, launched step by step from a host thread each" % G) if G > 1 else
-                          "hipGraph replay of all steps (main stream: search, connect; side stream: kd tie-order structure, never waited for)",
+                "launch": ("%d launch sequences side by side (porrt_grow_batch, option batch_streams), on streams chosen by measurement to sit on "
+                           "different hardware queues, launched step by step from a host thread each; the tie order comes from the goal path of "
+                           "the kd-tree, tracked inside the connect kernel (kd_lazy), the whole structure is built after the steps for the rows a tie asks for" % G) if G > 1 else
+                          "hipGraph replay of all steps (search, connect; the tie order from the goal path of the kd-tree, tracked inside the connect kernel)",
+                "kd_lazy": sets[0][0].get_option("kd_lazy"),
+                "kd_built_after_the_steps": [e.get_option("kd_built_after") for e in (sets[0][0], sets[0][Q_launch] if G > 1 else sets[0][0])],
             },
         }
         if prof["scan_s"] > 0:

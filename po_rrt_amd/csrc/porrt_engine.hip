@@ -2872,7 +2872,7 @@ int porrt_get_trees(porrt_ctx *const *ctxs, uint32_t n_ctx, double *const *xy, i
         maxN = std::max<size_t>(maxN, ctxs[q]->n_nodes);
     }
     if (hipSetDevice(top->device) != hipSuccess) { top->set_err("hipSetDevice"); return PORRT_ERR_DEVICE; }
-    const uint32_t W = std::min<uint32_t>(8u, n_ctx);
+    const uint32_t W = std::min<uint32_t>(8u, n_ctx);          // (4 / 8 / 12 / 16 workers fetch 256 trees in 25 / 23 / 23.5 / 23.5 ms: the copies set the time)
     const size_t slot = (maxN * 28u + 4095u) & ~(size_t)4095u;          // nx, ny, dist_root (f64) and parent (i32) of one tree
     // every worker's slot must hold the largest tree of THIS call; slots are kept across calls, each with its own size
     if (top->dl_pin.size() < W) { top->dl_pin.resize(W, nullptr); top->dl_pin_cap.resize(W, 0); }
