@@ -267,8 +267,9 @@ int porrt_get_metrics(const porrt_ctx *ctx, porrt_metrics *out);
 int porrt_set_option(porrt_ctx *ctx, const char *name, int64_t value);
 /* what was in force: "launch_mode" (the last porrt_grow_batch led by this context: 0 = one launch sequence, G = G sequences side by
  * side on streams chosen by measurement, -G = G sequences on the contexts' own streams -- the probe found no parallel set, e.g. under a
- * profiler that serialises kernels), "pipeline", "group_lanes", "kd_lazy", "kd_built_after" (1: a tie of the last grow needed the
- * whole kd structure, which was built after its steps) */
+ * profiler that serialises kernels), "pipeline", "group_lanes", "kd_lazy", "kd_built_after" (1: a tie of the last grow -- of the batch
+ * this context led -- needed the whole kd structure, which was built after its steps), "kd_lca_steps" (this context's own need: 1 + the
+ * last step with a tie that took that structure, 0 = none) */
 int porrt_get_option(const porrt_ctx *ctx, const char *name, int64_t *value);
 
 /* Device arithmetic self-test: sqrt and divide of n doubles on the GPU versus the host's correctly
