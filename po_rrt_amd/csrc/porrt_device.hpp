@@ -1408,7 +1408,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
     // the all-free window around the new node's pixel (clr) crosses free pixels only and is not walked.
     double bt = INF;
     int bj = 0x7FFFFFFF;
-    uint32_t nvalid = 0;
+    uint32_t nvalid = 0, leq = 0;
     int j0 = -1;                // first candidate of this lane, register resident
     double cost0 = -1.0, tot0 = INF, dA0 = 0.0;
     uint32_t bi = 0, bjx = 0, clr_b = 0;
@@ -1432,11 +1432,14 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
         else { L.set_val(a, ok ? cost : -1.0); L.set_dA(a, dA); }
         if (ok) {
             ++nvalid;
-            if (total < bt || (total == bt && j < bj)) { bt = total; bj = j; }
+            // (leq: how many of this lane's valid candidates share its minimum -- the ties are counted here, not by a pass of their own)
+            if (total < bt) { bt = total; bj = j; leq = 1u; }
+            else if (total == bt) { ++leq; bj = j < bj ? j : bj; }
         }
     }
     PORRT_T0();
     nvalid = tm.sum(nvalid);
+    const double my_bt = bt;
     tm.argmin(bt, bj);
     PORRT_TACC_B(rc, 4);
     int best;
@@ -1464,10 +1467,10 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
                 }
             }
         };
-        each_tie([&](int j) { ++n_tie; tie_max = j > tie_max ? j : tie_max; });
-        n_tie = tm.sum(n_tie);
+        n_tie = tm.sum(my_bt == bt ? leq : 0u);
         best = bj;
         if (n_tie > 1) {
+            each_tie([&](int j) { tie_max = j > tie_max ? j : tie_max; });
             tie_max = tm.max_i(tie_max);
             uint32_t kd_done = 0, unused = 0;
             if (tl == 0) kd_done = __hip_atomic_load(&rc.cnt->kd_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
