@@ -361,3 +361,20 @@ def test_goal_path_tie_order_and_the_build_after_the_steps(eng_mod):
     for j in (0, 5):
         o, _ = run_orc(cases.Case(c2, seed=j), 1024)
         assert_same(es[j], o)
+
+
+def test_loop_condition_batch_rows_that_need_the_kd_structure(eng_mod):
+    """a TAMP-shaped batch (members with loop conditions, ending at different steps) in which some rows' ties need the whole kd
+    structure: it is built after the steps for those rows, up to the step that asked -- those rows against the oracle"""
+    K = 128
+    cs = _tamp_cases(384)
+    engs = [cases.configure(eng_mod.Engine(), c) for c in cs]
+    eng_mod.Engine.grow_batch(engs, [c.start for c in cs], cs[0].max_step, cs[0].search_radius, 2500, K, n_iter_max=10000)
+    asked = [j for j, e in enumerate(engs) if e.get_option("kd_lca_steps") > 0]
+    assert asked, "384 rows of this workload hold such a row"
+    for j in asked[:3]:
+        o, _ = run_orc(cs[j], K)
+        assert_same(engs[j], o)
+    for j in (0, 383):
+        o, _ = run_orc(cs[j], K)
+        assert_same(engs[j], o)
