@@ -307,6 +307,18 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
+    # outside the timed region: what the last overlapped fetch left in the caller's arrays against the contexts' own porrt_get_tree,
+    # for the first and last member of each launch sequence (the fetch ran on a thread beside the growing batch of the other set;
+    # tests/test_gpu_parity_r3.py::test_trees_fetched_beside_a_growing_batch checks every member and the oracle)
+    fetch_checked = True
+    for j in sorted({0, max(Q_launch - 1, 0), min(Q_launch, Q - 1), Q - 1}):
+        exy, eparent, edist = engs[j].tree()
+        m = len(eparent)
+        fetch_checked = fetch_checked and m == engs[j].num_nodes() and np.array_equal(bufs[j][0][:m].view(np.uint64), exy.view(np.uint64)) \
+            and np.array_equal(bufs[j][1][:m], eparent) and np.array_equal(bufs[j][2][:m].view(np.uint64), edist.view(np.uint64))
+    if not fetch_checked:
+        raise SystemExit("bench: a tree fetched beside the growing batch differs from its context's own porrt_get_tree")
+
     # the same steps with the trees left on the device (a caller that only downloads the winner): the second figure of the line
     barrier()
     t1 = time.perf_counter()
@@ -404,6 +416,7 @@ def main():
                            "the kd-tree, tracked inside the connect kernel (kd_lazy), the whole structure is built after the steps for the rows a tie asks for" % G) if G > 1 else
                           "hipGraph replay of all steps (search, connect; the tie order from the goal path of the kd-tree, tracked inside the connect kernel)",
                 "kd_lazy": sets[0][0].get_option("kd_lazy"),
+                "fetch_checked": fetch_checked,
                 "kd_built_after_the_steps": [e.get_option("kd_built_after") for e in (sets[0][0], sets[0][Q_launch] if G > 1 else sets[0][0])],
             },
         }
@@ -495,7 +508,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(case, args)
         if not args.no_belief and world == 1:
             # the rows after the growth are extras of the line: a failure there must not cost the headline measurement
-            for key, fn in (("tamp_queries", tamp_queries), ("belief_space", belief_space), ("prm_roadmap", prm_roadmap), ("mm_prm", mm_prm)):
+            for key, fn in (("tamp_queries", tamp_queries), ("map4_pomdp", map4_pomdp), ("belief_space", belief_space), ("prm_roadmap", prm_roadmap), ("mm_prm", mm_prm)):
                 try:
                     out["config"][key] = fn(local_rank, not args.no_cpu_baseline)
                 except Exception as ex:                      # noqa: BLE001
@@ -643,6 +656,65 @@ def belief_space(device, with_cpu):
                                "sample": "the same PTO graph with 8 of the 12 worlds possible (255 beliefs, %d edges): build_belief_graph %.2f s, "
                                          "conditional_dijkstra %.2f s (%.1f M edges/s; root cost %r); C restatement of pto.rs:185-275, "
                                          "belief_graph.rs:89-175 (oracle/belief.c, oracle/dp.c)" % (Eo, dt, dt2, Eo / dt2 / 1e6, float(d[0]))}
+    return out
+
+
+def map4_pomdp(device, with_cpu):
+    """The reference's OWN recorded problem, outside the timed region: test_plan_on_navigation_map4_pomdp (main.rs:893-908) on the one
+    raster of the reference that is recoverable here (paper_map_4.pgm, embedded in data/maps_paper/map_4/map.svg; zone k = the door of
+    map_door_k.svg): PTO::grow_graph(start (0.8, -0.8), goal (-0.8, 0.8) in all 16 worlds, max_step 0.1, search_radius 5, n_iter_min 5000,
+    n_iter_max 100000), plan_belief_space(uniform prior over the 16 worlds) = build_belief_graph + conditional_dijkstra + extract_policy.
+    Per phase, the median of five seeds, at K = 1 (the reference's loop, one sample per step) and at K = 256; the C restatement beside
+    it; the reference's own recorded timings as context (results/maps_paper/map_4/costs_and_timings_5000_20.txt:2-4, CPU not stated)."""
+    import numpy as np
+    import cases
+    import po_rrt_amd
+    prior = [1.0 / 16] * 16
+    out = {"what": "main.rs:893-908 on paper_map_4.pgm: PTO growth (n_iter_min 5000) -> belief graph over the reachable beliefs of 16 worlds -> expected "
+                   "costs -> policy; ms per phase, median of 5 seeds",
+           "reference_recorded_ms": {"graph_creation": 61.574401, "belief_expansion": 538.1212920999999, "dynamic_programming": 270.77340795000003,
+                                     "total_with_refinement": 873.5060905999999, "cost_x_7.65": 43.990279797576896,
+                                     "source": "results/maps_paper/map_4/costs_and_timings_5000_20.txt (30 true-random runs, refined policy, CPU not stated): context, not a baseline"}}
+    e = po_rrt_amd.Engine(device)
+    for K in (1, 256):
+        rows = []
+        for seed in range(6):                 # (the first run carries the one-off allocations and the belief tables of the prior: dropped)
+            case = cases.cfg_map4(5000, seed)
+            cases.configure(e, case)
+            t0 = time.perf_counter()
+            cases.grow(e, case, K=K)
+            t1 = time.perf_counter()
+            e.build_belief_graph(prior)
+            t2 = time.perf_counter()
+            e.compute_expected_costs()
+            t3 = time.perf_counter()
+            (oid, par, leaf), root_cost = e.extract_policy()
+            t4 = time.perf_counter()
+            rows.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0, e.num_iterations(), e.num_nodes(), e.bg_num_edges(), 7.65 * root_cost, len(oid)))
+        r = np.median(np.array(rows[1:], dtype=np.float64), axis=0)
+        out["K=%d" % K] = {"ms_growth": 1e3 * r[0], "ms_belief_expansion": 1e3 * r[1], "ms_expected_costs": 1e3 * r[2], "ms_policy": 1e3 * r[3],
+                            "ms_total": 1e3 * r[4], "iterations": r[5], "graph_nodes": r[6], "belief_graph_edges": r[7], "cost_x_7.65": r[8],
+                            "policy_nodes": r[9]}
+    e.close()
+    if with_cpu:
+        from oracle import orc
+        rows = []
+        for seed in range(1, 4):
+            case = cases.cfg_map4(5000, seed)
+            o = cases.configure(orc.Oracle(), case)
+            t0 = time.perf_counter()
+            cases.grow(o, case, K=1, algo=orc.ALGO_SEQ)
+            t1 = time.perf_counter()
+            o.build_belief_graph(prior)
+            t2 = time.perf_counter()
+            d = o.expected_costs()
+            t3 = time.perf_counter()
+            rows.append((t1 - t0, t2 - t1, t3 - t2, t3 - t0, 7.65 * float(d[0])))
+        r = np.median(np.array(rows), axis=0)
+        out["cpu_baseline"] = {"value": 1e3 * r[3], "unit": "ms per plan (growth + belief expansion + expected costs)", "cores": 1, "kind": "port",
+                               "ms_growth": 1e3 * r[0], "ms_belief_expansion": 1e3 * r[1], "ms_expected_costs": 1e3 * r[2], "cost_x_7.65": r[4],
+                               "sample": "the full problem, seeds 1..3, median; C restatement of pto.rs:55-139,185-275, belief_graph.rs:89-175 (the reference's "
+                                         "own sequential loop with its kd-tree)"}
     return out
 
 

@@ -1350,7 +1350,11 @@ __device__ __forceinline__ GlobalList global_list(const RunConst &rc, uint32_t b
 // tree, neighbourhoods of the goal point), everything in the sample's slice of the global list arrays.  Either way only
 // the actual rewire candidates are left in memory for the commit pass, compacted -- for MemHits in place: a candidate's
 // position is at most its entry index, and an entry is read before anything is written in its round.
-constexpr uint32_t kLdsHits = 80;
+#ifndef PORRT_LDS_HITS
+#define PORRT_LDS_HITS 80
+#endif
+constexpr uint32_t kLdsHits = PORRT_LDS_HITS;        // (even: the next sample's doubles stay 8-byte aligned)
+static_assert(kLdsHits % 2u == 0u, "kLdsHits");
 constexpr uint32_t kHitBytes = kLdsHits * (4u + 8u + 8u + 8u);
 struct LdsHits {
     static constexpr bool kCompact = true;

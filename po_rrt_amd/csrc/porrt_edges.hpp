@@ -80,8 +80,9 @@ __global__ __launch_bounds__(256) void k_eo_scatter(const uint32_t *__restrict__
     bf_e[q] = (uint32_t)e; bf_to[q] = t;
 }
 
-// One wave per node: its bucket [off[x], off[x + 1]) ordered by key (keys are distinct inside a bucket: an edge f -> t exists once,
-// and ranks are a permutation) -- every element counts the keys below its own, which is its place.  A node has at most a few
+// One wave per node: its bucket [off[x], off[x + 1]) ordered by key -- every element counts the keys below its own, which is its place.
+// Keys are distinct inside a bucket for a graph this engine grew (an edge f -> t exists once, ranks are a permutation); equal keys
+// (a repeated edge in a loaded graph) are ordered by position, so the order is total and stable and every slot is written once.  A node has at most a few
 // hundred neighbours (the radius search's hits); buckets of up to kSegLds entries are staged in LDS, longer ones (the dense
 // start of a belief-space graph) are counted against the keys in memory.
 constexpr uint32_t kSegLds = 512;
@@ -102,14 +103,14 @@ __global__ __launch_bounds__(256) void k_eo_segsort(const unsigned long long *__
         for (uint32_t i = lane; i < L; i += 64u) {
             const uint32_t ki = s_key[wv][i];
             uint32_t below = 0;
-            for (uint32_t j = 0; j < L; ++j) below += s_key[wv][j] < ki ? 1u : 0u;       // (all lanes read one word: a broadcast)
+            for (uint32_t j = 0; j < L; ++j) { const uint32_t kj = s_key[wv][j]; below += (kj < ki || (kj == ki && j < i)) ? 1u : 0u; }       // (all lanes read one word: a broadcast)
             out[a + below] = gv[i];
         }
     } else {
         for (uint32_t i = lane; i < L; i += 64u) {
             const uint32_t ki = gk[i];
             uint32_t below = 0;
-            for (uint32_t j = 0; j < L; ++j) below += gk[j] < ki ? 1u : 0u;
+            for (uint32_t j = 0; j < L; ++j) { const uint32_t kj = gk[j]; below += (kj < ki || (kj == ki && j < i)) ? 1u : 0u; }
             out[a + below] = gv[i];
         }
     }

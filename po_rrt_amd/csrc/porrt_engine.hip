@@ -2803,13 +2803,16 @@ static int grow_batch_each(porrt_ctx *const *ctxs, uint32_t n_ctx, const double 
     auto part = [&](uint32_t g) {
         porrt_ctx *Lg = ctxs[lo[g]];
         hipStream_t own = Lg->stream, own2 = Lg->stream2;
+        bool swapped2 = false;
         // On these streams the steps are launched one by one: a replayed hipGraph puts its branches on streams of the runtime's
         // choosing, and two replays side by side then share a queue more often than not (135-141 against 160 M expansions/s);
         // the launches (~900 per sub-batch) stay ahead of the GPU from a host thread each.
-        if (have_streams) { Lg->stream = top->sub_streams[g]; if (per == 2u) Lg->stream2 = top->sub_streams[G + g]; Lg->sub_eager = true; }
+        if (have_streams) { Lg->stream = top->sub_streams[g]; if (per == 2u) { Lg->stream2 = top->sub_streams[G + g]; swapped2 = true; } Lg->sub_eager = true; }
         Lg->opt_kd_inline = top->opt_kd_inline;
         rcs[g] = grow_batch(ctxs + lo[g], lo[g + 1] - lo[g], starts + 2 * (size_t)lo[g], max_step, search_radius, n_iter_min + lo[g], n_iter_max + lo[g], batch_K, mode);
-        Lg->stream = own; Lg->stream2 = own2; Lg->sub_eager = false;
+        // the side stream goes back only if it was lent one of the measured streams: a leader that had none and made its own inside
+        // grow_batch (ensure_side_stream: no measured set, or kd_inline) keeps it for its lifetime instead of dropping it every call
+        Lg->stream = own; if (swapped2) Lg->stream2 = own2; Lg->sub_eager = false;
     };
     {
         ThreadJoiner tj;
@@ -3341,7 +3344,14 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "graph")) c->opt_graph = value != 0;
     else if (!strcmp(name, "group_lanes")) { if (value != -1 && value != 0 && value != 16 && value != 32 && value != 64) { c->set_err("group_lanes: -1 (auto), 0, 16, 32 or 64"); return PORRT_ERR_INVALID; } c->opt_group_req = (int)value; }
     else if (!strcmp(name, "dp_sweeps")) c->opt_dp_sweeps = value != 0;
-    else if (!strcmp(name, "pipeline")) c->opt_pipeline = (value >= 2 && value <= 4) ? (int)value : (value ? 1 : 0);
+    else if (!strcmp(name, "pipeline")) {
+#ifndef PORRT_DEV_NONCOOP
+        // 3 = the persistent step loop launched WITHOUT the co-residency guarantee of a cooperative launch (its barriers then rest on
+        // the two-second give-up alone): a developer build only (-DPORRT_DEV_NONCOOP), never through the shipped option parser
+        if (value == 3) { c->set_err("pipeline = 3 (non-cooperative persistent launch) is a developer build option"); return PORRT_ERR_INVALID; }
+#endif
+        c->opt_pipeline = (value >= 2 && value <= 4) ? (int)value : (value ? 1 : 0);
+    }
     else if (!strcmp(name, "batch_streams")) c->opt_batch_streams = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else if (!strcmp(name, "kd_after")) c->opt_kd_after = value != 0;
     else if (!strcmp(name, "kd_ride")) c->opt_kd_ride = value != 0;

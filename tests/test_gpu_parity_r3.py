@@ -186,20 +186,26 @@ def test_sub_batches_on_an_odd_number_of_contexts(eng_mod):
 _tamp_cases = cases.tamp_queries
 
 
-@pytest.mark.parametrize("n,K", [(12, 256), (40, 1024), (9, 64), (20, 128)])
-def test_batch_with_loop_condition_equals_single_grows(eng_mod, n, K):
+@pytest.mark.parametrize("n,K,lanes", [(12, 256, -1), (40, 1024, -1), (9, 64, -1), (20, 128, -1), (3, 256, -1), (5, 64, -1), (12, 256, 0)])
+def test_batch_with_loop_condition_equals_single_grows(eng_mod, n, K, lanes):
     """porrt_grow_batch with n_iter_min < n_iter_max: every member runs the loop of rrt.rs:109 on its own and leaves the later launches
     when it ends -- trees, iteration counts and sampler states equal those of separate porrt_grow calls (and the oracle's); members
-    end at different steps"""
+    end at different steps.  Fewer than eight members (a small TAMP batch) and group_lanes = 0 take the one-wave-per-sample kernels
+    under the rows' plans (k_near / k_connect_rrt / k_commit_rrt reading row_nb / row_i0, unpipelined, the kd side chain beside rows
+    that have stopped)"""
     cs = _tamp_cases(n)
     engs = [cases.configure(eng_mod.Engine(), c) for c in cs]
+    if lanes >= 0:
+        for e in engs:
+            e.set_option("group_lanes", lanes)
     eng_mod.Engine.grow_batch(engs, [c.start for c in cs], cs[0].max_step, cs[0].search_radius, 2500, K, n_iter_max=10000)
     its = []
     for c, e in zip(cs, engs):
         s, _ = run_gpu(eng_mod, c, K)
         assert_same(e, s)
         its.append(e.num_iterations())
-    if K >= 256:             # (with small steps every query of this set is solved by n_iter_min)
+    assert engs[0].get_option("group_lanes") == (16 if n >= 8 and lanes != 0 else 0)
+    if K >= 256 and n >= 9:  # (with small steps every query of this set is solved by n_iter_min)
         assert len(set(its)) > 1, "the members are meant to end at different steps: %s" % its
     assert min(its) >= 2500 and max(its) <= 10000
     for c, e in list(zip(cs, engs))[:4]:
@@ -244,10 +250,14 @@ def test_batch_each_with_budgets_of_their_own(eng_mod):
     assert rc == worst
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 4])
 def test_single_query_launch_forms_agree(eng_mod, pipeline):
     """the single query's steps as separate kernels (0), pipelined pairs (1), ONE persistent launch with barriers over the grid (2:
-    cooperative launch, 3: the same grid launched ordinarily), or one kernel per step (4) -- identical trees, against the oracle"""
+    cooperative launch), or one kernel per step (4) -- identical trees, against the oracle.  (3, the persistent grid launched
+    ordinarily, is a developer build's option: the shipped parser refuses it)"""
+    e0 = eng_mod.Engine()
+    with pytest.raises(Exception):
+        e0.set_option("pipeline", 3)
     for case, K in ((cases.cfg2(30000, seed=4), 1024), (cases.cfg2_obs(2500, seed=2), 512), (cases.cfg1(3000), 64)):
         e, _ = run_gpu(eng_mod, case, K, pipeline=pipeline)
         o, _ = run_orc(case, K)
@@ -378,3 +388,54 @@ def test_loop_condition_batch_rows_that_need_the_kd_structure(eng_mod):
     for j in (0, 383):
         o, _ = run_orc(cs[j], K)
         assert_same(engs[j], o)
+
+
+def test_trees_fetched_beside_a_growing_batch(eng_mod):
+    """the configuration bench.py's `value` is quoted on: porrt_get_trees of set A into the caller's arrays on a host thread WHILE
+    porrt_grow_batch grows set B (two sets of 32 contexts = two launch sequences each, roles swapped every round, so staging slots,
+    copy streams and the measured streams are reused) -- every fetched tree equals the context's own porrt_get_tree afterwards, and
+    two members per round equal the oracle"""
+    import threading
+    Q, n_iter, K = 32, 20000, 1024
+    case = cases.cfg2(n_iter)
+    sets = [[cases.configure(eng_mod.Engine(), case) for _ in range(Q)] for _ in range(2)]
+    cap = n_iter + 2
+    bufs = [(np.zeros((cap, 2)), np.zeros(cap, dtype=np.int64), np.zeros(cap)) for _ in range(Q)]
+
+    def grow(which, seed0):
+        for j, e in enumerate(sets[which]):
+            e.set_sampler((-1.0, -1.0), (1.0, 1.0), seed0 + j)
+        assert eng_mod.Engine.grow_batch(sets[which], [case.start] * Q, case.max_step, case.search_radius, n_iter, K) == 0
+
+    class Fetch(threading.Thread):
+        def __init__(self, which):
+            super().__init__()
+            self.which, self.err, self.out = which, None, None
+
+        def run(self):
+            try:
+                self.out = eng_mod.Engine.trees(sets[self.which], bufs)
+            except Exception as ex:      # noqa: BLE001
+                self.err = ex
+
+    grow(0, 1000)
+    for rnd in range(4):                       # round r: fetch the set grown in round r - 1 while the other set grows
+        a, b = rnd % 2, (rnd + 1) % 2
+        for xy, parent, dist in bufs:          # stale contents of the round before must not pass for this round's
+            xy.fill(-7.0); parent.fill(-7); dist.fill(-7.0)
+        f = Fetch(a)
+        f.start()
+        grow(b, 1000 + 100 * (rnd + 1))
+        f.join()
+        assert f.err is None, f.err
+        assert sets[b][0].get_option("launch_mode") in (2, -2)
+        for j, (e, (xy, parent, dist)) in enumerate(zip(sets[a], f.out)):
+            exy, eparent, edist = e.tree()
+            assert len(xy) == e.num_nodes() > 10000
+            assert np.array_equal(xy.view(np.uint64), exy.view(np.uint64)) and np.array_equal(parent, eparent) and np.array_equal(dist.view(np.uint64), edist.view(np.uint64)), \
+                "round %d: the tree of member %d fetched beside a growing batch differs from its own porrt_get_tree" % (rnd, j)
+        for j in (3, Q - 1):
+            o, _ = run_orc(cases.Case(case, seed=1000 + 100 * rnd + j), K)
+            xo, po, do = o.tree()
+            xy, parent, dist = f.out[j]
+            assert np.array_equal(parent, po) and np.array_equal(xy.view(np.uint64), xo.view(np.uint64)) and np.array_equal(dist.view(np.uint64), do.view(np.uint64))

@@ -268,6 +268,62 @@ def extract_paper_map():
     return np.array(Image.open(io.BytesIO(base64.b64decode(m))).convert("L"))
 
 
+def paper_door_rects(directory="/root/reference/data/maps_paper/map_4"):
+    """The reference's own door numbering of map_4: map_door_<k>.svg each hold ONE door's rectangle over the drawing of map.svg
+    (viewBox 5421.26 units = the 200 pixels of the raster; the layer is translated by (0, 4368.9), door 3's rectangle sits in a
+    nested group translated by (66.39, 638.71)).  Returns, per door k, (x0, x1, y0, y1) in viewBox units -- data read from the
+    reference's files, no source text."""
+    out = []
+    for k in range(4):
+        s = open(os.path.join(directory, "map_door_%d.svg" % k)).read()
+        s = re.sub(r'base64,[A-Za-z0-9+/=\s]+"', '"', s)
+        vb = [float(v) for v in re.search(r'viewBox="([^"]+)"', s).group(1).split()]
+        layer = [float(v) for v in re.search(r'id="layer1"\s+transform="translate\(([^)]+)\)"', s).group(1).split(",")]
+        # the one green shape of the file: a <rect> (doors 1-3) or a closed <path> of relative cubic segments (door 0)
+        g = re.search(r'<g\s+style="opacity:0.5"\s+id="g4168"\s+transform="translate\(([^)]+)\)"[^>/]*>(.*?)</g>', s, re.S)       # (not the self-closing, empty group)
+        inner = g.group(2) if g else ""
+        off = [float(v) for v in g.group(1).split(",")] if g and "fill:#00ff00" in inner else [0.0, 0.0]
+        m = re.search(r'<rect\s+style="[^"]*fill:#00ff00[^"]*"[^>]*?width="([^"]+)"\s+height="([^"]+)"\s+x="([^"]+)"\s+y="([^"]+)"', s, re.S)
+        if m:
+            w, h, x, y = (float(v) for v in m.groups())
+        else:
+            m = re.search(r'<path\s+style="[^"]*fill:#00ff00[^"]*"\s+d="m ([^"]+)"', s, re.S)
+            tok = m.group(1).replace(",", " ").split()
+            x, y = float(tok[0]), float(tok[1])
+            nums = [float(t) for t in tok[2:] if t not in ("c", "z")]
+            px, py, xs, ys = x, y, [x], [y]
+            for q in range(0, len(nums) - 5, 6):          # relative cubic: the third pair is the segment's end point
+                px, py = px + nums[q + 4], py + nums[q + 5]
+                xs.append(px); ys.append(py)
+            x, y, w, h = min(xs), min(ys), max(xs) - min(xs), max(ys) - min(ys)
+        x0, y0 = x + off[0] + layer[0], y + off[1] + layer[1]
+        out.append((x0 / vb[2], (x0 + w) / vb[2], y0 / vb[3], (y0 + h) / vb[3]))
+    return out
+
+
+def paper_zone_ids(occ, rects):
+    """Zone raster of map_4 with the reference's door numbering: door k of map_door_<k>.svg is the component of door pixels whose
+    columns its rectangle covers (the drawing and the embedded raster agree in x to a pixel; in y the raster sits about 11 rows
+    lower than the drawing, so columns decide -- they are distinct for all four doors).  rects: fractions of the drawing's width."""
+    comp, k = door_zone_ids(occ)
+    z = np.full(occ.shape, 255, np.uint8)
+    used = []
+    for door, (fx0, fx1, fy0, fy1) in enumerate(rects):
+        best, best_ov = -1, 0.0
+        for c in range(k):
+            ii, jj = np.where(comp == c)
+            ov = max(0.0, min(fx1 * occ.shape[1], jj.max() + 1) - max(fx0 * occ.shape[1], jj.min()))
+            ov /= (jj.max() + 1 - jj.min())
+            dy = abs((fy0 + fy1) / 2 * occ.shape[0] - (ii.min() + ii.max() + 1) / 2)
+            if ov > 0.7 and dy < 20 and ov > best_ov:
+                best, best_ov = c, ov
+        assert best >= 0 and best not in used, "door %d of the reference's svg matches no component of the raster" % door
+        used.append(best)
+        z[comp == best] = door
+    assert len(used) == k, "the raster holds a door the reference's svgs do not name"
+    return z, used
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--paper-map", action="store_true", help="re-extract the raster embedded in the reference's map_4 svg")
@@ -298,12 +354,20 @@ def main():
     paper = os.path.join(OUT, "paper_map_4.pgm")
     if args.paper_map:
         write_pgm(paper, extract_paper_map())
-    if os.path.exists(paper):
+    doors = os.path.join(OUT, "paper_map_4_doors.json")
+    if args.paper_map:                       # (needs /root/reference: the door rectangles are kept as a small data fixture)
+        import json
+        json.dump({"source": "data/maps_paper/map_4/map_door_{0..3}.svg: the green rectangle of each file as fractions (x0, x1, y0, y1) of the drawing",
+                   "rects": paper_door_rects()}, open(doors, "w"), indent=1)
+    if os.path.exists(paper) and os.path.exists(doors):
+        import json
         occ = read_pgm(paper)
-        z, k = door_zone_ids(occ)
+        z, used = paper_zone_ids(occ, json.load(open(doors))["rects"])
         write_pgm(os.path.join(OUT, "paper_map_4_zone_ids.pgm"), z)
-        print("paper_map_4: %d door zones" % k)
+        print("paper_map_4: zone k = door k of the reference's map_door_k.svg = connected component (scan order) %s" % used)
     for f in sorted(os.listdir(OUT)):
+        if not f.endswith(".pgm"):
+            continue
         a = read_pgm(os.path.join(OUT, f))
         print("%-46s free %.1f%%  low %.1f%%  high %.1f%%" % (f, 100 * (a == 255).mean(),
               100 * ((a >= 127) & (a < 255)).mean(), 100 * (a < 127).mean()))
