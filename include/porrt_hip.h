@@ -349,6 +349,18 @@ const char *porrt_comm_last_error(const porrt_comm *comm);
  * PORRT_ERR_PEER (porrt_comm_last_error names the rank); ranks called with different n_maps all get PORRT_ERR_INVALID. */
 int      porrt_exchange_best(porrt_comm *comm, porrt_ctx *const *ctxs, uint32_t n_ctx, const uint32_t *map_ids,
                              uint32_t n_maps, porrt_best_entry *winners);
+/* No rank leaves the sequence alone: once the first agreement is through, a rank whose HIP or RCCL call fails, whose RCCL reports an
+ * asynchronous error, or whose step is not finished after the time-out (default 120 s) ABORTS the communicator (ncclCommAbort) before
+ * it returns, so that the peers' pending collectives fail instead of waiting; every wait polls the stream and RCCL's error state,
+ * none blocks for good.  The communicator is unusable afterwards (every call returns PORRT_ERR_DEVICE): the job makes a new one. */
+int      porrt_comm_usable(const porrt_comm *comm);            /* 1, or 0 once a collective step failed on this rank */
+int      porrt_comm_set_timeout_ms(porrt_comm *comm, int ms);
+/* for the CPU tests of that protocol (no RCCL, no device): a stand-in communicator, and the function every failure of the real
+ * path goes through -- stage 0 = a local failure before the first agreement (a status word; returns `code`, the communicator stays
+ * usable), stage >= 1 = at or after it (the communicator is aborted); porrt_comm_test_aborts counts the aborts */
+porrt_comm *porrt_comm_test_new(int rank, int world);
+int      porrt_comm_test_fail(porrt_comm *comm, int stage, int code /* < 0 */);
+int      porrt_comm_test_aborts(const porrt_comm *comm);
 uint64_t porrt_exchange_num_nodes(const porrt_comm *comm, uint32_t map);
 int      porrt_exchange_get_tree(const porrt_comm *comm, uint32_t map, double *xy, int64_t *parent, double *dist_root);
 /* step 2 of the exchange on its own (pure host code): all[r * n_maps + m] -> win_rank[m] */

@@ -118,12 +118,16 @@ struct Counters {
 #define PORRT_TACC(rc, slot) do {} while (0)
 #endif
 // -DPORRT_TIMING=1: the timers of k_nn2, =2: those of k_conn2 (they share the slots)
+#ifndef PORRT_TIMING_FROM
+#define PORRT_TIMING_FROM 0
+#endif
 #if defined(PORRT_TIMING) && PORRT_TIMING == 1
-#define PORRT_TACC_A(rc, slot) PORRT_TACC(rc, slot)
+#define PORRT_TACC_A(rc, slot) do { if (b >= (uint32_t)PORRT_TIMING_FROM) PORRT_TACC(rc, slot); else t__0 = wall_clock64(); } while (0)
 #define PORRT_TACC_B(rc, slot) do { (void)t__0; } while (0)
 #elif defined(PORRT_TIMING)
 #define PORRT_TACC_A(rc, slot) do { (void)t__0; } while (0)
-#define PORRT_TACC_B(rc, slot) PORRT_TACC(rc, slot)
+// (-DPORRT_TIMING_FROM=<step>: only the steps from there on are accumulated -- the steady state without the dense first steps)
+#define PORRT_TACC_B(rc, slot) do { if (b >= (uint32_t)PORRT_TIMING_FROM) PORRT_TACC(rc, slot); else t__0 = wall_clock64(); } while (0)
 #else
 #define PORRT_TACC_A(rc, slot) do {} while (0)
 #define PORRT_TACC_B(rc, slot) do {} while (0)
@@ -1094,6 +1098,24 @@ __device__ __forceinline__ uint32_t rank_before(const RunConst &rc, uint32_t b, 
     r += __popcll(vm[k >> 6] & ((1ull << (k & 63u)) - 1ull));
     return r;
 }
+// Data movement inside a row of 16 lanes by DPP (a modifier of a vector move: no trip through the LDS crossbar, which is what
+// __shfl / ds_bpermute takes): rotate the row right by n lanes, or give every lane of a row the value of its lane n.  A group of 16
+// lanes per sample is exactly a DPP row; reductions over the group are four rotate-and-combine steps that leave every lane with the
+// result (any order of a commutative, associative combination gives the same bits: sums of integers, minima, lexicographic minima).
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned long long lo = dpp_u32<CTRL>((uint32_t)b), hi = dpp_u32<CTRL>((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(lo | (hi << 32)));
+}
+constexpr int kDppRowRor = 0x120;        // + n: row_ror:n
+constexpr int kDppRowBcast = 0x150;      // + n: row_newbcast:n (gfx90a and later)
+#ifndef PORRT_DPP
+#define PORRT_DPP 1
+#endif
+
 // The same by the `stride` lanes (a power of two <= 64, aligned in the wave) that serve sample k together, called by all of them:
 // a word of the mask per lane and a sum over the lanes instead of every lane reading every word (k is not wave-uniform when a
 // wave holds several samples, so those would be vector loads: up to 16 per lane at K = 1024).
@@ -1106,6 +1128,10 @@ __device__ __forceinline__ uint32_t rank_before_lanes(const RunConst &rc, uint32
         unsigned long long v = w <= wk ? vm[w] : 0ull;
         if (w == wk) v &= (1ull << (k & 63u)) - 1ull;
         r += (uint32_t)__popcll(v);
+    }
+    if (PORRT_DPP && stride == 16u) {          // (a compile-time constant at every call: the group size)
+        r += dpp_u32<kDppRowRor + 8>(r); r += dpp_u32<kDppRowRor + 4>(r); r += dpp_u32<kDppRowRor + 2>(r); r += dpp_u32<kDppRowRor + 1>(r);
+        return r;
     }
     for (uint32_t off = stride >> 1; off > 0; off >>= 1) r += (uint32_t)__shfl_xor((int)r, (int)off);
     return r;
@@ -1292,19 +1318,39 @@ struct GTeam {
     __device__ __forceinline__ T shfl(T v, int src) const { return __shfl(v, (int)base + src); }
     __device__ __forceinline__ void sync() const {}
     __device__ __forceinline__ uint32_t sum(uint32_t v) const {
+        if constexpr (GL == 16 && PORRT_DPP) {
+            v += dpp_u32<kDppRowRor + 8>(v); v += dpp_u32<kDppRowRor + 4>(v); v += dpp_u32<kDppRowRor + 2>(v); v += dpp_u32<kDppRowRor + 1>(v);
+            return v;
+        }
         for (int off = GL / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
         return v;
     }
     __device__ __forceinline__ int min_i(int v) const {
+        if constexpr (GL == 16 && PORRT_DPP) {
+            int o;
+            o = (int)dpp_u32<kDppRowRor + 8>((uint32_t)v); v = o < v ? o : v;
+            o = (int)dpp_u32<kDppRowRor + 4>((uint32_t)v); v = o < v ? o : v;
+            o = (int)dpp_u32<kDppRowRor + 2>((uint32_t)v); v = o < v ? o : v;
+            o = (int)dpp_u32<kDppRowRor + 1>((uint32_t)v); v = o < v ? o : v;
+            return v;
+        }
         for (int off = GL / 2; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o < v ? o : v; }
         return v;
     }
     __device__ __forceinline__ int max_i(int v) const { return -min_i(-v); }
     __device__ __forceinline__ void bcast2(uint32_t &a, uint32_t &b) const {
+        if constexpr (GL == 16 && PORRT_DPP) { a = dpp_u32<kDppRowBcast>(a); b = dpp_u32<kDppRowBcast>(b); return; }
         a = (uint32_t)__shfl((int)a, (int)base);
         b = (uint32_t)__shfl((int)b, (int)base);
     }
+    template <int N>
+    __device__ __forceinline__ void argmin_step(double &t, int &j) const {
+        const double ot = dpp_f64<kDppRowRor + N>(t);
+        const int oj = (int)dpp_u32<kDppRowRor + N>((uint32_t)j);
+        if (ot < t || (ot == t && oj < j)) { t = ot; j = oj; }
+    }
     __device__ __forceinline__ void argmin(double &t, int &j) const {
+        if constexpr (GL == 16 && PORRT_DPP) { argmin_step<8>(t, j); argmin_step<4>(t, j); argmin_step<2>(t, j); argmin_step<1>(t, j); return; }
         for (int off = GL / 2; off > 0; off >>= 1) {
             const double ot = __shfl_xor(t, off);
             const int oj = __shfl_xor(j, off);

@@ -16,8 +16,10 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <limits>
 #include <string>
 #include <vector>
@@ -42,8 +44,26 @@ struct porrt_comm {
         uint32_t n = 0;
     };
     std::vector<Tree> trees;           // per map: the winning tree, on this rank's device
+    bool broken = false;               // a collective step failed on this rank: the communicator was aborted and takes no further call
+    bool test_mode = false;            // made by porrt_comm_test_new: no RCCL, no device (the failure protocol alone, for the CPU tests)
+    int aborts = 0;                    // how often the communicator was aborted (0 or 1)
+    int timeout_ms = 120000;           // how long a collective step may stay unfinished before this rank aborts it
     void set_err(const std::string &s) { err = s; }
 };
+
+// No rank may leave a collective sequence alone.  Before the first agreement a local failure is a status word the others see
+// (comm_agree); AFTER it, a rank that fails locally -- a HIP or RCCL call returning an error, an RCCL asynchronous error, a step
+// that does not finish within timeout_ms -- ABORTS the communicator before it returns: ncclCommAbort tears this rank's
+// connections down, the peers' pending collectives see an asynchronous error (comm_wait polls ncclCommGetAsyncError, no
+// hipStreamSynchronize that could wait for ever) and abort theirs.  The communicator is then unusable: every later call
+// returns PORRT_ERR_DEVICE at once, the job makes a new one.
+static int comm_fail(porrt_comm *c, int code, const std::string &msg) {
+    c->set_err(msg + " -- communicator aborted, make a new one");
+    if (c->comm) { (void)ncclCommAbort(c->comm); c->comm = nullptr; }
+    c->broken = true;
+    ++c->aborts;
+    return code;
+}
 
 #define XCHK(c, x)                                                                                  \
     do {                                                                                            \
@@ -55,6 +75,34 @@ struct porrt_comm {
         ncclResult_t r_ = (x);                                                                      \
         if (r_ != ncclSuccess) { (c)->set_err(std::string(#x) + ": " + ncclGetErrorString(r_)); return PORRT_ERR_DEVICE; } \
     } while (0)
+
+#define XABORT(c, x)                                                                                \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) return comm_fail((c), PORRT_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define NABORT(c, x)                                                                                \
+    do {                                                                                            \
+        ncclResult_t r_ = (x);                                                                      \
+        if (r_ != ncclSuccess) return comm_fail((c), PORRT_ERR_DEVICE, std::string(#x) + ": " + ncclGetErrorString(r_)); \
+    } while (0)
+
+// Waits for the communicator's stream without ever waiting for good: the stream is polled together with RCCL's asynchronous
+// error state, and a step that is neither done nor failed after timeout_ms is given up (a peer that died, or left).
+static int comm_wait(porrt_comm *c, const char *what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) return PORRT_OK;
+        if (q != hipErrorNotReady) return comm_fail(c, PORRT_ERR_DEVICE, std::string("exchange_best: ") + what + ": " + hipGetErrorString(q));
+        ncclResult_t ar = ncclSuccess;
+        if (c->comm && ncclCommGetAsyncError(c->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
+            return comm_fail(c, PORRT_ERR_PEER, std::string("exchange_best: ") + what + ": RCCL reports " + ncclGetErrorString(ar) + " (a peer failed or left)");
+        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > c->timeout_ms) return comm_fail(c, PORRT_ERR_PEER, std::string("exchange_best: ") + what + " did not finish within " + std::to_string(c->timeout_ms) + " ms");
+        if (spin > 64) std::this_thread::sleep_for(std::chrono::microseconds(spin > 4096 ? 1000 : 20));
+    }
+}
 
 static void comm_free_tree(porrt_comm::Tree &t) {
     if (t.nx) (void)hipFree(t.nx);
@@ -95,8 +143,9 @@ porrt_comm *porrt_comm_create(int device, int rank, int world, const uint8_t id[
 
 void porrt_comm_destroy(porrt_comm *c) {
     if (!c) return;
+    if (c->test_mode) { delete c; return; }
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream && !c->broken) (void)hipStreamSynchronize(c->stream);
     for (auto &t : c->trees) comm_free_tree(t);
     if (c->d_send) (void)hipFree(c->d_send);
     if (c->d_recv) (void)hipFree(c->d_recv);
@@ -147,10 +196,11 @@ int porrt_exchange_agree(const int32_t *words /* world x 2 */, uint32_t world, u
 static int comm_agree(porrt_comm *c, int local, uint32_t n_maps, const char *what) {
     int32_t mine[2] = {(int32_t)local, (int32_t)n_maps};
     std::vector<int32_t> all(2 * (size_t)c->world);
-    XCHK(c, hipMemcpyAsync(c->d_status, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
-    NCHK(c, ncclAllGather(c->d_status, c->d_status + 2, 2, ncclInt32, c->comm, c->stream));
-    XCHK(c, hipMemcpyAsync(all.data(), c->d_status + 2, all.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    XCHK(c, hipStreamSynchronize(c->stream));
+    // (a failure in here is a failure inside a collective step: the peers are in the same all-gather)
+    XABORT(c, hipMemcpyAsync(c->d_status, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+    NABORT(c, ncclAllGather(c->d_status, c->d_status + 2, 2, ncclInt32, c->comm, c->stream));
+    XABORT(c, hipMemcpyAsync(all.data(), c->d_status + 2, all.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    { const int w = comm_wait(c, what); if (w != PORRT_OK) return w; }
     int32_t bad = -1;
     const int r = porrt_exchange_agree(all.data(), (uint32_t)c->world, (uint32_t)c->rank, &bad);
     if (r == PORRT_ERR_PEER) c->set_err(std::string("exchange_best: rank ") + std::to_string(bad) + " failed " + what + " (code " + std::to_string(all[2 * bad]) + "); no rank went on");
@@ -165,6 +215,7 @@ extern "C" {
 // (comm_agree) -- either every rank enters the step or none does; nothing returns between ncclGroupStart and ncclGroupEnd.
 int porrt_exchange_best(porrt_comm *c, porrt_ctx *const *ctxs, uint32_t n_ctx, const uint32_t *map_ids, uint32_t n_maps, porrt_best_entry *winners) {
     if (!c) return PORRT_ERR_INVALID;                        // no communicator: nothing to take part with
+    if (c->broken || !c->comm) { c->set_err("exchange_best: this communicator was aborted after a failed collective step (or is a test stand-in): make a new one"); return PORRT_ERR_DEVICE; }
     int local = PORRT_OK;
     auto fail = [&](int code, const std::string &msg) { if (local == PORRT_OK) { local = code; c->set_err(msg); } };
     if (hipSetDevice(c->device) != hipSuccess) fail(PORRT_ERR_DEVICE, "exchange_best: hipSetDevice");
@@ -208,11 +259,12 @@ int porrt_exchange_best(porrt_comm *c, porrt_ctx *const *ctxs, uint32_t n_ctx, c
     int st = comm_agree(c, local, n_maps, "before the all-gather");
     if (st != PORRT_OK) return st;
     // ---- 1. all-gather of the tables
-    XCHK(c, hipMemcpyAsync(c->d_send, mine.data(), n_maps * sizeof(porrt_best_entry), hipMemcpyHostToDevice, c->stream));
-    NCHK(c, ncclAllGather(c->d_send, c->d_recv, n_maps * sizeof(porrt_best_entry), ncclUint8, c->comm, c->stream));
+    // (from here on every rank is inside the sequence: a local failure aborts the communicator, XABORT / NABORT / comm_wait)
+    XABORT(c, hipMemcpyAsync(c->d_send, mine.data(), n_maps * sizeof(porrt_best_entry), hipMemcpyHostToDevice, c->stream));
+    NABORT(c, ncclAllGather(c->d_send, c->d_recv, n_maps * sizeof(porrt_best_entry), ncclUint8, c->comm, c->stream));
     std::vector<porrt_best_entry> all(need);
-    XCHK(c, hipMemcpyAsync(all.data(), c->d_recv, need * sizeof(porrt_best_entry), hipMemcpyDeviceToHost, c->stream));
-    XCHK(c, hipStreamSynchronize(c->stream));
+    XABORT(c, hipMemcpyAsync(all.data(), c->d_recv, need * sizeof(porrt_best_entry), hipMemcpyDeviceToHost, c->stream));
+    { const int w = comm_wait(c, "the all-gather of the tables"); if (w != PORRT_OK) return w; }
     // ---- 2. winners (the same decision on every rank), and room for their trees -- allocated before the broadcasts are agreed on
     std::vector<int32_t> win(n_maps);
     porrt_exchange_decide(all.data(), (uint32_t)c->world, n_maps, win.data());
@@ -238,7 +290,7 @@ int porrt_exchange_best(porrt_comm *c, porrt_ctx *const *ctxs, uint32_t n_ctx, c
     if (st != PORRT_OK) return st;
     // ---- 3. the winning trees, device to device.  Every rank issues the same calls; an RCCL error is remembered and the group closed all the same.
     ncclResult_t nerr = ncclGroupStart();
-    if (nerr != ncclSuccess) { c->set_err(std::string("ncclGroupStart: ") + ncclGetErrorString(nerr)); return PORRT_ERR_DEVICE; }
+    if (nerr != ncclSuccess) return comm_fail(c, PORRT_ERR_DEVICE, std::string("ncclGroupStart: ") + ncclGetErrorString(nerr));
     for (uint32_t m = 0; m < n_maps; ++m) {
         porrt_comm::Tree &t = c->trees[m];
         if (win[m] < 0) { winners[m].cost = std::numeric_limits<double>::infinity(); winners[m].rank = -1; winners[m].n_nodes = 0; continue; }
@@ -255,11 +307,38 @@ int porrt_exchange_best(porrt_comm *c, porrt_ctx *const *ctxs, uint32_t n_ctx, c
     }
     const ncclResult_t gend = ncclGroupEnd();
     if (nerr == ncclSuccess) nerr = gend;
-    const hipError_t herr = hipStreamSynchronize(c->stream);
-    if (nerr != ncclSuccess) { for (auto &t : c->trees) t.n = 0; c->set_err(std::string("exchange_best: ncclBroadcast: ") + ncclGetErrorString(nerr)); return PORRT_ERR_DEVICE; }
-    if (herr != hipSuccess) { for (auto &t : c->trees) t.n = 0; c->set_err(std::string("exchange_best: ") + hipGetErrorString(herr)); return PORRT_ERR_DEVICE; }
+    if (nerr != ncclSuccess) { for (auto &t : c->trees) t.n = 0; return comm_fail(c, PORRT_ERR_DEVICE, std::string("exchange_best: ncclBroadcast: ") + ncclGetErrorString(nerr)); }
+    const int w = comm_wait(c, "the broadcasts of the winning trees");
+    if (w != PORRT_OK) { for (auto &t : c->trees) t.n = 0; return w; }
     return PORRT_OK;
 }
+
+// 1 while the communicator takes calls; 0 once a collective step failed on this rank (it was aborted then: make a new one)
+int porrt_comm_usable(const porrt_comm *c) { return c && !c->broken && (c->comm || c->test_mode) ? 1 : 0; }
+
+int porrt_comm_set_timeout_ms(porrt_comm *c, int ms) {
+    if (!c || ms < 1) return PORRT_ERR_INVALID;
+    c->timeout_ms = ms;
+    return PORRT_OK;
+}
+
+// ---- for the CPU tests of the failure protocol (no RCCL, no device): a stand-in communicator and the ONE function every
+// failure of the real path goes through.  stage 0: a local failure before the first agreement (a status word: the communicator
+// stays usable, the code comes back); stage >= 1: a failure at or after the first agreement (inside comm_agree, in the all-gather,
+// between the agreements, in the broadcast group, a timed-out wait): the communicator is aborted and refuses every later call.
+porrt_comm *porrt_comm_test_new(int rank, int world) {
+    if (world < 1 || rank < 0 || rank >= world) return nullptr;
+    porrt_comm *c = new porrt_comm();
+    c->rank = rank; c->world = world; c->test_mode = true;
+    return c;
+}
+int porrt_comm_test_fail(porrt_comm *c, int stage, int code) {
+    if (!c || !c->test_mode || code >= 0) return PORRT_ERR_INVALID;
+    if (c->broken) { c->set_err("exchange_best: this communicator was aborted after a failed collective step: make a new one"); return PORRT_ERR_DEVICE; }
+    if (stage <= 0) { c->set_err("exchange_best: local failure before the first agreement (agreed on by all ranks, nobody is left waiting)"); return code; }
+    return comm_fail(c, code, std::string("exchange_best: simulated failure at stage ") + std::to_string(stage));
+}
+int porrt_comm_test_aborts(const porrt_comm *c) { return c ? c->aborts : -1; }
 
 uint64_t porrt_exchange_num_nodes(const porrt_comm *c, uint32_t map) { return c && map < c->trees.size() ? c->trees[map].n : 0; }
 

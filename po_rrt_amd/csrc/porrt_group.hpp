@@ -205,11 +205,20 @@ __device__ __forceinline__ double nn_bound_group(const RunConst &rc, const GTeam
         }
         double d2 = INF;
         if (r >= 0 && (uint32_t)r < N) d2 = dist2(as_global(rc.nx)[r], as_global(rc.ny)[r], qx, qy);
-        for (int off = 8; off > 0; off >>= 1) {           // lanes 0..15 of the group hold everything
-            const double o = __shfl_xor(d2, off);
-            d2 = o < d2 ? o : d2;
+        if constexpr (GL == 16 && PORRT_DPP) {
+            double o;
+            o = dpp_f64<kDppRowRor + 8>(d2); d2 = o < d2 ? o : d2;
+            o = dpp_f64<kDppRowRor + 4>(d2); d2 = o < d2 ? o : d2;
+            o = dpp_f64<kDppRowRor + 2>(d2); d2 = o < d2 ? o : d2;
+            o = dpp_f64<kDppRowRor + 1>(d2); d2 = o < d2 ? o : d2;
+            m = d2;                                        // (every lane of the row holds the minimum)
+        } else {
+            for (int off = 8; off > 0; off >>= 1) {       // lanes 0..15 of the group hold everything
+                const double o = __shfl_xor(d2, off);
+                d2 = o < d2 ? o : d2;
+            }
+            m = tm.shfl(d2, 0);
         }
-        m = tm.shfl(d2, 0);
         if (m < INF) break;
     }
     if (m == INF) m = dist2(as_global(rc.nx)[0], as_global(rc.ny)[0], qx, qy);      // the root always exists
@@ -701,8 +710,11 @@ __device__ __attribute__((noinline)) void heavy_sample_wave(const RunConst &rc, 
     }
 }
 
+#ifndef PORRT_CONN2_WAVES
+#define PORRT_CONN2_WAVES 4
+#endif
 template <int GL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_conn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords, uint32_t lazy) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PORRT_CONN2_WAVES, 8))) void k_conn2(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords, uint32_t lazy) {
     static_assert(GL == 16 || GL == 32 || GL == 64, "group size");
     constexpr uint32_t SPB = 256u / GL;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];

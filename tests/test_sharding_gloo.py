@@ -111,6 +111,37 @@ def test_agree_rules():
     assert sharding.agree_from_gathered([(0, 1)], 0) == (0, -1)
 
 
+def test_a_rank_that_fails_inside_the_sequence_aborts_its_communicator():
+    """porrt_exchange.hpp, comm_fail: before the first agreement a local failure is a status word -- the code comes back and the
+    communicator stays usable; at or after it (inside comm_agree, the all-gather, between the agreements, the broadcast group, a
+    wait that timed out) the rank aborts its communicator before returning, exactly once, and every later call is refused -- no
+    rank is left inside a collective the failed rank never enters.  Stand-in communicators (no RCCL, no device): the function
+    every failure of the real path goes through."""
+    from po_rrt_amd import load_library
+    L = load_library()
+    for stage in (1, 2, 3, 4):
+        c = L.porrt_comm_test_new(1, 4)
+        assert c and L.porrt_comm_usable(c) == 1 and L.porrt_comm_test_aborts(c) == 0
+        assert L.porrt_comm_test_fail(c, 0, -5) == -5                      # before the first agreement: nothing is torn down
+        assert L.porrt_comm_usable(c) == 1 and L.porrt_comm_test_aborts(c) == 0
+        assert L.porrt_comm_test_fail(c, stage, -4) == -4                  # inside the sequence: aborted
+        assert L.porrt_comm_usable(c) == 0 and L.porrt_comm_test_aborts(c) == 1
+        assert b"aborted" in L.porrt_comm_last_error(c)
+        assert L.porrt_comm_test_fail(c, stage, -9) == -4                  # (refused: PORRT_ERR_DEVICE)
+        assert L.porrt_comm_test_aborts(c) == 1                            # (once)
+        # the real entry point refuses an aborted communicator before it touches a device or a peer
+        import ctypes as C
+        import numpy as np
+        from po_rrt_amd.engine import BEST_ENTRY
+        win = np.zeros(1, dtype=BEST_ENTRY)
+        ids = np.zeros(1, dtype=np.uint32)
+        assert L.porrt_exchange_best(c, (C.c_void_p * 1)(), 0, ids, 1, win.ctypes.data_as(C.c_void_p)) == -4
+        assert b"make a new one" in L.porrt_comm_last_error(c)
+        assert L.porrt_comm_set_timeout_ms(c, 0) == -1 and L.porrt_comm_set_timeout_ms(c, 5000) == 0
+        L.porrt_comm_destroy(c)
+    assert not L.porrt_comm_test_new(4, 4) and L.porrt_comm_usable(None) == 0
+
+
 AGREE_WORKER = textwrap.dedent("""
     import os, sys
     sys.path[:0] = [%(root)r]

@@ -10,7 +10,10 @@ import re, sys
 s = open(sys.argv[1]).read()
 md = s[s.index("amdhsa.kernels:"):]
 for blk in re.split(r"\n  - ", md)[1:]:
-    name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+    m = re.search(r"\n\s+\.name:\s+(_Z\S+)", blk)
+    if not m:
+        continue
+    name = m.group(1)
     if not any(t in name for t in sys.argv[2:]):
         continue
     g = lambda k: (re.search(r"\.%s:\s+(\S+)" % k, blk) or [None, "?"])[1]

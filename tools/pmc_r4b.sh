@@ -12,17 +12,14 @@ OUT=$R/gpurun_out/pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT/raw
 cd /tmp && export TMPDIR=/tmp
 SETS=(
- "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum"
- "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum"
- "TCC_EA0_WRREQ_LEVEL_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum"
- "TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum"
- "TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_STALL_MULTI_MISS_sum TCP_UTCL1_SERIALIZATION_STALL_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum"
- "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN1_sum"
- "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE GRBM_TA_BUSY"
- "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAIT_INST_ANY SQ_INSTS_VALU GRBM_TC_BUSY GRBM_UTCL2_BUSY"
- "SQC_DCACHE_REQ SQC_DCACHE_MISSES SQC_TC_STALL SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_INSTS_LDS SQ_INST_LEVEL_LDS SQ_INSTS_SALU"
- "FETCH_SIZE"
- "WRITE_SIZE"
+ "TCP_TOTAL_ACCESSES_sum TCP_TOTAL_READ_sum TCP_TOTAL_WRITE_sum TCP_TOTAL_CACHE_ACCESSES_sum"
+ "TCP_TCP_TA_ADDR_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum TCP_TCR_RDRET_STALL_sum"
+ "TCP_TAGRAM0_REQ_sum TCP_TAGRAM1_REQ_sum TCP_TAGRAM2_REQ_sum TCP_TAGRAM3_REQ_sum"
+ "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_WRITE_TAGCONFLICT_STALL_CYCLES_sum TCP_ATOMIC_TAGCONFLICT_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum"
+ "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU"
+ "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_LEVEL_WAVES"
+ "TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum TCC_ATOMIC_sum"
+ "TCC_TAG_STALL_sum TCC_BUSY_sum TCC_CYCLE_sum TCC_SRC_FIFO_FULL_sum"
 )
 one_pass() {   # Q index set...: 0 ok, 1 ordinary failure, 2 timed out (then no further GPU step in this call)
   local Q=$1 i=$2; shift 2
@@ -51,8 +48,8 @@ for Q in $QS; do
     i=$((i+1))
   done
 done
-# (a pass with TA counters has hung on this pool before: once, last, bounded)
-# (a pass with TA counters timed out on this pool in rounds 2, 3 and 4: not run any more)
+# (TA counter passes hang on this pool -- twice now: not run; TD counters, unknown, last and bounded)
+[ $STOP -eq 0 ] && one_pass 128 99 TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum TD_STORE_WAVEFRONT_sum
 python3 $R/tools/pmc_r4_summary.py $OUT
 # the raw per-dispatch tables are large: keep only the step kernels' rows
 for f in $OUT/raw/*.csv; do
