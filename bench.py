@@ -578,6 +578,18 @@ def belief_traffic():
     return sum((2.0 * v["fetch_bytes_per_launch_raw"] + v["write_bytes_per_launch"]) * v["launches"] for v in ks) / builds if ks else None
 
 
+def dp_traffic():
+    """HBM bytes of one expected-costs computation (all k_dp_* launches: 2 x FETCH_SIZE + WRITE_SIZE) from the committed counter passes
+    (tools/profile_belief.sh on the same 4095-belief graph: two computations; the sweep kernels have not changed since)"""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r1_belief_pmc_traffic.json")))
+    except Exception:
+        return None
+    ks = [v for k, v in pm.items() if k.startswith("k_dp_")]
+    runs = max(1, min((v["launches"] for k, v in pm.items() if k.startswith("k_dp_fill")), default=2))
+    return sum((2.0 * v["fetch_bytes_per_launch_raw"] + v["write_bytes_per_launch"]) * v["launches"] for v in ks) / runs if ks else None
+
+
 def belief_space(device, with_cpu):
     """The rows after the growth (SURVEY 8f.1-2), outside the timed region: PTO::plan_belief_space (pto.rs:151-183) on the
     12-shelf problem of main.rs:386-408 -- a PTO graph of 20000 iterations expanded over the 4095 reachable beliefs
@@ -632,7 +644,9 @@ def belief_space(device, with_cpu):
         "expected_costs": {"ms_wall": 1e3 * min(dps), "ms_device": 1e3 * info["device_s"], "sweeps": info["sweeps"], "root_cost": root_cost,
                            "roofline": {"bound": "hbm", "kernel": "k_dp_level_sweep", "achieved": 10.0 * info["sweep_rows"] / info["device_s"] / 1e9, "peak": 8000.0,
                                         "unit": "GB/s", "frac": 10.0 * info["sweep_rows"] / info["device_s"] / 1e9 / 8000.0,
-                                        "algorithmic_bytes": 10.0 * info["sweep_rows"], "sweep_rows": info["sweep_rows"], "traffic": None,
+                                        "algorithmic_bytes": 10.0 * info["sweep_rows"], "sweep_rows": info["sweep_rows"], "traffic": dp_traffic(),
+                                        "traffic_source": "profiles/r1_belief_pmc_traffic.json (committed: separate --pmc passes of FETCH_SIZE and WRITE_SIZE over two "
+                                                          "computations on the same 4095-belief graph, all k_dp_* launches summed; not measured in this run)",
                                         "note": "a sweep passes over its level's rows: per row the change flag read and the next one written (1 B each) and the "
                                                 "cost (8 B) -- 10 B per row and sweep, summed over the %d sweeps (the rows a sweep actually re-evaluates also read "
                                                 "their neighbours' costs: not counted), over the device time of the whole computation (HIP events)" % info["sweeps"]},
@@ -741,8 +755,12 @@ def tamp_queries(device, with_cpu, n_queries=1024, K=128, opts=()):
         t0 = time.perf_counter()
         po_rrt_amd.Engine.grow_batch(engs, starts, 0.1, 2.0, 2500, K, n_iter_max=10000)
         dt = time.perf_counter() - t0
-        runs.append((dt, sum(e.num_nodes() - 1 for e in engs), sum(e.num_iterations() for e in engs), sum(1 for e in engs if e.num_final() > 0)))
-    dt, nodes, its, solved = sorted(runs[1:])[1]
+        # SURVEY 8(d)'s bytes of both step kernels per row and step: 24 N_b + 36 K + 28 K_valid + W H; a row's N_b taken as growing linearly
+        # to its final size over its own steps (the tree sizes per step stay on the device)
+        alg = sum((-(-e.num_iterations() // K)) * (24.0 * 0.5 * e.num_nodes() + 36.0 * K + 200.0 * 200.0) + 28.0 * (e.num_nodes() - 1) for e in engs)
+        runs.append((dt, sum(e.num_nodes() - 1 for e in engs), sum(e.num_iterations() for e in engs), sum(1 for e in engs if e.num_final() > 0), alg,
+                     sum(e.get_option("compactions") for e in (engs[0], engs[len(engs) // 2]))))
+    dt, nodes, its, solved, alg, ncomp = sorted(runs[1:])[1]
     costs = po_rrt_amd.Engine.best_cost_batch(engs)
     for e in engs:                      # (a thousand contexts: freed here, not by the collector in the middle of the next row)
         e.close()
@@ -750,7 +768,12 @@ def tamp_queries(device, with_cpu, n_queries=1024, K=128, opts=()):
                    "n_iter_max 10000, K = %d): each runs the loop of rrt.rs:109 and leaves the launches when it ends" % (n_queries, K),
            "ms_wall": 1e3 * dt, "queries_per_s": n_queries / dt, "node_expansions_per_s": nodes / dt, "iterations_per_s": its / dt,
            "mean_iterations_per_query": its / n_queries, "queries_solved": solved, "queries_with_a_path_cost": int(np.isfinite(costs).sum()),
-           "ms_creating_the_contexts_once": 1e3 * t_make, "batch_K": K}
+           "ms_creating_the_contexts_once": 1e3 * t_make, "batch_K": K, "row_compactions": ncomp,
+           "roofline": {"bound": "hbm", "kernel": "k_nn2 + k_conn2 (both step kernels of every step of the batch)", "achieved": alg / dt / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": alg / dt / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg, "traffic": None,
+                        "note": "SURVEY 8(d)'s per-step bytes (24 N_b + 36 K + 28 K_valid + W H per row) summed over every row's own steps, N_b taken as linear in "
+                                "the step, over the WALL time of the call (preparation, the rows' schedule and the read-back included) -- these trees stay in the "
+                                "young-tree regime of the step kernels (DESIGN.md section 14), which is latency- and slot-bound like the headline's (section 6)"}}
     if with_cpu:
         from oracle import orc
         m = 32

@@ -262,14 +262,16 @@ int porrt_get_metrics(const porrt_ctx *ctx, porrt_metrics *out);
  * beside the steps: measured slower), "kd_lazy" (RRT* with the group kernels, i.e. batches: 1 (default) = beside the steps only the
  * goal path of the reference's kd-tree is kept -- it orders every tie between copies of the goal point and their parent -- and the
  * whole structure is built after the steps in the rare run where two other nodes tie; 0 = the whole structure beside the steps on
- * a second stream, as a single query does), "kd_claim_threads", "kd_ride", "kd_inline", "early_wave_steps", "dp_sweeps".  None of
+ * a second stream, as a single query does), "kd_claim_threads", "kd_ride", "kd_inline", "early_wave_steps", "dp_sweeps", "compact_rows" (1, default: a
+ * porrt_grow_batch whose members end at different steps launches its later steps on the members that still have work).  None of
  * them changes a result. */
 int porrt_set_option(porrt_ctx *ctx, const char *name, int64_t value);
 /* what was in force: "launch_mode" (the last porrt_grow_batch led by this context: 0 = one launch sequence, G = G sequences side by
  * side on streams chosen by measurement, -G = G sequences on the contexts' own streams -- the probe found no parallel set, e.g. under a
  * profiler that serialises kernels), "pipeline", "group_lanes", "kd_lazy", "kd_built_after" (1: a tie of the last grow -- of the batch
  * this context led -- needed the whole kd structure, which was built after its steps), "kd_lca_steps" (this context's own need: 1 + the
- * last step with a tie that took that structure, 0 = none) */
+ * last step with a tie that took that structure, 0 = none), "compactions" (how often the last batch this context led gathered the
+ * members still running) */
 int porrt_get_option(const porrt_ctx *ctx, const char *name, int64_t *value);
 
 /* Device arithmetic self-test: sqrt and divide of n doubles on the GPU versus the host's correctly

@@ -3192,6 +3192,44 @@ __global__ __launch_bounds__(64) void k_row_sched(const RunConst *__restrict__ r
 }
 
 // porrt_grow_batch: every member's counters and final tree size into one array, so that the host needs one copy
+// A batch whose rows end at different steps (k_row_sched): the rows that still have work at step b, in their order, then rows that
+// have none as padding up to `slots` -- one workgroup.  A row has work at step b while it runs, and at the step after its last one
+// (sched_stop == b: its rewire commit rides in that step's search kernel).  k_rows_gather copies the rows' run constants into
+// the array the step kernels are launched on from then on, so that their grids shrink with the batch.
+__global__ __launch_bounds__(1024) void k_rows_compact(const RunConst *__restrict__ rcp, uint32_t Q, uint32_t b, uint32_t slots, uint32_t *__restrict__ live_idx) {
+    __shared__ uint32_t s_wsum[16], s_base, s_dead;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_base = 0; s_dead = 0xFFFFFFFFu; }
+    __syncthreads();
+    for (uint32_t q0 = 0; q0 < Q; q0 += 1024u) {
+        const uint32_t q = q0 + threadIdx.x;
+        bool keep = false;
+        if (q < Q) {
+            const uint32_t stop = rcp[q].cnt->sched_stop;
+            keep = stop == 0xFFFFFFFFu || stop >= b;
+            if (!keep) atomicMin(&s_dead, q);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_wsum[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = s_base;
+        for (uint32_t w = 0; w < wv; ++w) off += s_wsum[w];
+        if (keep) { const uint32_t pos = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); if (pos < slots) live_idx[pos] = q; }
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t t = 0; for (uint32_t w = 0; w < 16u; ++w) t += s_wsum[w]; s_base += t; }
+        __syncthreads();
+    }
+    // padding: a row without work (there is one whenever fewer rows are kept than the batch holds); a full array needs none
+    const uint32_t kept = s_base, dead = s_dead;
+    for (uint32_t i = kept + threadIdx.x; i < slots; i += 1024u) live_idx[i] = dead != 0xFFFFFFFFu ? dead : 0u;
+}
+__global__ __launch_bounds__(256) void k_rows_gather(const RunConst *__restrict__ rcp, const uint32_t *__restrict__ live_idx, RunConst *__restrict__ out) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(rcp + live_idx[blockIdx.x]);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + blockIdx.x);
+    static_assert(sizeof(RunConst) % 4 == 0, "copied by words");
+    for (uint32_t w = threadIdx.x; w < sizeof(RunConst) / 4u; w += 256u) dst[w] = src[w];
+}
+
 struct BatchOut { Counters cnt; uint32_t nodes, pad; };
 __global__ __launch_bounds__(64) void k_batch_gather(const RunConst *__restrict__ rcp, uint32_t steps, BatchOut *__restrict__ out) {
     if (threadIdx.x) return;

@@ -196,6 +196,8 @@ struct porrt_ctx {
     bool kd_lazy = false, kd_build_now = false;    // in force for the running grow; the build after the steps is being launched
     int kd_full_build(const std::vector<std::pair<uint32_t, uint32_t>> &segs);
     uint32_t opt_claim_threads = 0;        // "kd_claim_threads": 0 = the engine's choice (256 beside a batch's step kernels), else 256 / 512 / 1024
+    int opt_compact = 1;                   // "compact_rows": a batch whose rows end at different steps launches its later steps on the rows that still have work
+    uint32_t n_compactions = 0;            //   how often the last such batch led by this context gathered them ("compactions")
     int opt_kd_ride = 0;                   // "kd_ride": 1 = also for several contexts the hints and deferred ties ride in the next group's locate kernel
     uint32_t kd_after_K = 0;               // batch_K of the running launch sequence (the deferred groups need it)
     // "group_lanes": lanes per sample of the RRT* step kernels.  16 / 32 / 64: k_nn2 + k_conn2 (several samples per wave: fewer
@@ -300,6 +302,9 @@ struct porrt_ctx {
     uint32_t batch_nodes = 0;
     BatchOut *d_batch_out = nullptr;       // leader of a batch: gathered counters of the members
     uint32_t *d_active = nullptr, *h_active = nullptr;     // leader of a batch with step plans: rows still running per step (device / pinned host)
+    RunConst *d_rcarr_c[2] = {nullptr, nullptr};           //   and the rows that still have work, compacted (two buffers in turn), with their indices
+    uint32_t *d_live_idx = nullptr;
+    size_t rcarr_c_cap = 0;
     size_t active_cap = 0;
     std::vector<RunConst> rc_staging;      // leader of a batch: the members' RunConst, uploaded in one copy
     std::vector<uint32_t> worlds_staging;  // sampled worlds of the last upload (PTO)
@@ -2345,7 +2350,9 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         if (L->graph_exec) { (void)hipGraphExecDestroy(L->graph_exec); L->graph_exec = nullptr; }
     }
     const uint32_t vwords = (K + 63) / 64;
+    const bool host_dbg = getenv("PORRT_DEBUG_HOST") != nullptr;       // where the host's time goes in a batch (developer)
     for (int attempt = 0; attempt < 12; ++attempt) {
+        const double th0 = now_s();
         // every member: buffers, run constants, root, samples
         for (uint32_t q = 0; q < n; ++q) {
             hipStream_t own = cs[q]->stream;
@@ -2355,6 +2362,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             if (r) { if (cs[q] != L) L->set_err(cs[q]->err); return r; }
             if (cs[q]->run_lds_bytes != L->run_lds_bytes) { L->set_err("porrt_grow_batch: the contexts' rasters need different LDS tiles (max_step * ppm differs)"); return PORRT_ERR_INVALID; }
         }
+        const double th1 = now_s();
         L->opt_group = L->opt_group_req < 0 ? (n >= 8 ? 16u : 0u) : (uint32_t)L->opt_group_req;
         L->kd_lazy = L->opt_kd_lazy && L->opt_group != 0 && mode == PORRT_MODE_RRT && !L->opt_kd_after;
         L->kd_built_after = 0;
@@ -2426,6 +2434,22 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             ScopedEvents<RING> ring;
             if (ring.create() != hipSuccess) { sched_rc = PORRT_ERR_DEVICE; return 0; }
             (void)hipMemsetAsync(L->d_active, 0, (B_pot + 2u) * sizeof(uint32_t), L->stream);
+            // Rows that have ended still cost every later launch their workgroups' start and exit (a TAMP-shaped batch: most rows
+            // end at n_iter_min, a few run on to n_iter_max).  When the count the host last saw has fallen to three quarters of the
+            // rows launched, the rows that still have work are gathered into a compact array of run constants and the step kernels
+            // are launched on that one (k_rows_compact / k_rows_gather; the count is two steps old, so never too small: rows only end).
+            // Not with a kd chain beside the steps (its kernels are launched on the same rows, from another stream).
+            const bool can_compact = L->opt_compact && n >= 64u && (L->kd_lazy || mode == PORRT_MODE_PTO);
+            if (can_compact && L->rcarr_c_cap < n) {
+                for (int k = 0; k < 2; ++k) { if (L->d_rcarr_c[k]) (void)hipFree(L->d_rcarr_c[k]); L->d_rcarr_c[k] = nullptr; }
+                if (L->d_live_idx) (void)hipFree(L->d_live_idx);
+                L->d_live_idx = nullptr; L->rcarr_c_cap = 0;
+                if (hipMalloc((void **)&L->d_rcarr_c[0], (size_t)n * sizeof(RunConst)) != hipSuccess || hipMalloc((void **)&L->d_rcarr_c[1], (size_t)n * sizeof(RunConst)) != hipSuccess ||
+                    hipMalloc((void **)&L->d_live_idx, (size_t)n * sizeof(uint32_t)) != hipSuccess) { sched_rc = PORRT_ERR_DEVICE; return 0; }
+                L->rcarr_c_cap = n;
+            }
+            int pp = 0;
+            L->n_compactions = 0;
             uint32_t cb = 0;
             for (; cb < B_pot; ++cb) {
                 if (cb >= first_dec) {
@@ -2433,12 +2457,26 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
                     (void)hipMemcpyAsync(L->h_active + cb, L->d_active + cb, sizeof(uint32_t), hipMemcpyDeviceToHost, L->stream);
                     (void)hipEventRecord(ring.e[cb % RING], L->stream);
                 }
+                if (can_compact && cb >= first_dec + LAG + 1u) {
+                    // h_active[cb - LAG - 1] was read when step cb - 1 was launched: rows running then, an upper bound of the rows with work now
+                    const uint32_t seen = L->h_active[cb - LAG - 1u], slots = std::min<uint32_t>(n, (seen + 7u) & ~7u);
+                    if (slots && slots * 4u <= L->launch_Q * 3u) {
+                        hipLaunchKernelGGL(k_rows_compact, dim3(1), dim3(1024), 0, L->stream, (const RunConst *)L->d_rcarr, n, cb, slots, L->d_live_idx);
+                        hipLaunchKernelGGL(k_rows_gather, dim3(slots), dim3(256), 0, L->stream, (const RunConst *)L->d_rcarr, (const uint32_t *)L->d_live_idx, L->d_rcarr_c[pp]);
+                        L->launch_rcp = L->d_rcarr_c[pp];
+                        L->launch_Q = slots;
+                        pp ^= 1;
+                        ++L->n_compactions;
+                    }
+                }
                 L->launch_step(cb, 0u, nbmax[cb], vwords, L->run_lds_bytes, prof, ev_used, 0u, 0u);
                 if (cb >= first_dec + LAG) {
                     if (hipEventSynchronize(ring.e[(cb - LAG) % RING]) != hipSuccess) { sched_rc = PORRT_ERR_DEVICE; break; }
                     if (L->h_active[cb - LAG] == 0u) { ++cb; break; }
                 }
             }
+            L->launch_rcp = L->d_rcarr;          // what follows the steps (the last rewire commit, the kd structure where a tie asks, the results) takes every row
+            L->launch_Q = n;
             L->join_side();
             return cb;
         };
@@ -2456,6 +2494,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             L->join_side();
             return cb;
         };
+        const double th2 = now_s();
         uint32_t steps = 0;
         if (sched) {
             steps = sched_steps();
@@ -2477,6 +2516,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
         } else {
             steps = all_steps();
         }
+        const double th3 = now_s();
         HIPCHK_CTX(L, hipEventRecord(e1, L->stream));
         // every member's counters and final tree size: gathered on the device, one copy, one sync for all
         if (L->batch_out_cap < n) {
@@ -2510,6 +2550,7 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
                 HIPCHK_CTX(L, hipStreamSynchronize(L->stream));
             }
         }
+        const double th4 = now_s();
         for (uint32_t q = 0; q < n; ++q) { cs[q]->batch_hc = h_out[q].cnt; cs[q]->batch_nodes = h_out[q].nodes; }
         {
             hipError_t e = hipGetLastError();
@@ -2531,6 +2572,9 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
             else if (r < 0) { if (cs[q] != L) L->set_err(cs[q]->err); return r; }
             else if (r > worst) worst = r;
         }
+        if (host_dbg) fprintf(stderr, "[porrt] batch of %u (host): members %.2f ms, upload + preparation launches %.2f ms, step launches %.2f ms (%u steps), "
+                                      "wait + gather (+ kd build) %.2f ms, finish %.2f ms; device %.2f ms\n", n, 1e3 * (th1 - th0), 1e3 * (th2 - th1), 1e3 * (th3 - th2), steps,
+                              1e3 * (th4 - th3), 1e3 * (now_s() - th4), (double)ms);
         if (!retry && prof && sched && getenv("PORRT_DEBUG_STEPS")) {
             for (uint32_t s2 = 0; s2 < steps && (size_t)(4 * s2 + 3) < ev_used; ++s2) {
                 float a = 0, r2 = 0;
@@ -2628,6 +2672,8 @@ void porrt_destroy(porrt_ctx *c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->d_rcarr) (void)hipFree(c->d_rcarr);
     if (c->d_batch_out) (void)hipFree(c->d_batch_out);
+    for (int k = 0; k < 2; ++k) if (c->d_rcarr_c[k]) (void)hipFree(c->d_rcarr_c[k]);
+    if (c->d_live_idx) (void)hipFree(c->d_live_idx);
     if (c->d_active) (void)hipFree(c->d_active);
     if (c->h_active) (void)hipHostFree(c->h_active);
 
@@ -2809,6 +2855,7 @@ static int grow_batch_each(porrt_ctx *const *ctxs, uint32_t n_ctx, const double 
         // the launches (~900 per sub-batch) stay ahead of the GPU from a host thread each.
         if (have_streams) { Lg->stream = top->sub_streams[g]; if (per == 2u) { Lg->stream2 = top->sub_streams[G + g]; swapped2 = true; } Lg->sub_eager = true; }
         Lg->opt_kd_inline = top->opt_kd_inline;
+        Lg->opt_compact = top->opt_compact;
         rcs[g] = grow_batch(ctxs + lo[g], lo[g + 1] - lo[g], starts + 2 * (size_t)lo[g], max_step, search_radius, n_iter_min + lo[g], n_iter_max + lo[g], batch_K, mode);
         // the side stream goes back only if it was lent one of the measured streams: a leader that had none and made its own inside
         // grow_batch (ensure_side_stream: no measured set, or kd_inline) keeps it for its lifetime instead of dropping it every call
@@ -3332,6 +3379,7 @@ int porrt_get_option(const porrt_ctx *c, const char *name, int64_t *value) {
     else if (!strcmp(name, "group_lanes")) *value = c->opt_group;
     else if (!strcmp(name, "kd_lazy")) *value = c->kd_lazy ? 1 : 0;                 // in force for the last grow (of a batch: ask its first context)
     else if (!strcmp(name, "kd_lca_steps")) *value = (int64_t)c->counters.lca_next;      // this context's own need: 1 + the last step with a tie that took the structure
+    else if (!strcmp(name, "compactions")) *value = c->n_compactions;               // how often the last batch this context led gathered its running rows
     else if (!strcmp(name, "kd_built_after")) *value = c->kd_built_after;           // 1: a tie of the last grow needed the whole kd structure, built after the steps
     else return PORRT_ERR_INVALID;
     return PORRT_OK;
@@ -3358,6 +3406,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "kd_lazy")) c->opt_kd_lazy = value == 2 ? 2 : (value != 0);
     else if (!strcmp(name, "kd_claim_threads")) { if (value != 0 && value != 256 && value != 512 && value != 1024) return PORRT_ERR_INVALID; c->opt_claim_threads = (uint32_t)value; }
     else if (!strcmp(name, "kd_inline")) c->opt_kd_inline = value != 0;
+    else if (!strcmp(name, "compact_rows")) c->opt_compact = value != 0;
     else if (!strcmp(name, "early_wave_steps")) c->opt_early_wave = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 64));
     else if (!strcmp(name, "kd_group")) c->opt_kd_group = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else { c->set_err(std::string("unknown option ") + name); return PORRT_ERR_INVALID; }

@@ -390,6 +390,41 @@ def test_loop_condition_batch_rows_that_need_the_kd_structure(eng_mod):
         assert_same(engs[j], o)
 
 
+@pytest.mark.parametrize("Q,K", [(1024, 128), (192, 256)])
+def test_tamp_batch_at_bench_size_and_compacted_rows(eng_mod, Q, K):
+    """bench.py's TAMP row, argument for argument (1024 queries, K = 128, n_iter_min 2500, n_iter_max 10000, two launch sequences), and
+    a batch whose members end at very different steps (K = 256: a step moves the frontier less often, some queries need most of their
+    budget), where the later steps are launched on the rows that still have work (k_rows_compact / k_rows_gather): the same trees,
+    iteration counts and sampler states with and without that; the first and last member of each launch sequence, the member that ran
+    longest and one whose ties needed the kd structure after the steps against the oracle"""
+    cs = _tamp_cases(Q)
+    res, ncomp = {}, {}
+    for compact in (1, 0):
+        engs = [cases.configure(eng_mod.Engine(), c) for c in cs]
+        engs[0].set_option("compact_rows", compact)
+        eng_mod.Engine.grow_batch(engs, [c.start for c in cs], cs[0].max_step, cs[0].search_radius, 2500, K, n_iter_max=10000)
+        ncomp[compact] = engs[0].get_option("compactions") + engs[Q // 2].get_option("compactions")
+        res[compact] = engs
+    its = [e.num_iterations() for e in res[1]]
+    assert min(its) >= 2500 and max(its) <= 10000 and ncomp[0] == 0
+    if K == 256:
+        assert max(its) > 2 * min(its), "members are meant to end at very different steps: %d .. %d" % (min(its), max(its))
+        assert ncomp[1] > 0, "the later steps were meant to run on the gathered rows"
+    for a, b in zip(res[1], res[0]):
+        assert a.num_iterations() == b.num_iterations() and a.num_nodes() == b.num_nodes()
+    for j in range(0, Q, 37):
+        assert_same(res[1][j], res[0][j])
+    late = int(np.argmax(its))
+    asked = [j for j, e in enumerate(res[1]) if e.get_option("kd_lca_steps") > 0]
+    if Q == 1024:
+        assert asked, "1024 rows of this workload hold a row whose ties need the kd structure"
+    for j in sorted({0, Q // 2 - 1, Q // 2, Q - 1, late} | set(asked[:1])):
+        o, _ = run_orc(cs[j], K)
+        assert_same(res[1][j], o)
+    for e in res[0] + res[1]:
+        e.close()
+
+
 def test_trees_fetched_beside_a_growing_batch(eng_mod):
     """the configuration bench.py's `value` is quoted on: porrt_get_trees of set A into the caller's arrays on a host thread WHILE
     porrt_grow_batch grows set B (two sets of 32 contexts = two launch sequences each, roles swapped every round, so staging slots,
