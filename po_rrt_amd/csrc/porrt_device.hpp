@@ -2685,7 +2685,11 @@ __global__ __launch_bounds__(256) void k_kd_link(const RunConst *__restrict__ rc
     if (w == (int)(N + t)) { kd_publish(rc, N, m, m.cur); return; }
     if ((uint32_t)w < N) { atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW); return; }    // cannot happen: the slot was empty in the old tree
     kd_step_below(rc, m, (uint32_t)w - N, as_global(rc.kd_rec)[w].x, as_global(rc.kd_rec)[w].y);
-    rc.kd_losers[atomicAdd(&rc.cnt->n_losers, 1u)] = m;
+    // (at most n_new <= kClaimMax losers per group, and the claim kernel takes the count back to zero; the bound is checked all the
+    // same -- an append past the array would be a fault of the whole GPU, an error code is not)
+    const uint32_t li = atomicAdd(&rc.cnt->n_losers, 1u);
+    if (li < kClaimMax) rc.kd_losers[li] = m;
+    else atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW);
 }
 
 // A workgroup barrier that waits for the LDS traffic only: the rounds below talk through LDS alone, and a barrier that also
@@ -2715,7 +2719,7 @@ __global__ __launch_bounds__(TPB) void k_kd_claim(const RunConst *__restrict__ r
     const uint32_t N = as_global(rc.n_at)[b0], b = b0 + nsteps - 1u;
     const uint32_t n_new = kd_group_size(rc, b0, nsteps, vwords);
     if (n_new > CAP) { if (threadIdx.x == 0) atomicOr(&rc.cnt->err, (uint32_t)ERR_GPATH_OVERFLOW); return; }
-    const uint32_t n_l = rc.cnt->n_losers;
+    const uint32_t n_l = rc.cnt->n_losers < kClaimMax ? rc.cnt->n_losers : kClaimMax;      // (k_kd_link stores no loser past the array)
     auto grec = as_global(rc.kd_rec);
 #ifdef PORRT_CLAIM_PROBE
     const unsigned long long pt0 = wall_clock64();

@@ -152,9 +152,94 @@ __global__ __launch_bounds__(256) void k_eo_adjacency(const uint32_t *__restrict
     }
 }
 
-// Orders the E edges (d_from, d_to, d_val: the growth kernels' arrays) of a graph of N nodes whose pre-order ranks are h_rank.
+// ---- the pre-order rank of every node in the reference's kd-tree of the coordinates (KdTree::add in id order, nearest_neighbor.rs:29-46;
+// the order of :101-117), on the device.  The tree is built a level per round by the whole GPU -- every node not yet placed bids for
+// the empty child slot its descent has reached (atomicMin of its id: sequential insertion gives a slot to the lowest id among the
+// nodes whose paths reach it, and those all reach it in the same round), k_kd1_settle places the winners and lets the others step
+// below them -- then every node counts itself into its ancestors (subtree sizes) and walks to the root once more for its rank.
+// (k_seg_kd_ranks, porrt_prm.hpp, is the same for many small trees, a workgroup each.)
+constexpr int kKd1Empty = 0x7FFFFFFF;
+constexpr uint32_t kKd1Placed = 0x80000000u;
+__global__ __launch_bounds__(256) void k_kd1_init(uint32_t N, int *__restrict__ child, int *__restrict__ par, uint32_t *__restrict__ dep, uint32_t *__restrict__ size) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    child[2 * (size_t)t] = kKd1Empty; child[2 * (size_t)t + 1] = kKd1Empty;
+    par[t] = t ? 0 : -1;                       // (until a node is placed: the node its descent stands at)
+    dep[t] = t ? 0u : kKd1Placed;              // depth of that node; the root is placed
+    size[t] = 1u;
+}
+__device__ __forceinline__ size_t kd1_slot(const double *x, const double *y, uint32_t t, int c, uint32_t d) {
+    const bool left = (d & 1u) ? (as_global(y)[t] < as_global(y)[c]) : (as_global(x)[t] < as_global(x)[c]);      // strictly less goes left (nearest_neighbor.rs:33-35)
+    return 2 * (size_t)c + (left ? 0 : 1);
+}
+__global__ __launch_bounds__(256) void k_kd1_bid(const double *__restrict__ x, const double *__restrict__ y, uint32_t N, int *__restrict__ child,
+                                                 const int *__restrict__ par, const uint32_t *__restrict__ dep) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    const uint32_t d = as_global(dep)[t];
+    if (d & kKd1Placed) return;
+    atomicMin(&child[kd1_slot(x, y, t, as_global(par)[t], d)], (int)t);
+}
+__global__ __launch_bounds__(256) void k_kd1_settle(const double *__restrict__ x, const double *__restrict__ y, uint32_t N, const int *__restrict__ child,
+                                                    int *__restrict__ par, uint32_t *__restrict__ dep, uint32_t *__restrict__ more) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    const uint32_t d = as_global(dep)[t];
+    if (d & kKd1Placed) return;
+    const int w = as_global(child)[kd1_slot(x, y, t, as_global(par)[t], d)];
+    if (w == (int)t) { dep[t] = kKd1Placed | (d + 1u); return; }
+    par[t] = w; dep[t] = d + 1u;
+    *more = 1u;
+}
+__global__ __launch_bounds__(256) void k_kd1_sizes(uint32_t N, const int *__restrict__ par, uint32_t *__restrict__ size) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    for (int a = as_global(par)[t]; a >= 0; a = as_global(par)[a]) atomicAdd(&size[a], 1u);
+}
+__global__ __launch_bounds__(256) void k_kd1_ranks(uint32_t N, const int *__restrict__ child, const int *__restrict__ par, const uint32_t *__restrict__ size,
+                                                   uint32_t *__restrict__ rank) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    uint32_t r = 0;
+    int v = (int)t;
+    for (int a = as_global(par)[v]; a >= 0; v = a, a = as_global(par)[a]) {
+        r += 1u;
+        const int l = as_global(child)[2 * (size_t)a];
+        if (l != v && l != kKd1Empty) r += as_global(size)[l];            // the path turns right at a: a's left subtree comes first
+    }
+    rank[t] = r;
+}
+// ranks of the N nodes at (d_x, d_y) into `rank` (device), scratch from the state's slots
+static int kd_ranks_device(EdgeOrderState &st, size_t N, const double *d_x, const double *d_y, uint32_t *rank, hipStream_t s, std::string &err) {
+    int *child, *par;
+    uint32_t *dep, *size, *more;
+    int r;
+    constexpr uint32_t kGroup = 16;
+    if ((r = eo_alloc(st, child, 2 * N, err)) || (r = eo_alloc(st, par, N, err)) || (r = eo_alloc(st, dep, N, err)) || (r = eo_alloc(st, size, N, err)) ||
+        (r = eo_alloc(st, more, kGroup, err)))
+        return r;
+    const dim3 block(256), grid((unsigned)((std::max<size_t>(N, 1) + 255) / 256));
+    hipLaunchKernelGGL(k_kd1_init, grid, block, 0, s, (uint32_t)N, child, par, dep, size);
+    uint32_t h_more[kGroup];
+    for (size_t rounds = 0; rounds <= N; rounds += kGroup) {
+        EO_HIP(hipMemsetAsync(more, 0, kGroup * sizeof(uint32_t), s));
+        for (uint32_t k = 0; k < kGroup; ++k) {
+            hipLaunchKernelGGL(k_kd1_bid, grid, block, 0, s, d_x, d_y, (uint32_t)N, child, (const int *)par, (const uint32_t *)dep);
+            hipLaunchKernelGGL(k_kd1_settle, grid, block, 0, s, d_x, d_y, (uint32_t)N, (const int *)child, par, dep, more + k);
+        }
+        EO_HIP(hipMemcpyAsync(h_more, more, sizeof h_more, hipMemcpyDeviceToHost, s));
+        EO_HIP(hipStreamSynchronize(s));
+        if (!h_more[kGroup - 1]) break;          // the group's last round placed the last node (or an earlier one did)
+    }
+    hipLaunchKernelGGL(k_kd1_sizes, grid, block, 0, s, (uint32_t)N, (const int *)par, size);
+    hipLaunchKernelGGL(k_kd1_ranks, grid, block, 0, s, (uint32_t)N, (const int *)child, (const int *)par, (const uint32_t *)size, rank);
+    return PORRT_OK;
+}
+
+// Orders the E edges (d_from, d_to, d_val: the growth kernels' arrays) of a graph of N nodes; the nodes' pre-order ranks come from
+// h_rank (host) or, when that is null, are made on the device from the coordinates (d_x, d_y).
 static int edge_order_build(EdgeOrderState &st, uint64_t tag, size_t N, size_t E, const uint32_t *d_from, const uint32_t *d_to, const uint32_t *d_val,
-                            const std::vector<uint32_t> &h_rank, hipStream_t s, std::string &err) {
+                            const std::vector<uint32_t> *h_rank, const double *d_x, const double *d_y, hipStream_t s, std::string &err) {
     const double t0 = bg_now();
     st.next_slot = 0;
     st.tag = ~0ull;
@@ -172,7 +257,8 @@ static int edge_order_build(EdgeOrderState &st, uint64_t tag, size_t N, size_t E
         (r = eo_alloc(st, bf_to, E, err)) || (r = eo_alloc(st, ord0, E, err)) || (r = eo_alloc(st, ord1, E, err)) || (r = eo_alloc(st, ordf, E, err)) ||
         (r = eo_alloc(st, off_to, N + 2, err)) || (r = eo_alloc(st, off_from, N + 2, err)) || (r = eo_alloc(st, tot, nblk + 2, err)))
         return r;
-    EO_HIP(hipMemcpyAsync(rank, h_rank.data(), N * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (h_rank) EO_HIP(hipMemcpyAsync(rank, h_rank->data(), N * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    else if ((r = kd_ranks_device(st, N, d_x, d_y, rank, s, err))) return r;
     EO_HIP(hipMemsetAsync(deg_to, 0, (N + 1) * sizeof(uint32_t), s));
     EO_HIP(hipMemsetAsync(deg_from, 0, (N + 1) * sizeof(uint32_t), s));
     EO_HIP(hipMemsetAsync(cur_to, 0, (N + 1) * sizeof(uint32_t), s));

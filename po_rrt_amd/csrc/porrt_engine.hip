@@ -147,6 +147,27 @@ uint64_t ones(int n) { return n >= 64 ? ~0ULL : ((1ULL << n) - 1); }
 
 #include "porrt_mmprm.hpp"
 
+// Device scratch that outlives a call: numbered slots that only grow (a caller that builds roadmaps again and again pays for its
+// buffers once: a dozen hipMalloc / hipFree pairs cost more than the kernels they serve).
+struct GrowScratch {
+    std::vector<std::pair<void *, size_t>> slots;
+    template <class T> hipError_t get(size_t slot, T *&p, size_t n) {
+        if (slots.size() <= slot) slots.resize(slot + 1, {nullptr, 0});
+        const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        if (slots[slot].second < bytes) {
+            if (slots[slot].first) (void)hipFree(slots[slot].first);
+            slots[slot] = {nullptr, 0};
+            void *q = nullptr;
+            const hipError_t e = hipMalloc(&q, bytes + bytes / 8);
+            if (e != hipSuccess) return e;
+            slots[slot] = {q, bytes + bytes / 8};
+        }
+        p = (T *)slots[slot].first;
+        return hipSuccess;
+    }
+    void free_all() { for (auto &sl : slots) if (sl.first) (void)hipFree(sl.first); slots.clear(); }
+};
+
 struct porrt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -196,6 +217,7 @@ struct porrt_ctx {
     bool kd_lazy = false, kd_build_now = false;    // in force for the running grow; the build after the steps is being launched
     int kd_full_build(const std::vector<std::pair<uint32_t, uint32_t>> &segs);
     uint32_t opt_claim_threads = 0;        // "kd_claim_threads": 0 = the engine's choice (256 beside a batch's step kernels), else 256 / 512 / 1024
+    int opt_host_ranks = 0;                // "host_ranks": 1 = the kd pre-order ranks of a graph's nodes (edge order) from a host kd-tree instead of the device's
     int opt_compact = 1;                   // "compact_rows": a batch whose rows end at different steps launches its later steps on the rows that still have work
     uint32_t n_compactions = 0;            //   how often the last such batch led by this context gathered them ("compactions")
     int opt_kd_ride = 0;                   // "kd_ride": 1 = also for several contexts the hints and deferred ties ride in the next group's locate kernel
@@ -323,6 +345,7 @@ struct porrt_ctx {
     int ensure_edge_order();
     int grow_prm(const double start[2], double max_step, double search_radius, uint64_t n_iter);
     MmState mm;                            // porrt_grow_mm_prm: the mode tree and the modes' roadmaps
+    GrowScratch mm_scratch;                //   and the device buffers of roadmaps_of_modes, kept across calls
     int grow_mm_prm(const double start[2], const double *initial_belief, uint32_t n_worlds_in, double max_step, double search_radius, uint64_t n_iter_per_belief);
     int roadmaps_of_modes(double max_step, double search_radius);
     int roadmap_of_points(const std::vector<double> &xy, double max_step, double search_radius, std::vector<uint32_t> &efrom, std::vector<uint32_t> &eto, double &dev_s);
@@ -1563,16 +1586,18 @@ static HostKd *host_kd_of(porrt_ctx *c) {                            // built on
 } // namespace
 
 // The pre-order rank of every node in the kd-tree of the coordinates (sequential KdTree::add in id order,
-// nearest_neighbor.rs:29-46) on the host, then the edge order and the adjacency lists on the device (porrt_edges.hpp).
+// nearest_neighbor.rs:29-46), the edge order and the adjacency lists: all on the device (porrt_edges.hpp).
 int porrt_ctx::ensure_edge_order() {
     if (eo.tag == results_tag) return PORRT_OK;
-    int r = download(DL_TREE);
-    if (r) return r;
+    HIPCHK(hipSetDevice(device));
     const size_t N = n_nodes;
-    const HostKd *kd = host_kd_of(this);
-    const std::vector<int> &ch0 = kd->left, &ch1 = kd->right;
-    std::vector<uint32_t> rank(N, 0);
-    {
+    std::string e;
+    int r;
+    if (opt_host_ranks) {                    // (developer option "host_ranks": the ranks from a kd-tree built on the host, as before round 4)
+        if ((r = download(DL_TREE))) return r;
+        const HostKd *kd = host_kd_of(this);
+        const std::vector<int> &ch0 = kd->left, &ch1 = kd->right;
+        std::vector<uint32_t> rank(N, 0);
         std::vector<int> stack;
         uint32_t next = 0;
         if (N) stack.push_back(0);
@@ -1583,9 +1608,10 @@ int porrt_ctx::ensure_edge_order() {
             if (ch1[n] >= 0) stack.push_back(ch1[n]);      // left subtree first (popped first)
             if (ch0[n] >= 0) stack.push_back(ch0[n]);
         }
+        r = edge_order_build(eo, results_tag, N, (size_t)counters.n_edges, d_efrom.p, d_eto.p, d_etv.p, &rank, nullptr, nullptr, stream, e);
+    } else {
+        r = edge_order_build(eo, results_tag, N, (size_t)counters.n_edges, d_efrom.p, d_eto.p, d_etv.p, nullptr, d_nx.p, d_ny.p, stream, e);
     }
-    std::string e;
-    r = edge_order_build(eo, results_tag, N, (size_t)counters.n_edges, d_efrom.p, d_eto.p, d_etv.p, rank, stream, e);
     if (r) set_err(e);
     return r;
 }
@@ -1840,7 +1866,8 @@ struct DeviceScratch {
 };
 
 // All modes' roadmaps at once (k_mm_connect / k_mm_order, porrt_prm.hpp): nodes end to end, the kd pre-order rank of every node
-// from a host kd-tree per mode, one count / scan / fill / order sequence, one download.
+// from the mode's kd-tree built on the device (k_seg_kd_ranks: a workgroup per mode), one count / scan / fill / order sequence, one
+// download.
 int porrt_ctx::roadmaps_of_modes(double max_step, double search_radius) {
     HIPCHK(hipSetDevice(device));
     size_t NT = 0, max_n = 0;
@@ -1849,33 +1876,18 @@ int porrt_ctx::roadmaps_of_modes(double max_step, double search_radius) {
     if (NT == 0) return PORRT_OK;
     if (NT + 1 >= 0x7FFFFFFFull) { set_err("too many roadmap nodes"); return PORRT_ERR_INVALID; }
     std::vector<double> hx(NT), hy(NT);
-    std::vector<uint32_t> base(NT), rank(NT);
+    std::vector<uint32_t> base(NT), seg(mm.modes.size() + 1, 0);
     std::vector<size_t> off(mm.modes.size() + 1, 0);
     {
-        std::vector<double> mx, my;
-        std::vector<int> stack;
         size_t at = 0;
         for (size_t mi = 0; mi < mm.modes.size(); ++mi) {
             const MmMode &m = mm.modes[mi];
             const size_t n = m.xy.size() / 2;
-            off[mi] = at;
-            mx.resize(n); my.resize(n);
-            for (size_t t = 0; t < n; ++t) { mx[t] = m.xy[2 * t]; my[t] = m.xy[2 * t + 1]; hx[at + t] = mx[t]; hy[at + t] = my[t]; base[at + t] = (uint32_t)at; }
-            if (n) {
-                const HostKd kd(mx, my);                         // KdTree::add in node order (nearest_neighbor.rs:29-46)
-                uint32_t next = 0;
-                stack.assign(1, 0);
-                while (!stack.empty()) {                         // pre-order: node, left subtree, right subtree (:101-117)
-                    const int nd = stack.back();
-                    stack.pop_back();
-                    rank[at + (size_t)nd] = next++;
-                    if (kd.right[nd] >= 0) stack.push_back(kd.right[nd]);
-                    if (kd.left[nd] >= 0) stack.push_back(kd.left[nd]);
-                }
-            }
+            off[mi] = at; seg[mi] = (uint32_t)at;
+            for (size_t t = 0; t < n; ++t) { hx[at + t] = m.xy[2 * t]; hy[at + t] = m.xy[2 * t + 1]; base[at + t] = (uint32_t)at; }
             at += n;
         }
-        off[mm.modes.size()] = at;
+        off[mm.modes.size()] = at; seg[mm.modes.size()] = (uint32_t)at;
     }
     HIPCHK(d_radT2.reserve(max_n + 8)); HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_cls.reserve(2 * (size_t)W * H + 16));
     int r = layout_buffers();
@@ -1892,16 +1904,18 @@ int porrt_ctx::roadmaps_of_modes(double max_step, double search_radius) {
     rc.visibility = visibility;
     rc.rad_T2 = d_radT2.p;
     HIPCHK(hipMemcpyAsync(d_rc.p, &rc, sizeof rc, hipMemcpyHostToDevice, stream));
-    DeviceScratch sc;                                    // freed on every way out
+    GrowScratch &sc = mm_scratch;                        // kept by the context: the next call finds its buffers
     double *dx = nullptr, *dy = nullptr;
-    uint32_t *dbase = nullptr, *drank = nullptr, *ddeg = nullptr, *derr = nullptr, *dtmp = nullptr, *dfrom = nullptr, *dto = nullptr;
+    uint32_t *dbase = nullptr, *drank = nullptr, *ddeg = nullptr, *derr = nullptr, *dtmp = nullptr, *dfrom = nullptr, *dto = nullptr, *dseg = nullptr, *daux = nullptr, *dsz = nullptr;
+    int *dchild = nullptr, *dpar = nullptr;
     unsigned long long *doff = nullptr, *dtot = nullptr;
-    HIPCHK(sc.get(dx, NT)); HIPCHK(sc.get(dy, NT)); HIPCHK(sc.get(dbase, NT)); HIPCHK(sc.get(drank, NT)); HIPCHK(sc.get(ddeg, NT)); HIPCHK(sc.get(derr, 1));
-    HIPCHK(sc.get(doff, NT + 1)); HIPCHK(sc.get(dtot, (NT + kScanTile - 1) / kScanTile + 2));
+    HIPCHK(sc.get(0, dx, NT)); HIPCHK(sc.get(1, dy, NT)); HIPCHK(sc.get(2, dbase, NT)); HIPCHK(sc.get(3, drank, NT)); HIPCHK(sc.get(4, ddeg, NT)); HIPCHK(sc.get(5, derr, 1));
+    HIPCHK(sc.get(6, doff, NT + 1)); HIPCHK(sc.get(7, dtot, (NT + kScanTile - 1) / kScanTile + 2));
+    HIPCHK(sc.get(11, dseg, seg.size())); HIPCHK(sc.get(12, dchild, 2 * NT)); HIPCHK(sc.get(13, dpar, NT)); HIPCHK(sc.get(14, daux, NT)); HIPCHK(sc.get(15, dsz, NT));
     HIPCHK(hipMemcpyAsync(dx, hx.data(), NT * 8, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(dy, hy.data(), NT * 8, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(dbase, base.data(), NT * 4, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(drank, rank.data(), NT * 4, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(dseg, seg.data(), seg.size() * 4, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemsetAsync(derr, 0, sizeof(uint32_t), stream));
     MmConst p{};
     p.NT = (uint32_t)NT; p.x = dx; p.y = dy; p.base = dbase; p.rank = drank; p.rad_T2 = d_radT2.p; p.deg = ddeg; p.edge_off = doff; p.err = derr;
@@ -1909,13 +1923,15 @@ int porrt_ctx::roadmaps_of_modes(double max_step, double search_radius) {
     HIPCHK(evs.create());
     HIPCHK(hipEventRecord(evs.e[0], stream));
     const dim3 wgrid((unsigned)((NT + 3) / 4)), block(256);
+    // every mode's kd-tree and the pre-order ranks of its nodes (what orders a node's neighbours), a workgroup per mode
+    hipLaunchKernelGGL(k_seg_kd_ranks, dim3((unsigned)mm.modes.size()), block, 0, stream, (const double *)dx, (const double *)dy, (const uint32_t *)dseg, dchild, dpar, daux, dsz, drank);
     hipLaunchKernelGGL(k_mm_connect<false>, wgrid, block, 0, stream, (const RunConst *)d_rc.p, p);
     bg_scan(ddeg, NT, dtot, doff, stream);
     unsigned long long E = 0;
     HIPCHK(hipMemcpyAsync(&E, doff + NT, sizeof E, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     if (E >= 0xFFFFFFFFull) { set_err("multi-modal PRM: edge list too long"); return PORRT_ERR_CAPACITY; }
-    HIPCHK(sc.get(dtmp, E)); HIPCHK(sc.get(dfrom, E)); HIPCHK(sc.get(dto, E));
+    HIPCHK(sc.get(8, dtmp, E)); HIPCHK(sc.get(9, dfrom, E)); HIPCHK(sc.get(10, dto, E));
     p.tmp = dtmp; p.efrom = dfrom; p.eto = dto;
     hipLaunchKernelGGL(k_mm_connect<true>, wgrid, block, 0, stream, (const RunConst *)d_rc.p, p);
     hipLaunchKernelGGL(k_mm_order, wgrid, block, 0, stream, p);
@@ -2672,6 +2688,7 @@ void porrt_destroy(porrt_ctx *c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->d_rcarr) (void)hipFree(c->d_rcarr);
     if (c->d_batch_out) (void)hipFree(c->d_batch_out);
+    c->mm_scratch.free_all();
     for (int k = 0; k < 2; ++k) if (c->d_rcarr_c[k]) (void)hipFree(c->d_rcarr_c[k]);
     if (c->d_live_idx) (void)hipFree(c->d_live_idx);
     if (c->d_active) (void)hipFree(c->d_active);
@@ -3407,6 +3424,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "kd_claim_threads")) { if (value != 0 && value != 256 && value != 512 && value != 1024) return PORRT_ERR_INVALID; c->opt_claim_threads = (uint32_t)value; }
     else if (!strcmp(name, "kd_inline")) c->opt_kd_inline = value != 0;
     else if (!strcmp(name, "compact_rows")) c->opt_compact = value != 0;
+    else if (!strcmp(name, "host_ranks")) { c->opt_host_ranks = value != 0; c->eo.tag = ~0ull; }
     else if (!strcmp(name, "early_wave_steps")) c->opt_early_wave = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 64));
     else if (!strcmp(name, "kd_group")) c->opt_kd_group = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));
     else { c->set_err(std::string("unknown option ") + name); return PORRT_ERR_INVALID; }

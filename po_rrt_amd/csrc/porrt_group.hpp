@@ -113,97 +113,6 @@ __device__ __forceinline__ void gscan_disc(const RunConst &rc, uint32_t b, const
     }
 }
 
-// The same walk for a YOUNG tree (the caller's choice: N below kSubScanN), with the slots of a page taken a sub-level at a time (GL slots:
-// one per lane) from up to RQ regions at once.  While a tree holds a node or two per region the disc of radius max_step meets a
-// dozen or two regions, and the page-at-a-time walk above spends a trip to memory on each for that node; here RQ regions share a
-// trip.  Sub-level s of a region = slots [GL s, GL s + GL) of its page s / (64 / GL).  Loads are unconditional (a lane without a slot
-// reads its page's first slot: the same line, no branch) with 32-bit offsets from the arrays' bases.  The visiting order differs from
-// the walk above (sub-level by sub-level instead of region by region): no caller depends on it -- hits are a set, every choice
-// between equal candidates is made on ids or the kd order.  (For a grown tree, whose regions fill their pages, it is the slower walk:
-// profiles/r4_conn2_experiments.txt.)
-template <int GL, int RQ, bool WITHD, class Visit>
-__device__ __forceinline__ void gscan_disc_sub(const RunConst &rc, uint32_t b, const GTeam<GL> &tm, double qx, double qy, double rho, uint32_t N, Visit visit) {
-    const uint32_t gl = tm.gl;
-    int cx0, cy0, cx1, cy1;
-    rep_cell(rc, qx - rho, qy - rho, kRG, cx0, cy0);
-    rep_cell(rc, qx + rho, qy + rho, kRG, cx1, cy1);
-    const uint32_t x0 = (uint32_t)cx0, y0 = (uint32_t)cy0;
-    const uint32_t w = (uint32_t)(cx1 - cx0 + 1), nreg = w * (uint32_t)(cy1 - cy0 + 1);
-    if (nreg * 16u > N) {           // streaming the id-ordered arrays is cheaper than walking empty regions
-        constexpr int U = (int)kPage / GL;
-        auto gx = as_global(rc.nx), gy = as_global(rc.ny), gdA = as_global(rc.distA);
-        for (uint32_t j0 = 0; j0 < N; j0 += (uint32_t)(U * GL)) {
-            double x[U], y[U], d[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t j = j0 + (uint32_t)(GL * u) + gl;
-                x[u] = gx[j < N ? j : 0u];
-                y[u] = gy[j < N ? j : 0u];
-                d[u] = WITHD ? gdA[j < N ? j : 0u] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (j0 + (uint32_t)(GL * u) < N) visit(x[u], y[u], d[u], (int)(j0 + (uint32_t)(GL * u) + gl), j0 + (uint32_t)(GL * u) + gl < N);
-        }
-        return;
-    }
-    constexpr uint32_t SPP = kPage / (uint32_t)GL;               // sub-levels per page
-    auto gcnt = as_global(rc.rg_cnt) + (b & 1u) * kRegions;
-    auto gdir = as_global(rc.rg_dir);
-    const auto bxy = (GPTR(const char))(uintptr_t)rc.pg_xy;
-    const auto bid = (GPTR(const char))(uintptr_t)rc.pg_id;
-    const auto bpd = (GPTR(const char))(uintptr_t)rc.pg_d;
-    for (uint32_t r0 = 0; r0 < nreg; r0 += (uint32_t)GL) {
-        const uint32_t r = r0 + gl;
-        uint32_t reg = 0, cnt = 0;
-        if (r < nreg) {
-            const uint32_t ry = r / w;
-            reg = (y0 + ry) * kRG + x0 + (r - ry * w);
-            cnt = gcnt[reg];
-        }
-        uint32_t page = reg, page_next = 0;                      // the first page of a region is static
-        for (uint32_t sl = 0;; ++sl) {
-            const uint32_t have = cnt > sl * (uint32_t)GL ? cnt - sl * (uint32_t)GL : 0u;
-            unsigned long long m = tm.ballot(have > 0u);
-            if (!m) break;
-            const uint32_t sub = sl % SPP;
-            // the next page's id is fetched while this page's sub-levels are walked
-            if (sub == 0u) { page_next = 0; if (have > kPage) page_next = gdir[(size_t)reg * rc.rg_maxp + sl / SPP + 1u]; }
-            while (m) {
-                uint32_t idx[RQ], pc[RQ];
-#pragma unroll
-                for (int q = 0; q < RQ; ++q) {
-                    idx[q] = 0; pc[q] = 0;
-                    if (m) {
-                        const int l = (int)__builtin_ctzll(m);
-                        m &= m - 1;
-                        const uint32_t h = tm.shfl(have, l);
-                        pc[q] = h < (uint32_t)GL ? h : (uint32_t)GL;
-                        idx[q] = tm.shfl(page, l) * kPage + sub * (uint32_t)GL + (gl < pc[q] ? gl : 0u);
-                    }
-                }
-                dbl2 v[RQ];
-                double d[RQ];
-                int id[RQ];
-#pragma unroll
-                for (int q = 0; q < RQ; ++q) {
-                    v[q] = *(GPTR(const dbl2))(bxy + (idx[q] << 4));
-                    id[q] = *(GPTR(const int))(bid + (idx[q] << 2));
-                    d[q] = WITHD ? *(GPTR(const double))(bpd + (idx[q] << 3)) : 0.0;
-                }
-#pragma unroll
-                for (int q = 0; q < RQ; ++q)
-                    if (pc[q]) visit(v[q].x, v[q].y, d[q], id[q], gl < pc[q]);
-            }
-            if (sub == SPP - 1u) page = page_next;
-        }
-    }
-}
-#ifndef PORRT_SCAN_SUB_N
-#define PORRT_SCAN_SUB_N 0
-#endif
-constexpr uint32_t kSubScanN = PORRT_SCAN_SUB_N;       // trees smaller than this are searched sub-level by sub-level (0: never)
-
 // ---- where a workgroup works
 // Workgroups are dealt to the 8 XCDs round-robin in launch order, and each XCD has its own 4 MiB L2.  A launch serves Q
 // queries (grid rows) whose trees share nothing, so the (x, row) pair a workgroup works on is rearranged: XCD c takes
@@ -857,12 +766,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PORRT_CONN2
         const MemHits M = mem_hits(rc, b, k);
         L.out_id = M.out_id; L.out_val = M.out_val; L.out_cnt = M.out_cnt; L.out_cap = M.out_cap;
         PORRT_TACC_B(rc, 0);
-        auto scan = [&](auto visit) {
-            // (N is uniform over the workgroup: one row, one step)
-            if (kSubScanN && N < kSubScanN) gscan_disc_sub<GL, 4, true>(rc, b, tm, px, py, disc_radius(T2, px, py), N, visit);
-            else gscan_disc<GL, 1, true>(rc, b, tm, px, py, disc_radius(T2, px, py), N, visit);
-        };
-        scan([&](double x, double y, double dA, int jd, bool ok) {
+        gscan_disc<GL, 1, true>(rc, b, tm, px, py, disc_radius(T2, px, py), N, [&](double x, double y, double dA, int jd, bool ok) {
             const bool in = ok && dist2(x, y, px, py) <= T2;
             const unsigned long long hm = tm.ballot(in);
             const uint32_t pos = tot + (uint32_t)__popcll(hm & ((1ull << tm.gl) - 1ull));

@@ -144,6 +144,68 @@ __global__ __launch_bounds__(256) void k_mm_connect(const RunConst *__restrict__
     if (err) atomicOr(p.err, err);
 }
 
+// The pre-order rank of every node in the reference's kd-tree of its segment (KdTree::add in node order, nearest_neighbor.rs:29-46;
+// the order KdTree::nearest_neighbors lists nodes in, :101-117), for many segments at once -- one workgroup per segment (a mode's
+// roadmap nodes).  The tree is built a level per round: every node not yet placed bids for the empty child slot its descent has
+// reached (atomicMin of the node's index: sequential insertion gives the slot to the lowest index among the nodes whose paths reach
+// it, and those all reach it in the same round), the winner is placed, the others step below it.  Then every node counts itself
+// into its ancestors (subtree sizes) and walks to the root once more for its rank: 1 per step down, plus the left subtree where the
+// path turns right.  child / parent / aux / sz are scratch of NT entries (child: 2 NT); values written by atomics are read back with
+// atomic loads (they are made in L2, past the CU's L1).
+constexpr int kSegKdEmpty = 0x7FFFFFFF;
+__global__ __launch_bounds__(256) void k_seg_kd_ranks(const double *__restrict__ x, const double *__restrict__ y, const uint32_t *__restrict__ seg_off,
+                                                      int *__restrict__ child, int *__restrict__ parent, uint32_t *__restrict__ aux, uint32_t *__restrict__ sz,
+                                                      uint32_t *__restrict__ rank) {
+    const uint32_t o = seg_off[blockIdx.x], n = seg_off[blockIdx.x + 1] - o;
+    if (n == 0) return;
+    constexpr uint32_t kPlaced = 0x80000000u;
+    auto gx = as_global(x) + o, gy = as_global(y) + o;
+    int *ch = child + 2 * (size_t)o, *par = parent + o;
+    uint32_t *dep = aux + o, *size = sz + o;
+    for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) {
+        ch[2 * t] = kSegKdEmpty; ch[2 * t + 1] = kSegKdEmpty;
+        par[t] = t ? 0 : -1;                   // (until a node is placed: the node its descent stands at)
+        dep[t] = t ? 0u : kPlaced;             // depth of that node; the root is placed
+        size[t] = 1u;
+    }
+    __syncthreads();
+    auto slot_of = [&](uint32_t t, int c, uint32_t d) {
+        const bool left = (d & 1u) ? (gy[t] < gy[c]) : (gx[t] < gx[c]);          // nearest_neighbor.rs:33-35: strictly less goes left
+        return 2 * c + (left ? 0 : 1);
+    };
+    for (;;) {
+        for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) {
+            const uint32_t d = dep[t];
+            if (d & kPlaced) continue;
+            atomicMin(&ch[slot_of(t, par[t], d)], (int)t);
+        }
+        __syncthreads();
+        int more = 0;
+        for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) {
+            const uint32_t d = dep[t];
+            if (d & kPlaced) continue;
+            const int w = __hip_atomic_load(&ch[slot_of(t, par[t], d)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (w == (int)t) dep[t] = kPlaced | (d + 1u);
+            else { par[t] = w; dep[t] = d + 1u; more = 1; }
+        }
+        if (!__syncthreads_or(more)) break;
+    }
+    // subtree sizes: every node counts itself into its ancestors
+    for (uint32_t t = threadIdx.x; t < n; t += blockDim.x)
+        for (int a = par[t]; a >= 0; a = par[a]) atomicAdd(&size[a], 1u);
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) {
+        uint32_t r = 0;
+        int v = (int)t;
+        for (int a = par[v]; a >= 0; v = a, a = par[a]) {
+            r += 1u;
+            const int l = __hip_atomic_load(&ch[2 * a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (l != v && l != kSegKdEmpty) r += __hip_atomic_load(&size[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the path turns right at a: a's left subtree comes first
+        }
+        rank[o + t] = r;
+    }
+}
+
 // a node's neighbours by ascending pre-order rank (ranks are distinct): position = number of smaller ranks in the list
 __global__ __launch_bounds__(256) void k_mm_order(MmConst p) {
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / 64u, lane = threadIdx.x & 63u;
