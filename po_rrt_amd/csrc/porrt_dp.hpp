@@ -555,6 +555,14 @@ static int dp_extract_policy(DpState &st, bool implicit, BeliefOf belief_of, Pro
     while (!lifo.empty()) {
         const auto [pol, bn] = lifo.back();
         lifo.pop_back();
+        // The reference's walk has no memory (belief_graph.rs:193-213): where the best child of a node leads back to a node on the
+        // walk's own path -- two graph nodes at one place are joined by edges of cost 0 and may each be the other's first best child --
+        // it never ends.  Here that is an error at once, not a policy of 2^24 nodes.
+        for (int64_t up = st.pol_parent[pol]; up >= 0; up = st.pol_parent[(size_t)up])
+            if (st.pol_original[(size_t)up] == bn) {
+                err = "extract_policy: the walk returns to a belief node on its own path (zero-cost edges between nodes at one place); the reference does not terminate here";
+                return PORRT_ERR_INVALID;
+            }
         if (implicit) hipLaunchKernelGGL(k_dp_row<true>, dim3(1), dim3(256), 0, s, st.last, (unsigned long long)bn, st.d_row, kDpRowCap, st.d_row_count);
         else hipLaunchKernelGGL(k_dp_row<false>, dim3(1), dim3(256), 0, s, st.last, (unsigned long long)bn, st.d_row, kDpRowCap, st.d_row_count);
         // one copy brings the count (item 0) and the first 255 children; longer rows need a second one

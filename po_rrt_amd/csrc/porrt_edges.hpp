@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_eo_adjacency(const uint32_t *__restrict
 // ---- the pre-order rank of every node in the reference's kd-tree of the coordinates (KdTree::add in id order, nearest_neighbor.rs:29-46;
 // the order of :101-117), on the device.  The tree is built a level per round by the whole GPU -- every node not yet placed bids for
 // the empty child slot its descent has reached (atomicMin of its id: sequential insertion gives a slot to the lowest id among the
-// nodes whose paths reach it, and those all reach it in the same round), k_kd1_settle places the winners and lets the others step
+// nodes whose paths reach it, and those all reach it in the same round), the next round places the winners and lets the others step
 // below them -- then every node counts itself into its ancestors (subtree sizes) and walks to the root once more for its rank.
 // (k_seg_kd_ranks, porrt_prm.hpp, is the same for many small trees, a workgroup each.)
 constexpr int kKd1Empty = 0x7FFFFFFF;
@@ -172,23 +172,27 @@ __device__ __forceinline__ size_t kd1_slot(const double *x, const double *y, uin
     const bool left = (d & 1u) ? (as_global(y)[t] < as_global(y)[c]) : (as_global(x)[t] < as_global(x)[c]);      // strictly less goes left (nearest_neighbor.rs:33-35)
     return 2 * (size_t)c + (left ? 0 : 1);
 }
-__global__ __launch_bounds__(256) void k_kd1_bid(const double *__restrict__ x, const double *__restrict__ y, uint32_t N, int *__restrict__ child,
-                                                 const int *__restrict__ par, const uint32_t *__restrict__ dep) {
+// one round: a node that bid in the round before looks at its slot -- its own id: placed; another's: it steps below that node --, and
+// every node still on its way bids for the slot below the node it stands at.  All such nodes stand at the same depth (they start at
+// the root together and go down a level per round), so the slots read in a round (that depth's) are never the slots written in it (the
+// next depth's): one kernel per round is enough.
+constexpr uint32_t kKd1Bid = 0x40000000u;
+__global__ __launch_bounds__(256) void k_kd1_round(const double *__restrict__ x, const double *__restrict__ y, uint32_t N, int *__restrict__ child,
+                                                   int *__restrict__ par, uint32_t *__restrict__ dep, uint32_t *__restrict__ more) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= N) return;
-    const uint32_t d = as_global(dep)[t];
+    uint32_t d = as_global(dep)[t];
     if (d & kKd1Placed) return;
-    atomicMin(&child[kd1_slot(x, y, t, as_global(par)[t], d)], (int)t);
-}
-__global__ __launch_bounds__(256) void k_kd1_settle(const double *__restrict__ x, const double *__restrict__ y, uint32_t N, const int *__restrict__ child,
-                                                    int *__restrict__ par, uint32_t *__restrict__ dep, uint32_t *__restrict__ more) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= N) return;
-    const uint32_t d = as_global(dep)[t];
-    if (d & kKd1Placed) return;
-    const int w = as_global(child)[kd1_slot(x, y, t, as_global(par)[t], d)];
-    if (w == (int)t) { dep[t] = kKd1Placed | (d + 1u); return; }
-    par[t] = w; dep[t] = d + 1u;
+    int c = as_global(par)[t];
+    if (d & kKd1Bid) {
+        d &= ~kKd1Bid;
+        const int w = as_global(child)[kd1_slot(x, y, t, c, d)];
+        if (w == (int)t) { dep[t] = kKd1Placed | (d + 1u); return; }
+        c = w; d += 1u;
+        par[t] = c;
+    }
+    atomicMin(&child[kd1_slot(x, y, t, c, d)], (int)t);
+    dep[t] = d | kKd1Bid;
     *more = 1u;
 }
 __global__ __launch_bounds__(256) void k_kd1_sizes(uint32_t N, const int *__restrict__ par, uint32_t *__restrict__ size) {
@@ -214,7 +218,7 @@ static int kd_ranks_device(EdgeOrderState &st, size_t N, const double *d_x, cons
     int *child, *par;
     uint32_t *dep, *size, *more;
     int r;
-    constexpr uint32_t kGroup = 16;
+    constexpr uint32_t kGroup = 32;
     if ((r = eo_alloc(st, child, 2 * N, err)) || (r = eo_alloc(st, par, N, err)) || (r = eo_alloc(st, dep, N, err)) || (r = eo_alloc(st, size, N, err)) ||
         (r = eo_alloc(st, more, kGroup, err)))
         return r;
@@ -223,10 +227,8 @@ static int kd_ranks_device(EdgeOrderState &st, size_t N, const double *d_x, cons
     uint32_t h_more[kGroup];
     for (size_t rounds = 0; rounds <= N; rounds += kGroup) {
         EO_HIP(hipMemsetAsync(more, 0, kGroup * sizeof(uint32_t), s));
-        for (uint32_t k = 0; k < kGroup; ++k) {
-            hipLaunchKernelGGL(k_kd1_bid, grid, block, 0, s, d_x, d_y, (uint32_t)N, child, (const int *)par, (const uint32_t *)dep);
-            hipLaunchKernelGGL(k_kd1_settle, grid, block, 0, s, d_x, d_y, (uint32_t)N, (const int *)child, par, dep, more + k);
-        }
+        for (uint32_t k = 0; k < kGroup; ++k)
+            hipLaunchKernelGGL(k_kd1_round, grid, block, 0, s, d_x, d_y, (uint32_t)N, child, par, dep, more + k);
         EO_HIP(hipMemcpyAsync(h_more, more, sizeof h_more, hipMemcpyDeviceToHost, s));
         EO_HIP(hipStreamSynchronize(s));
         if (!h_more[kGroup - 1]) break;          // the group's last round placed the last node (or an earlier one did)

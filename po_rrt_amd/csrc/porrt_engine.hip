@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) void k_batch_prep(const RunConst *__restrict__
         for (unsigned long long i = tid; i < n4; i += nth) z[i] = make_uint4(0u, 0u, 0u, 0u);
         for (unsigned long long i = 4ull * n4 + tid; i < rc.zero_words; i += nth) rc.zero0[i] = 0u;
     }
-    for (unsigned long long i = tid; i < (unsigned long long)kRepTotal; i += nth) rc.rep[i] = -1;
+    for (unsigned long long i = tid; i < (unsigned long long)kRepInts; i += nth) rc.rep[i] = -1;        // (ids -1; the positions behind them NaN)
     {   // final flags of the nodes this grow may create (connect_rrt_sample only writes the set ones)
         unsigned long long *f8 = reinterpret_cast<unsigned long long *>(rc.final_flag);
         const unsigned long long n8 = ((unsigned long long)rc.sched_max_nodes + 7ull) / 8ull;
@@ -1031,7 +1031,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(d_gid.reserve(Nmax));
         HIPCHK(d_perm.reserve((steps_max + 2) * Kpad)); HIPCHK(d_ssx.reserve((steps_max + 2) * Kpad)); HIPCHK(d_ssy.reserve((steps_max + 2) * Kpad));
         HIPCHK(d_bqx.reserve(Kpad)); HIPCHK(d_bqy.reserve(Kpad)); HIPCHK(d_bqk.reserve(Kpad)); HIPCHK(d_t2at.reserve(steps_max + 4));
-        HIPCHK(d_rep.reserve(kRepTotal));
+        HIPCHK(d_rep.reserve(kRepInts));
         HIPCHK(d_sched_i0.reserve(steps_max + 4)); HIPCHK(d_sched_nb.reserve(steps_max + 4));
         HIPCHK(d_kdrec.reserve(Nmax)); HIPCHK(d_gx.reserve(Nmax + 16)); HIPCHK(d_gy.reserve(Nmax + 16)); HIPCHK(d_kdup.reserve(Nmax)); HIPCHK(d_kddepth.reserve(Nmax)); HIPCHK(d_kdgexit.reserve(Nmax));
         HIPCHK(d_radT2.reserve(Nmax + 8));
@@ -1071,7 +1071,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.cand_K = K; c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_xy = d_candxy.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
     c.rad_T2 = d_radT2.p;
     c.e_from = d_efrom.p; c.e_to = d_eto.p; c.e_tv = d_etv.p; c.e_cap = (uint32_t)d_efrom.n;
-    c.rep = d_rep.p;
+    c.rep = d_rep.p; c.rep_f = reinterpret_cast<flt2 *>(d_rep.p + kRepTotal);
     {
         // box of the bound pyramid and of the region grid (points outside it fall into the border cells)
         double x0 = std::min(s_low[0], start[0]), x1 = std::max(s_up[0], start[0]);
@@ -1186,7 +1186,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
             }
             HIPCHK(hipMemsetAsync(z0, 0, (size_t)(z1 - z0), stream));
         }
-        HIPCHK(hipMemsetAsync(d_rep.p, 0xFF, kRepTotal * sizeof(int), stream));
+        HIPCHK(hipMemsetAsync(d_rep.p, 0xFF, kRepInts * sizeof(int), stream));
         HIPCHK(hipMemsetAsync(d_finalflag.p, 0, (size_t)((Nmax + 7) & ~7ull), stream));      // connect_rrt_sample only writes the set flags
         t_setup += now_s() - t0;
     }

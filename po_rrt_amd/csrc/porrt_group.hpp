@@ -493,17 +493,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PORRT_NN2_W
     uint32_t err = 0;
     int cls_own = CLS_FREE;
     if (rc.has_grid) cls_own = state_class(rc, sqx, sqy, &err);
+    // The cells carry their node's position rounded to f32 (rep_f): every node they name is older than this step (the pyramid is
+    // written by the connect kernels of the steps before), so a cell that is not empty is a node of the snapshot, and its true position
+    // lies within perr of the rounded one -- the test is made that much stricter.  (An empty cell is a NaN: no comparison holds.)
+    const double perr = 1.3e-7 * (fabs(sqx) + fabs(sqy) + 2.0 * lim);
+    const double limf = lim - perr, limf2 = limf > 0.0 ? (limf * limf < t2b ? limf * limf : t2b * (1.0 - 1e-6)) : -1.0;
+    (void)lim2;
     for (int l = 0; l < 2 && !easy; ++l) {           // the finest cells; then, for a thin tree, the 3x3 cells of the next level
         int cx, cy;
         const int G = rep_dim(l);
         rep_cell(rc, sqx, sqy, G, cx, cy);
-        int r = -1;
+        bool near = false;
         if (tm.gl < 9u) {
             const int x = cx + (int)(tm.gl % 3u) - 1, y = cy + (int)(tm.gl / 3u) - 1;
-            if (x >= 0 && y >= 0 && x < G && y < G) r = as_global(rc.rep)[rep_off(l) + y * G + x];
+            if (x >= 0 && y >= 0 && x < G && y < G) {
+                const flt2 pf = as_global(rc.rep_f)[rep_off(l) + y * G + x];
+                near = dist2((double)pf.x, (double)pf.y, sqx, sqy) <= limf2;
+            }
         }
-        bool near = false;
-        if (r >= 0 && (uint32_t)r < N) near = dist2(as_global(rc.nx)[r], as_global(rc.ny)[r], sqx, sqy) <= lim2;
         easy = tm.ballot(near) != 0ull;
     }
     PORRT_TACC_A(rc, 0);

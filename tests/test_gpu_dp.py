@@ -173,3 +173,33 @@ def test_large_graph_few_beliefs(eng_mod):
     assert e.num_nodes() > 21000
     assert np.array_equal(de.view(np.uint64), do.view(np.uint64))
     assert np.isfinite(de[0])
+
+
+def test_policy_walk_that_does_not_terminate_is_an_error(eng_mod):
+    """extract_policy (belief_graph.rs:184-217) has no memory: on the reference's own recorded problem (main.rs:893-908, paper_map_4.pgm) grown by
+    its own loop (K = 1) with seed 0, two graph nodes at one place are each the other's first best child and the walk never ends -- the C
+    restatement runs into its cap, the engine says so at once; seed 1 gives a policy, node for node the oracle's"""
+    import time
+    prior = [1.0 / 16] * 16
+    for seed, ends in ((0, False), (1, True)):
+        case = cases.cfg_map4(5000, seed)
+        e = cases.configure(eng_mod.Engine(), case)
+        cases.grow(e, case, K=1)
+        e.build_belief_graph(prior)
+        e.compute_expected_costs()
+        o = cases.configure(orc.Oracle(), case)
+        cases.grow(o, case, K=1, algo=orc.ALGO_SEQ)
+        o.build_belief_graph(prior)
+        d = o.expected_costs()
+        assert d[0] == e.expected_cost_of(0)
+        if ends:
+            (oid, par, leaf), _ = e.extract_policy()
+            ooid, opar, oleaf = o.extract_policy(d)
+            assert np.array_equal(oid, ooid) and np.array_equal(par, opar) and np.array_equal(leaf, oleaf)
+        else:
+            t0 = time.perf_counter()
+            with pytest.raises(eng_mod.PorrtError, match="returns to a belief node on its own path"):
+                e.extract_policy()
+            assert time.perf_counter() - t0 < 1.0
+            with pytest.raises(RuntimeError):
+                o.extract_policy(d, cap=1 << 14)
