@@ -217,7 +217,8 @@ struct porrt_ctx {
     bool kd_lazy = false, kd_build_now = false;    // in force for the running grow; the build after the steps is being launched
     int kd_full_build(const std::vector<std::pair<uint32_t, uint32_t>> &segs);
     uint32_t opt_claim_threads = 0;        // "kd_claim_threads": 0 = the engine's choice (256 beside a batch's step kernels), else 256 / 512 / 1024
-    int opt_host_ranks = 0;                // "host_ranks": 1 = the kd pre-order ranks of a graph's nodes (edge order) from a host kd-tree instead of the device's
+    int opt_host_ranks = 1;                // "host_ranks": 1 (default) = the kd pre-order ranks of a graph's nodes (edge order) from the host kd-tree; 0 = made on the
+                                           //   device (k_kd1_*): measured slower for one deep tree (a level per launch), and PRM::plan_path needs the host tree anyway
     int opt_compact = 1;                   // "compact_rows": a batch whose rows end at different steps launches its later steps on the rows that still have work
     uint32_t n_compactions = 0;            //   how often the last such batch led by this context gathered them ("compactions")
     int opt_kd_ride = 0;                   // "kd_ride": 1 = also for several contexts the hints and deferred ties ride in the next group's locate kernel
@@ -1586,14 +1587,15 @@ static HostKd *host_kd_of(porrt_ctx *c) {                            // built on
 } // namespace
 
 // The pre-order rank of every node in the kd-tree of the coordinates (sequential KdTree::add in id order,
-// nearest_neighbor.rs:29-46), the edge order and the adjacency lists: all on the device (porrt_edges.hpp).
+// nearest_neighbor.rs:29-46) -- from the host's kd-tree, or (option host_ranks = 0) made on the device --, then the edge order and
+// the adjacency lists on the device (porrt_edges.hpp).
 int porrt_ctx::ensure_edge_order() {
     if (eo.tag == results_tag) return PORRT_OK;
     HIPCHK(hipSetDevice(device));
     const size_t N = n_nodes;
     std::string e;
     int r;
-    if (opt_host_ranks) {                    // (developer option "host_ranks": the ranks from a kd-tree built on the host, as before round 4)
+    if (opt_host_ranks) {                    // (the default; option "host_ranks" = 0 makes them on the device, below)
         if ((r = download(DL_TREE))) return r;
         const HostKd *kd = host_kd_of(this);
         const std::vector<int> &ch0 = kd->left, &ch1 = kd->right;

@@ -120,3 +120,22 @@ def test_prm_plan_path_equals_oracle(eng_mod):
     assert pe.shape == po.shape and np.array_equal(pe, po)
     with pytest.raises(RuntimeError):
         cases.configure(eng_mod.Engine(), cases.cfg2(100)).prm_plan_path((0.0, 0.0), (0.5, 0.5))      # no roadmap
+
+
+def test_edge_order_with_ranks_made_on_the_device(eng_mod):
+    """option host_ranks = 0: the kd pre-order ranks that order a node's neighbours come from a kd-tree built on the device (k_kd1_*: a
+    level per launch) instead of the host's -- the same edge lists, on a roadmap (shallow tree) and on a belief-space graph (deep tree)"""
+    grid, zones, domain, vis, max_step, search_radius, n_iter, seed = PRM_CASES["benchmark_like_large_radius"]
+    e, o = pair(eng_mod, grid, zones, domain, vis, seed)
+    e.set_option("host_ranks", 0)
+    e.grow_prm((0.0, -0.8), max_step, search_radius, n_iter)
+    o.grow_prm((0.0, -0.8), max_step, search_radius, n_iter)
+    assert_same_roadmap(e, o)
+    case = cases.cfg3(3000, 3000)
+    res = []
+    for host in (1, 0):
+        g = cases.configure(eng_mod.Engine(), case)
+        g.set_option("host_ranks", host)
+        cases.grow(g, case, K=64)
+        res.append(g.edges())
+    assert all(np.array_equal(a, b) for a, b in zip(*res)) and len(res[0][0]) > 10000
