@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option for every context (porrt_set_option), e.g. group_lanes=32")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps run with per-kernel HIP events for `roofline`")
     ap.add_argument("--launch-check", action="store_true", help="start the ranks, rendezvous over gloo and stop (no GPU needed)")
+    ap.add_argument("--pin", action="store_true", help="fetch the trees by one kernel writing into the caller's arrays, pinned once (porrt_host_pin), instead of staging copies: "
+                                                        "16 ms instead of 25 for 256 trees on an idle GPU, but 208 instead of 230 M/s beside a growing batch")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure the HBM traffic of the step kernels")
     ap.add_argument("--pmc-child", action="store_true", help="(internal) one grow step of --queries queries and nothing else: what the counter passes profile")
     args = ap.parse_args()
@@ -235,6 +237,16 @@ def main():
     # 410 MB of fresh pages costs three times the copies)
     cap = args.n_iter + 2
     bufs = [(np.zeros((cap, 2)), np.zeros(cap, dtype=np.int64), np.zeros(cap)) for _ in range(Q)]
+    # --pin: ... and handed to the device once (porrt_host_pin): the fetch is then one kernel writing every tree into them in its final
+    # layout.  Faster by itself (the link's 51 GB/s against 33), but the batch growing beside it loses more than the fetch gains, so the
+    # staged path (copies into pinned staging, host threads laying the trees out) stays the bench's
+    trees_pinned = args.pin
+    if trees_pinned:
+        try:
+            po_rrt_amd.Engine.pin_buffers(bufs)
+        except Exception as ex:              # noqa: BLE001
+            sys.stderr.write("bench: the tree arrays could not be pinned (%s): staged fetch\n" % ex)
+            trees_pinned = False
     import threading
 
     class Fetch(threading.Thread):
@@ -429,6 +441,7 @@ def main():
                           "hipGraph replay of all steps (search, connect; the tie order from the goal path of the kd-tree, tracked inside the connect kernel)",
                 "kd_lazy": sets[0][0].get_option("kd_lazy"),
                 "fetch_checked": fetch_checked,
+                "trees_fetched_into_pinned_arrays": trees_pinned,
                 "kd_built_after_the_steps": [e.get_option("kd_built_after") for e in (sets[0][0], sets[0][Q_launch] if G > 1 else sets[0][0])],
             },
         }

@@ -127,6 +127,13 @@ int      porrt_get_tree(const porrt_ctx *ctx, double *xy /* N*2 */, int64_t *par
  * (xy[q]: N_q*2 doubles, parent[q]: N_q, dist_root[q]: N_q; an array of pointers, or single entries, may be NULL). */
 int      porrt_get_trees(porrt_ctx *const *ctxs, uint32_t n_ctx, double *const *xy, int64_t *const *parent,
                          double *const *dist_root);
+/* A caller that fetches trees again and again into the same arrays can hand those arrays to the device once: porrt_host_pin page-locks
+ * [p, p + bytes) and maps it for the GPU (hipHostRegister), and a porrt_get_trees whose every output array lies inside pinned ranges
+ * lets ONE kernel write all the trees straight into the caller's arrays in their final layout -- no staging copies, no host threads
+ * re-packing them.  The range must stay allocated until porrt_host_unpin (a freed and re-used address would be written through the
+ * old mapping).  Arrays that are not pinned take the staged path above; the results are the same. */
+int      porrt_host_pin(void *p, size_t bytes);
+int      porrt_host_unpin(void *p);
 uint64_t porrt_num_final(const porrt_ctx *ctx);
 int      porrt_get_final_ids(const porrt_ctx *ctx, uint64_t *ids);
 int      porrt_get_final_masks(const porrt_ctx *ctx, uint64_t *masks);

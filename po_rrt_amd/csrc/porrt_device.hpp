@@ -3247,6 +3247,25 @@ __global__ __launch_bounds__(256) void k_rows_gather(const RunConst *__restrict_
     for (uint32_t w = threadIdx.x; w < sizeof(RunConst) / 4u; w += 256u) dst[w] = src[w];
 }
 
+// porrt_get_trees into arrays the caller has pinned (porrt_host_pin): one descriptor per tree, grid.y = trees; the kernel reads the
+// node arrays and writes the caller's layout over the link -- xy interleaved, the parent widened to 64 bits, dist_root (32 B per node,
+// every store a full line of a wave).
+struct TreeOut {
+    const double *nx, *ny, *dist;
+    const int *parent;
+    double *oxy, *odist;       // host addresses as the device sees them (or null)
+    long long *oparent;
+    unsigned long long n;
+};
+__global__ __launch_bounds__(256) void k_trees_out(const TreeOut *__restrict__ trees) {
+    const TreeOut t = trees[blockIdx.y];
+    for (unsigned long long j = (unsigned long long)blockIdx.x * 256u + threadIdx.x; j < t.n; j += (unsigned long long)gridDim.x * 256u) {
+        if (t.oxy) { dbl2 v; v.x = as_global(t.nx)[j]; v.y = as_global(t.ny)[j]; reinterpret_cast<dbl2 *>(t.oxy)[j] = v; }
+        if (t.oparent) t.oparent[j] = (long long)as_global(t.parent)[j];
+        if (t.odist) t.odist[j] = as_global(t.dist)[j];
+    }
+}
+
 struct BatchOut { Counters cnt; uint32_t nodes, pad; };
 __global__ __launch_bounds__(64) void k_batch_gather(const RunConst *__restrict__ rcp, uint32_t steps, BatchOut *__restrict__ out) {
     if (threadIdx.x) return;

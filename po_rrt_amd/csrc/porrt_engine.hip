@@ -24,6 +24,7 @@
 #include <cstring>
 #include <string>
 #include <system_error>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <limits>
@@ -250,6 +251,10 @@ struct porrt_ctx {
     std::vector<void *> dl_pin;
     std::vector<hipStream_t> dl_streams;
     std::vector<size_t> dl_pin_cap;                 // bytes of each pinned slot (slots made by different calls differ)
+    hipStream_t dl_out_stream = nullptr;            // porrt_get_trees into pinned arrays: its stream (highest priority),
+    TreeOut *d_tree_out = nullptr;                  //   the trees' descriptors on the device
+    size_t d_tree_out_cap = 0;
+    uint32_t opt_tree_out_blocks = 4;               // "tree_out_blocks": workgroups per tree of that kernel
     bool sub_eager = false;                        // leader of a sub-batch on measured streams: launch step by step (see porrt_grow_batch)
     int last_launch_mode = 0;                      // how the last porrt_grow_batch led by this context ran: 0 one sequence (hipGraph / eager), G >= 2 sequences
                                                    // on measured streams, -G sequences on the contexts' own streams (the stream probe found no set: e.g. under a profiler)
@@ -2676,6 +2681,8 @@ void porrt_destroy(porrt_ctx *c) {
     for (hipStream_t st : c->sub_streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (hipStream_t st : c->dl_streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (void *q : c->dl_pin) if (q) (void)hipHostFree(q);
+    if (c->dl_out_stream) { (void)hipStreamSynchronize(c->dl_out_stream); (void)hipStreamDestroy(c->dl_out_stream); }
+    if (c->d_tree_out) (void)hipFree(c->d_tree_out);
     // a batch leader going away takes its RunConst array with it: its members must not look for it any more
     for (porrt_ctx *m : c->batch_members) if (m && m != c && m->batch_leader == c) m->batch_leader = nullptr;
     if (c->batch_leader && c->batch_leader != c)
@@ -2927,6 +2934,48 @@ int porrt_get_tree(const porrt_ctx *cc, double *xy, int64_t *parent, double *dis
     return PORRT_OK;
 }
 
+// ---- host ranges the caller has pinned for porrt_get_trees (porrt_host_pin): start -> (bytes, the device's address of the start)
+namespace {
+struct PinnedRange { size_t bytes; char *dev; };
+std::mutex g_pin_mutex;
+std::map<uintptr_t, PinnedRange> g_pins;
+// the device's address of host address p if [p, p + bytes) lies inside one pinned range, else null
+void *pinned_dev_ptr(const void *p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_pin_mutex);
+    auto it = g_pins.upper_bound((uintptr_t)p);
+    if (it == g_pins.begin()) return nullptr;
+    --it;
+    const uintptr_t off = (uintptr_t)p - it->first;
+    if (off > it->second.bytes || bytes > it->second.bytes - off) return nullptr;
+    return it->second.dev + off;
+}
+} // namespace
+
+int porrt_host_pin(void *p, size_t bytes) {
+    if (!p || !bytes) return PORRT_ERR_INVALID;
+    return abi_guard([&]() {
+        std::lock_guard<std::mutex> lk(g_pin_mutex);
+        if (g_pins.count((uintptr_t)p)) return (int)PORRT_ERR_INVALID;
+        if (hipHostRegister(p, bytes, hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return (int)PORRT_ERR_DEVICE; }
+        void *d = nullptr;
+        if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess || !d) { (void)hipGetLastError(); (void)hipHostUnregister(p); return (int)PORRT_ERR_DEVICE; }
+        g_pins[(uintptr_t)p] = PinnedRange{bytes, (char *)d};
+        return (int)PORRT_OK;
+    });
+}
+
+int porrt_host_unpin(void *p) {
+    if (!p) return PORRT_ERR_INVALID;
+    return abi_guard([&]() {
+        std::lock_guard<std::mutex> lk(g_pin_mutex);
+        auto it = g_pins.find((uintptr_t)p);
+        if (it == g_pins.end()) return (int)PORRT_ERR_INVALID;
+        g_pins.erase(it);
+        if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return (int)PORRT_ERR_DEVICE; }
+        return (int)PORRT_OK;
+    });
+}
+
 // porrt_get_tree for many contexts of one device at once (the trees of a porrt_grow_batch): a few worker threads, each with a
 // pinned staging slot and a copy stream of its own, fetch the trees straight from the device arrays (four asynchronous copies
 // per tree at the link's speed) and lay them out in the caller's arrays while the other workers' copies are in flight.  The
@@ -2941,6 +2990,42 @@ int porrt_get_trees(porrt_ctx *const *ctxs, uint32_t n_ctx, double *const *xy, i
         maxN = std::max<size_t>(maxN, ctxs[q]->n_nodes);
     }
     if (hipSetDevice(top->device) != hipSuccess) { top->set_err("hipSetDevice"); return PORRT_ERR_DEVICE; }
+    // every output array inside a range the caller pinned (porrt_host_pin): one kernel writes all the trees into the caller's arrays
+    {
+        std::vector<TreeOut> desc(n_ctx);
+        bool direct = true;
+        for (uint32_t q = 0; q < n_ctx && direct; ++q) {
+            const porrt_ctx *c = ctxs[q];
+            const size_t N = c->n_nodes;
+            TreeOut &t = desc[q];
+            t.nx = c->d_nx.p; t.ny = c->d_ny.p; t.dist = c->d_distA.p; t.parent = c->d_parent.p; t.n = N;
+            t.oxy = nullptr; t.odist = nullptr; t.oparent = nullptr;
+            if (xy && xy[q]) { t.oxy = (double *)pinned_dev_ptr(xy[q], N * 16); direct = direct && t.oxy; }
+            if (parent && parent[q]) { t.oparent = (long long *)pinned_dev_ptr(parent[q], N * 8); direct = direct && t.oparent; }
+            if (dist_root && dist_root[q]) { t.odist = (double *)pinned_dev_ptr(dist_root[q], N * 8); direct = direct && t.odist; }
+        }
+        if (direct) {
+            if (!top->dl_out_stream) {
+                // the highest priority the device offers: the kernel is a few hundred workgroups that mostly wait for the link, and a
+                // batch growing beside it would otherwise keep them waiting for wave slots (82 ms instead of 16 for 256 trees)
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+                if (hipStreamCreateWithPriority(&top->dl_out_stream, hipStreamNonBlocking, hi) != hipSuccess) { top->dl_out_stream = nullptr; top->set_err("hipStreamCreate"); return PORRT_ERR_DEVICE; }
+            }
+            if (top->d_tree_out_cap < n_ctx) {
+                if (top->d_tree_out) (void)hipFree(top->d_tree_out);
+                top->d_tree_out = nullptr; top->d_tree_out_cap = 0;
+                if (hipMalloc((void **)&top->d_tree_out, (size_t)n_ctx * sizeof(TreeOut)) != hipSuccess) { top->set_err("hipMalloc (tree descriptors)"); return PORRT_ERR_DEVICE; }
+                top->d_tree_out_cap = n_ctx;
+            }
+            hipStream_t st = top->dl_out_stream;
+            // a few workgroups per tree: the link, not the GPU, sets the pace, and the batch growing beside this keeps its wave slots
+            if (hipMemcpyAsync(top->d_tree_out, desc.data(), (size_t)n_ctx * sizeof(TreeOut), hipMemcpyHostToDevice, st) != hipSuccess) { top->set_err("porrt_get_trees: descriptor upload"); return PORRT_ERR_DEVICE; }
+            hipLaunchKernelGGL(k_trees_out, dim3(top->opt_tree_out_blocks, n_ctx), dim3(256), 0, st, (const TreeOut *)top->d_tree_out);
+            if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { top->set_err("porrt_get_trees: direct write failed"); return PORRT_ERR_DEVICE; }
+            return PORRT_OK;
+        }
+    }
     const uint32_t W = std::min<uint32_t>(8u, n_ctx);          // (4 / 8 / 12 / 16 workers fetch 256 trees in 25 / 23 / 23.5 / 23.5 ms: the copies set the time)
     const size_t slot = (maxN * 28u + 4095u) & ~(size_t)4095u;          // nx, ny, dist_root (f64) and parent (i32) of one tree
     // every worker's slot must hold the largest tree of THIS call; slots are kept across calls, each with its own size
@@ -3426,6 +3511,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "kd_claim_threads")) { if (value != 0 && value != 256 && value != 512 && value != 1024) return PORRT_ERR_INVALID; c->opt_claim_threads = (uint32_t)value; }
     else if (!strcmp(name, "kd_inline")) c->opt_kd_inline = value != 0;
     else if (!strcmp(name, "compact_rows")) c->opt_compact = value != 0;
+    else if (!strcmp(name, "tree_out_blocks")) c->opt_tree_out_blocks = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 1024));
     else if (!strcmp(name, "host_ranks")) { c->opt_host_ranks = value != 0; c->eo.tag = ~0ull; }
     else if (!strcmp(name, "early_wave_steps")) c->opt_early_wave = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 64));
     else if (!strcmp(name, "kd_group")) c->opt_kd_group = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 8));

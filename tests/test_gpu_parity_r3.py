@@ -169,6 +169,40 @@ def test_trees_with_growing_counts_and_sizes(eng_mod):
             assert np.array_equal(xy2, exy) and np.array_equal(parent2, eparent) and np.array_equal(dist2, edist)
 
 
+def test_trees_into_pinned_arrays(eng_mod):
+    """porrt_host_pin: a porrt_get_trees whose output arrays are all pinned writes them by one kernel (xy interleaved, parents widened)
+    -- the same arrays as the staged path and as porrt_get_tree, over several calls with other trees; partly pinned arrays take the
+    staged path; unpinning twice and pinning twice are errors, not crashes"""
+    n_ctx = 12
+    engs = [eng_mod.Engine() for _ in range(n_ctx)]
+    cap = 14000
+    bufs = [(np.zeros((cap, 2)), np.zeros(cap, dtype=np.int64), np.zeros(cap)) for _ in range(n_ctx)]
+    eng_mod.Engine.pin_buffers(bufs)
+    with pytest.raises(eng_mod.PorrtError):
+        eng_mod.Engine.pin_buffers(bufs[:1])
+    try:
+        for n_iter in (9000, 12400, 6000):
+            cs = [cases.cfg2(n_iter, seed=90 + s) for s in range(n_ctx)]
+            for e, c in zip(engs, cs):
+                cases.configure(e, c)
+            eng_mod.Engine.grow_batch(engs, [c.start for c in cs], cs[0].max_step, cs[0].search_radius, n_iter, 512)
+            for xy, parent, dist in bufs:
+                xy.fill(-3.0); parent.fill(-3); dist.fill(-3.0)
+            got = eng_mod.Engine.trees(engs, bufs)
+            staged = eng_mod.Engine.trees(engs)
+            for e, (xy, parent, dist), (sxy, sparent, sdist) in zip(engs, got, staged):
+                exy, eparent, edist = e.tree()
+                assert np.array_equal(xy.view(np.uint64), exy.view(np.uint64)) and np.array_equal(parent, eparent) and np.array_equal(dist.view(np.uint64), edist.view(np.uint64))
+                assert np.array_equal(sxy, exy) and np.array_equal(sparent, eparent) and np.array_equal(sdist, edist)
+            assert all(np.all(b[1][e.num_nodes():] == -3) for e, b in zip(engs, bufs)), "nothing is written past a tree's end"
+        mixed = bufs[:-1] + [(np.zeros((cap, 2)), bufs[-1][1], bufs[-1][2])]        # one array outside the pinned ranges: the staged path
+        got = eng_mod.Engine.trees(engs, mixed)
+        assert np.array_equal(got[-1][0], engs[-1].tree()[0]) and np.array_equal(got[0][1], engs[0].tree()[1])
+    finally:
+        eng_mod.Engine.unpin_buffers(bufs)
+    assert eng_mod.load_library().porrt_host_unpin(bufs[0][0].ctypes.data) == -1
+
+
 def test_sub_batches_on_an_odd_number_of_contexts(eng_mod):
     """batch_streams = 2 on 33 and on 9 contexts (uneven split) gives the trees of one launch sequence"""
     for n_ctx, n_iter in ((33, 3000), (9, 5000)):
@@ -425,8 +459,10 @@ def test_tamp_batch_at_bench_size_and_compacted_rows(eng_mod, Q, K):
         e.close()
 
 
-def test_trees_fetched_beside_a_growing_batch(eng_mod):
-    """the configuration bench.py's `value` is quoted on: porrt_get_trees of set A into the caller's arrays on a host thread WHILE
+@pytest.mark.parametrize("pinned", [True, False], ids=["pinned_arrays", "staged"])
+def test_trees_fetched_beside_a_growing_batch(eng_mod, pinned):
+    """the configuration bench.py's `value` is quoted on (pinned: the caller's arrays handed to the device once, one kernel writes the trees;
+    staged: copies through pinned staging and host threads): porrt_get_trees of set A into the caller's arrays on a host thread WHILE
     porrt_grow_batch grows set B (two sets of 32 contexts = two launch sequences each, roles swapped every round, so staging slots,
     copy streams and the measured streams are reused) -- every fetched tree equals the context's own porrt_get_tree afterwards, and
     two members per round equal the oracle"""
@@ -436,6 +472,8 @@ def test_trees_fetched_beside_a_growing_batch(eng_mod):
     sets = [[cases.configure(eng_mod.Engine(), case) for _ in range(Q)] for _ in range(2)]
     cap = n_iter + 2
     bufs = [(np.zeros((cap, 2)), np.zeros(cap, dtype=np.int64), np.zeros(cap)) for _ in range(Q)]
+    if pinned:
+        eng_mod.Engine.pin_buffers(bufs)
 
     def grow(which, seed0):
         for j, e in enumerate(sets[which]):
@@ -474,3 +512,5 @@ def test_trees_fetched_beside_a_growing_batch(eng_mod):
             xo, po, do = o.tree()
             xy, parent, dist = f.out[j]
             assert np.array_equal(parent, po) and np.array_equal(xy.view(np.uint64), xo.view(np.uint64)) and np.array_equal(dist.view(np.uint64), do.view(np.uint64))
+    if pinned:
+        eng_mod.Engine.unpin_buffers(bufs)

@@ -26,3 +26,17 @@ for rep in range(3):
     t5 = time.perf_counter()
     print("sizes %.2f ms, np.empty %.2f ms, pointers %.2f ms, get_trees %.2f ms, again into the same arrays %.2f ms" %
           tuple(1e3 * d for d in (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)), flush=True)
+# the same into arrays handed to the device once (porrt_host_pin): one kernel writes the caller's layout over the link
+cap = max(e.num_nodes() for e in engs)
+bufs = [(np.zeros((cap, 2)), np.zeros(cap, dtype=np.int64), np.zeros(cap)) for _ in range(Q)]
+t0 = time.perf_counter()
+po_rrt_amd.Engine.pin_buffers(bufs)
+print("pinning %d arrays (%.0f MB): %.1f ms" % (3 * Q, sum(a.nbytes for b in bufs for a in b) / 1e6, 1e3 * (time.perf_counter() - t0)), flush=True)
+for blocks in (4, 16, 64):
+    engs[0].set_option("tree_out_blocks", blocks)
+    for rep in range(3):
+        t0 = time.perf_counter()
+        po_rrt_amd.Engine.trees(engs, bufs)
+        dt = time.perf_counter() - t0
+    print("pinned arrays, %d workgroups per tree: %.2f ms (%.1f GB/s over the link)" % (blocks, 1e3 * dt, sum(32.0 * e.num_nodes() for e in engs) / dt / 1e9), flush=True)
+po_rrt_amd.Engine.unpin_buffers(bufs)
