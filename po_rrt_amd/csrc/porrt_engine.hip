@@ -255,6 +255,7 @@ struct porrt_ctx {
     TreeOut *d_tree_out = nullptr;                  //   the trees' descriptors on the device
     size_t d_tree_out_cap = 0;
     uint32_t opt_tree_out_blocks = 4;               // "tree_out_blocks": workgroups per tree of that kernel
+    uint32_t opt_fetch_workers = 8;                 // "fetch_workers": host threads (each with a copy stream and a staging slot) of the staged porrt_get_trees
     bool sub_eager = false;                        // leader of a sub-batch on measured streams: launch step by step (see porrt_grow_batch)
     int last_launch_mode = 0;                      // how the last porrt_grow_batch led by this context ran: 0 one sequence (hipGraph / eager), G >= 2 sequences
                                                    // on measured streams, -G sequences on the contexts' own streams (the stream probe found no set: e.g. under a profiler)
@@ -3026,7 +3027,7 @@ int porrt_get_trees(porrt_ctx *const *ctxs, uint32_t n_ctx, double *const *xy, i
             return PORRT_OK;
         }
     }
-    const uint32_t W = std::min<uint32_t>(8u, n_ctx);          // (4 / 8 / 12 / 16 workers fetch 256 trees in 25 / 23 / 23.5 / 23.5 ms: the copies set the time)
+    const uint32_t W = std::min<uint32_t>(top->opt_fetch_workers, n_ctx);          // (4 / 8 / 12 / 16 workers fetch 256 trees in 25 / 23 / 23.5 / 23.5 ms: the copies set the time)
     const size_t slot = (maxN * 28u + 4095u) & ~(size_t)4095u;          // nx, ny, dist_root (f64) and parent (i32) of one tree
     // every worker's slot must hold the largest tree of THIS call; slots are kept across calls, each with its own size
     if (top->dl_pin.size() < W) { top->dl_pin.resize(W, nullptr); top->dl_pin_cap.resize(W, 0); }
@@ -3511,6 +3512,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "kd_claim_threads")) { if (value != 0 && value != 256 && value != 512 && value != 1024) return PORRT_ERR_INVALID; c->opt_claim_threads = (uint32_t)value; }
     else if (!strcmp(name, "kd_inline")) c->opt_kd_inline = value != 0;
     else if (!strcmp(name, "compact_rows")) c->opt_compact = value != 0;
+    else if (!strcmp(name, "fetch_workers")) c->opt_fetch_workers = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 32));
     else if (!strcmp(name, "tree_out_blocks")) c->opt_tree_out_blocks = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 1024));
     else if (!strcmp(name, "host_ranks")) { c->opt_host_ranks = value != 0; c->eo.tag = ~0ull; }
     else if (!strcmp(name, "early_wave_steps")) c->opt_early_wave = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 64));
