@@ -502,8 +502,9 @@ def main():
                 "traffic_source": pm_src,
                 "traffic_note": "HBM bytes per launch = 2 x FETCH_SIZE (gfx950 counts a 128-B request as 64 B for wide streaming reads; for gathers "
                                 "the raw figure may be the truer one) + WRITE_SIZE, each from its own rocprofv3 --pmc pass (they do not fit one) over one grow "
-                                "step of the same queries, run as child processes of this bench after the timed region (kernels are serialised while "
-                                "counters are collected)",
+                                "step of the same queries, run as child processes of this bench after the timed region.  Kernels are SERIALISED while "
+                                "counters are collected, avg_launch_us is measured under the overlap of the launch sequences: traffic is bytes per launch, "
+                                "not to be divided by avg_launch_us for a bandwidth (the kernel alone takes ~440 us where the overlapped figure is ~690)",
                 "traffic_raw": {k: pm[k] for k in pm if k.startswith("k_conn2") or k.startswith("k_nn2")} if pm else None,
                 "avg_launch_us": dom_us,
                 "launches": L,
