@@ -3238,6 +3238,9 @@ __global__ __launch_bounds__(1024) void k_rows_compact(const RunConst *__restric
     }
     // padding: a row without work (there is one whenever fewer rows are kept than the batch holds); a full array needs none
     const uint32_t kept = s_base, dead = s_dead;
+    // (the host sizes `slots` from a count of running rows that is two steps old, and rows only end: more rows with work than slots
+    // cannot happen -- if it did, a row would silently miss its steps, so it is an error of the batch instead)
+    if (kept > slots && threadIdx.x == 0) atomicOr(&rcp[0].cnt->err, (uint32_t)ERR_PAGE_OVERFLOW);
     for (uint32_t i = kept + threadIdx.x; i < slots; i += 1024u) live_idx[i] = dead != 0xFFFFFFFFu ? dead : 0u;
 }
 __global__ __launch_bounds__(256) void k_rows_gather(const RunConst *__restrict__ rcp, const uint32_t *__restrict__ live_idx, RunConst *__restrict__ out) {
