@@ -358,6 +358,12 @@ const char *porrt_comm_last_error(const porrt_comm *comm);
  * PORRT_ERR_PEER (porrt_comm_last_error names the rank); ranks called with different n_maps all get PORRT_ERR_INVALID. */
 int      porrt_exchange_best(porrt_comm *comm, porrt_ctx *const *ctxs, uint32_t n_ctx, const uint32_t *map_ids,
                              uint32_t n_maps, porrt_best_entry *winners);
+/* The collective part alone, for a caller that keeps its own best tree per map: mine[m] = (cost, n_nodes) of this rank's best tree of map m
+ * (n_nodes 0 = none; the rank field is filled in), views[m] = where its arrays live (device pointers); the same protocol, results and
+ * getters as porrt_exchange_best, which is this after evaluating the contexts. */
+struct porrt_tree_device_view_s;
+int      porrt_exchange_tables(porrt_comm *comm, const porrt_best_entry *mine, const struct porrt_tree_device_view_s *views,
+                               uint32_t n_maps, porrt_best_entry *winners);
 /* No rank leaves the sequence alone: once the first agreement is through, a rank whose HIP or RCCL call fails, whose RCCL reports an
  * asynchronous error, or whose step is not finished after the time-out (default 120 s) ABORTS the communicator (ncclCommAbort) before
  * it returns, so that the peers' pending collectives fail instead of waiting; every wait polls the stream and RCCL's error state,
@@ -368,6 +374,19 @@ int      porrt_comm_set_timeout_ms(porrt_comm *comm, int ms);
  * path goes through -- stage 0 = a local failure before the first agreement (a status word; returns `code`, the communicator stays
  * usable), stage >= 1 = at or after it (the communicator is aborted); porrt_comm_test_aborts counts the aborts */
 porrt_comm *porrt_comm_test_new(int rank, int world);
+/* ... and a communicator over a transport the test brings: the exchange's whole sequence (agreements, all-gather, decision, the
+ * broadcasts from whichever rank wins, the getters) then runs between CPU processes on host memory -- tests/test_sharding_gloo.py drives
+ * it with two ranks over gloo.  Every function returns 0 or an error; "device" buffers are what alloc returns. */
+typedef struct {
+    void *self;
+    int   (*all_gather)(void *self, const void *send, void *recv, size_t bytes_per_rank);     /* recv: world x bytes, rank order */
+    int   (*broadcast)(void *self, const void *send, void *recv, size_t bytes, int root);     /* send is read on the root only */
+    void *(*alloc)(void *self, size_t bytes);
+    void  (*release)(void *self, void *p);
+    int   (*fetch)(void *self, void *host_dst, const void *src, size_t bytes);
+    int   (*abort)(void *self);                                                               /* may be NULL */
+} porrt_comm_ops;
+porrt_comm *porrt_comm_test_new_ops(int rank, int world, const porrt_comm_ops *ops);          /* ops must outlive the communicator */
 int      porrt_comm_test_fail(porrt_comm *comm, int stage, int code /* < 0 */);
 int      porrt_comm_test_aborts(const porrt_comm *comm);
 uint64_t porrt_exchange_num_nodes(const porrt_comm *comm, uint32_t map);
@@ -380,7 +399,7 @@ int      porrt_exchange_agree(const int32_t *words /* world x 2 */, uint32_t wor
 
 /* The grown tree where it lives: device pointers into the context's arena (valid until the context's
  * next grow or its destruction).  n_nodes = 0 when there are no results. */
-typedef struct {
+typedef struct porrt_tree_device_view_s {
     const double *nx, *ny, *dist_root;
     const int32_t *parent;       /* -1 = root */
     uint64_t n_nodes;

@@ -34,9 +34,8 @@ struct porrt_comm {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
-    porrt_best_entry *d_send = nullptr, *d_recv = nullptr;
-    int32_t *d_status = nullptr;       // [2] this rank's status word, then [2 * world] the gathered ones (made with the communicator: agreeing must not need an allocation)
-    size_t table_cap = 0;
+    uint8_t *d_stage = nullptr;        // device staging of the all-gathers: this rank's bytes, then world x bytes (made before a sequence starts:
+    size_t stage_cap = 0;              //   agreeing must not need an allocation)
     struct Tree {
         double *nx = nullptr, *ny = nullptr, *dist = nullptr;
         int *parent = nullptr;
@@ -44,6 +43,7 @@ struct porrt_comm {
         uint32_t n = 0;
     };
     std::vector<Tree> trees;           // per map: the winning tree, on this rank's device
+    const porrt_comm_ops *ops = nullptr;   // stand-in transport (porrt_comm_test_new_ops: the CPU tests' collectives over host memory) or null = RCCL
     bool broken = false;               // a collective step failed on this rank: the communicator was aborted and takes no further call
     bool test_mode = false;            // made by porrt_comm_test_new: no RCCL, no device (the failure protocol alone, for the CPU tests)
     int aborts = 0;                    // how often the communicator was aborted (0 or 1)
@@ -60,6 +60,7 @@ struct porrt_comm {
 static int comm_fail(porrt_comm *c, int code, const std::string &msg) {
     c->set_err(msg + " -- communicator aborted, make a new one");
     if (c->comm) { (void)ncclCommAbort(c->comm); c->comm = nullptr; }
+    if (c->ops && c->ops->abort) (void)c->ops->abort(c->ops->self);
     c->broken = true;
     ++c->aborts;
     return code;
@@ -104,11 +105,65 @@ static int comm_wait(porrt_comm *c, const char *what) {
     }
 }
 
-static void comm_free_tree(porrt_comm::Tree &t) {
-    if (t.nx) (void)hipFree(t.nx);
-    if (t.ny) (void)hipFree(t.ny);
-    if (t.dist) (void)hipFree(t.dist);
-    if (t.parent) (void)hipFree(t.parent);
+// ---- the transport under the exchange: RCCL on the communicator's stream, or the stand-in a test handed in (host memory all the way:
+// "device" buffers are whatever its alloc returns).  Every function returns PORRT_OK or has aborted the communicator (comm_fail).
+static int xg_alloc(porrt_comm *c, void **p, size_t bytes) {
+    *p = nullptr;
+    if (c->ops) { *p = c->ops->alloc(c->ops->self, bytes); return *p ? PORRT_OK : PORRT_ERR_DEVICE; }
+    return hipMalloc(p, bytes) == hipSuccess ? PORRT_OK : PORRT_ERR_DEVICE;
+}
+static void xg_free(porrt_comm *c, void *p) {
+    if (!p) return;
+    if (c->ops) c->ops->release(c->ops->self, p);
+    else (void)hipFree(p);
+}
+// every rank's `bytes` at h_send, gathered in rank order into h_recv (world x bytes); host memory on both sides
+static int xg_all_gather(porrt_comm *c, const void *h_send, void *h_recv, size_t bytes, const char *what) {
+    if (c->ops) {
+        const int r = c->ops->all_gather(c->ops->self, h_send, h_recv, bytes);
+        return r ? comm_fail(c, PORRT_ERR_DEVICE, std::string("exchange_best: ") + what + ": the transport's all-gather failed (" + std::to_string(r) + ")") : PORRT_OK;
+    }
+    const size_t need = bytes * ((size_t)c->world + 1);
+    if (c->stage_cap < need) {                    // (grown before the sequence starts: exchange_tables reserves the largest size it will use)
+        if (c->d_stage) (void)hipFree(c->d_stage);
+        c->d_stage = nullptr; c->stage_cap = 0;
+        if (hipMalloc((void **)&c->d_stage, need) != hipSuccess) return comm_fail(c, PORRT_ERR_DEVICE, std::string("exchange_best: ") + what + ": hipMalloc of the gather buffer");
+        c->stage_cap = need;
+    }
+    XABORT(c, hipMemcpyAsync(c->d_stage, h_send, bytes, hipMemcpyHostToDevice, c->stream));
+    NABORT(c, ncclAllGather(c->d_stage, c->d_stage + bytes, bytes, ncclUint8, c->comm, c->stream));
+    XABORT(c, hipMemcpyAsync(h_recv, c->d_stage + bytes, bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+    return comm_wait(c, what);
+}
+struct XgBcast { const void *src; void *dst; size_t bytes; int root; };
+// all broadcasts of one exchange, issued together (one RCCL group); every rank passes the same list (src only matters on the root)
+static int xg_broadcasts(porrt_comm *c, const std::vector<XgBcast> &items, const char *what) {
+    if (c->ops) {
+        for (const XgBcast &it : items) {
+            const int r = c->ops->broadcast(c->ops->self, it.src, it.dst, it.bytes, it.root);
+            if (r) return comm_fail(c, PORRT_ERR_DEVICE, std::string("exchange_best: ") + what + ": the transport's broadcast failed (" + std::to_string(r) + ")");
+        }
+        return PORRT_OK;
+    }
+    ncclResult_t nerr = ncclGroupStart();
+    if (nerr != ncclSuccess) return comm_fail(c, PORRT_ERR_DEVICE, std::string("ncclGroupStart: ") + ncclGetErrorString(nerr));
+    for (const XgBcast &it : items) {        // an RCCL error is remembered and the group closed all the same
+        ncclResult_t r;
+        if (nerr == ncclSuccess && (r = ncclBroadcast(it.src, it.dst, it.bytes, ncclUint8, it.root, c->comm, c->stream)) != ncclSuccess) nerr = r;
+    }
+    const ncclResult_t gend = ncclGroupEnd();
+    if (nerr == ncclSuccess) nerr = gend;
+    if (nerr != ncclSuccess) return comm_fail(c, PORRT_ERR_DEVICE, std::string("exchange_best: ncclBroadcast: ") + ncclGetErrorString(nerr));
+    return comm_wait(c, what);
+}
+// bytes of a winning tree's buffer to the host
+static int xg_fetch(porrt_comm *c, void *h_dst, const void *src, size_t bytes) {
+    if (c->ops) return c->ops->fetch(c->ops->self, h_dst, src, bytes) ? PORRT_ERR_DEVICE : PORRT_OK;
+    return hipMemcpy(h_dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? PORRT_OK : PORRT_ERR_DEVICE;
+}
+
+static void comm_free_tree(porrt_comm *c, porrt_comm::Tree &t) {
+    xg_free(c, t.nx); xg_free(c, t.ny); xg_free(c, t.dist); xg_free(c, t.parent);
     t = porrt_comm::Tree();
 }
 
@@ -131,9 +186,10 @@ porrt_comm *porrt_comm_create(int device, int rank, int world, const uint8_t id[
     c->device = device; c->rank = rank; c->world = world;
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&c->d_status, (2 + 2 * (size_t)world) * sizeof(int32_t)) != hipSuccess ||
+    c->stage_cap = 4096 * ((size_t)world + 1);          // room for the status words and for tables of 256 maps without another allocation
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&c->d_stage, c->stage_cap) != hipSuccess ||
         ncclCommInitRank(&c->comm, world, u, rank) != ncclSuccess) {
-        if (c->d_status) (void)hipFree(c->d_status);
+        if (c->d_stage) (void)hipFree(c->d_stage);
         if (c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return nullptr;
@@ -143,13 +199,11 @@ porrt_comm *porrt_comm_create(int device, int rank, int world, const uint8_t id[
 
 void porrt_comm_destroy(porrt_comm *c) {
     if (!c) return;
-    if (c->test_mode) { delete c; return; }
+    if (c->test_mode) { for (auto &t : c->trees) comm_free_tree(c, t); delete c; return; }
     (void)hipSetDevice(c->device);
     if (c->stream && !c->broken) (void)hipStreamSynchronize(c->stream);
-    for (auto &t : c->trees) comm_free_tree(t);
-    if (c->d_send) (void)hipFree(c->d_send);
-    if (c->d_recv) (void)hipFree(c->d_recv);
-    if (c->d_status) (void)hipFree(c->d_status);
+    for (auto &t : c->trees) comm_free_tree(c, t);
+    if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -197,15 +251,76 @@ static int comm_agree(porrt_comm *c, int local, uint32_t n_maps, const char *wha
     int32_t mine[2] = {(int32_t)local, (int32_t)n_maps};
     std::vector<int32_t> all(2 * (size_t)c->world);
     // (a failure in here is a failure inside a collective step: the peers are in the same all-gather)
-    XABORT(c, hipMemcpyAsync(c->d_status, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
-    NABORT(c, ncclAllGather(c->d_status, c->d_status + 2, 2, ncclInt32, c->comm, c->stream));
-    XABORT(c, hipMemcpyAsync(all.data(), c->d_status + 2, all.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    { const int w = comm_wait(c, what); if (w != PORRT_OK) return w; }
+    { const int w = xg_all_gather(c, mine, all.data(), sizeof mine, what); if (w != PORRT_OK) return w; }
     int32_t bad = -1;
     const int r = porrt_exchange_agree(all.data(), (uint32_t)c->world, (uint32_t)c->rank, &bad);
     if (r == PORRT_ERR_PEER) c->set_err(std::string("exchange_best: rank ") + std::to_string(bad) + " failed " + what + " (code " + std::to_string(all[2 * bad]) + "); no rank went on");
     else if (r != PORRT_OK && local == PORRT_OK) c->set_err("exchange_best: the ranks were called with different numbers of maps");
     return r;
+}
+
+// The collective part of the exchange on this rank's per-map entries (cost, n_nodes) and the arrays of its trees: steps 0-3 of the
+// header.  `local` = what went wrong on this rank before it got here (the others learn it in the first agreement).
+static int exchange_tables(porrt_comm *c, int local, const porrt_best_entry *mine, const porrt_tree_device_view *view, uint32_t n_maps, porrt_best_entry *winners) {
+    auto fail = [&](int code, const std::string &msg) { if (local == PORRT_OK) { local = code; c->set_err(msg); } };
+    const size_t need = (size_t)n_maps * (size_t)c->world;
+    // the gather buffer for the tables, before the sequence starts (a failure here is still a status word)
+    if (local == PORRT_OK && !c->ops && c->stage_cap < n_maps * sizeof(porrt_best_entry) * ((size_t)c->world + 1)) {
+        if (c->d_stage) (void)hipFree(c->d_stage);
+        c->d_stage = nullptr; c->stage_cap = 0;
+        const size_t want = n_maps * sizeof(porrt_best_entry) * ((size_t)c->world + 1);
+        if (hipMalloc((void **)&c->d_stage, want) != hipSuccess) fail(PORRT_ERR_DEVICE, "exchange_best: hipMalloc of the gathered tables");
+        else c->stage_cap = want;
+    }
+    if (!c->ops && !c->d_stage) {                 // (no buffer to agree through: nothing collective can be said any more)
+        return comm_fail(c, PORRT_ERR_DEVICE, "exchange_best: no gather buffer");
+    }
+    int st = comm_agree(c, local, n_maps, "before the all-gather");
+    if (st != PORRT_OK) return st;
+    // ---- 1. all-gather of the tables (from here on every rank is inside the sequence: a local failure aborts the communicator)
+    std::vector<porrt_best_entry> all(need);
+    st = xg_all_gather(c, mine, all.data(), n_maps * sizeof(porrt_best_entry), "the all-gather of the tables");
+    if (st != PORRT_OK) return st;
+    // ---- 2. winners (the same decision on every rank), and room for their trees -- allocated before the broadcasts are agreed on
+    std::vector<int32_t> win(n_maps);
+    porrt_exchange_decide(all.data(), (uint32_t)c->world, n_maps, win.data());
+    if (c->trees.size() < n_maps) c->trees.resize(n_maps);
+    for (uint32_t m = 0; m < n_maps; ++m) {
+        porrt_comm::Tree &t = c->trees[m];
+        t.n = 0;
+        if (win[m] < 0 || local != PORRT_OK) continue;
+        const size_t n = (size_t)all[(size_t)win[m] * n_maps + m].n_nodes;
+        if (t.cap < n) {
+            comm_free_tree(c, t);
+            if (xg_alloc(c, (void **)&t.nx, n * 8) || xg_alloc(c, (void **)&t.ny, n * 8) || xg_alloc(c, (void **)&t.dist, n * 8) || xg_alloc(c, (void **)&t.parent, n * 4)) {
+                comm_free_tree(c, t);
+                fail(PORRT_ERR_DEVICE, "exchange_best: allocation of a winning tree's buffers");
+                continue;
+            }
+            t.cap = n;
+        }
+        if (win[m] == c->rank && view[m].n_nodes != n) fail(PORRT_ERR_INVALID, "exchange_best: the winning context's tree changed during the exchange");
+    }
+    st = comm_agree(c, local, n_maps, "before the broadcasts");
+    if (st != PORRT_OK) return st;
+    // ---- 3. the winning trees, device to device.  Every rank issues the same calls.
+    std::vector<XgBcast> items;
+    for (uint32_t m = 0; m < n_maps; ++m) {
+        porrt_comm::Tree &t = c->trees[m];
+        if (win[m] < 0) { winners[m].cost = std::numeric_limits<double>::infinity(); winners[m].rank = -1; winners[m].n_nodes = 0; continue; }
+        winners[m] = all[(size_t)win[m] * n_maps + m];
+        const size_t n = (size_t)winners[m].n_nodes;
+        t.n = (uint32_t)n;
+        const void *sx = t.nx, *sy = t.ny, *sd = t.dist, *sp = t.parent;
+        if (win[m] == c->rank) { sx = view[m].nx; sy = view[m].ny; sd = view[m].dist_root; sp = view[m].parent; }
+        items.push_back({sx, t.nx, n * 8, win[m]});
+        items.push_back({sy, t.ny, n * 8, win[m]});
+        items.push_back({sd, t.dist, n * 8, win[m]});
+        items.push_back({sp, t.parent, n * 4, win[m]});
+    }
+    st = xg_broadcasts(c, items, "the broadcasts of the winning trees");
+    if (st != PORRT_OK) { for (auto &t : c->trees) t.n = 0; return st; }
+    return PORRT_OK;
 }
 
 extern "C" {
@@ -247,70 +362,26 @@ int porrt_exchange_best(porrt_comm *c, porrt_ctx *const *ctxs, uint32_t n_ctx, c
             else mine[m].n_nodes = (int32_t)view[m].n_nodes;
         }
     }
-    const size_t need = (size_t)n_maps * (size_t)c->world;
-    if (local == PORRT_OK && c->table_cap < need) {
-        if (c->d_send) (void)hipFree(c->d_send);
-        if (c->d_recv) (void)hipFree(c->d_recv);
-        c->d_send = c->d_recv = nullptr; c->table_cap = 0;
-        if (hipMalloc((void **)&c->d_send, n_maps * sizeof(porrt_best_entry)) != hipSuccess || hipMalloc((void **)&c->d_recv, need * sizeof(porrt_best_entry)) != hipSuccess)
-            fail(PORRT_ERR_DEVICE, "exchange_best: hipMalloc of the gathered tables");
-        else c->table_cap = need;
-    }
-    int st = comm_agree(c, local, n_maps, "before the all-gather");
-    if (st != PORRT_OK) return st;
-    // ---- 1. all-gather of the tables
-    // (from here on every rank is inside the sequence: a local failure aborts the communicator, XABORT / NABORT / comm_wait)
-    XABORT(c, hipMemcpyAsync(c->d_send, mine.data(), n_maps * sizeof(porrt_best_entry), hipMemcpyHostToDevice, c->stream));
-    NABORT(c, ncclAllGather(c->d_send, c->d_recv, n_maps * sizeof(porrt_best_entry), ncclUint8, c->comm, c->stream));
-    std::vector<porrt_best_entry> all(need);
-    XABORT(c, hipMemcpyAsync(all.data(), c->d_recv, need * sizeof(porrt_best_entry), hipMemcpyDeviceToHost, c->stream));
-    { const int w = comm_wait(c, "the all-gather of the tables"); if (w != PORRT_OK) return w; }
-    // ---- 2. winners (the same decision on every rank), and room for their trees -- allocated before the broadcasts are agreed on
-    std::vector<int32_t> win(n_maps);
-    porrt_exchange_decide(all.data(), (uint32_t)c->world, n_maps, win.data());
-    if (c->trees.size() < n_maps) c->trees.resize(n_maps);
+    return exchange_tables(c, local, mine.data(), view.data(), n_maps, winners);
+}
+
+int porrt_exchange_tables(porrt_comm *c, const porrt_best_entry *mine, const porrt_tree_device_view *views, uint32_t n_maps, porrt_best_entry *winners) {
+    if (!c) return PORRT_ERR_INVALID;
+    if (c->broken || (!c->comm && !c->ops)) { c->set_err("exchange_tables: this communicator was aborted after a failed collective step: make a new one"); return PORRT_ERR_DEVICE; }
+    int local = PORRT_OK;
+    if (!c->ops && hipSetDevice(c->device) != hipSuccess) { local = PORRT_ERR_DEVICE; c->set_err("exchange_tables: hipSetDevice"); }
+    if (!mine || !views || !n_maps || !winners) { if (local == PORRT_OK) { local = PORRT_ERR_INVALID; c->set_err("exchange_tables: arguments"); } }
+    std::vector<porrt_best_entry> m2(n_maps ? n_maps : 1);
+    std::vector<porrt_tree_device_view> v2(n_maps ? n_maps : 1);
     for (uint32_t m = 0; m < n_maps; ++m) {
-        porrt_comm::Tree &t = c->trees[m];
-        t.n = 0;
-        if (win[m] < 0 || local != PORRT_OK) continue;
-        const size_t n = (size_t)all[(size_t)win[m] * n_maps + m].n_nodes;
-        if (t.cap < n) {
-            comm_free_tree(t);
-            if (hipMalloc((void **)&t.nx, n * 8) != hipSuccess || hipMalloc((void **)&t.ny, n * 8) != hipSuccess ||
-                hipMalloc((void **)&t.dist, n * 8) != hipSuccess || hipMalloc((void **)&t.parent, n * 4) != hipSuccess) {
-                comm_free_tree(t);
-                fail(PORRT_ERR_DEVICE, "exchange_best: hipMalloc of a winning tree's buffers");
-                continue;
-            }
-            t.cap = n;
+        m2[m].cost = std::numeric_limits<double>::infinity(); m2[m].rank = c->rank; m2[m].n_nodes = 0; v2[m] = porrt_tree_device_view{};
+        if (local != PORRT_OK) continue;
+        m2[m] = mine[m]; m2[m].rank = c->rank; v2[m] = views[m];
+        if (m2[m].n_nodes > 0 && (!v2[m].nx || !v2[m].ny || !v2[m].dist_root || !v2[m].parent || v2[m].n_nodes != (uint64_t)m2[m].n_nodes)) {
+            local = PORRT_ERR_INVALID; c->set_err("exchange_tables: an entry with nodes needs its tree's arrays (n_nodes of the view = n_nodes of the entry)");
         }
-        if (win[m] == c->rank && view[m].n_nodes != n) fail(PORRT_ERR_INVALID, "exchange_best: the winning context's tree changed during the exchange");
     }
-    st = comm_agree(c, local, n_maps, "before the broadcasts");
-    if (st != PORRT_OK) return st;
-    // ---- 3. the winning trees, device to device.  Every rank issues the same calls; an RCCL error is remembered and the group closed all the same.
-    ncclResult_t nerr = ncclGroupStart();
-    if (nerr != ncclSuccess) return comm_fail(c, PORRT_ERR_DEVICE, std::string("ncclGroupStart: ") + ncclGetErrorString(nerr));
-    for (uint32_t m = 0; m < n_maps; ++m) {
-        porrt_comm::Tree &t = c->trees[m];
-        if (win[m] < 0) { winners[m].cost = std::numeric_limits<double>::infinity(); winners[m].rank = -1; winners[m].n_nodes = 0; continue; }
-        winners[m] = all[(size_t)win[m] * n_maps + m];
-        const size_t n = (size_t)winners[m].n_nodes;
-        t.n = (uint32_t)n;
-        const void *sx = t.nx, *sy = t.ny, *sd = t.dist, *sp = t.parent;
-        if (win[m] == c->rank) { sx = view[m].nx; sy = view[m].ny; sd = view[m].dist_root; sp = view[m].parent; }
-        ncclResult_t r;
-        if (nerr == ncclSuccess && (r = ncclBroadcast(sx, t.nx, n, ncclFloat64, win[m], c->comm, c->stream)) != ncclSuccess) nerr = r;
-        if (nerr == ncclSuccess && (r = ncclBroadcast(sy, t.ny, n, ncclFloat64, win[m], c->comm, c->stream)) != ncclSuccess) nerr = r;
-        if (nerr == ncclSuccess && (r = ncclBroadcast(sd, t.dist, n, ncclFloat64, win[m], c->comm, c->stream)) != ncclSuccess) nerr = r;
-        if (nerr == ncclSuccess && (r = ncclBroadcast(sp, t.parent, n, ncclInt32, win[m], c->comm, c->stream)) != ncclSuccess) nerr = r;
-    }
-    const ncclResult_t gend = ncclGroupEnd();
-    if (nerr == ncclSuccess) nerr = gend;
-    if (nerr != ncclSuccess) { for (auto &t : c->trees) t.n = 0; return comm_fail(c, PORRT_ERR_DEVICE, std::string("exchange_best: ncclBroadcast: ") + ncclGetErrorString(nerr)); }
-    const int w = comm_wait(c, "the broadcasts of the winning trees");
-    if (w != PORRT_OK) { for (auto &t : c->trees) t.n = 0; return w; }
-    return PORRT_OK;
+    return exchange_tables(c, local, m2.data(), v2.data(), n_maps, winners);
 }
 
 // 1 while the communicator takes calls; 0 once a collective step failed on this rank (it was aborted then: make a new one)
@@ -332,6 +403,14 @@ porrt_comm *porrt_comm_test_new(int rank, int world) {
     c->rank = rank; c->world = world; c->test_mode = true;
     return c;
 }
+// a communicator over a transport the caller brings (the CPU tests: collectives over host memory between processes); porrt_exchange_tables
+// and the porrt_exchange_* getters work on it, porrt_exchange_best (which evaluates contexts on a device) does not
+porrt_comm *porrt_comm_test_new_ops(int rank, int world, const porrt_comm_ops *ops) {
+    if (world < 1 || rank < 0 || rank >= world || !ops || !ops->all_gather || !ops->broadcast || !ops->alloc || !ops->release || !ops->fetch) return nullptr;
+    porrt_comm *c = new porrt_comm();
+    c->rank = rank; c->world = world; c->test_mode = true; c->ops = ops;
+    return c;
+}
 int porrt_comm_test_fail(porrt_comm *c, int stage, int code) {
     if (!c || !c->test_mode || code >= 0) return PORRT_ERR_INVALID;
     if (c->broken) { c->set_err("exchange_best: this communicator was aborted after a failed collective step: make a new one"); return PORRT_ERR_DEVICE; }
@@ -348,15 +427,13 @@ int porrt_exchange_get_tree(const porrt_comm *cc, uint32_t map, double *xy, int6
     const porrt_comm::Tree &t = c->trees[map];
     const size_t n = t.n;
     if (!n) return PORRT_OK;
-    XCHK(c, hipSetDevice(c->device));
+    if (!c->ops) XCHK(c, hipSetDevice(c->device));
     std::vector<double> hx(n), hy(n);
     std::vector<int> hp(n);
-    XCHK(c, hipMemcpy(hx.data(), t.nx, n * 8, hipMemcpyDeviceToHost));
-    XCHK(c, hipMemcpy(hy.data(), t.ny, n * 8, hipMemcpyDeviceToHost));
-    XCHK(c, hipMemcpy(hp.data(), t.parent, n * 4, hipMemcpyDeviceToHost));
+    if (xg_fetch(c, hx.data(), t.nx, n * 8) || xg_fetch(c, hy.data(), t.ny, n * 8) || xg_fetch(c, hp.data(), t.parent, n * 4) ||
+        (dist_root && xg_fetch(c, dist_root, t.dist, n * 8))) { c->set_err("exchange_get_tree: copy from the device failed"); return PORRT_ERR_DEVICE; }
     if (xy) for (size_t i = 0; i < n; ++i) { xy[2 * i] = hx[i]; xy[2 * i + 1] = hy[i]; }
     if (parent) for (size_t i = 0; i < n; ++i) parent[i] = hp[i];
-    if (dist_root) XCHK(c, hipMemcpy(dist_root, t.dist, n * 8, hipMemcpyDeviceToHost));
     return PORRT_OK;
 }
 

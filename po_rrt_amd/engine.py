@@ -34,7 +34,7 @@ SYMBOLS = [
     "porrt_bg_compute_expected_costs", "porrt_bg_get_expected_costs", "porrt_bg_expected_cost_of", "porrt_bg_get_dp_info", "porrt_bg_get_dp_sweep_rows", "porrt_bg_extract_policy", "porrt_conditional_dijkstra",
     "porrt_comm_unique_id", "porrt_comm_create", "porrt_comm_destroy", "porrt_comm_last_error", "porrt_exchange_best", "porrt_exchange_num_nodes",
     "porrt_exchange_get_tree", "porrt_exchange_decide", "porrt_exchange_agree", "porrt_tree_device",
-    "porrt_host_pin", "porrt_host_unpin", "porrt_comm_usable", "porrt_comm_set_timeout_ms", "porrt_comm_test_new", "porrt_comm_test_fail", "porrt_comm_test_aborts",
+    "porrt_host_pin", "porrt_host_unpin", "porrt_exchange_tables", "porrt_comm_test_new_ops", "porrt_comm_usable", "porrt_comm_set_timeout_ms", "porrt_comm_test_new", "porrt_comm_test_fail", "porrt_comm_test_aborts",
     "porrt_grow_mm_prm", "porrt_mm_num_modes", "porrt_mm_num_transitions", "porrt_mm_num_beliefs", "porrt_mm_get_mode", "porrt_mm_get_mode_graph",
     "porrt_mm_get_transition", "porrt_mm_get_transition_pairs", "porrt_mm_get_seconds",
     "porrt_read_pgm", "porrt_read_pgm_mem", "porrt_graph_write_json", "porrt_graph_save_json", "porrt_graph_load_json", "porrt_graph_file_free",
@@ -151,6 +151,8 @@ def load_library():
     sig("porrt_tree_device", TreeDeviceView, vp)
     sig("porrt_host_pin", C.c_int, vp, C.c_size_t)
     sig("porrt_host_unpin", C.c_int, vp)
+    sig("porrt_exchange_tables", C.c_int, vp, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p)
+    sig("porrt_comm_test_new_ops", vp, C.c_int, C.c_int, C.c_void_p)
     sig("porrt_comm_usable", C.c_int, vp)
     sig("porrt_comm_set_timeout_ms", C.c_int, vp, C.c_int)
     sig("porrt_comm_test_new", vp, C.c_int, C.c_int)

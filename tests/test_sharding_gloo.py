@@ -142,6 +142,134 @@ def test_a_rank_that_fails_inside_the_sequence_aborts_its_communicator():
     assert not L.porrt_comm_test_new(4, 4) and L.porrt_comm_usable(None) == 0
 
 
+XCHG_WORKER = textwrap.dedent("""
+    import ctypes as C, datetime, os, sys
+    sys.path[:0] = [%(root)r]
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from po_rrt_amd import load_library
+    from po_rrt_amd.engine import BEST_ENTRY, TreeDeviceView
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=8))
+    L = load_library()
+
+    # ---- the transport: collectives over gloo on host memory; "device" buffers are numpy arrays kept alive here
+    AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+    BC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+    AL = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+    RL = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+    FE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+    AB = C.CFUNCTYPE(C.c_int, C.c_void_p)
+    class Ops(C.Structure):
+        _fields_ = [("self", C.c_void_p), ("all_gather", AG), ("broadcast", BC), ("alloc", AL), ("release", RL), ("fetch", FE), ("abort", AB)]
+    live, calls = {}, {"all_gather": 0, "broadcast": 0, "abort": 0, "fail_all_gather_at": -1}
+    def bytes_at(p, n):
+        return torch.from_numpy(np.frombuffer(C.string_at(p, n), dtype=np.uint8).copy())
+    def all_gather(_, send, recv, n):
+        calls["all_gather"] += 1
+        try:
+            outs = [torch.empty(n, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(outs, bytes_at(send, n))
+            for r in range(world):
+                C.memmove(recv + r * n, outs[r].numpy().ctypes.data, n)
+        except Exception as ex:                       # a peer that left: the collective times out
+            sys.stderr.write("rank " + str(rank) + ": all_gather failed: " + str(ex)[:80] + "\\n")
+            return 7
+        return 9 if calls["all_gather"] == calls["fail_all_gather_at"] else 0
+    def broadcast(_, send, recv, n, root):
+        calls["broadcast"] += 1
+        try:
+            buf = bytes_at(send, n) if rank == root else torch.empty(n, dtype=torch.uint8)
+            dist.broadcast(buf, root)
+            C.memmove(recv, buf.numpy().ctypes.data, n)
+        except Exception as ex:
+            return 7
+        return 0
+    def alloc(_, n):
+        a = np.zeros(max(n, 1), dtype=np.uint8)
+        live[a.ctypes.data] = a
+        return a.ctypes.data
+    def release(_, p):
+        live.pop(p, None)
+    def fetch(_, dst, src, n):
+        C.memmove(dst, src, n)
+        return 0
+    def abort(_):
+        calls["abort"] += 1
+        return 0
+    ops = Ops(None, AG(all_gather), BC(broadcast), AL(alloc), RL(release), FE(fetch), AB(abort))
+    comm = L.porrt_comm_test_new_ops(rank, world, C.byref(ops))
+    assert comm and L.porrt_comm_usable(comm) == 1
+
+    def tree(r, m, n):
+        g = np.random.default_rng(1000 * r + m)
+        return g.random(n), g.random(n), g.random(n), g.integers(-1, n, size=n).astype(np.int32)
+    def exchange(table, n_maps, bad_view=False):
+        ent = np.zeros(n_maps, dtype=BEST_ENTRY)
+        views = (TreeDeviceView * n_maps)()
+        keep = []
+        for m in range(n_maps):
+            cost, n = table.get(m, (np.inf, 0))
+            ent[m] = (cost, -5, n)
+            if n:
+                nx, ny, d, p = tree(rank, m, n)
+                keep.append((nx, ny, d, p))
+                views[m] = TreeDeviceView(nx.ctypes.data, ny.ctypes.data, d.ctypes.data, p.ctypes.data, n + (1 if bad_view else 0))
+        win = np.zeros(n_maps, dtype=BEST_ENTRY)
+        rc = L.porrt_exchange_tables(comm, ent.ctypes.data, C.addressof(views), n_maps, win.ctypes.data)
+        return rc, win
+
+    # ---- a clean exchange: map 0 is won by rank 1 (rank 0 receives a tree it does not own), map 1 ties on cost (the lower rank keeps it),
+    # map 2 has no solution anywhere
+    mine = {0: {0: (5.0, 100), 1: (2.0, 50)}, 1: {0: (3.0, 70), 1: (2.0, 60)}}[rank]
+    rc, win = exchange(mine, 3)
+    assert rc == 0, (rc, L.porrt_comm_last_error(comm))
+    assert [int(w["rank"]) for w in win] == [1, 0, -1] and [int(w["n_nodes"]) for w in win] == [70, 50, 0] and win["cost"][0] == 3.0
+    for m, (r, n) in enumerate([(1, 70), (0, 50)]):
+        assert L.porrt_exchange_num_nodes(comm, m) == n
+        xy, parent, d = np.zeros((n, 2)), np.zeros(n, dtype=np.int64), np.zeros(n)
+        assert L.porrt_exchange_get_tree(comm, m, xy, parent, d) == 0
+        nx, ny, dd, pp = tree(r, m, n)
+        assert np.array_equal(xy[:, 0], nx) and np.array_equal(xy[:, 1], ny) and np.array_equal(d, dd) and np.array_equal(parent, pp)
+    assert L.porrt_exchange_num_nodes(comm, 2) == 0
+    # ---- the ranks called with different numbers of maps: everybody out the same way, the communicator stays usable
+    rc, _ = exchange(mine, 3 if rank == 0 else 2)
+    assert rc == -1 and L.porrt_comm_usable(comm) == 1, rc
+    # ---- rank 1 fails locally before the first agreement (a view that does not match its entry): its own code there, PEER on rank 0
+    rc, _ = exchange(mine, 3, bad_view=(rank == 1))
+    assert rc == (-1 if rank == 1 else -8) and L.porrt_comm_usable(comm) == 1, rc
+    # ---- a second clean exchange with other winners: buffers are reused, larger trees re-allocated
+    mine2 = {0: {0: (1.0, 300)}, 1: {1: (4.0, 20), 2: (9.0, 10)}}[rank]
+    rc, win = exchange(mine2, 3)
+    assert rc == 0 and [int(w["rank"]) for w in win] == [0, 1, 1] and L.porrt_exchange_num_nodes(comm, 0) == 300
+    xy, parent, d = np.zeros((10, 2)), np.zeros(10, dtype=np.int64), np.zeros(10)
+    assert L.porrt_exchange_get_tree(comm, 2, xy, parent, d) == 0 and np.array_equal(d, tree(1, 2, 10)[2])
+    # ---- the transport fails on rank 1 INSIDE the sequence (the all-gather of the tables): rank 1 aborts its communicator and leaves;
+    # rank 0's next collective then fails (here: gloo times out, as a torn-down RCCL connection would make it fail) and it aborts its own
+    calls["fail_all_gather_at"] = calls["all_gather"] + 2 if rank == 1 else -1
+    rc, _ = exchange(mine, 3)
+    assert rc == -4 and L.porrt_comm_usable(comm) == 0 and calls["abort"] == 1, (rank, rc, calls)
+    assert L.porrt_exchange_tables(comm, None, None, 3, None) == -4           # refused from now on
+    print("rank", rank, "exchange ok", flush=True)
+    os._exit(0)
+""")
+
+
+def test_two_ranks_run_the_whole_exchange_over_a_stand_in_transport(tmp_path):
+    """porrt_exchange_tables -- the collective part of porrt_exchange_best: the agreements, the all-gather of the tables, the decision, the
+    broadcasts from whichever rank wins (incl. to a rank that does not own the winner), the getters -- between TWO processes, on a transport
+    the test brings (gloo over host memory; porrt_comm_test_new_ops).  RCCL itself is not exercised; everything above it is: clean
+    exchanges, differing map counts, a rank failing before the first agreement, and a rank whose transport fails inside the sequence
+    (it aborts its communicator; the other rank's next collective fails and it aborts its own)."""
+    script = tmp_path / "xchg_worker.py"
+    script.write_text(XCHG_WORKER % {"root": ROOT})
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29537", str(script)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.stdout.count("exchange ok") == 2, out.stdout[-2000:] + out.stderr[-4000:]
+
+
 AGREE_WORKER = textwrap.dedent("""
     import os, sys
     sys.path[:0] = [%(root)r]
