@@ -147,22 +147,34 @@ __global__ __launch_bounds__(256) void k_dp_row(DpConst g, unsigned long long bn
 //     a contiguous range), a wave works on one graph node for 64 beliefs -- the neighbour list and the edge weights are
 //     the same for all lanes, the neighbours' costs are 64 consecutive doubles.
 // Same fixpoint, same bits as the general sweeps; far fewer relaxations and coalesced ones.
+// One adjacency entry as a sweep wants it: 16 bytes, one (scalar) load -- the neighbour, what decides whether a belief may use the edge
+// (the neighbour's validity and the edge's, belief_graph.rs:114-121) and the edge's cost.
+struct __attribute__((aligned(16))) DpEdge {
+    uint32_t c;
+    uint32_t vv;                       // vid[c] | adj_val[k] << 8
+    double w;
+};
+
 struct DpLevelConst {
     BgConst g;                         // tables, adjacency, bit planes of the belief graph
-    const double *adj_w;               // per adjacency entry: norm2(node, neighbour)
+    const struct DpEdge *adj_e;        // per adjacency entry: neighbour, the two validities it depends on, norm2(node, neighbour)
     const uint32_t *rank;              // [B] belief -> position in the level order
     const uint32_t *belief_at;         // [B] position -> belief
     double *dist_p;                    // [N][B] by position
     uint32_t *flags;                   // [1 + s]: sweep s of a group improved something
 };
 
-__global__ __launch_bounds__(256) void k_dp_edge_weights(BgConst g, double *__restrict__ w) {
+__global__ __launch_bounds__(256) void k_dp_edge_weights(BgConst g, DpEdge *__restrict__ e) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= g.N) return;
     const double x = as_global(g.nx)[n], y = as_global(g.ny)[n];
     for (unsigned long long k = as_global(g.adj_off)[n]; k < as_global(g.adj_off)[n + 1]; ++k) {
         const uint32_t c = as_global(g.adj_id)[k];
-        w[k] = sqrt(dist2(x, y, as_global(g.nx)[c], as_global(g.ny)[c]));           // norm2(u.state, v.state), u = n
+        DpEdge o;
+        o.c = c;
+        o.vv = (uint32_t)as_global(g.vid)[c] | (uint32_t)as_global(g.adj_val)[k] << 8;
+        o.w = sqrt(dist2(x, y, as_global(g.nx)[c], as_global(g.ny)[c]));            // norm2(u.state, v.state), u = n
+        e[k] = o;
     }
 }
 
@@ -172,6 +184,10 @@ __global__ __launch_bounds__(256) void k_dp_level_finals(DpLevelConst L, const u
     const unsigned long long i = as_global(finals)[k];
     as_global(L.dist_p)[(size_t)(i / L.g.B) * L.g.B + as_global(L.rank)[i % L.g.B]] = 0.0;
 }
+
+// A sweep's workgroup looks first at ONE byte: whether any row of its item was marked for this sweep (the byte holds the stamp of the sweep
+// it was last marked for; two arrays alternate like the rows' marks, so nothing needs clearing) -- most workgroups of most sweeps end there.
+__host__ __device__ inline uint8_t dp_stamp(uint32_t sweep) { return (uint8_t)(sweep % 255u + 1u); }
 
 // thread -> (graph node n, position p in [p0, p0 + W)), position fastest
 __device__ __forceinline__ bool dp_level_thread(const DpLevelConst &L, uint32_t p0, uint32_t W, uint32_t &n, uint32_t &p) {
@@ -184,7 +200,9 @@ __device__ __forceinline__ bool dp_level_thread(const DpLevelConst &L, uint32_t 
 
 // Start of a level: observation nodes get their value (a sum over finished, deeper levels).  Every node with a finite
 // value (those and the finals) is a source: its neighbours are marked for the first sweep.
-__global__ __launch_bounds__(256) void k_dp_level_init(DpLevelConst L, uint32_t p0, uint32_t W, uint8_t *__restrict__ dirty) {
+// (and the byte of each marked row's item -- parts = 1: an item is 256 beliefs of one node; 4: 64 rows -- gets the first sweep's stamp)
+__global__ __launch_bounds__(256) void k_dp_level_init(DpLevelConst L, uint32_t p0, uint32_t W, uint8_t *__restrict__ dirty, uint8_t *__restrict__ item,
+                                                       uint32_t parts, uint32_t sweep) {
     uint32_t n, p;
     if (!dp_level_thread(L, p0, W, n, p)) return;
     const BgConst &g = L.g;
@@ -206,8 +224,12 @@ __global__ __launch_bounds__(256) void k_dp_level_init(DpLevelConst L, uint32_t 
         v = alt;
     }
     if (v < __builtin_huge_val())
-        for (unsigned long long k = as_global(g.adj_off)[n]; k < as_global(g.adj_off)[n + 1]; ++k)
-            as_global(dirty)[(size_t)as_global(g.adj_id)[k] * g.B + p] = 1;
+        for (unsigned long long k = as_global(g.adj_off)[n]; k < as_global(g.adj_off)[n + 1]; ++k) {
+            const uint32_t c = as_global(g.adj_id)[k];
+            as_global(dirty)[(size_t)c * g.B + p] = 1;
+            if (parts == 1u) as_global(item)[c * ((W + 255u) / 256u) + (p - p0) / 256u] = dp_stamp(sweep);
+            else as_global(item)[((size_t)c * W + (p - p0)) >> 6] = dp_stamp(sweep);
+        }
 }
 
 // One sweep over a level: action nodes whose neighbours improved take the best of (edge + neighbour).  Four lanes share a
@@ -215,9 +237,11 @@ __global__ __launch_bounds__(256) void k_dp_level_init(DpLevelConst L, uint32_t 
 // reads 128 contiguous bytes per neighbour) and split its neighbour list, which quarters the chain of dependent loads
 // that sets the duration of a sweep over a small level (13.8 ms instead of 23 for the 255-belief problem); a large
 // level is bandwidth bound and keeps one lane per row (PARTS = 1: 512 contiguous bytes per neighbour).
+// (`item` = what one workgroup of a sweep takes: 256 beliefs of one node, or 64 rows in four parts; a byte per item says whether any of
+// its rows is marked for the next sweep.)
 template <uint32_t kDpParts>
-__global__ __launch_bounds__(256) void k_dp_level_sweep(DpLevelConst L, uint32_t p0, uint32_t W, uint8_t *__restrict__ dirty_in,
-                                                        uint8_t *__restrict__ dirty_out, uint32_t slot) {
+__device__ __forceinline__ bool dp_sweep_item(const DpLevelConst &L, uint32_t p0, uint32_t W, uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
+                                              uint8_t *__restrict__ item_out, uint8_t stamp, uint32_t item, uint32_t &evaluated) {
     const BgConst &g = L.g;
     constexpr uint32_t kDpRowsPerWave = 64 / kDpParts;
     const uint32_t lane = threadIdx.x & 63u, part = lane / kDpRowsPerWave;
@@ -225,12 +249,12 @@ __global__ __launch_bounds__(256) void k_dp_level_sweep(DpLevelConst L, uint32_t
     uint32_t n, p;
     if (kDpParts == 1) {
         // a workgroup = 256 consecutive beliefs of ONE graph node: the node index is a scalar, no per-thread division
-        const uint32_t chunks = (W + 255u) / 256u, off = (blockIdx.x % chunks) * 256u + threadIdx.x;
-        n = blockIdx.x / chunks;
+        const uint32_t chunks = (W + 255u) / 256u, off = (item % chunks) * 256u + threadIdx.x;
+        n = item / chunks;
         in_range = off < W;
         p = p0 + (in_range ? off : 0u);
     } else {
-        const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 64;
+        const size_t wave = ((size_t)item * 256u + threadIdx.x) / 64;
         const size_t row = wave * kDpRowsPerWave + (lane % kDpRowsPerWave);
         in_range = row < (size_t)g.N * W;
         n = in_range ? (uint32_t)row / W : 0u;
@@ -249,18 +273,34 @@ __global__ __launch_bounds__(256) void k_dp_level_sweep(DpLevelConst L, uint32_t
         active = ((cb >> vn) & 1ull) && !((as_global(g.obs_bits)[bit >> 6] >> (bit & 63)) & 1ull) && old != 0.0;
     }
     const bool was_dirty = in_range && as_global(dirty_in)[ip] != 0;
-    if (!__ballot(was_dirty)) return;
-    const bool one_validity = g.n_validities == 1;
+    if (!__ballot(was_dirty)) return false;
+    evaluated += (active && part == 0) ? 1u : 0u;
     const unsigned long long a0 = as_global(g.adj_off)[n], a1 = as_global(g.adj_off)[n + 1];
+    const DpEdge *__restrict__ E = L.adj_e;
     double best = __builtin_huge_val();
-    if (active) {
-#pragma unroll 4
-        for (unsigned long long k = a0 + part; k < a1; k += kDpParts) {
-            const uint32_t c = as_global(g.adj_id)[k];
-            bool ok = true;
-            if (!one_validity) ok = ((cb >> as_global(g.vid)[c]) & 1ull) && ((cb >> as_global(g.adj_val)[k]) & 1ull);
-            const double a = as_global(L.adj_w)[k] + as_global(L.dist_p)[(size_t)c * g.B + p];
-            best = (ok && a < best) ? a : best;
+    // kDpBatch neighbours at a time: their entries first (one load each; scalar when the node is the workgroup's), then their costs, all in
+    // flight together -- nothing in a batch waits for anything else in it, whatever the number of validities.  (An index past the row's
+    // end repeats its last entry: min does not mind.)
+    constexpr uint32_t kDpBatch = kDpParts == 1 ? 12u : 10u;
+    if (active && a1 > a0) {
+        const unsigned long long alast = a1 - 1;
+        for (unsigned long long k = a0 + part; k < a1; k += (unsigned long long)kDpParts * kDpBatch) {
+            uint32_t ec[kDpBatch], ev[kDpBatch];
+            double ew[kDpBatch], dv[kDpBatch];
+#pragma unroll
+            for (uint32_t u = 0; u < kDpBatch; ++u) {
+                const unsigned long long kk = k + (unsigned long long)u * kDpParts;
+                const auto ep = as_global(E) + (kk < alast ? kk : alast);
+                ec[u] = ep->c; ev[u] = ep->vv; ew[u] = ep->w;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kDpBatch; ++u) dv[u] = as_global(L.dist_p)[(size_t)ec[u] * g.B + p];
+#pragma unroll
+            for (uint32_t u = 0; u < kDpBatch; ++u) {
+                const bool ok = ((cb >> (ev[u] & 0xFFu)) & (cb >> (ev[u] >> 8)) & 1ull) != 0;     // (one validity: bit 0 of every belief)
+                const double a = ew[u] + dv[u];
+                best = (ok && a < best) ? a : best;
+            }
         }
     }
     for (uint32_t d = kDpRowsPerWave; d < 64; d <<= 1) {                            // the parts of a row sit 16 lanes apart
@@ -269,14 +309,25 @@ __global__ __launch_bounds__(256) void k_dp_level_sweep(DpLevelConst L, uint32_t
     }
     const bool improved = active && best < old;
     if (improved) {
-        if (part == 0) {
-            as_global(L.dist_p)[ip] = best;
-            as_global(L.flags)[1 + slot] = 1;
+        if (part == 0) as_global(L.dist_p)[ip] = best;
+        for (unsigned long long k = a0 + part; k < a1; k += kDpParts) {             // whoever may use this node as a child
+            const uint32_t c = as_global(E)[k].c;
+            as_global(dirty_out)[(size_t)c * g.B + p] = 1;
+            if (kDpParts == 1) as_global(item_out)[c * ((W + 255u) / 256u) + (p - p0) / 256u] = stamp;       // ... and the item that row belongs to
+            else as_global(item_out)[((size_t)c * W + (p - p0)) >> 6] = stamp;
         }
-        for (unsigned long long k = a0 + part; k < a1; k += kDpParts)               // whoever may use this node as a child
-            as_global(dirty_out)[(size_t)as_global(g.adj_id)[k] * g.B + p] = 1;
     }
     if (was_dirty && part == 0) as_global(dirty_in)[ip] = 0;
+    return improved;
+}
+
+template <uint32_t kDpParts>
+__global__ __launch_bounds__(256) void k_dp_level_sweep(DpLevelConst L, uint32_t p0, uint32_t W, uint8_t *__restrict__ dirty_in,
+                                                        uint8_t *__restrict__ dirty_out, const uint8_t *__restrict__ item_in, uint8_t *__restrict__ item_out,
+                                                        uint32_t sweep, uint32_t slot) {
+    if (as_global(item_in)[blockIdx.x] != dp_stamp(sweep)) return;
+    uint32_t ev = 0;
+    if (dp_sweep_item<kDpParts>(L, p0, W, dirty_in, dirty_out, item_out, dp_stamp(sweep + 1u), blockIdx.x, ev)) as_global(L.flags)[1 + slot] = 1;
 }
 
 // dist[n * B + b] = dist_p[n * B + rank[b]]
@@ -301,6 +352,9 @@ struct DpState {
     uint8_t *d_dirty[2] = {nullptr, nullptr};
     size_t dirty_cap = 0;
     uint32_t *d_flags = nullptr;
+    uint32_t *h_pin = nullptr;                        // pinned: where the flags are read (a copy into pageable memory costs several times as much)
+    uint8_t *d_item[2] = {nullptr, nullptr};          // a byte per item (= workgroup of a sweep) of a level: the stamp of the sweep it was last marked for
+    size_t item_cap = 0;
     unsigned long long *d_finals = nullptr;
     size_t finals_cap = 0;
     DpConst last{};                                   // the graph of the last run (device pointers), for the policy walk
@@ -321,6 +375,10 @@ struct DpState {
         if (d_dist) (void)hipFree(d_dist);
         for (int k = 0; k < 2; ++k) if (d_dirty[k]) (void)hipFree(d_dirty[k]);
         if (d_flags) (void)hipFree(d_flags);
+        for (int k = 0; k < 2; ++k) { if (d_item[k]) (void)hipFree(d_item[k]); d_item[k] = nullptr; }
+        item_cap = 0;
+        if (h_pin) (void)hipHostFree(h_pin);
+        h_pin = nullptr;
         if (d_finals) (void)hipFree(d_finals);
         if (d_row) (void)hipFree(d_row);
         if (d_dist_l) (void)hipFree(d_dist_l);
@@ -382,7 +440,8 @@ static int dp_run(DpState &st, DpConst c, bool implicit, const std::vector<unsig
         hipLaunchKernelGGL(k_dp_set_finals, dim3((unsigned)((finals.size() + 255) / 256)), block, 0, s, c, (const unsigned long long *)st.d_finals,
                            (unsigned long long)finals.size(), st.d_dirty[0]);
     }
-    uint32_t sweeps = 0, h_flags[1 + kDpGroup];
+    if (!st.h_pin) DP_HIP(hipHostMalloc((void **)&st.h_pin, (1 + kDpGroup) * sizeof(uint32_t), hipHostMallocDefault));
+    uint32_t sweeps = 0, *h_flags = st.h_pin;
     unsigned long long sweep_rows = 0;
     int cur = 0;
     for (bool more = !finals.empty(); more;) {
@@ -393,7 +452,7 @@ static int dp_run(DpState &st, DpConst c, bool implicit, const std::vector<unsig
         }
         sweeps += kDpGroup;
         sweep_rows += (unsigned long long)n * kDpGroup;
-        DP_HIP(hipMemcpyAsync(h_flags, st.d_flags, sizeof h_flags, hipMemcpyDeviceToHost, s));
+        DP_HIP(hipMemcpyAsync(h_flags, st.d_flags, (1 + kDpGroup) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         DP_HIP(hipStreamSynchronize(s));
         if (h_flags[0]) break;
         more = h_flags[kDpGroup] != 0;                  // the last sweep of the group still improved something
@@ -462,14 +521,14 @@ static int dp_run_layered(DpState &st, BeliefGraphState &bg, DpConst c, const st
     }
     unsigned long long n_adj = 0;
     DP_HIP(hipMemcpy(&n_adj, bg.last.adj_off + N, sizeof n_adj, hipMemcpyDeviceToHost));
-    const size_t aux_bytes = (size_t)n_adj * sizeof(double) + 2 * B * sizeof(uint32_t) + 64;
+    const size_t aux_bytes = (size_t)n_adj * sizeof(DpEdge) + 2 * B * sizeof(uint32_t) + 64;
     if (st.aux_cap < aux_bytes) {
         if (st.d_aux) (void)hipFree(st.d_aux);
         st.d_aux = nullptr; st.aux_cap = 0;
         DP_HIP(hipMalloc(&st.d_aux, aux_bytes + aux_bytes / 8));
         st.aux_cap = aux_bytes + aux_bytes / 8;
     }
-    double *d_w = (double *)st.d_aux;
+    DpEdge *d_w = (DpEdge *)st.d_aux;
     uint32_t *d_rank = (uint32_t *)(d_w + n_adj), *d_belief_at = d_rank + B;
     ScopedEvents<2> evs;
     DP_HIP(evs.create());
@@ -483,29 +542,50 @@ static int dp_run_layered(DpState &st, BeliefGraphState &bg, DpConst c, const st
     hipLaunchKernelGGL(k_dp_edge_weights, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, bg.last, d_w);
     hipLaunchKernelGGL(k_dp_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st.d_dist_l, (unsigned long long)n, __builtin_huge_val());
     DpLevelConst L{};
-    L.g = bg.last; L.adj_w = d_w; L.rank = d_rank; L.belief_at = d_belief_at; L.dist_p = st.d_dist_l; L.flags = st.d_flags;
+    L.g = bg.last; L.adj_e = d_w; L.rank = d_rank; L.belief_at = d_belief_at; L.dist_p = st.d_dist_l; L.flags = st.d_flags;
     if (!finals.empty()) {
         DP_HIP(hipMemcpyAsync(st.d_finals, finals.data(), finals.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_dp_level_finals, dim3((unsigned)((finals.size() + 255) / 256)), dim3(256), 0, s, L, (const unsigned long long *)st.d_finals,
                            (unsigned long long)finals.size());
     }
-    uint32_t sweeps = 0, h_flags[1 + kDpGroup];
+    if (!st.h_pin) DP_HIP(hipHostMalloc((void **)&st.h_pin, (1 + kDpGroup) * sizeof(uint32_t), hipHostMallocDefault));
+    uint32_t sweeps = 0, *h_flags = st.h_pin;
     unsigned long long sweep_rows = 0;
+    {
+        size_t max_items = 0;
+        for (auto &lv : levels) {
+            const size_t W = lv.second - lv.first, rows = N * W;
+            const size_t items = rows < (2u << 20) ? (rows * 4 + 255) / 256 : N * ((W + 255) / 256);
+            max_items = items > max_items ? items : max_items;
+        }
+        if (st.item_cap < max_items) {
+            for (int k = 0; k < 2; ++k) { if (st.d_item[k]) (void)hipFree(st.d_item[k]); st.d_item[k] = nullptr; }
+            st.item_cap = 0;
+            for (int k = 0; k < 2; ++k) DP_HIP(hipMalloc((void **)&st.d_item[k], max_items + max_items / 8 + 64));
+            st.item_cap = max_items + max_items / 8 + 64;
+        }
+        // (stamps are never 0: a cleared byte matches no sweep.  The stamp of a sweep repeats after 255 sweeps and the bytes outlive levels --
+        // an old byte that matches costs its workgroup a look at its rows' marks, which decide)
+        DP_HIP(hipMemsetAsync(st.d_item[0], 0, st.item_cap, s));
+        DP_HIP(hipMemsetAsync(st.d_item[1], 0, st.item_cap, s));
+    }
     for (auto &lv : levels) {
         const uint32_t p0 = lv.first, W = lv.second - lv.first;
         const dim3 grid((unsigned)(((size_t)N * W + 255) / 256)), block(256);
         const bool split = (size_t)N * W < (2u << 20);                                 // small level: latency bound
         const dim3 sgrid(split ? (unsigned)(((size_t)N * W * 4 + 255) / 256) : (unsigned)(N * ((W + 255) / 256)));
-        hipLaunchKernelGGL(k_dp_level_init, grid, block, 0, s, L, p0, W, st.d_dirty[0]);
+        hipLaunchKernelGGL(k_dp_level_init, grid, block, 0, s, L, p0, W, st.d_dirty[0], st.d_item[sweeps & 1u], split ? 4u : 1u, sweeps);
         int cur = 0;
         for (bool more = true; more;) {
             DP_HIP(hipMemsetAsync(st.d_flags + 1, 0, kDpGroup * sizeof(uint32_t), s));
             for (uint32_t k = 0; k < kDpGroup; ++k, cur ^= 1)
-                if (split) hipLaunchKernelGGL(k_dp_level_sweep<4>, sgrid, block, 0, s, L, p0, W, st.d_dirty[cur], st.d_dirty[cur ^ 1], k);
-                else hipLaunchKernelGGL(k_dp_level_sweep<1>, sgrid, block, 0, s, L, p0, W, st.d_dirty[cur], st.d_dirty[cur ^ 1], k);
+                if (split) hipLaunchKernelGGL(k_dp_level_sweep<4>, sgrid, block, 0, s, L, p0, W, st.d_dirty[cur], st.d_dirty[cur ^ 1],
+                                              (const uint8_t *)st.d_item[(sweeps + k) & 1u], st.d_item[(sweeps + k + 1u) & 1u], sweeps + k, k);
+                else hipLaunchKernelGGL(k_dp_level_sweep<1>, sgrid, block, 0, s, L, p0, W, st.d_dirty[cur], st.d_dirty[cur ^ 1],
+                                        (const uint8_t *)st.d_item[(sweeps + k) & 1u], st.d_item[(sweeps + k + 1u) & 1u], sweeps + k, k);
             sweeps += kDpGroup;
             sweep_rows += (unsigned long long)N * W * kDpGroup;
-            DP_HIP(hipMemcpyAsync(h_flags, st.d_flags, sizeof h_flags, hipMemcpyDeviceToHost, s));
+            DP_HIP(hipMemcpyAsync(h_flags, st.d_flags, (1 + kDpGroup) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             DP_HIP(hipStreamSynchronize(s));
             more = h_flags[kDpGroup] != 0;
             if (sweeps > 4u * 1000u * 1000u) { err = "conditional_dijkstra: no fixpoint after 4M sweeps"; return PORRT_ERR_DEVICE; }

@@ -1660,13 +1660,14 @@ int porrt_ctx::compute_expected_costs() {
     const BeliefSpace &bs = bg.cache.space;
     const size_t B = bg.B;
     std::vector<unsigned long long> finals;
+    std::vector<uint64_t> possible(B, 0);             // per belief: the worlds it gives a probability > 0 (at most 64 worlds: the finality masks are words)
+    for (size_t b = 0; b < B; ++b)
+        for (uint32_t w = 0; w < bs.nw; ++w) possible[b] |= bs.at(b)[w] > 0.0 ? 1ull << w : 0ull;
     for (uint64_t id : h_final_ids) {                 // final_nodes_with_validities(): push order = ascending id here
         const uint64_t finality = h_finalmask[id];
         for (size_t b = 0; b < B; ++b) {
             if (!((bg.cache.compat[b] >> h_vid[id]) & 1ull)) continue;          // node_to_belief_nodes[final_id][b] is None
-            bool ok = true;                                                      // is_compatible(belief_state, validity)
-            for (uint32_t w = 0; w < bs.nw && ok; ++w) ok = !(bs.at(b)[w] > 0.0) || ((finality >> w) & 1ull);
-            if (ok) finals.push_back((unsigned long long)(id * B + b));
+            if (!(possible[b] & ~finality)) finals.push_back((unsigned long long)(id * B + b));     // is_compatible(belief_state, validity)
         }
     }
     DpConst c{};
