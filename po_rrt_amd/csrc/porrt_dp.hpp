@@ -260,29 +260,33 @@ __device__ __forceinline__ bool dp_sweep_item(const DpLevelConst &L, uint32_t p0
         n = in_range ? (uint32_t)row / W : 0u;
         p = p0 + (in_range ? (uint32_t)row - n * W : 0u);
     }
+    // first trip: everything that depends on (n, p) alone -- the row's mark, its belief, the node's validity and list
     const size_t ip = (size_t)n * g.B + p;
-    bool active = in_range && as_global(dirty_in)[ip] != 0;
+    const bool was_dirty = in_range && as_global(dirty_in)[ip] != 0;
+    const uint32_t b = as_global(L.belief_at)[p], vn = as_global(g.vid)[n];
+    const unsigned long long a0 = as_global(g.adj_off)[n], a1 = as_global(g.adj_off)[n + 1];
+    if (!__ballot(was_dirty)) return false;
+    // second trip, marked rows only: what decides whether the row moves at all (observation nodes and finals do not), its cost -- and,
+    // below, the first batch of its list, which waits for none of these
+    bool active = false;
     double old = 0.0;
     unsigned long long cb = 0;
-    if (active) {
-        const uint32_t b = as_global(L.belief_at)[p], vn = as_global(g.vid)[n];
+    if (was_dirty) {
         cb = as_global(g.compat)[b];
         const size_t bit = (size_t)n * g.B + b;
         old = as_global(L.dist_p)[ip];
-        // (observation nodes and finals do not move)
         active = ((cb >> vn) & 1ull) && !((as_global(g.obs_bits)[bit >> 6] >> (bit & 63)) & 1ull) && old != 0.0;
     }
-    const bool was_dirty = in_range && as_global(dirty_in)[ip] != 0;
-    if (!__ballot(was_dirty)) return false;
     evaluated += (active && part == 0) ? 1u : 0u;
-    const unsigned long long a0 = as_global(g.adj_off)[n], a1 = as_global(g.adj_off)[n + 1];
     const DpEdge *__restrict__ E = L.adj_e;
     double best = __builtin_huge_val();
     // kDpBatch neighbours at a time: their entries first (one load each; scalar when the node is the workgroup's), then their costs, all in
     // flight together -- nothing in a batch waits for anything else in it, whatever the number of validities.  (An index past the row's
     // end repeats its last entry: min does not mind.)
     constexpr uint32_t kDpBatch = kDpParts == 1 ? 12u : 10u;
-    if (active && a1 > a0) {
+    // (a small level is a chain of trips: there the list is fetched for every marked row, `active` -- known a trip later -- gates the
+    // result only; a wide level is bandwidth: rows that cannot move fetch nothing)
+    if ((kDpParts == 1 ? active : was_dirty) && a1 > a0) {
         const unsigned long long alast = a1 - 1;
         for (unsigned long long k = a0 + part; k < a1; k += (unsigned long long)kDpParts * kDpBatch) {
             uint32_t ec[kDpBatch], ev[kDpBatch];
