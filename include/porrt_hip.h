@@ -270,8 +270,9 @@ int porrt_get_metrics(const porrt_ctx *ctx, porrt_metrics *out);
  * goal path of the reference's kd-tree is kept -- it orders every tie between copies of the goal point and their parent -- and the
  * whole structure is built after the steps in the rare run where two other nodes tie; 0 = the whole structure beside the steps on
  * a second stream, as a single query does), "kd_claim_threads", "kd_ride", "kd_inline", "early_wave_steps", "dp_sweeps", "compact_rows" (1, default: a
- * porrt_grow_batch whose members end at different steps launches its later steps on the members that still have work).  None of
- * them changes a result. */
+ * porrt_grow_batch whose members end at different steps launches its later steps on the members that still have work), "box_table"
+ * (1, default: the group and roadmap kernels answer "is this segment free" from a summed-area table of the raster when the bounding
+ * box of its end pixels holds free pixels only, and walk it otherwise; 0 = always walk).  None of them changes a result. */
 int porrt_set_option(porrt_ctx *ctx, const char *name, int64_t value);
 /* what was in force: "launch_mode" (the last porrt_grow_batch led by this context: 0 = one launch sequence, G = G sequences side by
  * side on streams chosen by measurement, -G = G sequences on the contexts' own streams -- the probe found no parallel set, e.g. under a

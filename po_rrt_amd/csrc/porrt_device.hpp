@@ -121,13 +121,17 @@ struct Counters {
 #ifndef PORRT_TIMING_FROM
 #define PORRT_TIMING_FROM 0
 #endif
+#ifndef PORRT_TIMING_UNTIL
+#define PORRT_TIMING_UNTIL 0x7FFFFFFF
+#endif
 #if defined(PORRT_TIMING) && PORRT_TIMING == 1
-#define PORRT_TACC_A(rc, slot) do { if (b >= (uint32_t)PORRT_TIMING_FROM) PORRT_TACC(rc, slot); else t__0 = wall_clock64(); } while (0)
+#define PORRT_TACC_A(rc, slot) do { if (b >= (uint32_t)PORRT_TIMING_FROM && b < (uint32_t)PORRT_TIMING_UNTIL) PORRT_TACC(rc, slot); else t__0 = wall_clock64(); } while (0)
 #define PORRT_TACC_B(rc, slot) do { (void)t__0; } while (0)
 #elif defined(PORRT_TIMING)
 #define PORRT_TACC_A(rc, slot) do { (void)t__0; } while (0)
-// (-DPORRT_TIMING_FROM=<step>: only the steps from there on are accumulated -- the steady state without the dense first steps)
-#define PORRT_TACC_B(rc, slot) do { if (b >= (uint32_t)PORRT_TIMING_FROM) PORRT_TACC(rc, slot); else t__0 = wall_clock64(); } while (0)
+// (-DPORRT_TIMING_FROM=<step> [-DPORRT_TIMING_UNTIL=<step>]: only those steps are accumulated -- the steady state without the dense first
+// steps, or the dense first steps alone)
+#define PORRT_TACC_B(rc, slot) do { if (b >= (uint32_t)PORRT_TIMING_FROM && b < (uint32_t)PORRT_TIMING_UNTIL) PORRT_TACC(rc, slot); else t__0 = wall_clock64(); } while (0)
 #else
 #define PORRT_TACC_A(rc, slot) do {} while (0)
 #define PORRT_TACC_B(rc, slot) do {} while (0)
@@ -141,6 +145,21 @@ struct Counters {
 #define PORRT_TACC_C(rc, slot) do { (void)t__0; } while (0)
 #else
 #define PORRT_TACC_C(rc, slot) do {} while (0)
+#endif
+
+// =4: where a heavy sample's time goes (more hits than its LDS list holds: served by the whole wave, heavy_sample_wave) -- slot 0 its
+// hits read back, 1 the rays and costs of the hits, 4-7 as for =2 but for heavy samples only, 3 the whole of it
+#if defined(PORRT_TIMING) && PORRT_TIMING == 4
+#undef PORRT_TACC_B
+#define PORRT_TACC_B(rc, slot) do { (void)t__0; } while (0)
+#define PORRT_TACC_H(rc, slot) do { if (b >= (uint32_t)PORRT_TIMING_FROM && b < (uint32_t)PORRT_TIMING_UNTIL) PORRT_TACC(rc, slot); else t__0 = wall_clock64(); } while (0)
+#define PORRT_TACC_S(rc, slot) do { if (TeamT::kSize == 64 && b >= (uint32_t)PORRT_TIMING_FROM && b < (uint32_t)PORRT_TIMING_UNTIL) PORRT_TACC(rc, slot); else t__0 = wall_clock64(); } while (0)
+#elif defined(PORRT_TIMING)
+#define PORRT_TACC_H(rc, slot) do { (void)t__0; } while (0)
+#define PORRT_TACC_S(rc, slot) PORRT_TACC_B(rc, slot)
+#else
+#define PORRT_TACC_H(rc, slot) do {} while (0)
+#define PORRT_TACC_S(rc, slot) do {} while (0)
 #endif
 
 struct BestCost {
@@ -227,6 +246,7 @@ struct RunConst {
     double gp_x, gp_y;
     // grid
     const uint8_t *cls;
+    const uint32_t *sat;        // (H + 1) x (W + 1) summed-area table of the pixels that are not CLS_FREE: sat[i][j] = their number in rows < i, columns < j
     const uint8_t *clr;         // per pixel: Chebyshev distance to the nearest pixel that is not CLS_FREE or lies outside (0 on such a
                                 // pixel, capped at 255): a segment whose end pixels are closer than that crosses free pixels only
     uint32_t W, H;
@@ -375,6 +395,12 @@ struct GlobalGrid {
     const uint8_t *p;
     uint32_t W;
     __device__ __forceinline__ int at(uint32_t i, uint32_t j) const { return as_global(p)[i * W + j]; }
+    static constexpr bool kAskTable = false;
+};
+// ... and where the kernel has the registers for it (the group kernels, the roadmap kernels): segment_box_free before a walk -- one trip
+// instead of one per chunk
+struct TableGrid : GlobalGrid {
+    static constexpr bool kAskTable = true;
 };
 struct TileGrid {
     static constexpr int kRayChunk = 1;     // (the tile is in LDS: nothing to gain, and the one-wave-per-sample kernels have no registers to spare)
@@ -388,7 +414,15 @@ struct TileGrid {
         if (ri < TW && rj < TW) return lds[ri * TW + rj];
         return as_global(glob)[i * W + j];
     }
+    static constexpr bool kAskTable = false;     // (a walk through the LDS tile makes no trips, and the one-wave-per-sample kernels have no registers for the question)
 };
+
+// Is every pixel of the bounding box of two pixels free?  Four independent loads from the summed-area table.  (Pixels inside the raster.)
+__device__ __forceinline__ bool segment_box_free(const RunConst &rc, uint32_t ai, uint32_t aj, uint32_t bi, uint32_t bj) {
+    const uint32_t i0 = ai < bi ? ai : bi, i1 = (ai < bi ? bi : ai) + 1u, j0 = aj < bj ? aj : bj, j1 = (aj < bj ? bj : aj) + 1u, Ws = rc.W + 1u;
+    auto S = as_global(rc.sat);
+    return S[i1 * Ws + j1] - S[i0 * Ws + j1] - S[i1 * Ws + j0] + S[i0 * Ws + j0] == 0u;
+}
 
 // Traversed-space class of the segment a -> b (map_shelves_io.rs:187-203, map_io.rs:216-241), end points given as pixels
 // (to_pixel).  Returns CLS_FREE / CLS_LOW / CLS_HIGH / CLS_ZONE+z.  Raster faults set *err and read as CLS_HIGH.
@@ -397,6 +431,11 @@ __device__ int traversed_class_px(const RunConst &rc, const Grid &grid, uint32_t
     if (ai >= rc.H || bi >= rc.H || aj >= rc.W || bj >= rc.W) {
         *err |= ERR_RASTER;
         return CLS_HIGH;
+    }
+    // The walk stays inside the bounding box of its end pixels: where that box holds free pixels only -- most segments of a tree, whose
+    // nodes keep clear of nothing but are rarely around a corner from each other -- the answer takes one trip instead of a chain of chunks.
+    if constexpr (Grid::kAskTable) {
+        if (rc.sat != nullptr && segment_box_free(rc, ai, aj, bi, bj)) return CLS_FREE;       // (option "box_table" = 0: no table)
     }
     int x0 = (int)ai, y0 = (int)aj, x1 = (int)bi, y1 = (int)bj;
     int o = 0;
@@ -1465,6 +1504,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
 
     // pass 1: raycast every neighbour, total cost through it (rrt.rs:124, 137-140).  A ray whose end pixels lie inside
     // the all-free window around the new node's pixel (clr) crosses free pixels only and is not walked.
+    PORRT_T0();
     double bt = INF;
     int bj = 0x7FFFFFFF;
     uint32_t nvalid = 0, leq = 0;
@@ -1486,6 +1526,14 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
         if (rc.has_grid) to_pixel(rc, ax, ay, ai, aj);
         bool ok = true;
         if (rc.has_grid) ok = segment_in_clearance(ai, aj, bi, bjx, clr_b) || traversed_class_px(rc, grid, ai, aj, bi, bjx, &err) == CLS_FREE;
+#if defined(PORRT_TIMING) && PORRT_TIMING == 4
+        // (slot 2: rays walked, its count: hits -- of every sample, heavy or not; printed as walked / hits / 100)
+        if (b >= (uint32_t)PORRT_TIMING_FROM && b < (uint32_t)PORRT_TIMING_UNTIL) {
+            atomicAdd(&rc.cnt->tim[10], 1ull);
+            if (rc.has_grid && !segment_in_clearance(ai, aj, bi, bjx, clr_b) && !(rc.sat != nullptr && ai < rc.H && aj < rc.W && bi < rc.H && bjx < rc.W && segment_box_free(rc, ai, aj, bi, bjx)))
+                atomicAdd(&rc.cnt->tim[2], 1ull);
+        }
+#endif
         const double total = dA + cost;
         if (a == tl) { j0 = j; cost0 = ok ? cost : -1.0; tot0 = total; dA0 = dA; }
         else { L.set_val(a, ok ? cost : -1.0); L.set_dA(a, dA); }
@@ -1496,11 +1544,15 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
             else if (total == bt) { ++leq; bj = j < bj ? j : bj; }
         }
     }
-    PORRT_T0();
+#if defined(PORRT_TIMING) && PORRT_TIMING == 4
+    PORRT_TACC_S(rc, 1);
+#elif defined(PORRT_TIMING)
+    t__0 = wall_clock64();
+#endif
     nvalid = tm.sum(nvalid);
     const double my_bt = bt;
     tm.argmin(bt, bj);
-    PORRT_TACC_B(rc, 4);
+    PORRT_TACC_S(rc, 4);
     int best;
     double best_cost, dnew;
     bool deferred = false;
@@ -1631,7 +1683,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
         }
     }
 
-    PORRT_TACC_B(rc, 5);
+    PORRT_TACC_S(rc, 5);
     // new node (rrt.rs:148, 30-37) and goal test (rrt.rs:165-167)
     // SquareGoal test (common.rs:336-345), lane g <-> goal g; the goal table sits in the run constants (scalar cache)
     bool fin = false;
@@ -1711,7 +1763,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
             }
         }
     }
-    PORRT_TACC_B(rc, 6);
+    PORRT_TACC_S(rc, 6);
     // rewire phase 1 (rrt.rs:152-161): dist_root candidates, min wins
     auto gdB = as_global(reinterpret_cast<unsigned long long *>(swap ? rc.distA : rc.distB));
     if constexpr (ListT::kCompact) {
@@ -1740,7 +1792,7 @@ __device__ void connect_rrt_sample(const RunConst &rc, const TeamT &tm, const Li
             }
             if (tl == 0) *L.out_cnt = n_out;
         }
-        PORRT_TACC_B(rc, 7);
+        PORRT_TACC_S(rc, 7);
         return;
     } else {
     if (j0 >= 0) {

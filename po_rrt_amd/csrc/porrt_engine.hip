@@ -261,6 +261,7 @@ struct porrt_ctx {
                                                    // on measured streams, -G sequences on the contexts' own streams (the stream probe found no set: e.g. under a profiler)
     uint32_t sub_streams_tried = 0;                 // a probe for this many streams already failed: not repeated call after call
     std::vector<hipStream_t> sub_streams;          // first context of such a call: the sub-batches' main streams (see porrt_grow_batch)
+    bool opt_box_table = true;             // "box_table": a segment whose end pixels' bounding box is all free is not walked (summed-area table; 0 = always walk)
     bool opt_dp_sweeps = false;            // "dp_sweeps": expected costs by whole-graph sweeps instead of layer by layer
     uint32_t opt_cand_cap = 2048;
     uint64_t edge_per_node = 256, tie_pool_mult = 16;      // pool sizes: grown and the run replayed when one overflows (as the neighbour lists)
@@ -459,6 +460,10 @@ int porrt_ctx::layout_buffers() {
     return PORRT_OK;
 }
 
+// bytes of the raster planes on the device: classes, clearance, (aligned) summed-area table
+static inline size_t cls_sat_offset(size_t W, size_t H) { return (2 * W * H + 15) & ~(size_t)15; }
+static inline size_t cls_bytes(size_t W, size_t H) { return cls_sat_offset(W, H) + (H + 1) * (W + 1) * sizeof(uint32_t) + 16; }
+
 int porrt_ctx::build_cls() {
     if (!has_grid) return PORRT_OK;
     if (!cls_dirty) return PORRT_OK;
@@ -496,7 +501,21 @@ int porrt_ctx::build_cls() {
                 d[(size_t)i * W + j] = (uint8_t)v;
             }
     }
-    HIPCHK(hipMemcpyAsync(d_cls.p, cls.data(), 2 * n, hipMemcpyHostToDevice, stream));
+    // ... and behind that (16-byte aligned) the summed-area table of the pixels that are not free (segment_box_free)
+    const size_t sat_at = cls_sat_offset(W, H), Ws = (size_t)W + 1;
+    cls.resize(sat_at + (H + 1) * Ws * sizeof(uint32_t));
+    {
+        std::vector<uint32_t> sat((H + 1) * Ws, 0u);
+        for (size_t i = 0; i < H; ++i) {
+            uint32_t row = 0;
+            for (size_t j = 0; j < W; ++j) {
+                row += cls[i * W + j] == CLS_FREE ? 0u : 1u;
+                sat[(i + 1) * Ws + j + 1] = sat[i * Ws + j + 1] + row;
+            }
+        }
+        memcpy(cls.data() + sat_at, sat.data(), sat.size() * sizeof(uint32_t));
+    }
+    HIPCHK(hipMemcpyAsync(d_cls.p, cls.data(), cls.size(), hipMemcpyHostToDevice, stream));
     cls_dirty = false;
     return PORRT_OK;
 }
@@ -1047,7 +1066,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
             const uint64_t ecap = std::min<uint64_t>(Nmax * edge_per_node + 4096, 1ull << 31);
             HIPCHK(d_efrom.reserve(ecap)); HIPCHK(d_eto.reserve(ecap)); HIPCHK(d_etv.reserve(ecap));
         }
-        if (has_grid) HIPCHK(d_cls.reserve(2 * (size_t)W * H + 16));
+        if (has_grid) HIPCHK(d_cls.reserve(cls_bytes(W, H)));
         if (has_inj) HIPCHK(d_inj.reserve(inj_xy.size() + 2));
         int r = layout_buffers();
         if (r) return r;
@@ -1090,7 +1109,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     }
     c.kd_rec = d_kdrec.p; c.g_x = d_gx.p; c.g_y = d_gy.p; c.kd_up = d_kdup.p; c.kd_depth = d_kddepth.p; c.kd_gexit = d_kdgexit.p;
     c.g_id = d_gid.p; c.g_cap = (uint32_t)std::min<uint64_t>(d_gid.n, 0xFFFFFFFFull);
-    c.cls = d_cls.p; c.clr = d_cls.p + (size_t)W * H; c.W = W; c.H = H; c.low0 = low[0]; c.low1 = low[1]; c.ppm = ppm; c.domain = domain; c.has_grid = has_grid;
+    c.cls = d_cls.p; c.clr = d_cls.p + (size_t)W * H; c.sat = opt_box_table ? (const uint32_t *)(d_cls.p + cls_sat_offset(W, H)) : nullptr; c.W = W; c.H = H; c.low0 = low[0]; c.low1 = low[1]; c.ppm = ppm; c.domain = domain; c.has_grid = has_grid;
     c.n_validities = n_validities;
     for (int i = 0; i < n_validities; ++i) c.validities[i] = validities[i];
     c.all_worlds = ones(n_worlds);
@@ -1735,7 +1754,7 @@ int porrt_ctx::grow_prm(const double start[2], double max_step, double search_ra
     const uint64_t ecap = std::min<uint64_t>((uint64_t)N * 256 + 4096, 1ull << 30);
     HIPCHK(d_nx.reserve(N)); HIPCHK(d_ny.reserve(N)); HIPCHK(d_distA.reserve(N)); HIPCHK(d_parent.reserve(N)); HIPCHK(d_reachA.reserve(N));
     HIPCHK(d_vid.reserve(N)); HIPCHK(d_finalflag.reserve(N)); HIPCHK(d_finalmask.reserve(N)); HIPCHK(d_radT2.reserve(N + 8));
-    HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_cls.reserve(2 * (size_t)W * H + 16));       // classes + clearance plane (build_cls)
+    HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_cls.reserve(cls_bytes(W, H)));       // classes + clearance plane (build_cls)
     HIPCHK(d_efrom.reserve(ecap)); HIPCHK(d_eto.reserve(ecap)); HIPCHK(d_etv.reserve(ecap));
     int r = layout_buffers();
     if (r) return r;
@@ -1753,7 +1772,7 @@ int porrt_ctx::grow_prm(const double start[2], double max_step, double search_ra
     HIPCHK(hipMemsetAsync(d_finalflag.p, 0, N, stream));
     memset(&rc, 0, sizeof rc);
     rc.nx = d_nx.p; rc.ny = d_ny.p; rc.vid = d_vid.p;
-    rc.cls = d_cls.p; rc.clr = d_cls.p + (size_t)W * H; rc.W = W; rc.H = H; rc.low0 = low[0]; rc.low1 = low[1]; rc.ppm = ppm; rc.domain = domain; rc.has_grid = has_grid;
+    rc.cls = d_cls.p; rc.clr = d_cls.p + (size_t)W * H; rc.sat = opt_box_table ? (const uint32_t *)(d_cls.p + cls_sat_offset(W, H)) : nullptr; rc.W = W; rc.H = H; rc.low0 = low[0]; rc.low1 = low[1]; rc.ppm = ppm; rc.domain = domain; rc.has_grid = has_grid;
     rc.n_validities = n_validities;
     for (int i = 0; i < n_validities; ++i) rc.validities[i] = validities[i];
     rc.all_worlds = ones(n_worlds);
@@ -1898,7 +1917,7 @@ int porrt_ctx::roadmaps_of_modes(double max_step, double search_radius) {
         }
         off[mm.modes.size()] = at; seg[mm.modes.size()] = (uint32_t)at;
     }
-    HIPCHK(d_radT2.reserve(max_n + 8)); HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_cls.reserve(2 * (size_t)W * H + 16));
+    HIPCHK(d_radT2.reserve(max_n + 8)); HIPCHK(d_cnt.reserve(1)); HIPCHK(d_rc.reserve(1)); HIPCHK(d_cls.reserve(cls_bytes(W, H)));
     int r = layout_buffers();
     if (r) return r;
     cls_dirty = true;                                   // a re-layout loses the raster
@@ -1906,7 +1925,7 @@ int porrt_ctx::roadmaps_of_modes(double max_step, double search_radius) {
     rad_uploaded = 0;
     if ((r = ensure_radius_table(max_step, search_radius, max_n + 2))) return r;
     memset(&rc, 0, sizeof rc);
-    rc.cls = d_cls.p; rc.clr = d_cls.p + (size_t)W * H; rc.W = W; rc.H = H; rc.low0 = low[0]; rc.low1 = low[1]; rc.ppm = ppm; rc.domain = domain; rc.has_grid = has_grid;
+    rc.cls = d_cls.p; rc.clr = d_cls.p + (size_t)W * H; rc.sat = opt_box_table ? (const uint32_t *)(d_cls.p + cls_sat_offset(W, H)) : nullptr; rc.W = W; rc.H = H; rc.low0 = low[0]; rc.low1 = low[1]; rc.ppm = ppm; rc.domain = domain; rc.has_grid = has_grid;
     rc.n_validities = n_validities;
     for (int i = 0; i < n_validities; ++i) rc.validities[i] = validities[i];
     rc.all_worlds = ones(n_worlds);
@@ -3498,6 +3517,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "graph")) c->opt_graph = value != 0;
     else if (!strcmp(name, "group_lanes")) { if (value != -1 && value != 0 && value != 16 && value != 32 && value != 64) { c->set_err("group_lanes: -1 (auto), 0, 16, 32 or 64"); return PORRT_ERR_INVALID; } c->opt_group_req = (int)value; }
     else if (!strcmp(name, "dp_sweeps")) c->opt_dp_sweeps = value != 0;
+    else if (!strcmp(name, "box_table")) { c->opt_box_table = value != 0; c->cls_dirty = true; }
     else if (!strcmp(name, "pipeline")) {
 #ifndef PORRT_DEV_NONCOOP
         // 3 = the persistent step loop launched WITHOUT the co-residency guarantee of a cooperative launch (its barriers then rest on

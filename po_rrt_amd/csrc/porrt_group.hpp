@@ -649,7 +649,7 @@ __device__ __attribute__((noinline)) void clone_workgroup(const RunConst &rc, ui
     }
     __syncthreads();
     const uint32_t hc = cand_count(rc, b, kh);
-    GlobalGrid grid;            // the few rays outside the clearance window read the raster in memory
+    TableGrid grid;            // the few rays outside the clearance window read the raster in memory
     grid.p = rc.cls; grid.W = rc.W;
     Team<kConnectWaves> tmh;
     tmh.scr_d = s_d; tmh.scr_i = s_i; tmh.wave = wv; tmh.lane = lane;
@@ -680,10 +680,11 @@ __device__ __attribute__((noinline)) void heavy_sample_wave(const RunConst &rc, 
     constexpr uint32_t kWaveHits = (64u / (uint32_t)GL) * (kLdsHits * (uint32_t)(GL / 16));
     Team<1> tw;
     tw.scr_d = nullptr; tw.scr_i = nullptr; tw.wave = 0; tw.lane = lane;
-    GlobalGrid grid;
+    TableGrid grid;
     grid.p = rc.cls; grid.W = rc.W;
     const uint32_t cap = rc.cand_cap;
     const MemHits Mh = mem_hits(rc, b, kh);
+    PORRT_T0();
     if (toth <= kWaveHits) {
         LdsHits Wl;
         Wl.hx = reinterpret_cast<double *>(wb);
@@ -709,8 +710,10 @@ __device__ __attribute__((noinline)) void heavy_sample_wave(const RunConst &rc, 
             }
         }
         __builtin_amdgcn_wave_barrier();
+        PORRT_TACC_H(rc, 0);
         connect_rrt_sample(rc, tw, Wl, grid, b, kh, idh, pxh, pyh, toth, err, nullptr, 0, clrh, [&]() { return wave_nn(rc, b, N, pxh, pyh); });
         __builtin_amdgcn_wave_barrier();
+        PORRT_TACC_H(rc, 3);
     } else {
         connect_rrt_sample(rc, tw, Mh, grid, b, kh, idh, pxh, pyh, toth < cap ? toth : cap, err, nullptr, 0, clrh,
                            [&]() { return wave_nn(rc, b, N, pxh, pyh); });
@@ -752,7 +755,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PORRT_CONN2
     int clr_b = 0;
     bool heavy = false;
     const uint32_t cap = rc.cand_cap;
-    GlobalGrid grid;            // the few rays outside the clearance window read the raster in memory
+    TableGrid grid;            // the few rays outside the clearance window read the raster in memory
     grid.p = rc.cls; grid.W = rc.W;
     if (act) {
         // second round trip: the new node's id and the clearance around its pixel, beside the region counts of the search

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_prm_connect(const RunConst *__restrict_
     const double rw = T2 > 0.0 ? sqrt(T2) * p.inv_cell : 0.0;
     const uint32_t w = rw >= (double)p.G ? p.G : (uint32_t)rw + 1u;
     const uint32_t x_lo = cx > w ? cx - w : 0, x_hi = cx + w < p.G ? cx + w : p.G - 1, y_lo = cy > w ? cy - w : 0, y_hi = cy + w < p.G ? cy + w : p.G - 1;
-    GlobalGrid grid{rc.cls, rc.W};
+    TableGrid grid; grid.p = rc.cls; grid.W = rc.W;
     uint32_t err = 0, total = 0;
     const unsigned long long out0 = FILL ? as_global(p.edge_off)[i] : 0ull;
     for (uint32_t yy = y_lo; yy <= y_hi; ++yy) {
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_mm_connect(const RunConst *__restrict__
     if (li > 0) {
         const double px = as_global(p.x)[i], py = as_global(p.y)[i];
         const double T2 = as_global(p.rad_T2)[li + 1];                      // heuristic_radius(self.graph.nodes.len()) with the new node in
-        GlobalGrid grid{rc.cls, rc.W};
+        TableGrid grid; grid.p = rc.cls; grid.W = rc.W;
         const unsigned long long out0 = FILL ? as_global(p.edge_off)[i] : 0ull;
         for (uint32_t j0 = b; j0 < i; j0 += 64u) {
             const uint32_t j = j0 + lane;

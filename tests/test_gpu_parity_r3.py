@@ -121,6 +121,39 @@ def test_clearance_plane_saturates(eng_mod):
         assert_same(e, o, pto=mode == cases.PTO)
 
 
+def test_segments_around_many_corners(eng_mod):
+    """A raster strewn with small blocks (obstacles and low pixels): segments whose end pixels' bounding box holds a corner of a block are
+    the ones the summed-area table cannot answer (segment_box_free) and the walk must -- many of them here, beside many it can.  A
+    batch of nine through the group kernels and a single query, against the oracle; the same with the table switched off."""
+    W = 200
+    rng = np.random.default_rng(5)
+    occ = np.full((W, W), 255, np.uint8)
+    for _ in range(260):
+        i, j = rng.integers(4, W - 8, 2)
+        h, w = rng.integers(1, 5, 2)
+        occ[i:i + h, j:j + w] = 0 if rng.random() < 0.7 else 200
+    occ[95:105, 95:105] = 255                          # the start is free
+    def make(x, seed):
+        x.set_grid(occ, (-1.0, -1.0), (1.0, 1.0), cases.SHELF)
+        x.set_sampler((-1.0, -1.0), (1.0, 1.0), seed)
+        x.set_square_goal(np.array([(0.7, 0.7)]), np.array([1], dtype=np.uint64), 0.05)
+        return x
+    n_iter, K = 6000, 256
+    for table in (1, 0):
+        engs = [make(eng_mod.Engine(), 70 + s) for s in range(9)]
+        for e in engs:
+            e.set_option("box_table", table)
+        eng_mod.Engine.grow_batch(engs, [(0.0, 0.0)] * 9, 0.1, 2.0, n_iter, K)
+        for s in (0, 4, 8):
+            o = make(orc.Oracle(), 70 + s)
+            o.grow((0.0, 0.0), 0.1, 2.0, n_iter, n_iter, batch_K=K, mode=cases.RRT, algo=orc.ALGO_BATCHED_KD)
+            assert_same(engs[s], o)
+        e1 = make(eng_mod.Engine(), 70)
+        e1.set_option("box_table", table)
+        e1.grow((0.0, 0.0), 0.1, 2.0, n_iter, n_iter, batch_K=K, mode=cases.RRT)
+        assert_same(e1, engs[0])
+
+
 # results/maps_paper/map_4/costs_and_timings_5000_20.txt:6 and costs_and_timings_0_20.txt:6 (cost = policy.expected_costs x 7.65,
 # main.rs:63): mean +- std of the reference's own runs (true-random seeds, refined policy)
 REF_MAP4 = {5000: (43.990279797576896, 1.2547764494298754), 0: (45.17632675181604, 1.744800071643021)}
@@ -305,7 +338,8 @@ def test_single_query_launch_forms_agree(eng_mod, pipeline):
 
 
 @pytest.mark.parametrize("opts", [dict(kd_lazy=0), dict(kd_lazy=2), dict(kd_lazy=0, kd_after=1), dict(kd_lazy=0, kd_ride=1), dict(kd_lazy=0, kd_inline=1),
-                                  dict(early_wave_steps=5), dict(kd_lazy=0, kd_group=1), dict(kd_lazy=0, kd_group=4), dict(kd_lazy=0, kd_claim_threads=1024)],
+                                  dict(early_wave_steps=5), dict(kd_lazy=0, kd_group=1), dict(kd_lazy=0, kd_group=4), dict(kd_lazy=0, kd_claim_threads=1024),
+                                  dict(box_table=0)],
                          ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
 def test_engine_options_do_not_change_results(eng_mod, opts):
     """the developer options measured in DESIGN.md section 8 (the whole kd structure beside the steps instead of the goal path alone
