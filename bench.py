@@ -610,14 +610,12 @@ def belief_traffic():
 
 def dp_traffic():
     """HBM bytes of one expected-costs computation (all k_dp_* launches: 2 x FETCH_SIZE + WRITE_SIZE) from the committed counter passes
-    (tools/profile_belief.sh on the same 4095-belief graph: two computations; the sweep kernels have not changed since)"""
+    (tools/pmc_dp.sh on the same 4095-belief graph with this round's sweep kernels: profiles/r4_dp_pmc_traffic.json)"""
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r1_belief_pmc_traffic.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r4_dp_pmc_traffic.json")))
+        return float(pm["_all"]["hbm_bytes_2x_fetch_plus_write"])
     except Exception:
         return None
-    ks = [v for k, v in pm.items() if k.startswith("k_dp_")]
-    runs = max(1, min((v["launches"] for k, v in pm.items() if k.startswith("k_dp_fill")), default=2))
-    return sum((2.0 * v["fetch_bytes_per_launch_raw"] + v["write_bytes_per_launch"]) * v["launches"] for v in ks) / runs if ks else None
 
 
 def belief_space(device, with_cpu):
@@ -672,14 +670,15 @@ def belief_space(device, with_cpu):
                                  "traffic = HBM bytes of one build (2 x FETCH_SIZE + WRITE_SIZE summed over the k_bg_* and k_scan_* launches, "
                                  "separate --pmc passes on the same graph, profiles/r1_belief_pmc_traffic.json)"}},
         "expected_costs": {"ms_wall": 1e3 * min(dps), "ms_device": 1e3 * info["device_s"], "sweeps": info["sweeps"], "root_cost": root_cost,
-                           "roofline": {"bound": "hbm", "kernel": "k_dp_level_sweep", "achieved": 10.0 * info["sweep_rows"] / info["device_s"] / 1e9, "peak": 8000.0,
-                                        "unit": "GB/s", "frac": 10.0 * info["sweep_rows"] / info["device_s"] / 1e9 / 8000.0,
-                                        "algorithmic_bytes": 10.0 * info["sweep_rows"], "sweep_rows": info["sweep_rows"], "traffic": dp_traffic(),
-                                        "traffic_source": "profiles/r1_belief_pmc_traffic.json (committed: separate --pmc passes of FETCH_SIZE and WRITE_SIZE over two "
-                                                          "computations on the same 4095-belief graph, all k_dp_* launches summed; not measured in this run)",
-                                        "note": "a sweep passes over its level's rows: per row the change flag read and the next one written (1 B each) and the "
-                                                "cost (8 B) -- 10 B per row and sweep, summed over the %d sweeps (the rows a sweep actually re-evaluates also read "
-                                                "their neighbours' costs: not counted), over the device time of the whole computation (HIP events)" % info["sweeps"]},
+                           "roofline": {"bound": "hbm", "kernel": "k_dp_level_sweep", "achieved": (8.0 * E + 16.0 * nb) / info["device_s"] / 1e9, "peak": 8000.0,
+                                        "unit": "GB/s", "frac": (8.0 * E + 16.0 * nb) / info["device_s"] / 1e9 / 8000.0,
+                                        "algorithmic_bytes": 8.0 * E + 16.0 * nb, "sweep_rows": info["sweep_rows"], "traffic": dp_traffic(),
+                                        "traffic_source": "profiles/r4_dp_pmc_traffic.json (committed: separate --pmc passes of FETCH_SIZE and WRITE_SIZE over one "
+                                                          "computation on the same 4095-belief graph with these kernels, all k_dp_* launches summed; not measured in this run)",
+                                        "note": "algorithmic = every edge of the belief graph relaxed ONCE (the neighbour's cost, 8 B) and every row's cost read and "
+                                                "written once (16 B): what any method must move; the sweeps re-evaluate a row three times on average (%d sweeps), "
+                                                "which is why the measured traffic is ~5x that.  Until round 3 this block counted 10 B per row and sweep -- the flag "
+                                                "pass of kernels that no longer make one; over the device time of the whole computation (HIP events)" % info["sweeps"]},
                            "edge_relaxations_per_s_lower_bound": E / min(dps),
                            "note": "conditional_dijkstra as sweeps to the same fixpoint; every edge is relaxed at least once"},
         "extract_policy": {"ms_wall": 1e3 * t_policy, "policy_nodes": int(len(oid)), "leafs": int(leaf.sum())},
