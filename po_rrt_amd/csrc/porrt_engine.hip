@@ -2586,9 +2586,36 @@ static int grow_batch(porrt_ctx *const *cs, uint32_t n, const double *starts, do
                 std::vector<std::pair<uint32_t, uint32_t>> segs;
                 if (sched || S < steps) segs.emplace_back(S - 1u, K);                          // (rows cut their own steps: row_nb)
                 else segs.emplace_back(steps - 1u, (uint32_t)(n_iter - (uint64_t)(steps - 1u) * K));
+                // ... built for the rows that asked, not for the batch: in a batch of hundreds some row nearly always does, and the build
+                // of a row that has no such tie orders nothing (its records were settled from the goal path)
+                std::vector<uint32_t> asking;
+                for (uint32_t q = 0; q < n; ++q)
+                    if (h_out[q].cnt.n_lca && !(h_out[q].cnt.err & (ERR_CAND_OVERFLOW | ERR_RNG_RETRY))) asking.push_back(q);
+                const bool subset = asking.size() < n;
+                if (subset) {
+                    if (L->rcarr_c_cap < n) {
+                        for (int k = 0; k < 2; ++k) { if (L->d_rcarr_c[k]) (void)hipFree(L->d_rcarr_c[k]); L->d_rcarr_c[k] = nullptr; }
+                        if (L->d_live_idx) (void)hipFree(L->d_live_idx);
+                        L->d_live_idx = nullptr; L->rcarr_c_cap = 0;
+                        HIPCHK_CTX(L, hipMalloc((void **)&L->d_rcarr_c[0], (size_t)n * sizeof(RunConst)));
+                        HIPCHK_CTX(L, hipMalloc((void **)&L->d_rcarr_c[1], (size_t)n * sizeof(RunConst)));
+                        HIPCHK_CTX(L, hipMalloc((void **)&L->d_live_idx, (size_t)n * sizeof(uint32_t)));
+                        L->rcarr_c_cap = n;
+                    }
+                    HIPCHK_CTX(L, hipMemcpyAsync(L->d_live_idx, asking.data(), asking.size() * sizeof(uint32_t), hipMemcpyHostToDevice, L->stream));
+                    hipLaunchKernelGGL(k_rows_gather, dim3((unsigned)asking.size()), dim3(256), 0, L->stream, (const RunConst *)L->d_rcarr, (const uint32_t *)L->d_live_idx, L->d_rcarr_c[0]);
+                    L->launch_rcp = L->d_rcarr_c[0];
+                    L->launch_Q = (uint32_t)asking.size();
+                }
                 int r = L->kd_full_build(segs);
+                if (subset) {
+                    HIPCHK_CTX(L, hipStreamSynchronize(L->stream));        // (`asking` is the copy's source until it has run)
+                    L->launch_rcp = L->d_rcarr;
+                    L->launch_Q = n;
+                }
                 if (r) { L->set_err("porrt_grow_batch: kd structure after the steps"); return r; }
                 L->kd_built_after = 1;
+                if (host_dbg) fprintf(stderr, "[porrt] batch of %u: kd structure after the steps for %zu rows\n", n, asking.size());
                 hipLaunchKernelGGL(k_batch_gather, dim3(n), dim3(64), 0, L->stream, (const RunConst *)L->d_rcarr, sched ? steps : (uint32_t)((n_iter + K - 1) / K), L->d_batch_out);
                 HIPCHK_CTX(L, hipMemcpyAsync(h_out.data(), L->d_batch_out, (size_t)n * sizeof(BatchOut), hipMemcpyDeviceToHost, L->stream));
                 HIPCHK_CTX(L, hipStreamSynchronize(L->stream));

@@ -1,12 +1,26 @@
-#!/usr/bin/env python3
-"""developer probe: the TAMP-shaped row of bench.py at several (queries, K)"""
-import json, os, sys
+"""Developer probe: the bench's TAMP row alone -- n TAMP-shaped queries in one porrt_grow_batch (python tools/tamp_probe.py [n] [K] [reps] [opt=val ...])."""
+import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
+for p in (ROOT, os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
-import bench
-opts = [(a.split("=")[0], int(a.split("=")[1])) for a in sys.argv[1:] if "=" in a]
-for nq, K in [(int(a.split(":")[0]), int(a.split(":")[1])) for a in sys.argv[1:] if ":" in a] or [(1024, 128)]:
-    r = bench.tamp_queries(0, False, nq, K, opts)
-    print(nq, K, "ms %.1f" % r["ms_wall"], "queries/s %.0f" % r["queries_per_s"], "exp/s %.1fM" % (r["node_expansions_per_s"] / 1e6),
-          "mean its %.0f" % r["mean_iterations_per_query"], "solved", r["queries_solved"], "make ms %.0f" % r["ms_creating_the_contexts_once"], flush=True)
+import cases, po_rrt_amd
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+cs = cases.tamp_queries(n)
+engs = [cases.configure(po_rrt_amd.Engine(0), c) for c in cs]
+for e in engs:
+    for o in sys.argv[4:]:
+        k, v = o.split("=")
+        e.set_option(k, int(v))
+starts = [c.start for c in cs]
+for rep in range(reps):
+    for j, e in enumerate(engs):
+        e.set_sampler((-1.0, -1.0), (1.0, 1.0), 1000 * rep + j)
+    t0 = time.perf_counter()
+    po_rrt_amd.Engine.grow_batch(engs, starts, 0.1, 2.0, 2500, K, n_iter_max=10000)
+    dt = time.perf_counter() - t0
+    its = sum(e.num_iterations() for e in engs)
+    print("rep %d: %.2f ms, %.0f queries/s, %d iterations (max %d per query), %d nodes, kd built after the steps: %d, compactions %d" % (
+        rep, 1e3 * dt, n / dt, its, max(e.num_iterations() for e in engs), sum(e.num_nodes() - 1 for e in engs), engs[0].get_option("kd_built_after"),
+        engs[0].get_option("compactions")), flush=True)
