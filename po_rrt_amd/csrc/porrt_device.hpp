@@ -239,6 +239,7 @@ struct RunConst {
     int *loc_cur;               // per new node of the step: where k_kd_locate stopped (node, depth, G exit, flags)
     uint32_t *loc_dcur, *loc_gex, *loc_flags, *g_nd;
     double *g_nd_x, *g_nd_y;    // coordinates of the non-duplicate levels of G (contiguous, no indirection)
+    KdBox *g_nd_box;            // the goal point's cell after each of those levels (lazily tracked runs: g_track_step) -- nested, so the level a node leaves G at is a binary search
     int *g_id;                  // G[i] = node at depth i on the kd descent path of the goal point
     double *g_x, *g_y;          // its coordinates, contiguous (the path is scanned, not chased)
     uint32_t g_cap;
@@ -2034,6 +2035,20 @@ __device__ __forceinline__ void near_sample_lag(const RunConst &rc, uint32_t b, 
 }
 
 // X(b): workgroups [file(b)] [connect(b)] [search(b + 1)] [commit(cb): cnb samples, cb = b - 1 or none]
+// The cell of the goal point (px, py) after one more level of its path: the level's node (wx, wy) at depth `depth` sends it left or right
+// (nearest_neighbor.rs:32: `<` goes left, equal goes right), and a node follows the path through the level iff it lies on the same side.
+__device__ __forceinline__ KdBox g_box_after(const KdBox &prev, double wx, double wy, uint32_t depth, double px, double py) {
+    KdBox b = prev;
+    if (depth & 1u) { if (py < wy) b.hiy = wy < b.hiy ? wy : b.hiy; else b.loy = wy > b.loy ? wy : b.loy; }
+    else { if (px < wx) b.hix = wx < b.hix ? wx : b.hix; else b.lox = wx > b.lox ? wx : b.lox; }
+    return b;
+}
+__device__ __forceinline__ KdBox g_box_all() {
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    KdBox b;
+    b.lox = -INF; b.hix = INF; b.loy = -INF; b.hiy = INF;
+    return b;
+}
 __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords, uint8_t *lds);
 constexpr uint32_t kGTrackLds0 = 8192u + 512u + 272u + 192u * 20u, kGTrackLds = kGTrackLds0 + 256u * 16u + 160u * 16u;        // bytes of LDS g_track_step needs
 static_assert(kGTrackLds <= kFileLds, "g_track_step uses the filing scratch of k_step1_rrt");
@@ -2255,13 +2270,14 @@ __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32
 #else
 #define GT_MARK(slot) do {} while (0)
 #endif
-    constexpr uint32_t kNd = 192;                                            // non-duplicate levels staged in LDS (more: read from memory)
+    constexpr uint32_t kNd = 104;                                            // non-duplicate levels whose cells are staged in LDS (more: read from memory); 36 B each in the 192 x 20 B of the layout
     uint16_t *s_k = reinterpret_cast<uint16_t *>(lds);                       // [4096] sample of the t-th new node
     unsigned long long *s_cand = reinterpret_cast<unsigned long long *>(lds + 8192);      // [64] new nodes on G to its end
     uint32_t *s_wpre = reinterpret_cast<uint32_t *>(lds + 8192 + 512);       // [65] valid samples before each mask word
-    double *s_ndx = reinterpret_cast<double *>(lds + 8192 + 512 + 272);      // [kNd]
-    double *s_ndy = s_ndx + kNd;
-    uint32_t *s_ndi = reinterpret_cast<uint32_t *>(s_ndy + kNd);             // [kNd]
+    double *s_blx = reinterpret_cast<double *>(lds + 8192 + 512 + 272);      // [kNd] the goal point's cell after each level: lo x, hi x, lo y, hi y
+    double *s_bhx = s_blx + kNd, *s_bly = s_bhx + kNd, *s_bhy = s_bly + kNd;
+    uint32_t *s_ndi = reinterpret_cast<uint32_t *>(s_bhy + kNd);             // [kNd] the level's depth
+    static_assert(kNd * 36u <= 192u * 20u, "the staged levels' share of kGTrackLds0");
     constexpr uint32_t kApp = 256, kCand = 160;
     double *s_ax = reinterpret_cast<double *>(lds + kGTrackLds0), *s_ay = s_ax + kApp;      // the levels this step adds to G
     double *s_cx = s_ay + kApp, *s_cy = s_cx + kCand;                         // the nodes on G to its end, in id order
@@ -2278,7 +2294,8 @@ __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32
         if (tid == 63u) s_wpre[vwords] = inc;
     }
     for (uint32_t t2 = tid; t2 < n_nd && t2 < kNd; t2 += blockDim.x) {
-        s_ndi[t2] = as_global(rc.g_nd)[t2]; s_ndx[t2] = as_global(rc.g_nd_x)[t2]; s_ndy[t2] = as_global(rc.g_nd_y)[t2];
+        const KdBox bx = rc.g_nd_box[t2];
+        s_ndi[t2] = as_global(rc.g_nd)[t2]; s_blx[t2] = bx.lox; s_bhx[t2] = bx.hix; s_bly[t2] = bx.loy; s_bhy[t2] = bx.hiy;
     }
     __syncthreads();
     const uint32_t n_new = s_wpre[vwords];
@@ -2291,14 +2308,12 @@ __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32
     auto gex = as_global(rc.kd_gexit);
     const uint32_t qo = q_off(rc, b);
     GT_MARK(0);
-    // every new node against G as it stands before the step: four nodes per thread, their coordinates fetched together; the levels
-    // come through LDS kNd at a time (only this function adds levels in a lazily tracked run, one after the other: the list is in
-    // the order of the levels, and the first level a node fails is the one it leaves G at -- a random point fails one of the first
-    // few, a node by the goal point hundreds of levels later)
+    // every new node against G as it stands before the step: four nodes per thread, their coordinates fetched together.  A node follows G
+    // through a level iff it lies in the goal point's cell after that level, and the cells are nested: the first level it fails is found by
+    // bisection over the levels' cells (the first kNd of them in LDS) -- a node by the goal point used to walk a hundred levels one by one.
     for (uint32_t t0 = tid; t0 < ((n_new + blockDim.x - 1u) / blockDim.x) * blockDim.x; t0 += 4u * blockDim.x) {
         double cvx[4], cvy[4];
-        uint32_t cE[4];
-        bool open[4];
+        uint32_t cE[4], lo[4], hi[4];
 #pragma unroll
         for (uint32_t u = 0; u < 4u; ++u) {
             const uint32_t t = t0 + u * blockDim.x;
@@ -2306,29 +2321,30 @@ __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32
             cvx[u] = t < n_new ? as_global(rc.q_x)[qo + k] : 0.0;
             cvy[u] = t < n_new ? as_global(rc.q_y)[qo + k] : 0.0;
             cE[u] = 0xFFFFFFFFu;
-            open[u] = t < n_new && !(cvx[u] == px && cvy[u] == py);         // (a copy of the goal point passes every level)
+            const bool open = t < n_new && !(cvx[u] == px && cvy[u] == py);   // (a copy of the goal point passes every level)
+            lo[u] = 0u; hi[u] = open ? n_nd : 0u;                             // the first failed level lies in [lo, hi]; hi == n_nd: none fails
         }
-        for (uint32_t c0 = 0; c0 < n_nd; c0 += kNd) {
-            if (c0 != 0u || t0 != tid) {                                     // (the first chunk is staged above)
-                __syncthreads();
-                for (uint32_t t2 = tid; t2 < kNd && c0 + t2 < n_nd; t2 += blockDim.x) {
-                    s_ndi[t2] = as_global(rc.g_nd)[c0 + t2]; s_ndx[t2] = as_global(rc.g_nd_x)[c0 + t2]; s_ndy[t2] = as_global(rc.g_nd_y)[c0 + t2];
-                }
-                __syncthreads();
-            }
-            const uint32_t nl = n_nd - c0 < kNd ? n_nd - c0 : kNd;
-            bool any = false;
+        for (;;) {
+            bool more = false;
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) more = more || lo[u] < hi[u];
+            if (!more) break;
 #pragma unroll
             for (uint32_t u = 0; u < 4u; ++u) {
-                if (!open[u]) continue;
-                for (uint32_t s0 = 0; s0 < nl; ++s0) {
-                    const uint32_t ii = s_ndi[s0];
-                    const double wx = s_ndx[s0], wy = s_ndy[s0];
-                    if (kd_left(cvx[u], cvy[u], wx, wy, ii) != kd_left(px, py, wx, wy, ii)) { cE[u] = ii; open[u] = false; break; }
-                }
-                any = any || open[u];
+                if (lo[u] >= hi[u]) continue;
+                const uint32_t mid = (lo[u] + hi[u]) >> 1;
+                double blx, bhx, bly, bhy;
+                if (mid < kNd) { blx = s_blx[mid]; bhx = s_bhx[mid]; bly = s_bly[mid]; bhy = s_bhy[mid]; }
+                else { const KdBox bx = rc.g_nd_box[mid]; blx = bx.lox; bhx = bx.hix; bly = bx.loy; bhy = bx.hiy; }
+                const bool in = !(cvx[u] < blx) && cvx[u] < bhx && !(cvy[u] < bly) && cvy[u] < bhy;
+                if (in) lo[u] = mid + 1u; else hi[u] = mid;
             }
-            if (c0 + kNd < n_nd && !__syncthreads_or(any ? 1 : 0)) break;    // nobody is still on the path: the later levels are not needed
+        }
+        GT_MARK(4);
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t t = t0 + u * blockDim.x;
+            if (t < n_new && !(cvx[u] == px && cvy[u] == py) && lo[u] < n_nd) cE[u] = lo[u] < kNd ? s_ndi[lo[u]] : as_global(rc.g_nd)[lo[u]];
         }
 #pragma unroll
         for (uint32_t u = 0; u < 4u; ++u) {
@@ -2342,6 +2358,7 @@ __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32
         }
     }
     __syncthreads();
+    GT_MARK(5);
     // the coordinates of the nodes that stay on G to its end, in id order (the first kCand of them), for the wave below
     if (tid < 64u) {
         const uint32_t c = (uint32_t)__popcll(s_cand[tid]);
@@ -2364,6 +2381,7 @@ __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32
     // point -- nothing in the loop waits for memory.
     if (tid < 64u) {
         uint32_t len = glen0, nd_len = n_nd, fd0 = d0, fd1 = d1;
+        KdBox cell = n_nd ? rc.g_nd_box[n_nd - 1u] : g_box_all();  // the goal point's cell at the end of G
         auto gx = as_global(reinterpret_cast<unsigned long long *>(rc.g_x)), gy = as_global(reinterpret_cast<unsigned long long *>(rc.g_y));
         uint32_t c_at = 0;
         for (uint32_t w = 0; w < (n_new + 63u) / 64u; ++w) {
@@ -2409,6 +2427,8 @@ __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32
                         gex[N + t] = len | kOnG;
                         if (!(vx == px && vy == py)) {
                             as_global(rc.g_nd)[nd_len] = len; as_global(rc.g_nd_x)[nd_len] = vx; as_global(rc.g_nd_y)[nd_len] = vy;
+                            cell = g_box_after(cell, vx, vy, len, px, py);
+                            rc.g_nd_box[nd_len] = cell;
                         }
                     }
                 }
@@ -2442,7 +2462,7 @@ __global__ __launch_bounds__(256) void k_kd_reset(const RunConst *__restrict__ r
         rc.cnt->g_first_dup[0] = 0xFFFFFFFFu;
         rc.cnt->g_first_dup[1] = 0xFFFFFFFFu;
         if (x == rc.gp_x && y == rc.gp_y) { rc.cnt->g_first_dup[0] = 0; rc.cnt->g_nd_len = 0; }
-        else { rc.g_nd[0] = 0; rc.g_nd_x[0] = x; rc.g_nd_y[0] = y; rc.cnt->g_nd_len = 1; }
+        else { rc.g_nd[0] = 0; rc.g_nd_x[0] = x; rc.g_nd_y[0] = y; rc.g_nd_box[0] = g_box_after(g_box_all(), x, y, 0u, rc.gp_x, rc.gp_y); rc.cnt->g_nd_len = 1; }
         rc.kd_rec[0].child[0] = kEmpty; rc.kd_rec[0].child[1] = kEmpty;
         rc.cnt->kd_done = 1;
         rc.cnt->kd_snap = 0;

@@ -269,7 +269,7 @@ struct porrt_ctx {
     DevBuf<double> d_nx, d_ny, d_distA, d_distB, d_sx, d_sy, d_qx, d_qy, d_pgxy, d_pgd, d_candxy, d_candval, d_radT2, d_inj, d_ssx, d_ssy, d_bqx, d_bqy, d_t2at;
     DevBuf<int> d_parent, d_qnn, d_qvid, d_pgid, d_candid, d_gid, d_kdup;
     DevBuf<KdRec> d_kdrec;
-    DevBuf<KdBox> d_kdbox, d_locbox;
+    DevBuf<KdBox> d_kdbox, d_locbox, d_gndbox;
     DevBuf<KdMove> d_kdlosers;
     DevBuf<int> d_bcscratch;
     DevBuf<BestCost> d_bcout;
@@ -409,7 +409,7 @@ int porrt_ctx::layout_buffers() {
                               &d_kdrec, &d_gx, &d_gy, &d_rgdir, &d_rep, &d_kdbox, &d_locbox, &d_kdlosers, &d_gsnap, &d_pendoff, &d_pendn, &d_pendcur,
                               &d_pendnew, &d_pendpool, &d_kddepth, &d_kdgexit, &d_reachA, &d_reachB, &d_finalmask, &d_vid, &d_finalflag, &d_cls,
                               &d_nat, &d_sworld, &d_candcnt, &d_efrom, &d_eto, &d_etv, &d_rc, &d_jump, &d_loccur, &d_locdcur, &d_locgex, &d_locflags,
-                              &d_kdsurv, &d_gndx, &d_gndy, &d_kqx, &d_kqy, &d_kqvid, &d_bcscratch, &d_bcout, &d_bccursor, &d_perm, &d_pgd, &d_slotof, &d_ssx, &d_ssy, &d_bqx, &d_bqy, &d_t2at, &d_bqk, &d_rgocc, &d_sched_i0, &d_sched_nb};
+                              &d_kdsurv, &d_gndx, &d_gndy, &d_gndbox, &d_kqx, &d_kqy, &d_kqvid, &d_bcscratch, &d_bcout, &d_bccursor, &d_perm, &d_pgd, &d_slotof, &d_ssx, &d_ssy, &d_bqx, &d_bqy, &d_t2at, &d_bqk, &d_rgocc, &d_sched_i0, &d_sched_nb};
         for (DevBufBase *b2 : list) all_bufs.push_back(b2);
     }
     bool grow_needed = false;
@@ -437,7 +437,7 @@ int porrt_ctx::layout_buffers() {
     d_candid.p = (int *)d_candid.vp; d_gid.p = (int *)d_gid.vp; d_kdup.p = (int *)d_kdup.vp; d_kdrec.p = (KdRec *)d_kdrec.vp;
     d_gx.p = (double *)d_gx.vp; d_gy.p = (double *)d_gy.vp; d_rgcnt.p = (uint32_t *)d_rgcnt.vp; d_rgdir.p = (uint32_t *)d_rgdir.vp;
     d_rep.p = (int *)d_rep.vp;
-    d_kdbox.p = (KdBox *)d_kdbox.vp; d_locbox.p = (KdBox *)d_locbox.vp; d_kdlosers.p = (KdMove *)d_kdlosers.vp; d_bcscratch.p = (int *)d_bcscratch.vp; d_bcout.p = (BestCost *)d_bcout.vp; d_bccursor.p = (uint32_t *)d_bccursor.vp; d_kdhint.p = (unsigned long long *)d_kdhint.vp;
+    d_kdbox.p = (KdBox *)d_kdbox.vp; d_locbox.p = (KdBox *)d_locbox.vp; d_gndbox.p = (KdBox *)d_gndbox.vp; d_kdlosers.p = (KdMove *)d_kdlosers.vp; d_bcscratch.p = (int *)d_bcscratch.vp; d_bcout.p = (BestCost *)d_bcout.vp; d_bccursor.p = (uint32_t *)d_bccursor.vp; d_kdhint.p = (unsigned long long *)d_kdhint.vp;
     d_gsnap.p = (uint32_t *)d_gsnap.vp; d_pendoff.p = (uint32_t *)d_pendoff.vp; d_pendn.p = (uint32_t *)d_pendn.vp; d_pendcur.p = (uint32_t *)d_pendcur.vp;
     d_pendstate.p = (uint32_t *)d_pendstate.vp; d_pendnew.p = (int *)d_pendnew.vp; d_pendpool.p = (int *)d_pendpool.vp; d_kddepth.p = (uint32_t *)d_kddepth.vp; d_kdgexit.p = (uint32_t *)d_kdgexit.vp;
     d_reachA.p = (unsigned long long *)d_reachA.vp; d_reachB.p = (unsigned long long *)d_reachB.vp;
@@ -632,7 +632,7 @@ __global__ void k_init_root(const RunConst *__restrict__ rcp, double x, double y
     rc.cnt->g_first_dup[0] = 0xFFFFFFFFu;
     rc.cnt->g_first_dup[1] = 0xFFFFFFFFu;
     if (x == rc.gp_x && y == rc.gp_y) { rc.cnt->g_first_dup[0] = 0; rc.cnt->g_nd_len = 0; }
-    else { rc.g_nd[0] = 0; rc.g_nd_x[0] = x; rc.g_nd_y[0] = y; rc.cnt->g_nd_len = 1; }
+    else { rc.g_nd[0] = 0; rc.g_nd_x[0] = x; rc.g_nd_y[0] = y; rc.g_nd_box[0] = g_box_after(g_box_all(), x, y, 0u, rc.gp_x, rc.gp_y); rc.cnt->g_nd_len = 1; }
     KdRec rec;
     rec.x = x; rec.y = y; rec.child[0] = kEmpty; rec.child[1] = kEmpty;
     rc.kd_rec[0] = rec;
@@ -1052,7 +1052,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
         HIPCHK(d_candcnt.reserve(3 * (size_t)K)); HIPCHK(d_kdbox.reserve(Nmax)); HIPCHK(d_kdlosers.reserve(kClaimMax)); HIPCHK(d_bcscratch.reserve(8 * Nmax + 4096)); HIPCHK(d_bcout.reserve(1)); HIPCHK(d_bccursor.reserve(1)); HIPCHK(d_locbox.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_kdhint.reserve((size_t)kHG * kHG));
         HIPCHK(d_loccur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locdcur.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locgex.reserve(2 * (8 * (size_t)K + 4096))); HIPCHK(d_locflags.reserve(2 * (8 * (size_t)K + 4096)));
         HIPCHK(d_gsnap.reserve((steps_max + 4) * 4)); HIPCHK(d_pendoff.reserve(pend_cap)); HIPCHK(d_pendn.reserve(pend_cap)); HIPCHK(d_pendcur.reserve(pend_cap));
-        HIPCHK(d_pendstate.reserve(pend_cap)); HIPCHK(d_pendnew.reserve(pend_cap)); HIPCHK(d_pendpool.reserve(pool_cap)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_gndx.reserve(Nmax)); HIPCHK(d_gndy.reserve(Nmax));
+        HIPCHK(d_pendstate.reserve(pend_cap)); HIPCHK(d_pendnew.reserve(pend_cap)); HIPCHK(d_pendpool.reserve(pool_cap)); HIPCHK(d_kdsurv.reserve(Nmax)); HIPCHK(d_gndx.reserve(Nmax)); HIPCHK(d_gndy.reserve(Nmax)); HIPCHK(d_gndbox.reserve(Nmax));
         HIPCHK(d_kqx.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kqy.reserve((steps_max + 2) * Kpad)); HIPCHK(d_kqvid.reserve((steps_max + 2) * Kpad)); { const size_t np = (opt_pipeline == 4 && stage != 1 && K <= 1024) ? 3u : 2u; HIPCHK(d_candid.reserve(np * (size_t)K * cand_cap)); HIPCHK(d_candxy.reserve(2 * np * (size_t)K * cand_cap)); HIPCHK(d_candval.reserve((np == 3u ? 3u : 1u) * (size_t)K * cand_cap)); }
         HIPCHK(d_gid.reserve(Nmax));
         HIPCHK(d_perm.reserve((steps_max + 2) * Kpad)); HIPCHK(d_ssx.reserve((steps_max + 2) * Kpad)); HIPCHK(d_ssy.reserve((steps_max + 2) * Kpad));
@@ -1091,7 +1091,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     c.q_x = d_qx.p; c.q_y = d_qy.p; c.q_nn = d_qnn.p; c.q_vid = d_qvid.p;
     c.rg_cnt = d_rgcnt.p; c.rg_occ = d_rgocc.p; c.rg_dir = d_rgdir.p; c.pg_xy = d_pgxy.p; c.pg_id = d_pgid.p; c.pg_d = d_pgd.p; c.slot_of = d_slotof.p;
     c.rg_maxp = (uint32_t)(Nmax / kPage + 2); c.pg_cap = (uint32_t)(2ull * kRegions + Nmax / kPage + 8);
-    c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p; c.kd_box = d_kdbox.p; c.loc_box = d_locbox.p; c.kd_losers = d_kdlosers.p; c.bc_scratch = d_bcscratch.p; c.bc_cap = (uint32_t)std::min<size_t>(d_bcscratch.n, 0xFFFFFFFFu); c.bc_cursor = d_bccursor.p; c.bc_out = d_bcout.p; c.kd_hint = d_kdhint.p; c.g_snap = d_gsnap.p; c.loc_stride = 8 * K + 4096;
+    c.loc_cur = d_loccur.p; c.loc_dcur = d_locdcur.p; c.loc_gex = d_locgex.p; c.loc_flags = d_locflags.p; c.g_nd = d_kdsurv.p; c.g_nd_x = d_gndx.p; c.g_nd_y = d_gndy.p; c.g_nd_box = d_gndbox.p; c.kq_x = d_kqx.p; c.kq_y = d_kqy.p; c.kq_vid = d_kqvid.p; c.kd_box = d_kdbox.p; c.loc_box = d_locbox.p; c.kd_losers = d_kdlosers.p; c.bc_scratch = d_bcscratch.p; c.bc_cap = (uint32_t)std::min<size_t>(d_bcscratch.n, 0xFFFFFFFFu); c.bc_cursor = d_bccursor.p; c.bc_out = d_bcout.p; c.kd_hint = d_kdhint.p; c.g_snap = d_gsnap.p; c.loc_stride = 8 * K + 4096;
     c.pend_new = d_pendnew.p; c.pend_pool = d_pendpool.p; c.pend_off = d_pendoff.p; c.pend_n = d_pendn.p; c.pend_cur = d_pendcur.p; c.pend_state = d_pendstate.p;
     c.pend_cap = (uint32_t)std::min<uint64_t>(pend_cap, 0xFFFFFFFFull); c.pool_cap = (uint32_t)std::min<uint64_t>(pool_cap, 0xFFFFFFFFull);
     c.cand_K = K; c.cand_cnt = d_candcnt.p; c.cand_id = d_candid.p; c.cand_xy = d_candxy.p; c.cand_val = d_candval.p; c.cand_cap = cand_cap;
