@@ -266,10 +266,10 @@ int porrt_get_metrics(const porrt_ctx *ctx, porrt_metrics *out);
  * 4 (default) = ONE launch per step: the filing of a step's nodes and its rewire commit run beside the next step's kernels
  * (batch_K <= 1024, else as 1); 2 = all steps in one persistent cooperative launch with barriers over the grid (measured: far
  * slower on eight XCDs, kept for the record), "kd_after" (1 = the tie-order structure is built after the last step instead of
- * beside the steps: measured slower), "kd_lazy" (RRT* with the group kernels, i.e. batches: 1 (default) = beside the steps only the
- * goal path of the reference's kd-tree is kept -- it orders every tie between copies of the goal point and their parent -- and the
- * whole structure is built after the steps in the rare run where two other nodes tie; 0 = the whole structure beside the steps on
- * a second stream, as a single query does), "kd_claim_threads", "kd_ride", "kd_inline", "early_wave_steps", "dp_sweeps", "compact_rows" (1, default: a
+ * beside the steps: measured slower), "kd_lazy" (RRT*, batches and the default form of a single query: 1 (default; 2 is accepted and means the same) =
+ * beside the steps only the goal path of the reference's kd-tree is kept -- it orders every tie between copies of the goal point and
+ * their parent -- and the whole structure is built after the steps in the rare run where two other nodes tie; 0 = the whole structure
+ * beside the steps on a second stream), "kd_claim_threads", "kd_ride", "kd_inline", "early_wave_steps", "dp_sweeps", "compact_rows" (1, default: a
  * porrt_grow_batch whose members end at different steps launches its later steps on the members that still have work), "box_table"
  * (1, default: the group and roadmap kernels answer "is this segment free" from a summed-area table of the raster when the bounding
  * box of its end pixels holds free pixels only, and walk it otherwise; 0 = always walk).  None of them changes a result. */

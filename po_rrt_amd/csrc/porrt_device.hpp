@@ -2050,7 +2050,8 @@ __device__ __forceinline__ KdBox g_box_all() {
     return b;
 }
 __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords, uint8_t *lds);
-constexpr uint32_t kGTrackLds0 = 8192u + 512u + 272u + 192u * 20u, kGTrackLds = kGTrackLds0 + 256u * 16u + 160u * 16u;        // bytes of LDS g_track_step needs
+constexpr uint32_t kGTrackNd = 168u;                                         // levels of the goal path whose cells g_track_step stages in LDS (36 B each)
+constexpr uint32_t kGTrackLds0 = 8192u + 512u + 272u + kGTrackNd * 36u, kGTrackLds = kGTrackLds0 + 256u * 16u + 160u * 16u;        // bytes of LDS g_track_step needs
 static_assert(kGTrackLds <= kFileLds, "g_track_step uses the filing scratch of k_step1_rrt");
 template <bool LDSGRID>
 __global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_step1_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
@@ -2270,14 +2271,13 @@ __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32
 #else
 #define GT_MARK(slot) do {} while (0)
 #endif
-    constexpr uint32_t kNd = 104;                                            // non-duplicate levels whose cells are staged in LDS (more: read from memory); 36 B each in the 192 x 20 B of the layout
+    constexpr uint32_t kNd = kGTrackNd;                                      // non-duplicate levels whose cells are staged in LDS (more: read from memory -- a trip per probe)
     uint16_t *s_k = reinterpret_cast<uint16_t *>(lds);                       // [4096] sample of the t-th new node
     unsigned long long *s_cand = reinterpret_cast<unsigned long long *>(lds + 8192);      // [64] new nodes on G to its end
     uint32_t *s_wpre = reinterpret_cast<uint32_t *>(lds + 8192 + 512);       // [65] valid samples before each mask word
     double *s_blx = reinterpret_cast<double *>(lds + 8192 + 512 + 272);      // [kNd] the goal point's cell after each level: lo x, hi x, lo y, hi y
     double *s_bhx = s_blx + kNd, *s_bly = s_bhx + kNd, *s_bhy = s_bly + kNd;
     uint32_t *s_ndi = reinterpret_cast<uint32_t *>(s_bhy + kNd);             // [kNd] the level's depth
-    static_assert(kNd * 36u <= 192u * 20u, "the staged levels' share of kGTrackLds0");
     constexpr uint32_t kApp = 256, kCand = 160;
     double *s_ax = reinterpret_cast<double *>(lds + kGTrackLds0), *s_ay = s_ax + kApp;      // the levels this step adds to G
     double *s_cx = s_ay + kApp, *s_cy = s_cx + kCand;                         // the nodes on G to its end, in id order

@@ -212,7 +212,7 @@ struct porrt_ctx {
     bool opt_kd_after = false;
     int opt_kd_inline = 0;                 // "kd_inline": 1 = the kd groups run on the main stream between the steps (no side stream, no events): a sub-batch
                                            // needs one hardware queue instead of two, so four sub-batches fit the four queues
-    int opt_kd_lazy = 1;                   // "kd_lazy": 1 (default) = with the group kernels only the goal path of the kd order is kept beside the steps
+    int opt_kd_lazy = 1;                   // "kd_lazy": 1 (default; 2 means the same) = with the group kernels and in a single query's one-kernel-per-step form only the goal path of the kd order is kept beside the steps
                                            // (g_track_step) and the whole structure is built after them if a tie needs it; 0 = built beside the steps
     int kd_built_after = 0;
     bool kd_lazy = false, kd_build_now = false;    // in force for the running grow; the build after the steps is being launched
@@ -1307,9 +1307,10 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     launch_rcp = d_rc.p;
     launch_Q = 1;
     opt_group = opt_group_req < 0 ? 0u : (uint32_t)opt_group_req;
-    // (a single query's one-kernel-per-step form can carry the goal path's workgroup too -- opt_kd_lazy == 2 -- but there the workgroup is
-    // the longest of the step's kernel: measured 62 against 33 us per step)
-    kd_lazy = opt_kd_lazy && (opt_group != 0 || (lag_on && opt_kd_lazy == 2)) && mode == PORRT_MODE_RRT && !opt_kd_after;
+    // (a single query's one-kernel-per-step form carries the goal path's workgroup too: since the workgroup finds a node's exit level by
+    // bisection it is no longer than the step's other workgroups, and the side chain's kernels are not launched at all -- 4.23 against
+    // 4.59 ms per query)
+    kd_lazy = opt_kd_lazy && (opt_group != 0 || lag_on) && mode == PORRT_MODE_RRT && !opt_kd_after;
     kd_built_after = 0;
     if ((c.kd_lazy != 0u) != kd_lazy) {          // (the run constants were uploaded above)
         c.kd_lazy = kd_lazy ? 1u : 0u;

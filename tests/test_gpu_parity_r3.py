@@ -343,8 +343,8 @@ def test_single_query_launch_forms_agree(eng_mod, pipeline):
                          ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
 def test_engine_options_do_not_change_results(eng_mod, opts):
     """the developer options measured in DESIGN.md section 8 (the whole kd structure beside the steps instead of the goal path alone
-    -- kd_lazy = 0, with its variants: after the steps, hints riding in the locate kernel, group sizes, claim workgroup sizes -- the goal
-    path's workgroup in a single query's step kernel -- kd_lazy = 2 --, the first steps' connect pass with one wave per sample): same
+    -- kd_lazy = 0, with its variants: after the steps, hints riding in the locate kernel, group sizes, claim workgroup sizes; kd_lazy = 2, the
+    old name of what is now a single query's default too: the goal path's workgroup in its step kernel --, the first steps' connect pass with one wave per sample): same
     trees from a batch of nine and from a single query"""
     cs = [cases.cfg2(12000, seed=30 + s) for s in range(9)]
     engs = [cases.configure(eng_mod.Engine(), c) for c in cs]
@@ -358,7 +358,7 @@ def test_engine_options_do_not_change_results(eng_mod, opts):
     assert engs[0].get_option("launch_mode") == 0 and engs[0].get_option("group_lanes") == 16
     assert engs[0].get_option("kd_lazy") == (0 if opts.get("kd_lazy", 1) == 0 else 1)
     e, _ = run_gpu(eng_mod, cs[1], 1024, **opts)
-    assert e.get_option("kd_lazy") == (1 if opts.get("kd_lazy", 1) == 2 else 0)
+    assert e.get_option("kd_lazy") == (0 if opts.get("kd_lazy", 1) == 0 else 1)      # (a single query tracks the goal path in its step kernel by default since round 4)
     o, _ = run_orc(cs[1], 1024)
     assert_same(e, o)
     assert e.get_option("pipeline") == 4
@@ -412,6 +412,14 @@ def test_goal_path_tie_order_and_the_build_after_the_steps(eng_mod):
         cases.grow(e0, case, K=K)
         assert e0.get_option("kd_lazy") == 0 and e0.get_option("kd_built_after") == 0
         assert_same(e0, o)
+        # the default form of a single query (one kernel per step, the goal path's workgroup riding in it -- round 4): the same ties, the
+        # same build after the steps, the same tree; twice on one context (the second run starts from the first one's state)
+        e1 = cases.configure(eng_mod.Engine(), case)
+        for _ in range(2):
+            e1.set_samples(xy)
+            cases.grow(e1, case, K=K)
+            assert e1.get_option("group_lanes") == 0 and e1.get_option("kd_lazy") == 1 and e1.get_option("kd_built_after") == 1
+            assert_same(e1, o)
     # (b) a batch of eight, duplicates in three of them
     sets = [_dup_samples(n, 20 + j) if j % 3 == 0 else None for j in range(8)]
     engs, orcs = [], []
