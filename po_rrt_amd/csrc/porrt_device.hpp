@@ -2049,12 +2049,20 @@ __device__ __forceinline__ KdBox g_box_all() {
     b.lox = -INF; b.hix = INF; b.loy = -INF; b.hiy = INF;
     return b;
 }
-__device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords, uint8_t *lds);
+// (TAG: a copy of the function per kind of caller -- a function called from a kernel is compiled to the register budget that kernel ASKS for,
+// and the single query's step kernels ask for eight waves per SIMD: 0 = those, 1 = the kernels that leave it 128 registers)
+template <int TAG> __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords, uint8_t *lds);
 constexpr uint32_t kGTrackNd = 168u;                                         // levels of the goal path whose cells g_track_step stages in LDS (36 B each)
 constexpr uint32_t kGTrackLds0 = 8192u + 512u + 272u + kGTrackNd * 36u, kGTrackLds = kGTrackLds0 + 256u * 16u + 160u * 16u;        // bytes of LDS g_track_step needs
 static_assert(kGTrackLds <= kFileLds, "g_track_step uses the filing scratch of k_step1_rrt");
+// (what k_step1_rrt asks for: the kernel itself never fitted the 64 registers of eight waves per SIMD -- it takes 83 -- but a function it calls
+// is compiled to the budget it ASKS for, and the goal path's workgroup spilled in 64; at five waves the function gets 88 registers and a
+// single query takes 3.94 instead of 4.23 ms)
+#ifndef PORRT_STEP1_WAVES
+#define PORRT_STEP1_WAVES 5
+#endif
 template <bool LDSGRID>
-__global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_step1_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
+__global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per_eu(PORRT_STEP1_WAVES, 8))) void k_step1_rrt(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb,
                                                                    uint32_t i0_next, uint32_t nb_next, uint32_t vwords, uint32_t cb, uint32_t cnb, uint32_t lazy) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_tiles[];
     __shared__ double s_d[kConnectWaves];
@@ -2069,7 +2077,7 @@ __global__ __launch_bounds__(kConnectWaves * 64) __attribute__((amdgpu_waves_per
     if (bx == 0) { file_step_fast<kConnectWaves * 64u>(rc, b, nb, vwords, s_ins); return; }
     bx -= 1u;
     if (lazy) {                                  // the goal path of the kd order (kd_lazy): one workgroup, like the filing
-        if (bx == 0) { g_track_step(rc, b, nb, vwords, s_ins); return; }
+        if (bx == 0) { g_track_step<0>(rc, b, nb, vwords, s_ins); return; }
         bx -= 1u;
     }
     if (bx < cblocks) { connect_block<LDSGRID>(rc, b, nb, vwords, bx, lds_tiles, s_d, s_i, s_heavy, b & 1u); return; }
@@ -2264,7 +2272,7 @@ __global__ __launch_bounds__(256) void k_commit_rrt(const RunConst *__restrict__
 // then builds the whole structure after the steps, as with option kd_after, and k_tie_fix settles those records.  Equal costs
 // through different parents off G take coordinates made to collide; the copies of the goal point, the ties of every run that
 // reaches its goal, are all on G.
-__device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords, uint8_t *lds) {
+template <int TAG> __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32_t vwords, uint8_t *lds) {
 #ifdef PORRT_GTRACK_TIMING
     const unsigned long long gt0 = wall_clock64();
 #define GT_MARK(slot) do { if (threadIdx.x == 0) { atomicAdd(&rc.cnt->tim[slot], wall_clock64() - gt0); atomicAdd(&rc.cnt->tim[(slot) + 8], 1ull); } } while (0)
@@ -2450,6 +2458,16 @@ __device__ void g_track_step(const RunConst &rc, uint32_t b, uint32_t nb, uint32
         }
         GT_MARK(3);
     }
+}
+
+// The goal path's workgroup as a kernel of its own: a single query launches it on its side stream beside the step kernel (step b's new
+// nodes are known since the step kernel before; the step kernel after waits for it), one workgroup per row.
+__global__ __launch_bounds__(256) void k_gtrack(const RunConst *__restrict__ rcp, uint32_t b, uint32_t nb, uint32_t vwords) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_lds[kGTrackLds];
+    const RunConst &rc = rcp[blockIdx.y];
+    nb = row_nb(rc, b, nb);
+    if (nb == 0) return;
+    g_track_step<1>(rc, b, nb, vwords, s_lds);
 }
 
 // the kd state of a grow's start (k_init_root), for the full build after lazily tracked steps; grid (64, rows) x 256

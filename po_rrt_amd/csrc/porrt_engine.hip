@@ -261,6 +261,9 @@ struct porrt_ctx {
                                                    // on measured streams, -G sequences on the contexts' own streams (the stream probe found no set: e.g. under a profiler)
     uint32_t sub_streams_tried = 0;                 // a probe for this many streams already failed: not repeated call after call
     std::vector<hipStream_t> sub_streams;          // first context of such a call: the sub-batches' main streams (see porrt_grow_batch)
+    bool opt_gtrack_side = false;          // "gtrack_side": 1 = a single query's goal-path workgroup as a kernel of its own on the side stream, beside the step kernel (measured slower: 4.59 against 4.24 ms -- a cross-stream dependency per step); 0 (default) = a workgroup of the step kernel
+    bool gt_pend = false;                  //   a k_gtrack is in flight on the side stream (its event: ev_kd[gt_par])
+    uint32_t gt_par = 0;
     bool opt_box_table = true;             // "box_table": a segment whose end pixels' bounding box is all free is not walked (summed-area table; 0 = always walk)
     bool opt_dp_sweeps = false;            // "dp_sweeps": expected costs by whole-graph sweeps instead of layer by layer
     uint32_t opt_cand_cap = 2048;
@@ -680,7 +683,18 @@ void porrt_ctx::launch_step(uint32_t b, uint32_t i0, uint32_t nb, uint32_t vword
         ev();
         const uint32_t cb4 = (nb + kConnectWaves - 1) / kConnectWaves;
         const uint32_t cnb = commit_pend_b != 0xFFFFFFFFu ? commit_pend_nb : 0u;
-        const uint32_t lazy = kd_lazy ? 1u : 0u;
+        const bool gt_side = kd_lazy && opt_gtrack_side && !prof;
+        if (gt_side) {
+            // the goal path of step b's new nodes beside X(b): it needs what the kernel before X(b) left (recorded just above), and X(b) --
+            // whose connect pass reads the exit levels of the nodes before step b -- needs the goal path of step b - 1
+            if (gt_pend) (void)hipStreamWaitEvent(stream, ev_kd[gt_par], 0);
+            (void)hipStreamWaitEvent(stream2, ev_steered, 0);
+            hipLaunchKernelGGL(k_gtrack, dim3(1, Q), dim3(256), 0, stream2, rcp, b, nb, vwords);
+            gt_par ^= 1u;
+            (void)hipEventRecord(ev_kd[gt_par], stream2);
+            gt_pend = true;
+        }
+        const uint32_t lazy = (kd_lazy && !gt_side) ? 1u : 0u;
         const dim3 xg(cb4 + (nxt_nb + 3) / 4 + 1 + lazy + (cnb + 3) / 4, Q);
         if (lds_bytes) hipLaunchKernelGGL(k_step1_rrt<true>, xg, dim3(256), lds_bytes, stream, rcp, b, nb, nxt_i0, nxt_nb, vwords, commit_pend_b, cnb, lazy);
         else hipLaunchKernelGGL(k_step1_rrt<false>, xg, dim3(256), 0, stream, rcp, b, nb, nxt_i0, nxt_nb, vwords, commit_pend_b, cnb, lazy);
@@ -923,7 +937,11 @@ int porrt_ctx::launch_coop(uint32_t n_steps, uint32_t K, uint64_t n_iter, uint32
 void porrt_ctx::join_side() {
     flush_commit();
     if (!side_active) return;
-    if (kd_lazy && !kd_build_now) { side_active = false; return; }        // (the goal path rode in the step kernels; nothing runs beside them)
+    if (kd_lazy && !kd_build_now) {        // (the goal path rode in the step kernels, or beside them in kernels of its own: the last of those is waited for)
+        if (gt_pend) { (void)hipStreamWaitEvent(stream, ev_kd[gt_par], 0); gt_pend = false; }
+        side_active = false;
+        return;
+    }
     if (opt_kd_after || kd_build_now) {
         // the whole structure now, on the main stream: groups of as many steps as the claim kernel holds, in id order
         const RunConst *rcp = launch_rcp;
@@ -1312,6 +1330,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     // 4.59 ms per query)
     kd_lazy = opt_kd_lazy && (opt_group != 0 || lag_on) && mode == PORRT_MODE_RRT && !opt_kd_after;
     kd_built_after = 0;
+    gt_pend = false; gt_par = 0;
     if ((c.kd_lazy != 0u) != kd_lazy) {          // (the run constants were uploaded above)
         c.kd_lazy = kd_lazy ? 1u : 0u;
         HIPCHK(hipMemcpyAsync(d_rc.p, &c, sizeof c, hipMemcpyHostToDevice, stream));
@@ -1336,7 +1355,7 @@ int porrt_ctx::grow_once(const double start[2], double max_step, double search_r
     } else if (opt_graph && !prof && n_iter_min > 0) {
         // all steps up to n_iter_min as one hipGraph (two branches: main pipeline + kd insertion); the graph
         // only depends on the launch geometry, so it is instantiated once and replayed by later grows
-        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)launch_rcp, kd_group | ((uint64_t)opt_early_wave << 8) | ((uint64_t)launch_Q << 32) | ((uint64_t)opt_group << 48) | ((uint64_t)pipe_on << 56) | ((uint64_t)lag_on << 57)};
+        const uint64_t key[6] = {(uint64_t)mode, K, n_iter_min, lds_bytes, (uint64_t)(uintptr_t)launch_rcp, kd_group | ((uint64_t)opt_early_wave << 8) | ((uint64_t)launch_Q << 32) | ((uint64_t)opt_group << 48) | ((uint64_t)pipe_on << 56) | ((uint64_t)lag_on << 57) | ((uint64_t)kd_lazy << 58) | ((uint64_t)(kd_lazy && opt_gtrack_side) << 59)};
         if (!graph_exec || memcmp(key, graph_key, sizeof key)) {
             double t0 = now_s();
             if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -3546,6 +3565,7 @@ int porrt_set_option(porrt_ctx *c, const char *name, int64_t value) {
     else if (!strcmp(name, "group_lanes")) { if (value != -1 && value != 0 && value != 16 && value != 32 && value != 64) { c->set_err("group_lanes: -1 (auto), 0, 16, 32 or 64"); return PORRT_ERR_INVALID; } c->opt_group_req = (int)value; }
     else if (!strcmp(name, "dp_sweeps")) c->opt_dp_sweeps = value != 0;
     else if (!strcmp(name, "box_table")) { c->opt_box_table = value != 0; c->cls_dirty = true; }
+    else if (!strcmp(name, "gtrack_side")) c->opt_gtrack_side = value != 0;
     else if (!strcmp(name, "pipeline")) {
 #ifndef PORRT_DEV_NONCOOP
         // 3 = the persistent step loop launched WITHOUT the co-residency guarantee of a cooperative launch (its barriers then rest on

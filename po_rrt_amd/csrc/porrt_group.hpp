@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PORRT_CONN2
     nb = row_nb(rc, b, nb);
     if (nb == 0) return;                        // (a row that has stopped, or does not run this step)
     if (role == 0) { insert_step_pages(rc, b, nb, vwords, lds_dyn); return; }    // the page-filing workgroup
-    if (lazy && role == 2u) { g_track_step(rc, b, nb, vwords, lds_dyn); return; }
+    if (lazy && role == 2u) { g_track_step<1>(rc, b, nb, vwords, lds_dyn); return; }
     const uint32_t lane = threadIdx.x & 63u, si = threadIdx.x / GL;
     const uint32_t slot = bx * SPB + si;
     // first round trip: everything that depends on nothing
