@@ -270,7 +270,8 @@ int porrt_get_metrics(const porrt_ctx *ctx, porrt_metrics *out);
  * beside the steps only the goal path of the reference's kd-tree is kept -- it orders every tie between copies of the goal point and
  * their parent -- and the whole structure is built after the steps in the rare run where two other nodes tie; 0 = the whole structure
  * beside the steps on a second stream), "kd_claim_threads", "kd_ride", "kd_inline", "early_wave_steps", "dp_sweeps", "compact_rows" (1, default: a
- * porrt_grow_batch whose members end at different steps launches its later steps on the members that still have work), "box_table"
+ * porrt_grow_batch whose members end at different steps launches its later steps on the members that still have work), "gtrack_side" (1 = a single query's goal-path workgroup as a kernel
+ * of its own on the side stream; measured slower, 0 is the default: a workgroup of the step kernel), "box_table"
  * (1, default: the group and roadmap kernels answer "is this segment free" from a summed-area table of the raster when the bounding
  * box of its end pixels holds free pixels only, and walk it otherwise; 0 = always walk).  None of them changes a result. */
 int porrt_set_option(porrt_ctx *ctx, const char *name, int64_t value);
