@@ -339,7 +339,7 @@ def test_single_query_launch_forms_agree(eng_mod, pipeline):
 
 @pytest.mark.parametrize("opts", [dict(kd_lazy=0), dict(kd_lazy=2), dict(kd_lazy=0, kd_after=1), dict(kd_lazy=0, kd_ride=1), dict(kd_lazy=0, kd_inline=1),
                                   dict(early_wave_steps=5), dict(kd_lazy=0, kd_group=1), dict(kd_lazy=0, kd_group=4), dict(kd_lazy=0, kd_claim_threads=1024),
-                                  dict(box_table=0)],
+                                  dict(box_table=0), dict(gtrack_side=1)],
                          ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
 def test_engine_options_do_not_change_results(eng_mod, opts):
     """the developer options measured in DESIGN.md section 8 (the whole kd structure beside the steps instead of the goal path alone
@@ -384,6 +384,51 @@ def _dup_samples(n, seed):
     xy = np.stack([rng.uniform(-0.02, 0.02, n), rng.uniform(-0.92, -0.88, n)], axis=1)
     xy[::3] = xy[(np.arange(0, n, 3) // 7) * 2 + 1]          # exact duplicates of other samples: equal-cost parents off the goal path
     return xy
+
+
+def test_goal_path_longer_than_its_table(eng_mod):
+    """The goal path's workgroup finds the level a new node leaves the path at by bisection over the goal point's nested cells, the first 168 of
+    them in LDS, the rest in memory.  Samples marching up a diagonal towards the goal point each land in its cell and extend the path: 300
+    levels that are no copies of the goal point.  Exact duplicates of nodes along the path (they leave it one level below their original) and
+    points beside them (tied between the two) then ask for exit levels on both sides of the table's end.  Against the oracle: a single query
+    step by step (K = 1), in steps of 8, and a batch of nine through the group kernels."""
+    W = 200
+    occ = np.full((W, W), 255, np.uint8)
+    gp = np.array([0.2, -0.3])
+    d = 0.4 * 0.985 ** np.arange(300)
+    # (from above and right of the goal point: a node there stays on the path through the goal point's copies as well -- equal goes right --
+    # which the goal-biased iterations add from the hundredth iteration on)
+    chain = gp[None, :] + d[:, None] * np.array([1.0, 1.0])[None, :]
+    extra = []
+    for i in range(5, 300, 9):
+        extra.append(chain[i])                                   # a copy of a node of the path
+        extra.append(chain[i] + np.array([0.004, -0.003]))       # beside both: a tie between the node and its copy
+        extra.append(chain[i] + np.array([0.004, -0.003]))       # ... and once more, tied with the point before as well
+    rng = np.random.default_rng(3)
+    fill = np.stack([rng.uniform(0.15, 0.7, 400), rng.uniform(-0.35, 0.2, 400)], axis=1)
+    xy = np.concatenate([chain[1:], np.array(extra), fill])
+    n = len(xy)
+    n_iter = n - n // 100 - 5
+    def make(x, seed):
+        x.set_grid(occ, (-1.0, -1.0), (1.0, 1.0), cases.SHELF)
+        x.set_sampler((-1.0, -1.0), (1.0, 1.0), seed)
+        x.set_square_goal(np.array([gp]), np.array([1], dtype=np.uint64), 0.05)
+        x.set_samples(xy)
+        return x
+    start = tuple(chain[0])
+    for K in (1, 8):
+        e, o = make(eng_mod.Engine(), 5), make(orc.Oracle(), 5)
+        e.grow(start, 0.1, 2.0, n_iter, n_iter, batch_K=K, mode=cases.RRT)
+        o.grow(start, 0.1, 2.0, n_iter, n_iter, batch_K=K, mode=cases.RRT, algo=orc.ALGO_BATCHED_KD)
+        assert_same(e, o)
+        assert e.get_option("kd_lazy") == 1
+    engs = [make(eng_mod.Engine(), 5 + s) for s in range(9)]
+    eng_mod.Engine.grow_batch(engs, [start] * 9, 0.1, 2.0, n_iter, 8)
+    o = make(orc.Oracle(), 5)
+    o.grow(start, 0.1, 2.0, n_iter, n_iter, batch_K=8, mode=cases.RRT, algo=orc.ALGO_BATCHED_KD)
+    assert engs[0].get_option("kd_lazy") == 1                      # (what was in force for a batch: its first context says)
+    for e in engs[::4]:
+        assert_same(e, o)
 
 
 def test_goal_path_tie_order_and_the_build_after_the_steps(eng_mod):
