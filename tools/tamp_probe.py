@@ -1,16 +1,20 @@
-"""Developer probe: the bench's TAMP row alone -- n TAMP-shaped queries in one porrt_grow_batch (python tools/tamp_probe.py [n] [K] [reps] [opt=val ...])."""
+"""Developer probe: the bench's TAMP row alone -- n TAMP-shaped queries in one porrt_grow_batch (python tools/tamp_probe.py [n] [K] [reps] [opt=val ...], or n:K)."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import cases, po_rrt_amd
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-K = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-reps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+args = sys.argv[1:]
+if args and ":" in args[0]:                      # (the older form: Q:K)
+    q, k = args[0].split(":")
+    args = [q, k] + args[1:]
+n = int(args[0]) if len(args) > 0 else 1024
+K = int(args[1]) if len(args) > 1 else 128
+reps = int(args[2]) if len(args) > 2 else 4
 cs = cases.tamp_queries(n)
 engs = [cases.configure(po_rrt_amd.Engine(0), c) for c in cs]
 for e in engs:
-    for o in sys.argv[4:]:
+    for o in args[3:]:
         k, v = o.split("=")
         e.set_option(k, int(v))
 starts = [c.start for c in cs]
