@@ -553,7 +553,7 @@ static int dp_run_layered(DpState &st, BeliefGraphState &bg, DpConst c, const st
                            (unsigned long long)finals.size());
     }
     if (!st.h_pin) DP_HIP(hipHostMalloc((void **)&st.h_pin, (1 + kDpGroup) * sizeof(uint32_t), hipHostMallocDefault));
-    uint32_t sweeps = 0, *h_flags = st.h_pin;
+    uint32_t sweeps = 0, *h_flags = st.h_pin, prev_level_sweeps = 0;
     unsigned long long sweep_rows = 0;
     {
         size_t max_items = 0;
@@ -579,21 +579,30 @@ static int dp_run_layered(DpState &st, BeliefGraphState &bg, DpConst c, const st
         const bool split = (size_t)N * W < (2u << 20);                                 // small level: latency bound
         const dim3 sgrid(split ? (unsigned)(((size_t)N * W * 4 + 255) / 256) : (unsigned)(N * ((W + 255) / 256)));
         hipLaunchKernelGGL(k_dp_level_init, grid, block, 0, s, L, p0, W, st.d_dirty[0], st.d_item[sweeps & 1u], split ? 4u : 1u, sweeps);
+        // Groups of sweeps between two looks from the host at "did the group's last sweep still improve something".  Levels of one graph
+        // take about as many sweeps as the level before them (the graph's depth in hops): the first group of a level is that count less
+        // one group, the following ones kDpGroup -- a look costs a synchronisation, a sweep past the fixpoint ends at its item bytes.
         int cur = 0;
-        for (bool more = true; more;) {
+        uint32_t level_sweeps = 0;
+        uint32_t G = prev_level_sweeps > 2u * kDpGroup ? ((prev_level_sweeps - kDpGroup) / kDpGroup) * kDpGroup : kDpGroup;
+        for (bool more = true; more; G = kDpGroup) {
             DP_HIP(hipMemsetAsync(st.d_flags + 1, 0, kDpGroup * sizeof(uint32_t), s));
-            for (uint32_t k = 0; k < kDpGroup; ++k, cur ^= 1)
+            for (uint32_t k = 0; k < G; ++k, cur ^= 1) {
+                const uint32_t slot = k + 1u == G ? kDpGroup - 1u : 0u;            // (the host reads the last sweep's word only)
                 if (split) hipLaunchKernelGGL(k_dp_level_sweep<4>, sgrid, block, 0, s, L, p0, W, st.d_dirty[cur], st.d_dirty[cur ^ 1],
-                                              (const uint8_t *)st.d_item[(sweeps + k) & 1u], st.d_item[(sweeps + k + 1u) & 1u], sweeps + k, k);
+                                              (const uint8_t *)st.d_item[(sweeps + k) & 1u], st.d_item[(sweeps + k + 1u) & 1u], sweeps + k, slot);
                 else hipLaunchKernelGGL(k_dp_level_sweep<1>, sgrid, block, 0, s, L, p0, W, st.d_dirty[cur], st.d_dirty[cur ^ 1],
-                                        (const uint8_t *)st.d_item[(sweeps + k) & 1u], st.d_item[(sweeps + k + 1u) & 1u], sweeps + k, k);
-            sweeps += kDpGroup;
-            sweep_rows += (unsigned long long)N * W * kDpGroup;
+                                        (const uint8_t *)st.d_item[(sweeps + k) & 1u], st.d_item[(sweeps + k + 1u) & 1u], sweeps + k, slot);
+            }
+            sweeps += G;
+            level_sweeps += G;
+            sweep_rows += (unsigned long long)N * W * G;
             DP_HIP(hipMemcpyAsync(h_flags, st.d_flags, (1 + kDpGroup) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             DP_HIP(hipStreamSynchronize(s));
             more = h_flags[kDpGroup] != 0;
             if (sweeps > 4u * 1000u * 1000u) { err = "conditional_dijkstra: no fixpoint after 4M sweeps"; return PORRT_ERR_DEVICE; }
         }
+        prev_level_sweeps = level_sweeps;
     }
     hipLaunchKernelGGL(k_dp_unpermute, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, L, st.d_dist);
     DP_HIP(hipEventRecord(ev1, s));
