@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n-iter", type=int, default=111500, help="iterations per query (~100k-node tree)")
     ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--queries", type=int, default=256, help="independent queries advanced together per step and GPU (on the device 212 M/s at 128, 241 at 256, 246 at 384, 250 at 512: 256 keeps the default run short and 95 GB of HBM in use)")
+    ap.add_argument("--queries", type=int, default=256, help="independent queries advanced together per step and GPU (on the device 244 M/s at 128, 253 at 256, 261 at 384, 264 at 512 at the end of round 4: 256 keeps the default run short and 95 GB of HBM in use)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event roofline pass")
     ap.add_argument("--no-single-query", action="store_true", help="skip the single-query (latency mode) reference run")
